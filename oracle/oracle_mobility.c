@@ -1,0 +1,494 @@
+/*
+ * oracle_mobility.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference's blob-level pairwise operators, used
+ * as the parity checker for the HIP path (tests/, __graft_entry__.smoke(),
+ * and bench.py's cpu_baseline leg).  Nothing under rigidmultiblobswall_amd/
+ * may link, import or call this file: the product path is the HIP library and
+ * it fails loudly when that library is missing.
+ *
+ * Parity status: PINNED.  Every function here is checked against golden
+ * vectors produced by running the reference's own Python
+ * (mobility/mobility_numba.py under a numba identity stub, and the dense
+ * builders in mobility/mobility.py) in the build container; see
+ * oracle/gen_golden.py and tests/test_oracle_golden.py.
+ *
+ * Structure (ours, not the reference's): one generic driver loop
+ * `matvec_driver` that walks targets x image boxes x sources and calls a
+ * per-kind "pair block" routine that fills a 3x3 block in hydrodynamic-radius
+ * units.  The reference instead has one 100+-line function per kind with the
+ * loops and the algebra inlined; the arithmetic of every block follows the
+ * reference formulas as written, cited per function below.
+ *
+ * All citations are relative to /root/reference/.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_PI 3.14159265358979323846264338327950288
+
+/* kinds: which 3x3 block of the grand mobility */
+enum { KIND_TT = 0, KIND_TR = 1, KIND_RT = 2, KIND_RR = 3 };
+
+/* 3x3 block, row-major: m[3*row+col] */
+typedef struct { double m[9]; } block3;
+
+/* ------------------------------------------------------------------------ */
+/* Unbounded RPY blocks.  Arguments are the separation in units of a.        */
+/* ------------------------------------------------------------------------ */
+
+/* translation-translation RPY block.
+ * mobility/mobility_numba.py:202-239 (self 4/3; far c1 = 1 + 2/(3 r^2),
+ * c2 = (1 - 2/r^2)/r^2, all times 1/r; near c1 = 4/3 (1 - 9r/32),
+ * c2 = 4/3 * 3/(32 r)). */
+static void rpy_tt(double rx, double ry, double rz, int self, block3 *B) {
+  double Mxx, Mxy, Mxz, Myy, Myz, Mzz;
+  if (self) {
+    Mxx = 4.0 / 3.0; Mxy = 0; Mxz = 0; Myy = Mxx; Myz = 0; Mzz = Mxx;
+  } else {
+    double r2 = rx * rx + ry * ry + rz * rz;
+    double r = sqrt(r2);
+    double invr = 1.0 / r;
+    double invr2 = invr * invr;
+    if (r > 2) {
+      double c1 = 1.0 + 2.0 / (3.0 * r2);
+      double c2 = (1.0 - 2.0 * invr2) * invr2;
+      Mxx = (c1 + c2 * rx * rx) * invr;
+      Mxy = (c2 * rx * ry) * invr;
+      Mxz = (c2 * rx * rz) * invr;
+      Myy = (c1 + c2 * ry * ry) * invr;
+      Myz = (c2 * ry * rz) * invr;
+      Mzz = (c1 + c2 * rz * rz) * invr;
+    } else {
+      double c1 = (4.0 / 3.0) * (1.0 - 0.28125 * r);
+      double c2 = (4.0 / 3.0) * 0.09375 * invr;
+      Mxx = c1 + c2 * rx * rx;
+      Mxy = c2 * rx * ry;
+      Mxz = c2 * rx * rz;
+      Myy = c1 + c2 * ry * ry;
+      Myz = c2 * ry * rz;
+      Mzz = c1 + c2 * rz * rz;
+    }
+  }
+  B->m[0] = Mxx; B->m[1] = Mxy; B->m[2] = Mxz;
+  B->m[3] = Mxy; B->m[4] = Myy; B->m[5] = Myz;
+  B->m[6] = Mxz; B->m[7] = Myz; B->m[8] = Mzz;
+}
+
+/* translation-rotation / rotation-translation RPY block (antisymmetric).
+ * mobility/mobility_numba.py:612-644 (tr) and :1001-1033 (rt): far
+ * eps.r / r^3, near (1/2)(1 - 3r/8) eps.r; self 0. */
+static void rpy_coupling(double rx, double ry, double rz, int self, block3 *B) {
+  double Mxy, Mxz, Myz;
+  if (self) {
+    Mxy = 0; Mxz = 0; Myz = 0;
+  } else {
+    double r2 = rx * rx + ry * ry + rz * rz;
+    double r = sqrt(r2);
+    double r3 = r2 * r;
+    double invr3 = 1.0 / r3;
+    if (r >= 2) {
+      Mxy = rz * invr3;
+      Mxz = -ry * invr3;
+      Myz = rx * invr3;
+    } else {
+      double c1 = 0.5 * (1.0 - 0.375 * r);
+      Mxy = c1 * rz;
+      Mxz = -c1 * ry;
+      Myz = c1 * rx;
+    }
+  }
+  B->m[0] = 0;    B->m[1] = Mxy;  B->m[2] = Mxz;
+  B->m[3] = -Mxy; B->m[4] = 0;    B->m[5] = Myz;
+  B->m[6] = -Mxz; B->m[7] = -Myz; B->m[8] = 0;
+}
+
+/* rotation-rotation RPY block.
+ * mobility/mobility_numba.py:1253-1290: self 1; far (-1/2 + 3/2 rr/r^2)/r^3;
+ * near c1 = 1 - 27r/32 + 5r^3/64, c2 = 9/(32r) - 3r/64. */
+static void rpy_rr(double rx, double ry, double rz, int self, block3 *B) {
+  double Mxx, Mxy, Mxz, Myy, Myz, Mzz;
+  if (self) {
+    Mxx = 1.0; Mxy = 0; Mxz = 0; Myy = 1.0; Myz = 0; Mzz = 1.0;
+  } else {
+    double r2 = rx * rx + ry * ry + rz * rz;
+    double r = sqrt(r2);
+    double r3 = r2 * r;
+    double invr = 1.0 / r;
+    double invr2 = 1.0 / r2;
+    double invr3 = 1.0 / r3;
+    if (r >= 2) {
+      double c1 = -0.5;
+      double c2 = 1.5 * invr2;
+      Mxx = (c1 + c2 * rx * rx) * invr3;
+      Mxy = (c2 * rx * ry) * invr3;
+      Mxz = (c2 * rx * rz) * invr3;
+      Myy = (c1 + c2 * ry * ry) * invr3;
+      Myz = (c2 * ry * rz) * invr3;
+      Mzz = (c1 + c2 * rz * rz) * invr3;
+    } else {
+      double c1 = 1.0 - 0.84375 * r + 0.078125 * r3;
+      double c2 = 0.28125 * invr - 0.046875 * r;
+      Mxx = c1 + c2 * rx * rx;
+      Mxy = c2 * rx * ry;
+      Mxz = c2 * rx * rz;
+      Myy = c1 + c2 * ry * ry;
+      Myz = c2 * ry * rz;
+      Mzz = c1 + c2 * rz * rz;
+    }
+  }
+  B->m[0] = Mxx; B->m[1] = Mxy; B->m[2] = Mxz;
+  B->m[3] = Mxy; B->m[4] = Myy; B->m[5] = Myz;
+  B->m[6] = Mxz; B->m[7] = Myz; B->m[8] = Mzz;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Single-wall (Swan & Brady) corrections, added in place to the RPY block.  */
+/* (rx, ry) in-plane separation / a, Rz = (z_i + z_j)/a, h = height / a of   */
+/* the blob the formula is anchored on (source for tt/rt/rr, target for tr). */
+/* ------------------------------------------------------------------------ */
+
+/* mobility/mobility_numba.py:241-276 */
+static void wall_tt(double rx, double ry, double Rz, double hj, int self, block3 *B) {
+  double *M = B->m;
+  if (self) {
+    double invZi = 1.0 / hj;
+    double invZi3 = invZi * invZi * invZi;
+    double invZi5 = invZi3 * invZi * invZi;
+    M[0] += -(9.0 * invZi - 2.0 * invZi3 + invZi5) / 12.0;
+    M[4] += -(9.0 * invZi - 2.0 * invZi3 + invZi5) / 12.0;
+    M[8] += -(9.0 * invZi - 4.0 * invZi3 + invZi5) / 6.0;
+  } else {
+    double h_hat = hj / Rz;
+    double invR = 1.0 / sqrt(rx * rx + ry * ry + Rz * Rz);
+    double ex = rx * invR, ey = ry * invR, ez = Rz * invR;
+    double invR3 = invR * invR * invR;
+    double invR5 = invR3 * invR * invR;
+    double ez2 = ez * ez;
+    double fact1 = -(3.0 * (1.0 + 2.0 * h_hat * (1.0 - h_hat) * ez2) * invR + 2.0 * (1.0 - 3.0 * ez2) * invR3 - 2.0 * (1.0 - 5.0 * ez2) * invR5) / 3.0;
+    double fact2 = -(3.0 * (1.0 - 6.0 * h_hat * (1.0 - h_hat) * ez2) * invR - 6.0 * (1.0 - 5.0 * ez2) * invR3 + 10.0 * (1.0 - 7.0 * ez2) * invR5) / 3.0;
+    double fact3 = ez * (3.0 * h_hat * (1.0 - 6.0 * (1.0 - h_hat) * ez2) * invR - 6.0 * (1.0 - 5.0 * ez2) * invR3 + 10.0 * (2.0 - 7.0 * ez2) * invR5) * 2.0 / 3.0;
+    double fact4 = ez * (3.0 * h_hat * invR - 10.0 * invR5) * 2.0 / 3.0;
+    double fact5 = -(3.0 * h_hat * h_hat * ez2 * invR + 3.0 * ez2 * invR3 + (2.0 - 15.0 * ez2) * invR5) * 4.0 / 3.0;
+    M[0] += fact1 + fact2 * ex * ex;
+    M[1] += fact2 * ex * ey;
+    M[2] += fact2 * ex * ez + fact3 * ex;
+    M[3] += fact2 * ey * ex;
+    M[4] += fact1 + fact2 * ey * ey;
+    M[5] += fact2 * ey * ez + fact3 * ey;
+    M[6] += fact2 * ez * ex + fact4 * ex;
+    M[7] += fact2 * ez * ey + fact4 * ey;
+    M[8] += fact1 + fact2 * ez * ez + fact3 * ez + fact4 * ez + fact5;
+  }
+}
+
+/* mobility/mobility_numba.py:646-679.  Caller passes the NEGATED in-plane
+ * separation and the TARGET height, as the reference does at :648-651. */
+static void wall_tr(double rx, double ry, double Rz, double hi, int self, block3 *B) {
+  double *M = B->m;
+  if (self) {
+    double invZi = 1.0 / hi;
+    double invZi4 = invZi * invZi * invZi * invZi;
+    M[1] -= -invZi4 * 0.125;
+    M[3] -= invZi4 * 0.125;
+  } else {
+    double h_hat = hi / Rz;
+    double invR = 1.0 / sqrt(rx * rx + ry * ry + Rz * Rz);
+    double invR2 = invR * invR;
+    double invR4 = invR2 * invR2;
+    double ex = rx * invR, ey = ry * invR, ez = Rz * invR;
+    double fact1 = invR2;
+    double fact2 = (6.0 * h_hat * ez * ez * invR2 + (1.0 - 10.0 * ez * ez) * invR4) * 2.0;
+    double fact3 = -ez * (3.0 * h_hat * invR2 - 5.0 * invR4) * 2.0;
+    double fact4 = -ez * (h_hat * invR2 - invR4) * 2.0;
+    M[0] -= -fact3 * ex * ey;
+    M[1] -= -fact1 * ez + fact3 * ex * ex - fact4;
+    M[2] -= fact1 * ey;
+    M[3] -= fact1 * ez - fact3 * ey * ey + fact4;
+    M[4] -= fact3 * ex * ey;
+    M[5] -= -fact1 * ex;
+    M[6] -= -fact1 * ey - fact2 * ey - fact3 * ey * ez;
+    M[7] -= fact1 * ex + fact2 * ex + fact3 * ex * ez;
+  }
+}
+
+/* mobility/mobility_numba.py:1035-1066 (source height) */
+static void wall_rt(double rx, double ry, double Rz, double hj, int self, block3 *B) {
+  double *M = B->m;
+  if (self) {
+    double invZi = 1.0 / hj;
+    double invZi4 = invZi * invZi * invZi * invZi;
+    M[1] += -invZi4 * 0.125;
+    M[3] += invZi4 * 0.125;
+  } else {
+    double h_hat = hj / Rz;
+    double invR = 1.0 / sqrt(rx * rx + ry * ry + Rz * Rz);
+    double invR2 = invR * invR;
+    double invR4 = invR2 * invR2;
+    double ex = rx * invR, ey = ry * invR, ez = Rz * invR;
+    double fact1 = invR2;
+    double fact2 = (6.0 * h_hat * ez * ez * invR2 + (1.0 - 10.0 * ez * ez) * invR4) * 2.0;
+    double fact3 = -ez * (3.0 * h_hat * invR2 - 5.0 * invR4) * 2.0;
+    double fact4 = -ez * (h_hat * invR2 - invR4) * 2.0;
+    M[0] -= -fact3 * ex * ey;
+    M[1] -= fact1 * ez - fact3 * ey * ey + fact4;
+    M[2] -= -fact1 * ey - fact2 * ey - fact3 * ey * ez;
+    M[3] -= -fact1 * ez + fact3 * ex * ex - fact4;
+    M[4] -= fact3 * ex * ey;
+    M[5] -= fact1 * ex + fact2 * ex + fact3 * ex * ez;
+    M[6] -= fact1 * ey;
+    M[7] -= -fact1 * ex;
+  }
+}
+
+/* mobility/mobility_numba.py:1292-1321 */
+static void wall_rr(double rx, double ry, double Rz, double hj, int self, block3 *B) {
+  double *M = B->m;
+  if (self) {
+    double invZi = 1.0 / hj;
+    double invZi3 = invZi * invZi * invZi;
+    M[0] += -invZi3 * 0.3125;
+    M[4] += -invZi3 * 0.3125;
+    M[8] += -invZi3 * 0.125;
+  } else {
+    double invR = 1.0 / sqrt(rx * rx + ry * ry + Rz * Rz);
+    double invR3 = invR * invR * invR;
+    double ex = rx * invR, ey = ry * invR, ez = Rz * invR;
+    double fact1 = ((1.0 - 6.0 * ez * ez) * invR3) * 0.5;
+    double fact2 = -(9.0 * invR3) / 6.0;
+    double fact3 = 3.0 * invR3 * ez;
+    double fact4 = 3.0 * invR3;
+    M[0] += fact1 + fact2 * ex * ex + fact4 * ey * ey;
+    M[1] += (fact2 - fact4) * ex * ey;
+    M[2] += fact2 * ex * ez;
+    M[3] += (fact2 - fact4) * ex * ey;
+    M[4] += fact1 + fact2 * ey * ey + fact4 * ex * ex;
+    M[5] += fact2 * ey * ez;
+    M[6] += fact2 * ez * ex + fact3 * ex;
+    M[7] += fact2 * ez * ey + fact3 * ey;
+    M[8] += fact1 + fact2 * ez * ez + fact3 * ez;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Pseudo-periodic nearest-image wrap.                                       */
+/* mobility/mobility_numba.py:184-192: r -= int(r/L + 0.5*sgn(r))*L; C's     */
+/* (long) cast truncates toward zero exactly as Python's int().              */
+/* ------------------------------------------------------------------------ */
+static inline double wrap_nearest(double r, double L) {
+  int sg = (r > 0) - (r < 0);
+  return r - (double)((long)(r / L + 0.5 * sg)) * L;
+}
+
+/* One (target i, source j, image box) block of kind `kind`, in units of a.
+ * `in_plane` zeroes the z rows/cols as mobility_numba.py:291-435 / :690-828. */
+static void pair_block(int kind, int wall, int in_plane, double rx, double ry, double rz,
+                       double zi, double zj, double inva, int self, block3 *B) {
+  double sx = rx * inva, sy = ry * inva, sz = rz * inva;
+  double Rz = (zi + zj) * inva;
+  switch (kind) {
+    case KIND_TT:
+      rpy_tt(sx, sy, sz, self, B);
+      if (in_plane) { B->m[2] = B->m[5] = B->m[6] = B->m[7] = B->m[8] = 0; }
+      if (wall) {
+        block3 W; memset(&W, 0, sizeof W);
+        wall_tt(sx, sy, Rz, zj * inva, self, &W);
+        if (in_plane) { W.m[2] = W.m[5] = W.m[6] = W.m[7] = W.m[8] = 0; }
+        for (int k = 0; k < 9; ++k) B->m[k] += W.m[k];
+      }
+      break;
+    case KIND_TR:
+      rpy_coupling(sx, sy, sz, self, B);
+      if (in_plane) { B->m[2] = B->m[5] = B->m[6] = B->m[7] = 0; }
+      if (wall) {
+        block3 W; memset(&W, 0, sizeof W);
+        wall_tr(-sx, -sy, Rz, zi * inva, self, &W);
+        if (in_plane) { W.m[2] = W.m[5] = W.m[6] = W.m[7] = 0; }
+        for (int k = 0; k < 9; ++k) B->m[k] += W.m[k];
+      }
+      break;
+    case KIND_RT:
+      rpy_coupling(sx, sy, sz, self, B);
+      if (wall) wall_rt(sx, sy, Rz, zj * inva, self, B);
+      break;
+    default: /* KIND_RR */
+      rpy_rr(sx, sy, sz, self, B);
+      if (wall) wall_rr(sx, sy, Rz, zj * inva, self, B);
+      break;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Generic driver: out[3i..] = norm * sum_boxes sum_j block(i,j) . v[3j..]    */
+/* Loop nest order (target, boxX, boxY, boxZ, source) and accumulation order */
+/* follow mobility/mobility_numba.py:166-281.                                */
+/* ------------------------------------------------------------------------ */
+static int matvec_driver(int kind, int wall, int in_plane, long N, const double *r,
+                         const double *v, double eta, double a, const double *L, double *out) {
+  if (N < 0 || !out) return 1;
+  if (N == 0) return 0;
+  if (!r || !v || !L) return 1;
+  const double inva = 1.0 / a;
+  double norm;
+  if (kind == KIND_TT) norm = 1.0 / (8.0 * ORACLE_PI * eta * a);
+  else if (kind == KIND_RR) norm = 1.0 / (8.0 * ORACLE_PI * eta * a * a * a);
+  else norm = 1.0 / (8.0 * ORACLE_PI * eta * a * a);
+  const int px = L[0] > 0, py = L[1] > 0, pz = L[2] > 0;
+
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long i = 0; i < N; ++i) {
+    double ux = 0, uy = 0, uz = 0;
+    const double xi = r[3 * i], yi = r[3 * i + 1], zi = r[3 * i + 2];
+    for (int bx = -px; bx <= px; ++bx)
+      for (int by = -py; by <= py; ++by)
+        for (int bz = -pz; bz <= pz; ++bz)
+          for (long j = 0; j < N; ++j) {
+            double rx = xi - r[3 * j], ry = yi - r[3 * j + 1], rz = zi - r[3 * j + 2];
+            if (px) rx = wrap_nearest(rx, L[0]) + bx * L[0];
+            if (py) ry = wrap_nearest(ry, L[1]) + by * L[1];
+            if (pz) rz = wrap_nearest(rz, L[2]) + bz * L[2];
+            const int self = (i == j) && bx == 0 && by == 0 && bz == 0;
+            block3 B;
+            pair_block(kind, wall, in_plane, rx, ry, rz, zi, r[3 * j + 2], inva, self, &B);
+            const double vx = v[3 * j], vy = v[3 * j + 1], vz = v[3 * j + 2];
+            ux += (B.m[0] * vx + B.m[1] * vy + B.m[2] * vz) * norm;
+            uy += (B.m[3] * vx + B.m[4] * vy + B.m[5] * vz) * norm;
+            uz += (B.m[6] * vx + B.m[7] * vy + B.m[8] * vz) * norm;
+          }
+    out[3 * i] = ux; out[3 * i + 1] = uy; out[3 * i + 2] = uz;
+  }
+  return 0;
+}
+
+/* Exported entry point.  kind in {0 tt, 1 tr, 2 rt, 3 rr}; wall in {0,1};
+ * in_plane only meaningful for tt/tr with wall=1.
+ * Positions must already be height-clamped by the caller when wall=1 (the
+ * reference does that in the Python wrapper, mobility/mobility.py:1150-1163). */
+int oracle_mobility_matvec(int kind, int wall, int in_plane, long N, const double *r,
+                           const double *v, double eta, double a, const double *L, double *out) {
+  if (kind < 0 || kind > 3) return 2;
+  return matvec_driver(kind, wall, in_plane, N, r, v, eta, a, L, out);
+}
+
+/* Subset variant for full-size spot checks: only the listed targets are
+ * evaluated (all N sources each).  out has 3*n_targets entries. */
+int oracle_mobility_matvec_targets(int kind, int wall, long N, const double *r, const double *v,
+                                   double eta, double a, const double *L, long n_targets,
+                                   const long *targets, double *out) {
+  if (kind < 0 || kind > 3) return 2;
+  const double inva = 1.0 / a;
+  double norm;
+  if (kind == KIND_TT) norm = 1.0 / (8.0 * ORACLE_PI * eta * a);
+  else if (kind == KIND_RR) norm = 1.0 / (8.0 * ORACLE_PI * eta * a * a * a);
+  else norm = 1.0 / (8.0 * ORACLE_PI * eta * a * a);
+  const int px = L[0] > 0, py = L[1] > 0, pz = L[2] > 0;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (long t = 0; t < n_targets; ++t) {
+    const long i = targets[t];
+    double ux = 0, uy = 0, uz = 0;
+    const double xi = r[3 * i], yi = r[3 * i + 1], zi = r[3 * i + 2];
+    for (int bx = -px; bx <= px; ++bx)
+      for (int by = -py; by <= py; ++by)
+        for (int bz = -pz; bz <= pz; ++bz)
+          for (long j = 0; j < N; ++j) {
+            double rx = xi - r[3 * j], ry = yi - r[3 * j + 1], rz = zi - r[3 * j + 2];
+            if (px) rx = wrap_nearest(rx, L[0]) + bx * L[0];
+            if (py) ry = wrap_nearest(ry, L[1]) + by * L[1];
+            if (pz) rz = wrap_nearest(rz, L[2]) + bz * L[2];
+            const int self = (i == j) && bx == 0 && by == 0 && bz == 0;
+            block3 B;
+            pair_block(kind, wall, 0, rx, ry, rz, zi, r[3 * j + 2], inva, self, &B);
+            const double vx = v[3 * j], vy = v[3 * j + 1], vz = v[3 * j + 2];
+            ux += (B.m[0] * vx + B.m[1] * vy + B.m[2] * vz) * norm;
+            uy += (B.m[3] * vx + B.m[4] * vy + B.m[5] * vz) * norm;
+            uz += (B.m[6] * vx + B.m[7] * vy + B.m[8] * vz) * norm;
+          }
+    out[3 * t] = ux; out[3 * t + 1] = uy; out[3 * t + 2] = uz;
+  }
+  return 0;
+}
+
+/* Dense 3N x 3N matrix of one kind (row-major), same blocks as the matvec.
+ * Used to check symmetry / SPD properties and the dense builders
+ * (mobility/mobility.py:967-1013 rotne_prager_tensor, :1018-1116
+ * single_wall_fluid_mobility) on small N.  Non-periodic only. */
+int oracle_mobility_dense(int kind, int wall, long N, const double *r, double eta, double a,
+                          double *Mout) {
+  if (kind < 0 || kind > 3) return 2;
+  const double inva = 1.0 / a;
+  double norm;
+  if (kind == KIND_TT) norm = 1.0 / (8.0 * ORACLE_PI * eta * a);
+  else if (kind == KIND_RR) norm = 1.0 / (8.0 * ORACLE_PI * eta * a * a * a);
+  else norm = 1.0 / (8.0 * ORACLE_PI * eta * a * a);
+  const long ld = 3 * N;
+  for (long i = 0; i < N; ++i)
+    for (long j = 0; j < N; ++j) {
+      block3 B;
+      pair_block(kind, wall, 0, r[3 * i] - r[3 * j], r[3 * i + 1] - r[3 * j + 1],
+                 r[3 * i + 2] - r[3 * j + 2], r[3 * i + 2], r[3 * j + 2], inva, i == j, &B);
+      for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) Mout[(3 * i + p) * ld + 3 * j + q] = B.m[3 * p + q] * norm;
+    }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Blob-blob soft repulsion, all pairs, minimal image only.                   */
+/* multi_bodies/forces_numba.py:12-55: F_i = sum_{j!=i} f0(r) (r_j - r_i),    */
+/* f0 = -(eps/b) exp(-(r-2a)/b)/r for r > 2a, else -(eps/b)/max(r,1e-25).     */
+/* ------------------------------------------------------------------------ */
+int oracle_blob_blob_force(long N, const double *r, const double *L, double eps, double b,
+                           double a, double *out) {
+  if (N < 0 || !out) return 1;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long i = 0; i < N; ++i) {
+    double fx = 0, fy = 0, fz = 0;
+    for (long j = 0; j < N; ++j) {
+      if (i == j) continue;
+      double dr[3];
+      for (int k = 0; k < 3; ++k) {
+        dr[k] = r[3 * j + k] - r[3 * i + k];
+        if (L[k] > 0) dr[k] = wrap_nearest(dr[k], L[k]);
+      }
+      double rn = sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+      double f0;
+      if (rn > 2 * a) f0 = -((eps / b) * exp(-(rn - 2.0 * a) / b) / rn);
+      else f0 = -((eps / b) / fmax(rn, 1e-25));
+      fx += f0 * dr[0]; fy += f0 * dr[1]; fz += f0 * dr[2];
+    }
+    out[3 * i] = fx; out[3 * i + 1] = fy; out[3 * i + 2] = fz;
+  }
+  return 0;
+}
+
+/* Height clamp + damping diagonal of the Python wrappers
+ * (mobility/mobility.py:52-64 shift_heights uses `<=`, :67-84
+ * damping_matrix_B uses `<`).  r_eff gets the clamped copy, bdiag (N entries)
+ * the per-blob factor; returns 1 in *overlap if any blob is below z = a. */
+int oracle_wall_regularisation(long N, const double *r, double a, double *r_eff, double *bdiag,
+                               int *overlap) {
+  int ov = 0;
+  for (long i = 0; i < N; ++i) {
+    double z = r[3 * i + 2];
+    r_eff[3 * i] = r[3 * i];
+    r_eff[3 * i + 1] = r[3 * i + 1];
+    r_eff[3 * i + 2] = (z <= a) ? a : z;
+    if (z < a) { bdiag[i] = z / a; ov = 1; } else bdiag[i] = 1.0;
+  }
+  if (overlap) *overlap = ov;
+  return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
