@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: RPY-wall M.f matvecs/s on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one single_wall_mobility_trans_times_force product (BASELINE.json configs[1]: 1e4
+random blobs above a wall, fp64) with positions and the force vector already resident in HBM:
+all-gather of the force blocks (N > 1 only) + pair sweep + chunk reduction.  Targets are sharded
+over the ranks; total work is fixed => "strong" scaling.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel (the pair sweep): algorithmic flops 211 N^2 per launch
+                / average launch duration from HIP events on the launch stream, against the fp64
+                vector peak.  The path is FP64-VALU bound, not HBM bound; the HBM view
+                (algorithmic 72 N bytes per launch, PMC traffic) is reported beside it.
+  cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N=1)
+  sweep         the same product at larger N_blobs (the metric is "... vs N_blobs")
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_PAIR = {"tt_wall": 211.0}     # reference as-written op count, SURVEY.md 8(d)
+FP64_VECTOR_PEAK_TFLOPS = 78.6          # MI355X fp64 vector = 1/2 of the 157.3 TF fp32 vector peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def d2_cloud(N, seed=0):
+  """5 % volume fraction, a = 0.5, eta = 1, z in [1.1a, 1.1a + Lbox)."""
+  rng = np.random.RandomState(seed)
+  a, eta = 0.5, 1.0
+  Lbox = (N * (4.0 / 3.0) * np.pi * a ** 3 / 0.05) ** (1.0 / 3.0)
+  r = rng.rand(N, 3) * Lbox
+  r[:, 2] += 1.1 * a
+  return r, rng.randn(N, 3), eta, a
+
+
+def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, device):
+  from rigidmultiblobswall_amd.distributed import partition
+  r, f, eta, a = d2_cloud(n_blobs, seed=0)
+  b, e, _ = partition(n_blobs, world, rank)
+  sm.set_local_positions(torch.as_tensor(r[b:e].reshape(-1), device=device), n_blobs, a, wall=True)
+  f_local = torch.as_tensor(f[b:e].reshape(-1), device=device)
+  out = torch.empty(3 * (e - b), dtype=torch.float64, device=device)
+
+  def step():
+    sm.matvec_local("tt", f_local, eta, out=out)
+
+  for _ in range(warmup):
+    step()
+  torch.cuda.synchronize(device)
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize(device)
+  backend.ctx.timing_reset()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  torch.cuda.synchronize(device)
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize(device)
+  dt = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+  kern_ms = backend.ctx.timing_collect(steps)
+  kern_ms_avg = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
+  if world > 1:
+    t = torch.tensor([kern_ms_avg], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    kern_ms_avg = float(t.item())
+  return dict(dt=dt, kern_ms=kern_ms_avg, launch=backend.ctx.last_launch(), out=out, r=r, f=f, eta=eta, a=a,
+              n_local=e - b, begin=b, end=e)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--blobs", type=int, default=10000, help="N_blobs of the headline workload (configs[1] = 1e4)")
+  ap.add_argument("--no-sweep", action="store_true")
+  ap.add_argument("--no-cpu", action="store_true")
+  ap.add_argument("--traffic-bytes", type=float, default=None,
+                  help="HBM bytes per sweep launch from a separate rocprofv3 --pmc run (profiles/), if known")
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+  device = torch.device("cuda:%d" % local_rank)
+  torch.cuda.set_device(device)
+  if world > 1:
+    dist.init_process_group("nccl", device_id=device)
+  assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+  from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
+  backend = HipBackend(device)
+  backend.ctx.set_option("timing", 1)
+  sm = ShardedMobility(backend, device=device)
+
+  N = args.blobs
+  res = run_config(torch, dist, sm, backend, N, args.steps, args.warmup, world, rank, device)
+  ms_per_step = 1e3 * res["dt"] / args.steps
+  value = args.steps / res["dt"]
+
+  # roofline of the dominant kernel: this rank's launch covers n_local targets x N sources
+  pairs_per_launch = float(res["n_local"]) * N
+  flops = FLOPS_PER_PAIR["tt_wall"] * pairs_per_launch
+  achieved_tf = flops / (res["kern_ms"] * 1e-3) / 1e12
+  alg_bytes = 48.0 * N + 24.0 * res["n_local"]       # read r,f of all sources; write u of own targets
+  roofline = {
+      "bound": "valu_fp64", "kernel": "rmb::sweep_kernel<TT,wall>",
+      "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+      "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+      "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_per_launch,
+      "kernel_ms_avg": round(res["kern_ms"], 5), "launch": res["launch"],
+      "traffic": args.traffic_bytes,
+      "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+              "achieved": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+  }
+
+  line = {
+      "metric": "RPY-wall M.f matvecs/sec (single_wall_mobility_trans_times_force, N_blobs=%d)" % N,
+      "value": round(value, 3), "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+      "dtype": "f64", "data": "synthetic",
+      "config": {"workload": "configs[1]: %d random blobs above a wall (D2 cloud, 5%% volume fraction, seed 0), fp64, "
+                             "single_wall_mobility_trans_times_force; vectors resident in HBM" % N,
+                 "n_blobs": N, "parallelism": "targets sharded over %d rank(s), all-gather of f per matvec" % world},
+      "roofline": roofline,
+  }
+
+  if rank == 0 and world == 1 and not args.no_cpu:
+    from oracle import oracle
+    r, f, eta, a = res["r"], res["f"], res["eta"], res["a"]
+    # parity guard on the very output that was timed (subset of targets, all sources)
+    tg = np.random.RandomState(1).choice(N, min(64, N), replace=False)
+    r_eff, bdiag, _ = oracle.wall_regularisation(r, a)
+    ref = oracle.raw_matvec_targets("tt", 1, r_eff, f, eta, a, tg)
+    got = res["out"].cpu().numpy().reshape(-1, 3)[tg].reshape(-1)
+    line["parity_rel_err_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    # CPU baseline: same workload, fast-math OpenMP port, bounded to ~10-30 s
+    oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a, fast=True)   # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 40 and (time.perf_counter() - t_start < 12.0 or len(times) < 3):
+      t0 = time.perf_counter()
+      oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a, fast=True)
+      times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    line["cpu_baseline"] = {"value": round(1.0 / med, 4), "unit": "matvecs/s", "cores": oracle.num_threads(),
+                            "kind": "port",
+                            "sample": "%d full matvecs of the same %d-blob workload (median), oracle C port "
+                                      "-O3 -ffast-math -fopenmp" % (len(times), N)}
+
+  if not args.no_sweep:
+    sweep = []
+    for nb, st, wu in ((100000, 5, 1), (1000000, 2, 1) if world > 1 else (262144, 3, 1)):
+      rs = run_config(torch, dist, sm, backend, nb, st, wu, world, rank, device)
+      pairs = float(rs["n_local"]) * nb
+      sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
+                    "kernel_ms_avg": round(rs["kern_ms"], 3),
+                    "valu_fp64_tflops": round(211.0 * pairs / (rs["kern_ms"] * 1e-3) / 1e12, 2),
+                    "launch": rs["launch"]})
+    line["sweep"] = sweep
+
+  if rank == 0:
+    print(json.dumps(line), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,77 @@
+"""ctypes binding of librmb_mobility.so (C ABI declared in include/rmb_mobility.h).
+
+There is NO CPU fallback: if the HIP library is missing or no device is visible every compute
+call raises.  (The reference probes its backends and silently skips the missing ones,
+mobility/mobility.py:9-50; a silent fallback here would void the parity claims.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librmb_mobility.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+_lp = ctypes.POINTER(ctypes.c_long)
+
+KIND_TT, KIND_TR, KIND_RT, KIND_RR, KIND_TT_TR = 0, 1, 2, 3, 4
+KINDS = {"tt": KIND_TT, "tr": KIND_TR, "rt": KIND_RT, "rr": KIND_RR, "tt_tr": KIND_TT_TR}
+
+# every symbol include/rmb_mobility.h declares: (restype, argtypes)
+SYMBOLS = {
+    "rmb_version": (ctypes.c_char_p, []),
+    "rmb_last_error": (ctypes.c_char_p, []),
+    "rmb_device_count": (ctypes.c_int, []),
+    "rmb_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "rmb_ctx_destroy": (ctypes.c_int, [_vp]),
+    "rmb_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "rmb_ctx_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_long]),
+    "rmb_set_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_double, _vp, ctypes.c_int]),
+    "rmb_set_positions_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_double, _vp, ctypes.c_int]),
+    "rmb_set_target_range": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long]),
+    "rmb_matvec": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_matvec_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_blob_blob_force": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_blob_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_timing_collect": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
+    "rmb_timing_reset": (ctypes.c_int, [_vp]),
+    "rmb_last_launch": (ctypes.c_int, [_vp, _lp, _lp, _lp]),
+    "rmb_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "rmb_mobility_oneshot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp, _vp, _vp,
+                                            ctypes.c_double, ctypes.c_double, _vp, _vp]),
+    "rmb_forces_oneshot": (ctypes.c_int, [ctypes.c_long, _vp, _vp, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_double, _vp]),
+}
+
+_lib = None
+
+
+class RmbError(RuntimeError):
+  pass
+
+
+def load():
+  """Load the shared library (no GPU needed for loading / symbol checks)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise RmbError(
+          "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+      fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+      fn.restype = res
+      fn.argtypes = args
+    _lib = lib
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    msg = load().rmb_last_error()
+    raise RmbError("librmb_mobility error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+  return int(load().rmb_device_count())

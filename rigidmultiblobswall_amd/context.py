@@ -1,0 +1,146 @@
+"""Persistent device context: positions resident across the matvecs of a solve.
+
+Semantic list of SURVEY.md section 8(b): create/destroy, set_positions (upload + height clamp + B
+on device), matvec(kind), blob_blob_forces, timing.  The reference has no such object -- every
+pycuda call re-allocates and re-uploads (mobility/mobility_pycuda.py:2249-2266).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _as_f64(x, n3=None):
+  x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+  if n3 is not None and x.size != n3:
+    raise ValueError("expected %d values, got %d" % (n3, x.size))
+  return x
+
+
+def _ptr(x):
+  return ctypes.c_void_p(x.ctypes.data)
+
+
+class MobilityContext(object):
+  """One context = one GPU.  Host (numpy) and device (torch tensor) entry points."""
+
+  def __init__(self, device=0):
+    self._lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(self._lib.rmb_ctx_create(int(device), ctypes.byref(h)))
+    self._h = h
+    self.device = int(device)
+    self.n = 0
+    self.n_targets = 0
+    self.target_range = (0, 0)
+    self._keepalive = None
+
+  def close(self):
+    if getattr(self, "_h", None) is not None and self._h.value:
+      self._lib.rmb_ctx_destroy(self._h)
+      self._h = ctypes.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # --- configuration ---------------------------------------------------------------------------
+  def set_stream(self, stream_ptr):
+    _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+  def set_option(self, key, value):
+    _lib.check(self._lib.rmb_ctx_set_option(self._h, key.encode(), int(value)))
+
+  def set_positions(self, r_vectors, a, periodic_length=None, wall=True):
+    """r_vectors: numpy (N,3)/(3N,) or a CUDA torch float64 tensor (stays on device)."""
+    L = _as_f64(np.zeros(3) if periodic_length is None else periodic_length, 3)
+    if _is_torch_cuda(r_vectors):
+      r = r_vectors.contiguous().view(-1)
+      n = r.numel() // 3
+      _lib.check(self._lib.rmb_set_positions_device(self._h, ctypes.c_void_p(r.data_ptr()), n, float(a), _ptr(L),
+                                                    int(bool(wall))))
+      self._keepalive = r
+    else:
+      r = _as_f64(r_vectors)
+      n = r.size // 3
+      _lib.check(self._lib.rmb_set_positions(self._h, _ptr(r), n, float(a), _ptr(L), int(bool(wall))))
+    self.n = n
+    self.n_targets = n
+    self.target_range = (0, n)
+
+  def set_target_range(self, begin, end):
+    _lib.check(self._lib.rmb_set_target_range(self._h, int(begin), int(end)))
+    self.target_range = (int(begin), int(end))
+    self.n_targets = int(end) - int(begin)
+
+  # --- products --------------------------------------------------------------------------------
+  def matvec(self, kind, vec, eta, vec2=None, in_plane=False):
+    """Host path: numpy in, new numpy (3*n_targets,) out; synchronous."""
+    k = _lib.KINDS[kind] if isinstance(kind, str) else int(kind)
+    v = _as_f64(vec, 3 * self.n)
+    v2 = _as_f64(vec2, 3 * self.n) if vec2 is not None else None
+    out = np.empty(3 * self.n_targets)
+    _lib.check(self._lib.rmb_matvec(self._h, k, int(bool(in_plane)), _ptr(v), _ptr(v2) if v2 is not None else None,
+                                    float(eta), _ptr(out)))
+    return out
+
+  def matvec_device(self, kind, vec, eta, vec2=None, in_plane=False, out=None):
+    """Device path: CUDA float64 torch tensors; asynchronous on the context's stream."""
+    import torch
+    k = _lib.KINDS[kind] if isinstance(kind, str) else int(kind)
+    if not _is_torch_cuda(vec) or vec.numel() != 3 * self.n or not vec.is_contiguous():
+      raise ValueError("vec must be a contiguous CUDA float64 tensor with 3*n entries")
+    if vec2 is not None and (not _is_torch_cuda(vec2) or vec2.numel() != 3 * self.n or not vec2.is_contiguous()):
+      raise ValueError("vec2 must be a contiguous CUDA float64 tensor with 3*n entries")
+    if out is None:
+      out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=vec.device)
+    elif not _is_torch_cuda(out) or out.numel() != 3 * self.n_targets or not out.is_contiguous():
+      raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n_targets entries")
+    _lib.check(self._lib.rmb_matvec_device(self._h, k, int(bool(in_plane)), ctypes.c_void_p(vec.data_ptr()),
+                                           ctypes.c_void_p(vec2.data_ptr()) if vec2 is not None else None,
+                                           float(eta), ctypes.c_void_p(out.data_ptr())))
+    return out
+
+  def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
+    out = np.empty(3 * self.n_targets)
+    _lib.check(self._lib.rmb_blob_blob_force(self._h, float(repulsion_strength), float(debye_length),
+                                             float(blob_radius), _ptr(out)))
+    return out.reshape(self.n_targets, 3)
+
+  def blob_blob_force_device(self, repulsion_strength, debye_length, blob_radius, out=None, device=None):
+    import torch
+    if out is None:
+      out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=device or ("cuda:%d" % self.device))
+    _lib.check(self._lib.rmb_blob_blob_force_device(self._h, float(repulsion_strength), float(debye_length),
+                                                    float(blob_radius), ctypes.c_void_p(out.data_ptr())))
+    return out
+
+  # --- measurement -----------------------------------------------------------------------------
+  def timing_collect(self, max_n=8192):
+    buf = (ctypes.c_double * max_n)()
+    n = self._lib.rmb_timing_collect(self._h, buf, max_n)
+    if n < 0:
+      _lib.check(n)
+    return np.array(buf[:n])
+
+  def timing_reset(self):
+    _lib.check(self._lib.rmb_timing_reset(self._h))
+
+  def last_launch(self):
+    t, c, w = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+    _lib.check(self._lib.rmb_last_launch(self._h, ctypes.byref(t), ctypes.byref(c), ctypes.byref(w)))
+    return dict(tiles=t.value, chunks=c.value, workgroups=w.value)
+
+  def synchronize(self):
+    _lib.check(self._lib.rmb_ctx_synchronize(self._h))
+
+
+def _is_torch_cuda(x):
+  try:
+    import torch
+  except ImportError:
+    return False
+  return isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64

@@ -1,0 +1,313 @@
+// pair_ops.h -- matrix-free pair operators for the blob-level mobility products (gfx950, fp64).
+//
+// WHAT (reference semantics): for a target blob i and a source blob j the reference builds a
+// 3x3 block M_ij in units of the hydrodynamic radius a and multiplies it by the source vector
+//   tt  mobility/mobility_numba.py:199-281   RPY + Swan-Brady wall correction, u = M_tt f
+//   tr  mobility/mobility_numba.py:609-684   u = M_tr tau  (wall part anchored on the TARGET height)
+//   rt  mobility/mobility_numba.py:998-1071  w = M_rt f
+//   rr  mobility/mobility_numba.py:1250-1326 w = M_rr tau
+//
+// HOW (ours): the 3x3 block is never formed.  Every block is a combination of I, d d^T, R R^T,
+// z R^T, R z^T, z z^T and cross products, so M_ij v is evaluated directly as
+//   (scalar) v + (scalar) d + (scalar) R + (scalar) z
+// with d = r_i - r_j and R = (d_x, d_y, z_i + z_j) (the image separation).  Positions stay
+// UNSCALED (differences of the caller's coordinates are exact); every power of `a` is folded
+// into uniform constants (PairConsts, SGPR-resident) and the common prefactor 1/(8 pi eta) is
+// applied once per target in the epilogue.  The wall height ratio h = z/R_z only ever appears
+// multiplied by e_z = R_z/|R|, so g = h e_z = z/|R| and no division by R_z is needed.  The two
+// inverse square roots per pair are v_rsq_f64 + one cubic (Halley) correction step, not the
+// 30-instruction IEEE sqrt+divide sequence.  The near-field (r < 2a, overlapping blobs) RPY
+// branch is taken per wave only when some lane needs it.
+//
+// A pair costs ~90 fp64 VALU instructions for wall-tt (the reference's as-written count is 211).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rmb {
+
+enum Kind : int { KIND_TT = 0, KIND_TR = 1, KIND_RT = 2, KIND_RR = 3, KIND_TT_TR = 4, KIND_COUNT = 5 };
+
+// Uniform constants (host-computed from the blob radius a; see make_pair_consts in rmb_capi.hip).
+struct PairConsts {
+  double a2;       // a^2                (tau = a^2/R^2 in the wall corrections)
+  double four_a2;  // (2a)^2             far/near switch on r^2
+  // tt
+  double tt_k1;    // 2 a^2 / 3
+  double tt_k2;    // 2 a^2
+  double tt_n0;    // 4/(3a)             also the unbounded self term
+  double tt_n1;    // 3/(8 a^2)
+  double tt_n2;    // 1/(8 a^2)
+  // rr
+  double rr_m0;    // 1/a^3              also the unbounded self term
+  double rr_m1;    // 27/(32 a^4)
+  double rr_m2;    // 5/(64 a^6)
+  double rr_m3;    // 9/(32 a^4)
+  double rr_m4;    // 3/(64 a^6)
+  // tr / rt
+  double c_q0;     // 1/(2 a^3)
+  double c_q1;     // 3/(16 a^4)
+};
+
+struct Vec3 { double x, y, z; };
+
+// 1/sqrt(x): hardware seed (v_rsq_f64, ~2^-23 relative) + one third-order correction
+//   y' = y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2      -> relative error O(e^3), i.e. full fp64.
+__device__ __forceinline__ double rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double t = x * y;
+  double e = __builtin_fma(-t, y, 1.0);
+  double p = __builtin_fma(0.375, e, 0.5) * e;
+  return __builtin_fma(y, p, y);
+}
+
+// 1/x: v_rcp_f64 seed + third-order correction (used only outside the pair loop).
+__device__ __forceinline__ double rcp_f64(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  double p = __builtin_fma(e, e, e);
+  return __builtin_fma(y, p, y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tt:  u += [RPY_tt(d) + W_tt(d_x, d_y, R_z; z_j)] f          (common prefactor 1/(8 pi eta))
+// ---------------------------------------------------------------------------------------------
+template <bool WALL>
+__device__ __forceinline__ void pair_tt(const PairConsts& k, double dx, double dy, double dz, double Rz,
+                                        double zj, double fx, double fy, double fz, Vec3& u) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double ir = rsqrt_f64(r2);
+  const double ir2 = ir * ir;
+  const double pxy = __builtin_fma(dy, fy, dx * fx);
+  const double df = __builtin_fma(dz, fz, pxy);
+  // far field: (1/r) [ (1 + 2a^2/(3r^2)) I + (1 - 2a^2/r^2) d d^T / r^2 ]
+  double cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
+  double cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
+  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
+    // overlapping blobs: (4/(3a) - 3r/(8a^2)) I + d d^T/(8 a^2 r)
+    const double r = r2 * ir;
+    const bool near = r2 <= k.four_a2;
+    cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : cF;
+    cD = near ? k.tt_n2 * ir : cD;
+  }
+  cD *= df;
+  if constexpr (!WALL) {
+    u.x = __builtin_fma(cF, fx, u.x); u.x = __builtin_fma(cD, dx, u.x);
+    u.y = __builtin_fma(cF, fy, u.y); u.y = __builtin_fma(cD, dy, u.y);
+    u.z = __builtin_fma(cF, fz, u.z); u.z = __builtin_fma(cD, dz, u.z);
+  } else {
+    const double R2 = __builtin_fma(Rz, Rz, rho2);
+    const double iR = rsqrt_f64(R2);
+    const double iR2 = iR * iR;
+    const double tau = k.a2 * iR2;
+    const double ez = Rz * iR;
+    const double g = zj * iR;        // h e_z
+    const double uu = ez * ez;
+    const double dd = ez - g;
+    const double w = g * dd;         // h (1-h) e_z^2
+    const double q6 = ez * dd;       // (1-h) e_z^2
+    const double G1 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(10.0 / 3.0, uu, -2.0 / 3.0), __builtin_fma(-2.0, uu, 2.0 / 3.0)), __builtin_fma(2.0, w, 1.0));
+    const double G2 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-70.0 / 3.0, uu, 10.0 / 3.0), __builtin_fma(10.0, uu, -2.0)), __builtin_fma(-6.0, w, 1.0));
+    const double g2 = g + g;
+    const double G3 = __builtin_fma(ez * tau, __builtin_fma(tau, __builtin_fma(-140.0 / 3.0, uu, 40.0 / 3.0), __builtin_fma(20.0, uu, -4.0)), g2 * __builtin_fma(-6.0, q6, 1.0));
+    const double G4 = __builtin_fma(-20.0 / 3.0 * ez, tau * tau, g2);
+    const double G5 = -__builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-20.0, uu, 8.0 / 3.0), 4.0 * uu), g2 * g2);
+    const double Rf = __builtin_fma(Rz, fz, pxy);
+    const double E = iR * Rf;
+    const double cR = __builtin_fma(G3, fz, -G2 * E) * iR2;
+    const double cb = __builtin_fma(G5, fz, G4 * E) * iR;
+    cF = __builtin_fma(-G1, iR, cF);
+    const double cDR = cD + cR;
+    u.x = __builtin_fma(cF, fx, u.x); u.x = __builtin_fma(cDR, dx, u.x);
+    u.y = __builtin_fma(cF, fy, u.y); u.y = __builtin_fma(cDR, dy, u.y);
+    u.z = __builtin_fma(cF, fz, u.z); u.z = __builtin_fma(cD, dz, u.z);
+    u.z = __builtin_fma(cR, Rz, u.z); u.z += cb;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RPY coupling (tr and rt share it): c(r) (v x d),  c = 1/r^3 (far) or 1/(2a^3) - 3r/(16a^4)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double coupling_coeff(const PairConsts& k, double r2) {
+  const double ir = rsqrt_f64(r2);
+  double c = ir * ir * ir;
+  if (__builtin_expect(__any(r2 < k.four_a2), 0)) {
+    const double r = r2 * ir;
+    c = (r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : c;
+  }
+  return c;
+}
+
+// Wall factors shared by tr and rt; `zh` is the anchoring height (source for rt, target for tr).
+struct CouplingWall { double iR, f1, p, s, f3, ez; };
+
+__device__ __forceinline__ CouplingWall coupling_wall(const PairConsts& k, double rho2, double Rz, double zh) {
+  CouplingWall c;
+  const double R2 = __builtin_fma(Rz, Rz, rho2);
+  c.iR = rsqrt_f64(R2);
+  const double iR2 = c.iR * c.iR;
+  const double tau = k.a2 * iR2;
+  c.ez = Rz * c.iR;
+  const double g = zh * c.iR;
+  const double uu = c.ez * c.ez;
+  const double eztau = c.ez * tau;
+  c.f1 = iR2;
+  c.p = iR2 * (__builtin_fma(2.0, eztau - g, c.ez));                                    // ez - 2g + 2 ez tau
+  c.s = iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, __builtin_fma(12.0 * g, c.ez, 1.0));
+  c.f3 = -2.0 * iR2 * __builtin_fma(-5.0, eztau, 3.0 * g);
+  return c;
+}
+
+// rt:  w += [RPY_c(d) + W_rt] f      (wall anchored on SOURCE height z_j)
+template <bool WALL>
+__device__ __forceinline__ void pair_rt(const PairConsts& k, double dx, double dy, double dz, double Rz,
+                                        double zj, double vx, double vy, double vz, Vec3& u) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double c = coupling_coeff(k, r2);
+  double ax = __builtin_fma(vy, dz, -vz * dy) * c;
+  double ay = __builtin_fma(vz, dx, -vx * dz) * c;
+  double az = __builtin_fma(vx, dy, -vy * dx) * c;
+  if constexpr (WALL) {
+    const CouplingWall W = coupling_wall(k, rho2, Rz, zj);
+    const double ex = dx * W.iR, ey = dy * W.iR;
+    const double E = __builtin_fma(W.ez, vz, __builtin_fma(ey, vy, ex * vx));
+    const double kap = __builtin_fma(W.f3, E, W.s * vz);
+    ax += __builtin_fma(kap, ey, -W.p * vy);
+    ay += __builtin_fma(-kap, ex, W.p * vx);
+    az += W.f1 * __builtin_fma(ex, vy, -ey * vx);
+  }
+  u.x += ax; u.y += ay; u.z += az;
+}
+
+// tr:  u += [RPY_c(d) + W_tr] tau     (wall anchored on TARGET height z_i; reference negates rx, ry)
+template <bool WALL>
+__device__ __forceinline__ void pair_tr(const PairConsts& k, double dx, double dy, double dz, double Rz,
+                                        double zi, double vx, double vy, double vz, Vec3& u) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double c = coupling_coeff(k, r2);
+  double ax = __builtin_fma(vy, dz, -vz * dy) * c;
+  double ay = __builtin_fma(vz, dx, -vx * dz) * c;
+  double az = __builtin_fma(vx, dy, -vy * dx) * c;
+  if constexpr (WALL) {
+    const CouplingWall W = coupling_wall(k, rho2, Rz, zi);
+    const double ex = dx * W.iR, ey = dy * W.iR;
+    const double c0 = __builtin_fma(ex, vy, -ey * vx);
+    const double f3c0 = W.f3 * c0;
+    ax += __builtin_fma(W.f1 * ey, vz, __builtin_fma(W.p, vy, -f3c0 * ex));
+    ay -= __builtin_fma(W.f1 * ex, vz, __builtin_fma(W.p, vx, f3c0 * ey));
+    az += __builtin_fma(W.f3, W.ez, W.s) * c0;
+  }
+  u.x += ax; u.y += ay; u.z += az;
+}
+
+// rr:  w += [RPY_rr(d) + W_rr] tau
+template <bool WALL>
+__device__ __forceinline__ void pair_rr(const PairConsts& k, double dx, double dy, double dz, double Rz,
+                                        double vx, double vy, double vz, Vec3& u) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double ir = rsqrt_f64(r2);
+  const double ir2 = ir * ir;
+  const double ir3 = ir2 * ir;
+  const double pxy = __builtin_fma(dy, vy, dx * vx);
+  const double dv = __builtin_fma(dz, vz, pxy);
+  double cF = -0.5 * ir3;
+  double cD = 1.5 * ir3 * ir2;
+  if (__builtin_expect(__any(r2 < k.four_a2), 0)) {
+    const double r = r2 * ir;
+    const double r3 = r2 * r;
+    const bool near = r2 < k.four_a2;
+    cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : cF;
+    cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * ir) : cD;
+  }
+  cD *= dv;
+  if constexpr (!WALL) {
+    u.x = __builtin_fma(cF, vx, u.x); u.x = __builtin_fma(cD, dx, u.x);
+    u.y = __builtin_fma(cF, vy, u.y); u.y = __builtin_fma(cD, dy, u.y);
+    u.z = __builtin_fma(cF, vz, u.z); u.z = __builtin_fma(cD, dz, u.z);
+  } else {
+    const double R2 = __builtin_fma(Rz, Rz, rho2);
+    const double iR = rsqrt_f64(R2);
+    const double iR2 = iR * iR;
+    const double iR3 = iR2 * iR;
+    const double uu = Rz * Rz * iR2;
+    const double Rv = __builtin_fma(Rz, vz, pxy);
+    // x,y: iR3 { (3.5 - 6u) v - (1.5 E + 3 E_par) e },  z: iR3 { (0.5 - 3u) v_z + 1.5 E e_z },  e = R iR
+    const double iR5 = iR3 * iR2;
+    const double cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, cF);
+    const double cFz = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, cF);
+    const double cRxy = -iR5 * __builtin_fma(1.5, Rv, 3.0 * pxy);
+    const double cRz = 1.5 * iR5 * Rv;
+    const double cDR = cD + cRxy;
+    u.x = __builtin_fma(cFxy, vx, u.x); u.x = __builtin_fma(cDR, dx, u.x);
+    u.y = __builtin_fma(cFxy, vy, u.y); u.y = __builtin_fma(cDR, dy, u.y);
+    u.z = __builtin_fma(cFz, vz, u.z); u.z = __builtin_fma(cD, dz, u.z);
+    u.z = __builtin_fma(cRz, Rz, u.z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self terms (i == j, central box), added once per target in the epilogue.
+//   tt: mobility_numba.py:203-208,:245-252   rr: :1254-1259,:1295-1300
+//   tr: :653-657                             rt: :1040-1044
+// ---------------------------------------------------------------------------------------------
+template <int KIND, bool WALL>
+__device__ __forceinline__ void self_term(const PairConsts& k, double zi, double vx, double vy, double vz,
+                                          double wx, double wy, double wz, Vec3& u) {
+  (void)wx; (void)wy; (void)wz; (void)vz;
+  if constexpr (KIND == KIND_TT || KIND == KIND_TT_TR) {
+    double sxx = k.tt_n0, szz = k.tt_n0;
+    if constexpr (WALL) {
+      const double iz = 1.0 / zi, iz2 = iz * iz, iz3 = iz2 * iz, iz5 = iz3 * iz2;
+      const double a4 = k.a2 * k.a2;
+      sxx -= (9.0 * iz - 2.0 * k.a2 * iz3 + a4 * iz5) / 12.0;
+      szz -= (9.0 * iz - 4.0 * k.a2 * iz3 + a4 * iz5) / 6.0;
+    }
+    u.x = __builtin_fma(sxx, vx, u.x); u.y = __builtin_fma(sxx, vy, u.y); u.z = __builtin_fma(szz, vz, u.z);
+  }
+  if constexpr (KIND == KIND_RR) {
+    double sxx = k.rr_m0, szz = k.rr_m0;
+    if constexpr (WALL) {
+      const double iz = 1.0 / zi, iz3 = iz * iz * iz;
+      sxx -= 0.3125 * iz3;
+      szz -= 0.125 * iz3;
+    }
+    u.x = __builtin_fma(sxx, vx, u.x); u.y = __builtin_fma(sxx, vy, u.y); u.z = __builtin_fma(szz, vz, u.z);
+  }
+  if constexpr (WALL && KIND == KIND_TR) {
+    const double iz = 1.0 / zi, iz2 = iz * iz;
+    const double c = 0.125 * k.a2 * iz2 * iz2;
+    u.x = __builtin_fma(c, vy, u.x); u.y = __builtin_fma(-c, vx, u.y);
+  }
+  if constexpr (WALL && KIND == KIND_TT_TR) {
+    const double iz = 1.0 / zi, iz2 = iz * iz;
+    const double c = 0.125 * k.a2 * iz2 * iz2;
+    u.x = __builtin_fma(c, wy, u.x); u.y = __builtin_fma(-c, wx, u.y);
+  }
+  if constexpr (WALL && KIND == KIND_RT) {
+    const double iz = 1.0 / zi, iz2 = iz * iz;
+    const double c = 0.125 * k.a2 * iz2 * iz2;
+    u.x = __builtin_fma(-c, vy, u.x); u.y = __builtin_fma(c, vx, u.y);
+  }
+}
+
+// One pair of kind KIND.  (vx,vy,vz) is the source vector; (wx,wy,wz) the source torque for the
+// fused tt+tr kind (mobility/mobility_pycuda.py:1351-1375 evaluates both blocks in one pass).
+template <int KIND, bool WALL>
+__device__ __forceinline__ void pair_apply(const PairConsts& k, double dx, double dy, double dz, double zi,
+                                           double zj, double vx, double vy, double vz, double wx, double wy,
+                                           double wz, Vec3& u) {
+  const double Rz = zi + zj;
+  if constexpr (KIND == KIND_TT) pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+  if constexpr (KIND == KIND_TR) pair_tr<WALL>(k, dx, dy, dz, Rz, zi, vx, vy, vz, u);
+  if constexpr (KIND == KIND_RT) pair_rt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+  if constexpr (KIND == KIND_RR) pair_rr<WALL>(k, dx, dy, dz, Rz, vx, vy, vz, u);
+  if constexpr (KIND == KIND_TT_TR) {
+    pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+    pair_tr<WALL>(k, dx, dy, dz, Rz, zi, wx, wy, wz, u);
+  }
+}
+
+}  // namespace rmb

@@ -1,0 +1,506 @@
+// rmb_capi.hip -- C ABI (include/rmb_mobility.h) over the gfx950 sweep kernels.
+// Host side: context with resident packed positions, workspace, launch geometry, HIP-event timing.
+#include "../../include/rmb_mobility.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "matvec_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define RMB_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(RMB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return fail(RMB_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kTimingRing = 8192;
+
+}  // namespace
+
+struct rmb_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // resident configuration
+  long n = 0;
+  double a = 0.0;
+  double L[3] = {0, 0, 0};
+  int wall = 0;
+  bool have_positions = false;
+  long tgt_begin = 0, tgt_end = 0;
+  // device memory
+  DevBuf pos;      // double4[n]
+  DevBuf r_stage;  // raw positions staging (host entry)
+  DevBuf vec, vec2, out, partial;
+  // options
+  long opt_chunks = 0;
+  long opt_timing = 0;
+  // timing ring (events around the sweep kernel)
+  std::vector<hipEvent_t> ev0, ev1;
+  int ev_count = 0;  // events recorded since last reset (capped at ring size)
+  // last launch
+  long last_tiles = 0, last_chunks = 0, last_wgs = 0;
+};
+
+namespace {
+
+rmb::PairConsts make_pair_consts(double a) {
+  rmb::PairConsts k;
+  const double a2 = a * a, a3 = a2 * a, a4 = a2 * a2, a6 = a3 * a3;
+  k.a2 = a2;
+  k.four_a2 = 4.0 * a2;
+  k.tt_k1 = 2.0 * a2 / 3.0;
+  k.tt_k2 = 2.0 * a2;
+  k.tt_n0 = 4.0 / (3.0 * a);
+  k.tt_n1 = 3.0 / (8.0 * a2);
+  k.tt_n2 = 1.0 / (8.0 * a2);
+  k.rr_m0 = 1.0 / a3;
+  k.rr_m1 = 27.0 / (32.0 * a4);
+  k.rr_m2 = 5.0 / (64.0 * a6);
+  k.rr_m3 = 9.0 / (32.0 * a4);
+  k.rr_m4 = 3.0 / (64.0 * a6);
+  k.c_q0 = 1.0 / (2.0 * a3);
+  k.c_q1 = 3.0 / (16.0 * a4);
+  return k;
+}
+
+// Source-chunk count: enough workgroups (4 waves each, one per SIMD) to fill 256 CUs several
+// times over with little tail imbalance, without making chunks shorter than one LDS tile.
+void choose_chunks(long n_tgt, long n_src, long forced, long* n_chunks, long* chunk_len) {
+  const long tiles = (n_tgt + 63) / 64;
+  const long max_chunks = (n_src + rmb::kTile - 1) / rmb::kTile;
+  long c = 1;
+  if (forced > 0) {
+    c = forced;
+  } else if (tiles < 4096) {
+    // candidates: smallest c with >= 2048 workgroups, then look a little further for a count
+    // that is close to a multiple of 256 CUs x 4 resident workgroups
+    const long want = 2048;
+    long c_min = (want + tiles - 1) / tiles;
+    if (c_min < 1) c_min = 1;
+    double best = 1e30;
+    c = c_min;
+    for (long cand = c_min; cand <= c_min + 8; ++cand) {
+      const double wg = (double)(tiles * cand);
+      const double rounds = std::ceil(wg / 1024.0);
+      const double waste = rounds * 1024.0 / wg;  // >= 1
+      const double cost = waste + 0.01 * (double)(cand - c_min);
+      if (cost < best) { best = cost; c = cand; }
+    }
+  }
+  if (c > max_chunks) c = max_chunks;
+  if (c < 1) c = 1;
+  long len = (n_src + c - 1) / c;
+  len = ((len + rmb::kTile - 1) / rmb::kTile) * rmb::kTile;  // whole tiles per chunk
+  c = (n_src + len - 1) / len;
+  *n_chunks = c;
+  *chunk_len = len;
+}
+
+template <int KIND>
+int launch_sweep(rmb_ctx* c, const rmb::SweepArgs& a, dim3 grid, bool periodic) {
+  const dim3 block(rmb::kBlock);
+  if (c->wall) {
+    if (periodic) hipLaunchKernelGGL((rmb::sweep_kernel<KIND, true, true>), grid, block, 0, c->stream, a);
+    else          hipLaunchKernelGGL((rmb::sweep_kernel<KIND, true, false>), grid, block, 0, c->stream, a);
+  } else {
+    if (periodic) hipLaunchKernelGGL((rmb::sweep_kernel<KIND, false, true>), grid, block, 0, c->stream, a);
+    else          hipLaunchKernelGGL((rmb::sweep_kernel<KIND, false, false>), grid, block, 0, c->stream, a);
+  }
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int KIND>
+int launch_finalize(rmb_ctx* c, const rmb::SweepArgs& a, long n_tgt) {
+  const dim3 grid((unsigned)((n_tgt + 255) / 256)), block(256);
+  if (c->wall) hipLaunchKernelGGL((rmb::finalize_kernel<KIND, true>), grid, block, 0, c->stream, a);
+  else         hipLaunchKernelGGL((rmb::finalize_kernel<KIND, false>), grid, block, 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+int timing_begin(rmb_ctx* c, int* slot) {
+  *slot = -1;
+  if (!c->opt_timing) return 0;
+  if (c->ev0.empty()) {
+    c->ev0.resize(kTimingRing);
+    c->ev1.resize(kTimingRing);
+    for (int i = 0; i < kTimingRing; ++i) {
+      RMB_HIP(hipEventCreate(&c->ev0[i]));
+      RMB_HIP(hipEventCreate(&c->ev1[i]));
+    }
+  }
+  *slot = c->ev_count % kTimingRing;
+  RMB_HIP(hipEventRecord(c->ev0[*slot], c->stream));
+  return 0;
+}
+
+int timing_end(rmb_ctx* c, int slot) {
+  if (slot < 0) return 0;
+  RMB_HIP(hipEventRecord(c->ev1[slot], c->stream));
+  c->ev_count++;
+  return 0;
+}
+
+int check_ready(rmb_ctx* c) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (!c->have_positions) return fail(RMB_ERR_STATE, "rmb_set_positions has not been called");
+  return 0;
+}
+
+int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta,
+                       double* out) {
+  if (int rc = check_ready(c)) return rc;
+  if (kind < 0 || kind >= rmb::KIND_COUNT) return fail(RMB_ERR_ARG, "kind must be 0..4");
+  const long n_tgt = c->tgt_end - c->tgt_begin;
+  if (n_tgt == 0) return 0;
+  if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  if (kind == rmb::KIND_TT_TR && !v2) return fail(RMB_ERR_ARG, "RMB_TT_TR needs vec2 (torque)");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+
+  long n_chunks, chunk_len;
+  choose_chunks(n_tgt, c->n, c->opt_chunks, &n_chunks, &chunk_len);
+  const long tiles = (n_tgt + 63) / 64;
+  if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");
+
+  rmb::SweepArgs a;
+  a.pos = (const double4*)c->pos.p;
+  a.vec = v;
+  a.vec2 = v2;
+  a.out = out;
+  a.partial = nullptr;
+  a.n_src = c->n;
+  a.tgt_begin = c->tgt_begin;
+  a.tgt_end = c->tgt_end;
+  a.n_tgt_pad = 64 * tiles;
+  a.chunk_len = chunk_len;
+  a.n_chunks = (int)n_chunks;
+  a.in_plane = in_plane ? 1 : 0;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+  a.k = make_pair_consts(c->a);
+  if (n_chunks > 1) {
+    if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
+    a.partial = (double*)c->partial.p;
+  }
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  const dim3 grid((unsigned)tiles, (unsigned)n_chunks);
+  c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
+
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  int rc = 0;
+  switch (kind) {
+    case rmb::KIND_TT: rc = launch_sweep<rmb::KIND_TT>(c, a, grid, periodic); break;
+    case rmb::KIND_TR: rc = launch_sweep<rmb::KIND_TR>(c, a, grid, periodic); break;
+    case rmb::KIND_RT: rc = launch_sweep<rmb::KIND_RT>(c, a, grid, periodic); break;
+    case rmb::KIND_RR: rc = launch_sweep<rmb::KIND_RR>(c, a, grid, periodic); break;
+    default:           rc = launch_sweep<rmb::KIND_TT_TR>(c, a, grid, periodic); break;
+  }
+  if (rc) return rc;
+  if (int rc2 = timing_end(c, slot)) return rc2;
+  if (n_chunks > 1) {
+    switch (kind) {
+      case rmb::KIND_TT: rc = launch_finalize<rmb::KIND_TT>(c, a, n_tgt); break;
+      case rmb::KIND_TR: rc = launch_finalize<rmb::KIND_TR>(c, a, n_tgt); break;
+      case rmb::KIND_RT: rc = launch_finalize<rmb::KIND_RT>(c, a, n_tgt); break;
+      case rmb::KIND_RR: rc = launch_finalize<rmb::KIND_RR>(c, a, n_tgt); break;
+      default:           rc = launch_finalize<rmb::KIND_TT_TR>(c, a, n_tgt); break;
+    }
+  }
+  return rc;
+}
+
+int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
+  if (int rc = check_ready(c)) return rc;
+  const long n_tgt = c->tgt_end - c->tgt_begin;
+  if (n_tgt == 0) return 0;
+  if (!out) return fail(RMB_ERR_ARG, "null output pointer");
+  if (!(b > 0.0)) return fail(RMB_ERR_ARG, "debye_length must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  long n_chunks, chunk_len;
+  choose_chunks(n_tgt, c->n, c->opt_chunks, &n_chunks, &chunk_len);
+  const long tiles = (n_tgt + 63) / 64;
+  if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");
+  rmb::ForceArgs a;
+  a.pos = (const double4*)c->pos.p;
+  a.out = out;
+  a.partial = nullptr;
+  a.n_src = c->n;
+  a.tgt_begin = c->tgt_begin; a.tgt_end = c->tgt_end;
+  a.n_tgt_pad = 64 * tiles;
+  a.chunk_len = chunk_len;
+  a.n_chunks = (int)n_chunks;
+  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+  a.eps_over_b = eps / b;
+  a.inv_b = 1.0 / b;
+  a.two_a = 2.0 * blob_radius;
+  if (n_chunks > 1) {
+    if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
+    a.partial = (double*)c->partial.p;
+  }
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  const dim3 grid((unsigned)tiles, (unsigned)n_chunks), block(rmb::kBlock);
+  c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  if (periodic) hipLaunchKernelGGL((rmb::force_sweep_kernel<true>), grid, block, 0, c->stream, a);
+  else          hipLaunchKernelGGL((rmb::force_sweep_kernel<false>), grid, block, 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
+  if (n_chunks > 1) {
+    hipLaunchKernelGGL(rmb::force_finalize_kernel, dim3((unsigned)((n_tgt + 255) / 256)), dim3(256), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int set_positions_impl(rmb_ctx* c, const double* r_dev, long n, double a, const double* L, int wall) {
+  if (int rc = c->pos.reserve((size_t)(n > 0 ? n : 1) * sizeof(double4))) return rc;
+  if (n > 0) {
+    hipLaunchKernelGGL(rmb::pack_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, r_dev, n,
+                       a, wall ? 1 : 0, (double4*)c->pos.p);
+    RMB_HIP(hipGetLastError());
+  }
+  c->n = n;
+  c->a = a;
+  for (int k = 0; k < 3; ++k) c->L[k] = L ? L[k] : 0.0;
+  c->wall = wall ? 1 : 0;
+  c->tgt_begin = 0;
+  c->tgt_end = n;
+  c->have_positions = true;
+  return 0;
+}
+
+std::mutex g_default_mu;
+rmb_ctx* g_default_ctx = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+const char* rmb_version(void) { return "rmb_mobility 0.1 (gfx950)"; }
+const char* rmb_last_error(void) { return g_err.c_str(); }
+
+int rmb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rmb_ctx_create(int device, rmb_ctx** out) {
+  if (!out) return fail(RMB_ERR_ARG, "null ctx out pointer");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(RMB_ERR_NO_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + ")");
+  if (device < 0 || device >= n) return fail(RMB_ERR_ARG, "device index out of range");
+  RMB_HIP(hipSetDevice(device));
+  rmb_ctx* c = new rmb_ctx();
+  c->device = device;
+  *out = c;
+  return 0;
+}
+
+int rmb_ctx_destroy(rmb_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
+  for (auto e : c->ev0) (void)hipEventDestroy(e);
+  for (auto e : c->ev1) (void)hipEventDestroy(e);
+  delete c;
+  return 0;
+}
+
+int rmb_ctx_set_stream(rmb_ctx* c, void* s) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  c->stream = (hipStream_t)s;
+  return 0;
+}
+
+int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
+  if (!c || !key) return fail(RMB_ERR_ARG, "null context / key");
+  if (!strcmp(key, "chunks")) { c->opt_chunks = value; return 0; }
+  if (!strcmp(key, "timing")) { c->opt_timing = value; return 0; }
+  return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
+}
+
+int rmb_set_positions(rmb_ctx* c, const double* r, long n, double a, const double* L, int wall) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n < 0) return fail(RMB_ERR_ARG, "negative n");
+  if (n > 0 && !r) return fail(RMB_ERR_ARG, "null positions");
+  if (!(a > 0.0)) return fail(RMB_ERR_ARG, "blob radius must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  if (n > 0) {
+    if (int rc = c->r_stage.reserve((size_t)3 * n * sizeof(double))) return rc;
+    RMB_HIP(hipMemcpyAsync(c->r_stage.p, r, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  if (int rc = set_positions_impl(c, (const double*)c->r_stage.p, n, a, L, wall)) return rc;
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rmb_set_positions_device(rmb_ctx* c, const double* r_dev, long n, double a, const double* L, int wall) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n < 0) return fail(RMB_ERR_ARG, "negative n");
+  if (n > 0 && !r_dev) return fail(RMB_ERR_ARG, "null positions");
+  if (!(a > 0.0)) return fail(RMB_ERR_ARG, "blob radius must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  return set_positions_impl(c, r_dev, n, a, L, wall);
+}
+
+int rmb_set_target_range(rmb_ctx* c, long begin, long end) {
+  if (int rc = check_ready(c)) return rc;
+  if (begin < 0 || end < begin || end > c->n) return fail(RMB_ERR_STATE, "target range must satisfy 0 <= begin <= end <= n");
+  c->tgt_begin = begin;
+  c->tgt_end = end;
+  return 0;
+}
+
+int rmb_matvec_device(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out) {
+  return matvec_device_impl(c, kind, in_plane, v, v2, eta, out);
+}
+
+int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out) {
+  if (int rc = check_ready(c)) return rc;
+  const long n = c->n, n_tgt = c->tgt_end - c->tgt_begin;
+  if (n_tgt == 0) return 0;
+  if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  if (kind == rmb::KIND_TT_TR && !v2) return fail(RMB_ERR_ARG, "RMB_TT_TR needs vec2 (torque)");
+  RMB_HIP(hipSetDevice(c->device));
+  const size_t vb = (size_t)3 * n * sizeof(double), ob = (size_t)3 * n_tgt * sizeof(double);
+  if (int rc = c->vec.reserve(vb)) return rc;
+  if (int rc = c->out.reserve(ob)) return rc;
+  RMB_HIP(hipMemcpyAsync(c->vec.p, v, vb, hipMemcpyHostToDevice, c->stream));
+  const double* v2d = nullptr;
+  if (kind == rmb::KIND_TT_TR) {
+    if (int rc = c->vec2.reserve(vb)) return rc;
+    RMB_HIP(hipMemcpyAsync(c->vec2.p, v2, vb, hipMemcpyHostToDevice, c->stream));
+    v2d = (const double*)c->vec2.p;
+  }
+  if (int rc = matvec_device_impl(c, kind, in_plane, (const double*)c->vec.p, v2d, eta, (double*)c->out.p)) return rc;
+  RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rmb_blob_blob_force_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
+  return force_device_impl(c, eps, b, blob_radius, out);
+}
+
+int rmb_blob_blob_force(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
+  if (int rc = check_ready(c)) return rc;
+  const long n_tgt = c->tgt_end - c->tgt_begin;
+  if (n_tgt == 0) return 0;
+  if (!out) return fail(RMB_ERR_ARG, "null output pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  const size_t ob = (size_t)3 * n_tgt * sizeof(double);
+  if (int rc = c->out.reserve(ob)) return rc;
+  if (int rc = force_device_impl(c, eps, b, blob_radius, (double*)c->out.p)) return rc;
+  RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rmb_timing_collect(rmb_ctx* c, double* ms, int max_n) {
+  if (!c || !ms || max_n < 0) return fail(RMB_ERR_ARG, "bad timing_collect arguments");
+  if (hipSetDevice(c->device) != hipSuccess) return fail(RMB_ERR_HIP, "hipSetDevice failed");
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(RMB_ERR_HIP, "hipStreamSynchronize failed");
+  int have = c->ev_count < kTimingRing ? c->ev_count : kTimingRing;
+  if (have > max_n) have = max_n;
+  // most recent `have` entries, oldest first
+  for (int i = 0; i < have; ++i) {
+    const int idx = (c->ev_count - have + i) % kTimingRing;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, c->ev0[idx], c->ev1[idx]) != hipSuccess) return fail(RMB_ERR_HIP, "hipEventElapsedTime failed");
+    ms[i] = (double)t;
+  }
+  return have;
+}
+
+int rmb_timing_reset(rmb_ctx* c) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  c->ev_count = 0;
+  return 0;
+}
+
+int rmb_last_launch(rmb_ctx* c, long* tiles, long* chunks, long* wgs) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (tiles) *tiles = c->last_tiles;
+  if (chunks) *chunks = c->last_chunks;
+  if (wgs) *wgs = c->last_wgs;
+  return 0;
+}
+
+int rmb_ctx_synchronize(rmb_ctx* c) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  RMB_HIP(hipSetDevice(c->device));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int default_ctx(rmb_ctx** out) {
+  if (!g_default_ctx) {
+    if (int rc = rmb_ctx_create(0, &g_default_ctx)) return rc;
+  }
+  *out = g_default_ctx;
+  return 0;
+}
+
+int rmb_mobility_oneshot(int kind, int wall, int in_plane, long n, const double* r, const double* vec,
+                         const double* vec2, double eta, double a, const double* L, double* out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  rmb_ctx* c;
+  if (int rc = default_ctx(&c)) return rc;
+  if (int rc = rmb_set_positions(c, r, n, a, L, wall)) return rc;
+  return rmb_matvec(c, kind, in_plane, vec, vec2, eta, out);
+}
+
+int rmb_forces_oneshot(long n, const double* r, const double* L, double eps, double b, double blob_radius, double* out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  rmb_ctx* c;
+  if (int rc = default_ctx(&c)) return rc;
+  if (int rc = rmb_set_positions(c, r, n, blob_radius, L, 0)) return rc;
+  return rmb_blob_blob_force(c, eps, b, blob_radius, out);
+}
+
+}  // extern "C"

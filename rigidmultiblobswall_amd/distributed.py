@@ -1,0 +1,135 @@
+"""Target-sharded blob mobility over several GPUs (one process per GPU, torch.distributed).
+
+The reference is single-device; this layer has no counterpart there.  Its
+contract is "equal to the 1-GPU result to rounding".
+
+Sharding: blob index range [0, N) is cut into G contiguous blocks of ceil(N/G); rank g OWNS
+block g: it holds r_local, v_local and produces u_local for those targets.  Every rank needs all
+N sources, so there is exactly one exchange step per product:
+  * positions: all-gather once per configuration (set_positions), then packed on the device;
+  * source vector: all-gather (24 N bytes in total) before each matvec  -- RCCL over xGMI when the
+    process group's backend is "nccl";
+  * output: none (each rank keeps the targets it owns).
+The pair sweep on each rank is the same kernel as single-GPU, restricted to its target range
+(rmb_set_target_range), so per-target summation order does not depend on G beyond the source
+chunking.
+
+The compute backend is injected (`backend=`): the product default is the HIP context
+(`HipBackend`); the CPU test-suite injects an oracle-backed one to exercise partitioning and
+collectives under gloo.  There is no implicit CPU fallback.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .context import MobilityContext
+
+
+def partition(n, world_size, rank):
+  """Contiguous block partition: (begin, end, block) with block = ceil(n / world_size)."""
+  block = (n + world_size - 1) // world_size if world_size > 0 else n
+  begin = min(rank * block, n)
+  end = min((rank + 1) * block, n)
+  return begin, end, block
+
+
+class HipBackend(object):
+  """Per-rank compute on one MI355X through the C ABI; enqueues on torch's current stream."""
+
+  def __init__(self, device):
+    self.device = torch.device(device)
+    idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+    self.ctx = MobilityContext(idx)
+    self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+  def set_positions(self, r_full, a, L, wall):
+    self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+    self.ctx.set_positions(r_full, a, L, wall)
+
+  def set_target_range(self, begin, end):
+    self.ctx.set_target_range(begin, end)
+
+  def matvec(self, kind, v_full, eta, vec2_full=None, in_plane=False, out=None):
+    return self.ctx.matvec_device(kind, v_full, eta, vec2=vec2_full, in_plane=in_plane, out=out)
+
+  def blob_blob_force(self, eps, b, a, out=None):
+    return self.ctx.blob_blob_force_device(eps, b, a, out=out, device=self.device)
+
+
+class ShardedMobility(object):
+  """M.v with targets sharded over the ranks of a process group."""
+
+  def __init__(self, backend, group=None, device=None):
+    self.backend = backend
+    self.group = group
+    self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.device = torch.device(device) if device is not None else torch.device("cpu")
+    self.n = 0
+    self.begin = self.end = self.block = 0
+    self._gather_buf = None
+    self._gather_buf2 = None
+
+  # -- helpers ----------------------------------------------------------------------------------
+  def _all_gather_blocks(self, local_flat, buf):
+    """local_flat: (3*n_local,) -> view (3*n,) of the gathered, block-padded buffer."""
+    width = 3 * self.block
+    if self.world == 1:  # nothing to exchange: the local block IS the full vector
+      return local_flat, buf
+    if buf is None or buf.numel() != width * self.world:
+      buf = torch.empty(width * self.world, dtype=torch.float64, device=self.device)
+    send = local_flat
+    if local_flat.numel() != width:  # last (short or empty) block: pad so every rank sends `width`
+      send = torch.zeros(width, dtype=torch.float64, device=self.device)
+      send[:local_flat.numel()].copy_(local_flat)
+    dist.all_gather_into_tensor(buf, send.contiguous(), group=self.group)
+    # all blocks but the last are full, so the first 3n entries are the blobs in global order
+    return buf[:3 * self.n], buf
+
+  def _to_dev(self, x):
+    if isinstance(x, torch.Tensor):
+      return x.to(device=self.device, dtype=torch.float64).contiguous().view(-1)
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64).reshape(-1), device=self.device)
+
+  # -- API --------------------------------------------------------------------------------------
+  def set_local_positions(self, r_local, n_total, a, periodic_length=None, wall=True):
+    """Each rank passes the positions of the blobs it owns (partition(n_total, world, rank))."""
+    self.n = int(n_total)
+    self.begin, self.end, self.block = partition(self.n, self.world, self.rank)
+    r_local = self._to_dev(r_local)
+    if r_local.numel() != 3 * (self.end - self.begin):
+      raise ValueError("rank %d owns blobs [%d,%d) but got %d coordinates" %
+                       (self.rank, self.begin, self.end, r_local.numel()))
+    r_full, _ = self._all_gather_blocks(r_local, None)
+    L = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
+    self.backend.set_positions(r_full.clone(), a, L, wall)
+    self.backend.set_target_range(self.begin, self.end)
+
+  def set_positions(self, r_full, a, periodic_length=None, wall=True):
+    """Convenience: every rank passes the full (N,3) array; it keeps only its own block."""
+    r = self._to_dev(r_full)
+    n = r.numel() // 3
+    b, e, _ = partition(n, self.world, self.rank)
+    self.set_local_positions(r[3 * b:3 * e], n, a, periodic_length, wall)
+
+  def matvec_local(self, kind, v_local, eta, vec2_local=None, in_plane=False, out=None):
+    """v_local: this rank's block of the source vector -> this rank's block of M.v (device tensor)."""
+    v_local = self._to_dev(v_local)
+    v_full, self._gather_buf = self._all_gather_blocks(v_local, self._gather_buf)
+    v2_full = None
+    if vec2_local is not None:
+      v2_full, self._gather_buf2 = self._all_gather_blocks(self._to_dev(vec2_local), self._gather_buf2)
+    return self.backend.matvec(kind, v_full, eta, vec2_full=v2_full, in_plane=in_plane, out=out)
+
+  def matvec(self, kind, v_full, eta, vec2_full=None, in_plane=False):
+    """Full-vector convenience (every rank passes and receives all 3N entries): shards the input,
+    runs matvec_local, all-gathers the output.  Used by host-surface callers and the tests."""
+    v = self._to_dev(v_full)
+    v2 = self._to_dev(vec2_full) if vec2_full is not None else None
+    lo, hi = 3 * self.begin, 3 * self.end
+    u_local = self.matvec_local(kind, v[lo:hi], eta, None if v2 is None else v2[lo:hi], in_plane)
+    u_full, _ = self._all_gather_blocks(u_local.view(-1), None)
+    return u_full.clone()
+
+  def blob_blob_force_local(self, eps, b, a):
+    return self.backend.blob_blob_force(eps, b, a)

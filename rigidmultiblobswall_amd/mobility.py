@@ -1,0 +1,158 @@
+"""Blob-level mobility products -- the `mobility/mobility.py` plugin surface on MI355X.
+
+Same names, argument meaning and return layout as the reference's per-backend wrappers
+(`X_mobility_{trans,rot}_times_{force,torque}_<impl>(r_vectors, vec, eta, a, *args, **kwargs)
+-> ndarray(3N)`, mobility/mobility.py:187-615 and :1119-1341) with `<impl> = hip`.  A maintainer
+adds one `elif` per string in multi_bodies/multi_bodies.py:233-287.
+
+Differences in HOW, not WHAT:
+  * the height clamp and the B-damping (shift_heights / damping_matrix_B, mobility.py:52-84; the
+    latter an interpreted loop over N per call) run on the device, fused into position packing,
+    source staging and the output store;
+  * positions are uploaded once and stay resident while the caller keeps passing the same array
+    contents (GMRES and Lanczos call with fixed r_vectors: multi_bodies.py:445, :599);
+  * only `periodic_length` is read from kwargs; any other kwarg / positional extra is ignored, as
+    in the reference (callers pass step=, update_PC= ...).
+There is no CPU fallback: without the HIP library or a GPU these functions raise.
+"""
+import numpy as np
+import scipy.sparse
+
+from . import _lib
+from .context import MobilityContext
+
+_ctx = None
+_cached = None  # (r copy, a, L tuple, wall)
+
+
+def _context():
+  global _ctx
+  if _ctx is None:
+    _ctx = MobilityContext(0)
+  return _ctx
+
+
+def reset():
+  """Drop the module-level context (frees device memory)."""
+  global _ctx, _cached
+  if _ctx is not None:
+    _ctx.close()
+  _ctx = None
+  _cached = None
+
+
+def _bind_positions(r_vectors, a, L, wall):
+  global _cached
+  r = np.ascontiguousarray(r_vectors, dtype=np.float64).reshape(-1)
+  Lt = tuple(float(x) for x in np.asarray(L, dtype=np.float64).reshape(3))
+  ctx = _context()
+  c = _cached
+  if (c is not None and c[1] == float(a) and c[2] == Lt and c[3] == bool(wall) and c[0].size == r.size
+      and np.array_equal(c[0], r)):
+    if ctx.target_range != (0, ctx.n):
+      ctx.set_target_range(0, ctx.n)
+    return ctx
+  ctx.set_positions(r, a, Lt, wall)
+  _cached = (r.copy(), float(a), Lt, bool(wall))
+  return ctx
+
+
+def _product(kind, wall, in_plane, r_vectors, vec, eta, a, kwargs, vec2=None):
+  L = kwargs.get('periodic_length', np.array([0.0, 0.0, 0.0]))
+  ctx = _bind_positions(r_vectors, a, L, wall)
+  return ctx.matvec(kind, vec, eta, vec2=vec2, in_plane=in_plane)
+
+
+# ---------------------------------------------------------------------------------------------
+# Wall-overlap regularisation helpers (same returns as mobility/mobility.py:52-84), vectorised.
+# The *_hip products do NOT call these -- the device does the same arithmetic -- they are kept
+# for callers that use them directly (e.g. the per-body preconditioner builders).
+# ---------------------------------------------------------------------------------------------
+def shift_heights(r_vectors, blob_radius, *args, **kwargs):
+  '''z_effective = maximum(z, blob_radius); returns a copy (mobility/mobility.py:52-64).'''
+  r_effective = np.copy(r_vectors)
+  r_effective[r_vectors[:, 2] <= blob_radius, 2] = blob_radius
+  return r_effective
+
+
+def damping_matrix_B(r_vectors, blob_radius, *args, **kwargs):
+  '''(sparse diagonal B, overlap flag); B_ii = z_i/a for z_i < a else 1 (mobility/mobility.py:67-84).'''
+  r = np.asarray(r_vectors).reshape(-1, 3)
+  z = r[:, 2]
+  below = z < blob_radius
+  b = np.where(below, z / blob_radius, 1.0)
+  B = np.repeat(b, 3)
+  overlap = bool(np.any(below))
+  return (scipy.sparse.dia_matrix((B, 0), shape=(B.size, B.size)), overlap)
+
+
+# ---------------------------------------------------------------------------------------------
+# translation <- force
+# ---------------------------------------------------------------------------------------------
+def single_wall_mobility_trans_times_force_hip(r_vectors, force, eta, a, *args, **kwargs):
+  '''u = B M_tt(z_eff) B f above a no-slip wall (mobility/mobility.py:222-252, :1132-1163).'''
+  return _product('tt', True, False, r_vectors, force, eta, a, kwargs)
+
+
+def no_wall_mobility_trans_times_force_hip(r_vectors, force, eta, a, *args, **kwargs):
+  '''u = M_tt f, unbounded RPY (mobility/mobility.py:288-297, :1119-1129).'''
+  return _product('tt', False, False, r_vectors, force, eta, a, kwargs)
+
+
+def in_plane_mobility_trans_times_force_hip(r_vectors, force, eta, a, *args, **kwargs):
+  '''x,y rows/columns only of the wall M_tt (mobility/mobility.py:255-285, :1166-1197).'''
+  return _product('tt', True, True, r_vectors, force, eta, a, kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# translation <- torque
+# ---------------------------------------------------------------------------------------------
+def single_wall_mobility_trans_times_torque_hip(r_vectors, torque, eta, a, *args, **kwargs):
+  '''u = B M_tr(z_eff) B tau (mobility/mobility.py:427-452, :1213-1233).'''
+  return _product('tr', True, False, r_vectors, torque, eta, a, kwargs)
+
+
+def no_wall_mobility_trans_times_torque_hip(r_vectors, torque, eta, a, *args, **kwargs):
+  '''u = M_tr tau, unbounded (mobility/mobility.py:482-491, :1200-1210).'''
+  return _product('tr', False, False, r_vectors, torque, eta, a, kwargs)
+
+
+def in_plane_mobility_trans_times_torque_hip(r_vectors, torque, eta, a, *args, **kwargs):
+  '''in-plane wall M_tr (mobility/mobility.py:454-479, :1235-1255).'''
+  return _product('tr', True, True, r_vectors, torque, eta, a, kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# rotation <- force, rotation <- torque
+# ---------------------------------------------------------------------------------------------
+def single_wall_mobility_rot_times_force_hip(r_vectors, force, eta, a, *args, **kwargs):
+  '''w = B M_rt(z_eff) B f (mobility/mobility.py:300-325, :1273-1298).'''
+  return _product('rt', True, False, r_vectors, force, eta, a, kwargs)
+
+
+def no_wall_mobility_rot_times_force_hip(r_vectors, force, eta, a, *args, **kwargs):
+  '''w = M_rt f, unbounded (mobility/mobility.py:328-339, :1258-1270).'''
+  return _product('rt', False, False, r_vectors, force, eta, a, kwargs)
+
+
+def single_wall_mobility_rot_times_torque_hip(r_vectors, torque, eta, a, *args, **kwargs):
+  '''w = B M_rr(z_eff) B tau (mobility/mobility.py:342-367, :1316-1341).'''
+  return _product('rr', True, False, r_vectors, torque, eta, a, kwargs)
+
+
+def no_wall_mobility_rot_times_torque_hip(r_vectors, torque, eta, a, *args, **kwargs):
+  '''w = M_rr tau, unbounded (mobility/mobility.py:370-381, :1301-1313).'''
+  return _product('rr', False, False, r_vectors, torque, eta, a, kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused translation <- (force, torque)   (GPU-only in the reference too)
+# ---------------------------------------------------------------------------------------------
+def single_wall_mobility_trans_times_force_torque_hip(r_vectors, force, torque, eta, a, *args, **kwargs):
+  '''u = B (M_tt B f + M_tr B tau) in one sweep (mobility/mobility.py:384-410).'''
+  return _product('tt_tr', True, False, r_vectors, force, eta, a, kwargs, vec2=torque)
+
+
+def no_wall_mobility_trans_times_force_torque_hip(r_vectors, force, torque, eta, a, *args, **kwargs):
+  '''u = M_tt f + M_tr tau, unbounded (mobility/mobility.py:413-424).'''
+  return _product('tt_tr', False, False, r_vectors, force, eta, a, kwargs, vec2=torque)

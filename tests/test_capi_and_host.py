@@ -1,0 +1,78 @@
+"""CPU-side checks of the boundary: the HIP shared library loads (no GPU needed), exports every
+symbol include/rmb_mobility.h declares, reports "no device" loudly instead of falling back, and the
+host-side helpers mirror the reference semantics."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+  src = open(os.path.join(ROOT, "include", "rmb_mobility.h")).read()
+  src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+  return sorted(set(re.findall(r"\b(rmb_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+  from rigidmultiblobswall_amd import _lib
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  names = _declared_symbols()
+  assert len(names) >= 20
+  for n in names:
+    assert hasattr(lib, n), "missing export: " + n
+  # and the ctypes table covers exactly the header
+  assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_error_strings():
+  from rigidmultiblobswall_amd import _lib
+  lib = _lib.load()
+  assert b"gfx950" in lib.rmb_version()
+  assert isinstance(lib.rmb_last_error(), bytes)
+
+
+def test_no_silent_cpu_fallback():
+  """Without a GPU the product path must raise, never compute on the CPU."""
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  from rigidmultiblobswall_amd import _lib, mobility
+  assert _lib.device_count() == 0
+  r = np.random.rand(8, 3) + 1.0
+  with pytest.raises(_lib.RmbError):
+    mobility.single_wall_mobility_trans_times_force_hip(r, r, 1.0, 0.1)
+
+
+def test_wall_regularisation_helpers_match_reference_semantics(oracle):
+  """shift_heights uses `<=`, damping_matrix_B uses `<` (mobility/mobility.py:52-84)."""
+  from rigidmultiblobswall_amd import mobility
+  a = 0.25
+  r = np.array([[0, 0, 1.0], [1, 0, a], [0, 1, 0.1], [2, 2, -0.05], [3, 3, a * (1 + 1e-16)]])
+  re_ = mobility.shift_heights(r, a)
+  B, overlap = mobility.damping_matrix_B(r, a)
+  r_o, b_o, ov_o = oracle.wall_regularisation(r, a)
+  assert np.array_equal(re_.reshape(-1), r_o)
+  assert np.array_equal(B.diagonal(), np.repeat(b_o, 3))
+  assert overlap is True and ov_o is True
+  assert np.array_equal(r, np.array([[0, 0, 1.0], [1, 0, a], [0, 1, 0.1], [2, 2, -0.05], [3, 3, a * (1 + 1e-16)]]))
+  B2, ov2 = mobility.damping_matrix_B(r[:2], a)
+  assert ov2 is False and np.all(B2.diagonal() == 1.0)
+
+
+def test_partition_covers_range_without_overlap():
+  from rigidmultiblobswall_amd.distributed import partition
+  for n in (0, 1, 5, 64, 1000, 24576, 10 ** 6 + 3):
+    for g in (1, 2, 3, 4, 8):
+      spans = [partition(n, g, r) for r in range(g)]
+      assert spans[0][0] == 0 and spans[-1][1] == n
+      for (b0, e0, blk), (b1, e1, _) in zip(spans, spans[1:]):
+        assert e0 == b1 and e0 - b0 <= blk
+      full = [e - b for b, e, _ in spans]
+      # all blocks before the first short one are full (all-gather layout relies on it)
+      short = [i for i, c in enumerate(full) if c < spans[0][2]]
+      if short:
+        assert all(c == 0 for c in full[short[0] + 1:])

@@ -1,0 +1,328 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, the committed
+golden vectors from the reference, and size-independent properties at full size.
+
+Tolerances (fp64, relative L2 `|u - u_ref| / |u_ref|`, the reference's own metric,
+mobility/test_blobs.py:129-135), from BASELINE.md section 3 / SURVEY.md section 8(d):
+  1e-12  well-separated wall clouds (D2) and everything at N <= 1e4 vs the oracle
+  1e-10  dense overlapping clouds (D1, test_blobs distribution: long cancelling sums)
+  1e-13  G-shard vs 1-shard (same kernel, different target ranges)
+"""
+import numpy as np
+import pytest
+
+from conftest import KERNEL_KEYS, golden_files, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_D2 = 1e-12
+TOL_D1 = 1e-10
+TOL_SHARD = 1e-13
+
+
+@pytest.fixture(scope="module")
+def mob():
+  from rigidmultiblobswall_amd import mobility
+  return mobility
+
+
+@pytest.fixture(scope="module")
+def Ctx():
+  from rigidmultiblobswall_amd import MobilityContext
+  return MobilityContext
+
+
+def d1_cloud(N, seed=0):
+  """mobility/test_blobs.py:31-44 at constant number density."""
+  rng = np.random.RandomState(seed)
+  eta, a = 7.0, 0.13
+  s = (N / 1000.0) ** (1.0 / 3.0)
+  return s * 5 * a * rng.rand(N, 3), rng.randn(N, 3), eta, a
+
+
+def d2_cloud(N, seed=0):
+  """5% volume fraction above the wall, no blob below z = 1.1a."""
+  rng = np.random.RandomState(seed)
+  a, eta = 0.5, 1.0
+  Lbox = (N * (4.0 / 3.0) * np.pi * a ** 3 / 0.05) ** (1.0 / 3.0)
+  r = rng.rand(N, 3) * Lbox
+  r[:, 2] += 1.1 * a
+  return r, rng.randn(N, 3), eta, a
+
+
+ALL_STEMS = sorted(KERNEL_KEYS.values())
+
+
+# ---------------------------------------------------------------------------------------------
+# 1. golden vectors from the reference itself
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("g[123]_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_vectors(mob, path):
+  g = load_golden(path)
+  r, v, eta, a, L = g["r_vectors"], g["vector"], float(g["eta"]), float(g["a"]), g["periodic_length"]
+  for key, stem in KERNEL_KEYS.items():
+    if key not in g:
+      continue
+    u = getattr(mob, stem + "_hip")(r, v, eta, a, periodic_length=L)
+    assert u.shape == (3 * len(r),)
+    assert rel_err(u, g[key]) < TOL_D1, (key, rel_err(u, g[key]))
+
+
+@pytest.mark.parametrize("path", golden_files("g5_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_forces(path):
+  from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip
+  g = load_golden(path)
+  F = calc_blob_blob_forces_hip(g["r_vectors"], periodic_length=g["periodic_length"],
+                                repulsion_strength=float(g["repulsion_strength"]),
+                                debye_length=float(g["debye_length"]), blob_radius=float(g["blob_radius"]))
+  assert F.shape == g["force"].shape
+  assert rel_err(F, g["force"]) < TOL_D2
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. HIP vs oracle on seeded clouds, every kernel of the surface
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stem", ALL_STEMS)
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 513, 2000])
+def test_vs_oracle_d2(mob, oracle, stem, N):
+  r, v, eta, a = d2_cloud(N, seed=N)
+  u = getattr(mob, stem + "_hip")(r, v, eta, a)
+  ref = getattr(oracle, stem + "_oracle")(r, v, eta, a)
+  assert np.all(np.isfinite(u))
+  assert rel_err(u, ref) < TOL_D2, rel_err(u, ref)
+
+
+@pytest.mark.parametrize("stem", ALL_STEMS)
+def test_vs_oracle_d1_dense_overlapping(mob, oracle, stem):
+  r, v, eta, a = d1_cloud(3000, seed=3)   # ~1/7 of the blobs below z = a: B-damping path
+  assert np.sum(r[:, 2] < a) > 100
+  u = getattr(mob, stem + "_hip")(r, v, eta, a)
+  ref = getattr(oracle, stem + "_oracle")(r, v, eta, a)
+  assert rel_err(u, ref) < TOL_D1, rel_err(u, ref)
+
+
+def test_config2_size_1e4_wall_tt(mob, oracle):
+  """BASELINE.json configs[1]: 1e4 random blobs above a wall, single_wall_mobility_trans_times_force."""
+  r, f, eta, a = d2_cloud(10000, seed=0)
+  u = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  assert rel_err(u, ref) < TOL_D2, rel_err(u, ref)
+
+
+@pytest.mark.parametrize("stem", ["single_wall_mobility_trans_times_force", "no_wall_mobility_rot_times_torque",
+                                  "single_wall_mobility_trans_times_torque", "single_wall_mobility_rot_times_force"])
+@pytest.mark.parametrize("L", [(9.0, 11.0, 0.0), (7.5, 0.0, 0.0), (0.0, 8.0, 0.0)])
+def test_pseudo_periodic(mob, oracle, stem, L):
+  r, v, eta, a = d2_cloud(300, seed=7)
+  L = np.array(L)
+  u = getattr(mob, stem + "_hip")(r, v, eta, a, periodic_length=L)
+  ref = getattr(oracle, stem + "_oracle")(r, v, eta, a, periodic_length=L)
+  assert rel_err(u, ref) < TOL_D2, rel_err(u, ref)
+
+
+def test_fully_periodic_no_wall(mob, oracle):
+  r, v, eta, a = d2_cloud(200, seed=8)
+  L = np.array([9.0, 10.0, 11.0])
+  for stem in ("no_wall_mobility_trans_times_force", "no_wall_mobility_trans_times_torque"):
+    u = getattr(mob, stem + "_hip")(r, v, eta, a, periodic_length=L)
+    ref = getattr(oracle, stem + "_oracle")(r, v, eta, a, periodic_length=L)
+    assert rel_err(u, ref) < TOL_D2
+
+
+@pytest.mark.parametrize("wall", [True, False])
+def test_fused_force_torque(mob, oracle, wall):
+  """K11/K12 (mobility_pycuda.py:1266, :1394): one sweep == M_tt f + M_tr tau."""
+  r, f, eta, a = d1_cloud(1500, seed=9)
+  t = np.random.RandomState(10).randn(*f.shape)
+  pre = "single_wall" if wall else "no_wall"
+  u = getattr(mob, pre + "_mobility_trans_times_force_torque_hip")(r, f, t, eta, a)
+  ref = getattr(oracle, pre + "_mobility_trans_times_force_torque_oracle")(r, f, t, eta, a)
+  assert rel_err(u, ref) < TOL_D1
+  u2 = getattr(mob, pre + "_mobility_trans_times_force_hip")(r, f, eta, a) + \
+      getattr(mob, pre + "_mobility_trans_times_torque_hip")(r, t, eta, a)
+  assert rel_err(u, u2) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. boundary behaviour the callers rely on
+# ---------------------------------------------------------------------------------------------
+def test_inputs_not_mutated_flat_and_strided_inputs(mob, oracle):
+  r, f, eta, a = d1_cloud(700, seed=11)
+  r0, f0 = r.copy(), f.copy()
+  big = np.zeros(3 * 700 + 50)
+  big[:2100] = f.reshape(-1)
+  u_view = mob.single_wall_mobility_trans_times_force_hip(r, big[0:2100], eta, a)      # slice, as multi_bodies.py:445
+  u_flat = mob.single_wall_mobility_trans_times_force_hip(r.reshape(-1), f.reshape(-1), eta, a)
+  fs = np.asfortranarray(f)                                                                # non C-contiguous
+  u_f = mob.single_wall_mobility_trans_times_force_hip(r, fs, eta, a)
+  u = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a, step=3, update_PC=1)   # extra kwargs ignored
+  assert np.array_equal(r, r0) and np.array_equal(f, f0)
+  for other in (u_view, u_flat, u_f):
+    assert np.array_equal(u, other)
+  assert u.dtype == np.float64 and u.flags["C_CONTIGUOUS"] and u.flags["OWNDATA"]
+
+
+def test_empty_input(mob):
+  u = mob.single_wall_mobility_trans_times_force_hip(np.zeros((0, 3)), np.zeros((0, 3)), 1.0, 0.1)
+  assert u.shape == (0,)
+
+
+def test_blob_at_and_below_wall_has_zero_mobility(mob, oracle):
+  r, f, eta, a = d2_cloud(100, seed=12)
+  r[0, 2] = 0.0
+  r[1, 2] = -0.3 * a          # below the wall: B negative, as the reference computes it
+  r[2, 2] = a                 # exactly z = a: clamped by `<=`, B = 1
+  u = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  assert np.all(u.reshape(-1, 3)[0] == 0.0)
+  assert rel_err(u, ref) < TOL_D2
+
+
+def test_coincident_blobs_follow_reference_nan_policy(mob, oracle):
+  """Two distinct blobs at the same point: the reference divides by zero (mobility_numba.py:214)."""
+  r, f, eta, a = d2_cloud(10, seed=13)
+  r[4] = r[7]
+  u = mob.no_wall_mobility_trans_times_force_hip(r, f, eta, a).reshape(-1, 3)
+  assert not np.all(np.isfinite(u[4])) and not np.all(np.isfinite(u[7]))
+  ok = [i for i in range(10) if i not in (4, 7)]
+  assert np.all(np.isfinite(u[ok]))
+
+
+def test_positions_cache_is_invalidated(mob, oracle):
+  r, f, eta, a = d2_cloud(400, seed=14)
+  u1 = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
+  r2 = r.copy()
+  r2[17, 0] += 1e-6 * a          # RFD-sized displacement (doc/README.md:512-523) must be seen
+  u2 = mob.single_wall_mobility_trans_times_force_hip(r2, f, eta, a)
+  ref2 = oracle.single_wall_mobility_trans_times_force_oracle(r2, f, eta, a)
+  assert rel_err(u2, ref2) < TOL_D2
+  assert not np.array_equal(u1, u2)
+  u3 = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, 1.01 * a)
+  assert rel_err(u3, oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, 1.01 * a)) < TOL_D2
+
+
+def test_rfd_difference_is_resolved(mob, oracle):
+  """(M(r + d) - M(r)) f / delta with delta = 1e-6 a (quaternion_integrator_multi_bodies.py:1007)."""
+  r, f, eta, a = d2_cloud(500, seed=15)
+  W = np.random.RandomState(16).randn(*r.shape)
+  delta = 1e-6 * a
+  g_hip = (mob.single_wall_mobility_trans_times_force_hip(r + delta * W, f, eta, a) -
+           mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)) / delta
+  g_ref = (oracle.single_wall_mobility_trans_times_force_oracle(r + delta * W, f, eta, a) -
+           oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)) / delta
+  assert rel_err(g_hip, g_ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. persistent context, chunking, target shards
+# ---------------------------------------------------------------------------------------------
+def test_context_chunk_count_does_not_change_result(Ctx):
+  r, f, eta, a = d2_cloud(5000, seed=17)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, wall=True)
+  outs = []
+  for chunks in (1, 2, 7, 10):
+    ctx.set_option("chunks", chunks)
+    outs.append(ctx.matvec("tt", f, eta))
+    assert ctx.last_launch()["chunks"] == chunks
+  ctx.set_option("chunks", 0)
+  outs.append(ctx.matvec("tt", f, eta))
+  for o in outs[1:]:
+    assert rel_err(o, outs[0]) < TOL_SHARD
+  ctx.close()
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_target_shards_equal_single_range(Ctx, G):
+  """What each rank of a G-GPU job computes (rmb_set_target_range) concatenates to the 1-GPU result."""
+  from rigidmultiblobswall_amd.distributed import partition
+  r, f, eta, a = d1_cloud(4001, seed=18)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, wall=True)
+  for kind in ("tt", "rr"):
+    full = ctx.matvec(kind, f, eta)
+    parts = []
+    for g in range(G):
+      b, e, _ = partition(len(r), G, g)
+      ctx.set_target_range(b, e)
+      parts.append(ctx.matvec(kind, f, eta))
+      assert parts[-1].shape == (3 * (e - b),)
+    ctx.set_target_range(0, len(r))
+    assert rel_err(np.concatenate(parts), full) < TOL_SHARD
+  ctx.close()
+
+
+def test_device_resident_path_and_timing(Ctx, oracle):
+  import torch
+  r, f, eta, a = d2_cloud(3000, seed=19)
+  ctx = Ctx(0)
+  ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+  ctx.set_option("timing", 1)
+  rd = torch.as_tensor(r, device="cuda")
+  fd = torch.as_tensor(f.reshape(-1), device="cuda")
+  ctx.set_positions(rd, a, wall=True)
+  out = torch.empty(3 * 3000, dtype=torch.float64, device="cuda")
+  for _ in range(3):
+    ctx.matvec_device("tt", fd, eta, out=out)
+  torch.cuda.synchronize()
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  assert rel_err(out.cpu().numpy(), ref) < TOL_D2
+  ms = ctx.timing_collect()
+  assert len(ms) == 3 and np.all(ms > 0)
+  ctx.close()
+
+
+def test_sharded_mobility_single_process_world1(oracle):
+  """ShardedMobility with the HIP backend, world size 1 (the multi-rank logic is covered on CPU/gloo)."""
+  import torch
+  from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
+  r, f, eta, a = d2_cloud(1000, seed=20)
+  sm = ShardedMobility(HipBackend("cuda:0"), device="cuda:0")
+  sm.set_positions(r, a, wall=True)
+  u = sm.matvec("tt", f, eta)
+  torch.cuda.synchronize()
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  assert rel_err(u.cpu().numpy(), ref) < TOL_D2
+
+
+# ---------------------------------------------------------------------------------------------
+# 5. full-size (BASELINE.json sizes) through size-independent properties + oracle spot checks
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [24576, 100000])
+def test_large_linearity_symmetry_and_spot_check(Ctx, oracle, N):
+  r, f, eta, a = d2_cloud(N, seed=21)
+  g = np.random.RandomState(22).randn(*f.shape)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, wall=True)
+  Mf = ctx.matvec("tt", f, eta)
+  Mg = ctx.matvec("tt", g, eta)
+  # linearity
+  Mfg = ctx.matvec("tt", 2.0 * f - 0.5 * g, eta)
+  assert rel_err(Mfg, 2.0 * Mf - 0.5 * Mg) < 1e-12
+  # symmetry  g.M f = f.M g,  positivity f.M f > 0   (mobility_test.py:101-130)
+  gMf, fMg = np.dot(g.reshape(-1), Mf), np.dot(f.reshape(-1), Mg)
+  assert abs(gMf - fMg) < 1e-11 * (np.linalg.norm(g) * np.linalg.norm(Mf))
+  assert np.dot(f.reshape(-1), Mf) > 0
+  # transpose pair  g.M_tr f = f.M_rt g
+  Mtr_f = ctx.matvec("tr", f, eta)
+  Mrt_g = ctx.matvec("rt", g, eta)
+  assert abs(np.dot(g.reshape(-1), Mtr_f) - np.dot(f.reshape(-1), Mrt_g)) < 1e-11 * np.linalg.norm(g) * np.linalg.norm(Mtr_f)
+  # oracle on a random subset of targets (all N sources each)
+  tg = np.random.RandomState(23).choice(N, 48, replace=False)
+  r_eff, b, _ = oracle.wall_regularisation(r, a)
+  ref = oracle.raw_matvec_targets("tt", 1, r_eff, f, eta, a, tg)
+  got = Mf.reshape(-1, 3)[tg].reshape(-1)
+  assert rel_err(got, ref) < TOL_D2
+  ctx.close()
+
+
+def test_forces_vs_oracle_and_newton_third_law(oracle):
+  from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip
+  rng = np.random.RandomState(24)
+  N, a, b, eps = 5000, 0.13, 0.01, 3.92
+  r = rng.rand(N, 3) * (N ** (1.0 / 3.0)) * 2.2 * a
+  for L in (np.zeros(3), np.array([3.0, 3.5, 0.0])):
+    kw = dict(periodic_length=L, repulsion_strength=eps, debye_length=b, blob_radius=a)
+    F = calc_blob_blob_forces_hip(r, **kw)
+    ref = oracle.calc_blob_blob_forces_oracle(r, **kw)
+    assert rel_err(F, ref) < TOL_D2
+    assert np.abs(F.sum(axis=0)).max() < 1e-9 * np.abs(F).sum()     # pairwise antisymmetric
