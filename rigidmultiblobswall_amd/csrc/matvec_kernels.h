@@ -32,7 +32,7 @@ struct SweepArgs {
   long n_src;
   long tgt_begin, tgt_end;  // owned target index range (multi-GPU shard); targets index into pos as well
   long n_tgt_pad;           // 64 * gridDim.x
-  long chunk_len;           // sources per chunk (multiple of kTile except possibly the last)
+  long chunk_len;           // sources per chunk (multiple of kWaves)
   int n_chunks;
   int in_plane;             // zero v_z on load and u_z on store (in_plane_* kernels of the reference)
   double prefactor;         // 1/(8 pi eta)

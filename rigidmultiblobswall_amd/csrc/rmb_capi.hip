@@ -94,60 +94,57 @@ rmb::PairConsts make_pair_consts(double a) {
   return k;
 }
 
-// Source-chunk count: enough workgroups (4 waves each, one per SIMD) to fill 256 CUs several
-// times over with little tail imbalance, without making chunks shorter than one LDS tile.
-void choose_chunks(long n_tgt, long n_src, long forced, long* n_chunks, long* chunk_len) {
+// Source-chunk count.  A workgroup is 4 waves (one per SIMD); `slots` = 256 CUs x resident
+// workgroups per CU for this kernel.  Either everything is resident at once in one balanced round
+// (tiles*c just under `slots`), or there are enough rounds (>= 6) that the tail is small.
+void choose_chunks(long n_tgt, long n_src, long forced, long slots, long* n_chunks, long* chunk_len) {
   const long tiles = (n_tgt + 63) / 64;
-  const long max_chunks = (n_src + rmb::kTile - 1) / rmb::kTile;
   long c = 1;
   if (forced > 0) {
     c = forced;
-  } else if (tiles < 4096) {
-    // candidates: smallest c with >= 2048 workgroups, then look a little further for a count
-    // that is close to a multiple of 256 CUs x 4 resident workgroups
-    const long want = 2048;
-    long c_min = (want + tiles - 1) / tiles;
-    if (c_min < 1) c_min = 1;
-    double best = 1e30;
-    c = c_min;
-    for (long cand = c_min; cand <= c_min + 8; ++cand) {
-      const double wg = (double)(tiles * cand);
-      const double rounds = std::ceil(wg / 1024.0);
-      const double waste = rounds * 1024.0 / wg;  // >= 1
-      const double cost = waste + 0.01 * (double)(cand - c_min);
-      if (cost < best) { best = cost; c = cand; }
-    }
+  } else if (tiles <= slots) {
+    c = slots / tiles;
+  } else if (tiles < 6 * slots) {
+    c = (6 * slots + tiles - 1) / tiles;
   }
+  const long max_chunks = (n_src + 127) / 128;  // >= 32 sources per wave
   if (c > max_chunks) c = max_chunks;
   if (c < 1) c = 1;
   long len = (n_src + c - 1) / c;
-  len = ((len + rmb::kTile - 1) / rmb::kTile) * rmb::kTile;  // whole tiles per chunk
+  len = ((len + rmb::kWaves - 1) / rmb::kWaves) * rmb::kWaves;
   c = (n_src + len - 1) / len;
   *n_chunks = c;
   *chunk_len = len;
 }
 
-template <int KIND>
-int launch_sweep(rmb_ctx* c, const rmb::SweepArgs& a, dim3 grid, bool periodic) {
-  const dim3 block(rmb::kBlock);
-  if (c->wall) {
-    if (periodic) hipLaunchKernelGGL((rmb::sweep_kernel<KIND, true, true>), grid, block, 0, c->stream, a);
-    else          hipLaunchKernelGGL((rmb::sweep_kernel<KIND, true, false>), grid, block, 0, c->stream, a);
-  } else {
-    if (periodic) hipLaunchKernelGGL((rmb::sweep_kernel<KIND, false, true>), grid, block, 0, c->stream, a);
-    else          hipLaunchKernelGGL((rmb::sweep_kernel<KIND, false, false>), grid, block, 0, c->stream, a);
-  }
-  RMB_HIP(hipGetLastError());
-  return 0;
+typedef void (*sweep_fn)(const rmb::SweepArgs);
+typedef void (*final_fn)(const rmb::SweepArgs);
+
+struct KernelEntry { sweep_fn sweep; final_fn fin; int blocks_per_cu; };
+
+template <int KIND, bool WALL, bool PER>
+KernelEntry make_entry() {
+  KernelEntry e;
+  e.sweep = rmb::sweep_kernel<KIND, WALL, PER>;
+  e.fin = rmb::finalize_kernel<KIND, WALL>;
+  e.blocks_per_cu = 0;
+  return e;
 }
 
-template <int KIND>
-int launch_finalize(rmb_ctx* c, const rmb::SweepArgs& a, long n_tgt) {
-  const dim3 grid((unsigned)((n_tgt + 255) / 256)), block(256);
-  if (c->wall) hipLaunchKernelGGL((rmb::finalize_kernel<KIND, true>), grid, block, 0, c->stream, a);
-  else         hipLaunchKernelGGL((rmb::finalize_kernel<KIND, false>), grid, block, 0, c->stream, a);
-  RMB_HIP(hipGetLastError());
-  return 0;
+// [kind][wall][periodic]
+KernelEntry g_kernels[rmb::KIND_COUNT][2][2] = {
+#define RMB_ROW(K) {{make_entry<K, false, false>(), make_entry<K, false, true>()}, {make_entry<K, true, false>(), make_entry<K, true, true>()}}
+    RMB_ROW(rmb::KIND_TT), RMB_ROW(rmb::KIND_TR), RMB_ROW(rmb::KIND_RT), RMB_ROW(rmb::KIND_RR), RMB_ROW(rmb::KIND_TT_TR)
+#undef RMB_ROW
+};
+
+int resident_blocks(const void* fn, int* cache) {
+  if (*cache > 0) return *cache;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, rmb::kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+  if (nb > 8) nb = 8;
+  *cache = nb;
+  return nb;
 }
 
 int timing_begin(rmb_ctx* c, int* slot) {
@@ -190,8 +187,11 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   RMB_HIP(hipSetDevice(c->device));
 
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  KernelEntry& ke = g_kernels[kind][c->wall ? 1 : 0][periodic ? 1 : 0];
+  const long slots = 256L * resident_blocks((const void*)ke.sweep, &ke.blocks_per_cu);
   long n_chunks, chunk_len;
-  choose_chunks(n_tgt, c->n, c->opt_chunks, &n_chunks, &chunk_len);
+  choose_chunks(n_tgt, c->n, c->opt_chunks, slots, &n_chunks, &chunk_len);
   const long tiles = (n_tgt + 63) / 64;
   if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");
 
@@ -218,32 +218,19 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
     if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
     a.partial = (double*)c->partial.p;
   }
-  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   const dim3 grid((unsigned)tiles, (unsigned)n_chunks);
   c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
 
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  int rc = 0;
-  switch (kind) {
-    case rmb::KIND_TT: rc = launch_sweep<rmb::KIND_TT>(c, a, grid, periodic); break;
-    case rmb::KIND_TR: rc = launch_sweep<rmb::KIND_TR>(c, a, grid, periodic); break;
-    case rmb::KIND_RT: rc = launch_sweep<rmb::KIND_RT>(c, a, grid, periodic); break;
-    case rmb::KIND_RR: rc = launch_sweep<rmb::KIND_RR>(c, a, grid, periodic); break;
-    default:           rc = launch_sweep<rmb::KIND_TT_TR>(c, a, grid, periodic); break;
-  }
-  if (rc) return rc;
-  if (int rc2 = timing_end(c, slot)) return rc2;
+  hipLaunchKernelGGL(ke.sweep, grid, dim3(rmb::kBlock), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
   if (n_chunks > 1) {
-    switch (kind) {
-      case rmb::KIND_TT: rc = launch_finalize<rmb::KIND_TT>(c, a, n_tgt); break;
-      case rmb::KIND_TR: rc = launch_finalize<rmb::KIND_TR>(c, a, n_tgt); break;
-      case rmb::KIND_RT: rc = launch_finalize<rmb::KIND_RT>(c, a, n_tgt); break;
-      case rmb::KIND_RR: rc = launch_finalize<rmb::KIND_RR>(c, a, n_tgt); break;
-      default:           rc = launch_finalize<rmb::KIND_TT_TR>(c, a, n_tgt); break;
-    }
+    hipLaunchKernelGGL(ke.fin, dim3((unsigned)((n_tgt + 255) / 256)), dim3(256), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
   }
-  return rc;
+  return 0;
 }
 
 int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
@@ -253,8 +240,12 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   if (!out) return fail(RMB_ERR_ARG, "null output pointer");
   if (!(b > 0.0)) return fail(RMB_ERR_ARG, "debye_length must be positive");
   RMB_HIP(hipSetDevice(c->device));
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  static int force_occ[2] = {0, 0};
+  const void* ffn = periodic ? (const void*)rmb::force_sweep_kernel<true> : (const void*)rmb::force_sweep_kernel<false>;
+  const long slots = 256L * resident_blocks(ffn, &force_occ[periodic ? 1 : 0]);
   long n_chunks, chunk_len;
-  choose_chunks(n_tgt, c->n, c->opt_chunks, &n_chunks, &chunk_len);
+  choose_chunks(n_tgt, c->n, c->opt_chunks, slots, &n_chunks, &chunk_len);
   const long tiles = (n_tgt + 63) / 64;
   if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");
   rmb::ForceArgs a;
@@ -277,7 +268,6 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
     a.partial = (double*)c->partial.p;
   }
-  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   const dim3 grid((unsigned)tiles, (unsigned)n_chunks), block(rmb::kBlock);
   c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
   int slot;
