@@ -50,6 +50,27 @@ class RmbError(RuntimeError):
   pass
 
 
+def _preload_torch_hip_runtime():
+  """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (+ HSA) and asks
+  for it by file name, librmb_mobility.so asks for the SONAME libamdhip64.so.7: if ours pulls in
+  /opt/rocm's copy first, a later `import torch` loads a SECOND runtime, which then finds no GPU.
+  So when a torch installation is present, map its runtime first (without importing torch);
+  librmb_mobility.so and torch then share it.  Without torch the system runtime is used."""
+  import importlib.util
+  try:
+    spec = importlib.util.find_spec("torch")
+  except (ImportError, ValueError):
+    spec = None
+  if spec is None or not spec.submodule_search_locations:
+    return
+  cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+  if os.path.exists(cand):
+    try:
+      ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+      pass
+
+
 def load():
   """Load the shared library (no GPU needed for loading / symbol checks)."""
   global _lib
@@ -58,6 +79,7 @@ def load():
       raise RmbError(
           "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
           "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
       fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
