@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "matvec_kernels.h"
+#include "sym_kernels.h"
 
 namespace {
 
@@ -62,9 +63,13 @@ struct rmb_ctx {
   DevBuf pos;      // double4[n]
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial;
+  DevBuf symbuf;   // [counter (256 B)] [acc 3 x n_pad doubles] for the symmetric tt kernel
   // options
   long opt_chunks = 0;
   long opt_timing = 0;
+  long opt_symmetric = 1;      // use the symmetric (each unordered pair once) kernel where applicable
+  long opt_deterministic = 0;  // force the atomic-free sweep kernel everywhere
+  int last_path = 0;           // 0 = sweep, 1 = symmetric
   // timing ring (events around the sweep kernel)
   std::vector<hipEvent_t> ev0, ev1;
   int ev_count = 0;  // events recorded since last reset (capped at ring size)
@@ -176,6 +181,44 @@ int check_ready(rmb_ctx* c) {
   return 0;
 }
 
+int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out) {
+  const long n = c->n;
+  const long tiles = (n + 63) / 64;
+  const long n_pad = 64 * tiles;
+  const size_t acc_bytes = (size_t)3 * n_pad * sizeof(double);
+  if (int rc = c->symbuf.reserve(256 + acc_bytes)) return rc;
+  RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, 256 + acc_bytes, c->stream));
+  rmb::SymArgs a;
+  a.pos = (const double4*)c->pos.p;
+  a.vec = v;
+  a.counter = (unsigned int*)c->symbuf.p;
+  a.acc = (double*)((char*)c->symbuf.p + 256);
+  a.out = out;
+  a.n = n;
+  a.n_pad = n_pad;
+  a.n_tiles = (int)tiles;
+  a.n_units = tiles * (tiles + 1) / 2;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.k = make_pair_consts(c->a);
+  static int occ[2] = {0, 0};
+  const void* fn = c->wall ? (const void*)rmb::sym_tt_kernel<true> : (const void*)rmb::sym_tt_kernel<false>;
+  long blocks = 256L * resident_blocks(fn, &occ[c->wall ? 1 : 0]);
+  const long need = (a.n_units + rmb::kSymWaves - 1) / rmb::kSymWaves;
+  if (blocks > need) blocks = need;
+  c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  if (c->wall) hipLaunchKernelGGL(rmb::sym_tt_kernel<true>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+  else         hipLaunchKernelGGL(rmb::sym_tt_kernel<false>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
+  const dim3 fgrid((unsigned)((n + 255) / 256));
+  if (c->wall) hipLaunchKernelGGL(rmb::sym_tt_finalize_kernel<true>, fgrid, dim3(256), 0, c->stream, a);
+  else         hipLaunchKernelGGL(rmb::sym_tt_finalize_kernel<false>, fgrid, dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
 int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta,
                        double* out) {
   if (int rc = check_ready(c)) return rc;
@@ -188,6 +231,12 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
   RMB_HIP(hipSetDevice(c->device));
 
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  c->last_path = 0;
+  if (kind == rmb::KIND_TT && !periodic && !in_plane && c->opt_symmetric && !c->opt_deterministic &&
+      c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
+    c->last_path = 1;
+    return sym_tt_device(c, v, eta, out);
+  }
   KernelEntry& ke = g_kernels[kind][c->wall ? 1 : 0][periodic ? 1 : 0];
   const long slots = 256L * resident_blocks((const void*)ke.sweep, &ke.blocks_per_cu);
   long n_chunks, chunk_len;
@@ -334,7 +383,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
+  c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
   delete c;
@@ -351,6 +400,8 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!c || !key) return fail(RMB_ERR_ARG, "null context / key");
   if (!strcmp(key, "chunks")) { c->opt_chunks = value; return 0; }
   if (!strcmp(key, "timing")) { c->opt_timing = value; return 0; }
+  if (!strcmp(key, "symmetric")) { c->opt_symmetric = value; return 0; }
+  if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
 }
 

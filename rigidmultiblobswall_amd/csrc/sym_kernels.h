@@ -1,0 +1,227 @@
+// sym_kernels.h -- symmetric pair sweep for the translation-translation mobility (gfx950, fp64).
+//
+// The blob mobility is symmetric as a 3N x 3N matrix, M_ji = M_ij^T (for the wall part this is the
+// Swan-Brady reciprocity the reference's C++ twin also relies on, mobility/mobility.cpp:407-424).
+// sweep_kernel evaluates every ORDERED pair; here every UNORDERED pair is evaluated once and applied
+// to both blobs:   u_i += M_ij v_j   and   u_j += M_ij^T v_i.
+// The expensive part (two rsqrt, RPY coefficients, the five wall polynomials G1..G5) is shared; only the
+// cheap contractions are done twice.  With W = f1 I + f2 e e^T + f3 e z^T + f4 z e^T + f5 z z^T,
+//   W v   = f1 v + [f2 (e.v) + f3 v_z] e + [f4 (e.v) + f5 v_z] z
+//   W^T v = f1 v + [f2 (e.v) + f4 v_z] e + [f3 (e.v) + f5 v_z] z          (f3 <-> f4)
+// => ~110 VALU instructions per unordered pair instead of 2 x 93.
+//
+// Work decomposition: blobs are cut into tiles of 64; a work unit is a tile pair (I <= J).  One wave64
+// owns a unit: lane l holds blob i = 64 I + l in registers (position, its own vector v_i, accumulator u_i);
+// tile J sits in the wave's private LDS slab.  At step k lane l meets blob j = 64 J + ((l + k) & 63): the
+// "rotation" makes every lane touch a different j, so the transposed contribution is added to the
+// per-wave LDS accumulator of j without conflicts (ds_add_f64) and source records are plain per-lane
+// ds_read_b128 (48-byte records: conflict-free).  Diagonal units (I == J) run forward-only over
+// k = 1..63 (every ordered pair exactly once).  After 64 steps u_i (registers) and u_J (LDS) are flushed
+// to global SoA accumulators with global_atomic_add_f64; finalize adds the self term and scales.
+// Units are handed out dynamically (one agent-scope atomic counter), so all SIMDs finish together
+// whatever the clocks of their XCDs.  Summation order is therefore not fixed: results agree with the
+// deterministic sweep_kernel to rounding (~1e-15 relative) but are not bit-reproducible; the
+// "deterministic" context option selects sweep_kernel instead.
+#pragma once
+#include "pair_ops.h"
+
+namespace rmb {
+
+struct SymArgs {
+  const double4* pos;   // [n] packed positions
+  const double* vec;    // [3n] source vector (AoS)
+  double* acc;          // [3][n_pad] global SoA accumulators, zeroed before launch
+  unsigned int* counter;  // work counter, zeroed before launch
+  double* out;          // [3n] final output (AoS)
+  long n;
+  long n_pad;           // 64 * n_tiles
+  int n_tiles;
+  long n_units;         // n_tiles (n_tiles + 1) / 2
+  double prefactor;
+  PairConsts k;
+};
+
+constexpr int kSymWaves = 4;
+constexpr int kSymRecBytes = 48;
+
+// Both directions of one pair.  (vix..) = target's own vector, (vjx..) = source vector.
+// Adds M_ij v_j to ui and returns M_ij^T v_i in (tx,ty,tz).
+template <bool WALL>
+__device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, double dy, double dz, double Rz, double zj,
+                                            double vix, double viy, double viz, double vjx, double vjy, double vjz,
+                                            Vec3& ui, double& tx, double& ty, double& tz) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double ir = rsqrt_f64(r2);
+  const double ir2 = ir * ir;
+  double cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
+  double cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
+  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
+    const double r = r2 * ir;
+    const bool near = r2 <= k.four_a2;
+    cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : cF;
+    cD = near ? k.tt_n2 * ir : cD;
+  }
+  const double pj = __builtin_fma(dy, vjy, dx * vjx);   // in-plane parts of d.v_j and R.v_j
+  const double pi = __builtin_fma(dy, viy, dx * vix);
+  const double cDj = cD * __builtin_fma(dz, vjz, pj);
+  const double cDi = cD * __builtin_fma(dz, viz, pi);
+  if constexpr (!WALL) {
+    ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cDj, dx, ui.x);
+    ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cDj, dy, ui.y);
+    ui.z = __builtin_fma(cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
+    tx = __builtin_fma(cDi, dx, cF * vix);
+    ty = __builtin_fma(cDi, dy, cF * viy);
+    tz = __builtin_fma(cDi, dz, cF * viz);
+  } else {
+    const double R2 = __builtin_fma(Rz, Rz, rho2);
+    const double iR = rsqrt_f64(R2);
+    const double iR2 = iR * iR;
+    const double tau = k.a2 * iR2;
+    const double ez = Rz * iR;
+    const double g = zj * iR;
+    const double uu = ez * ez;
+    const double dd = ez - g;
+    const double w = g * dd;
+    const double q6 = ez * dd;
+    const double G1 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(10.0 / 3.0, uu, -2.0 / 3.0), __builtin_fma(-2.0, uu, 2.0 / 3.0)), __builtin_fma(2.0, w, 1.0));
+    const double G2 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-70.0 / 3.0, uu, 10.0 / 3.0), __builtin_fma(10.0, uu, -2.0)), __builtin_fma(-6.0, w, 1.0));
+    const double g2 = g + g;
+    const double G3 = __builtin_fma(ez * tau, __builtin_fma(tau, __builtin_fma(-140.0 / 3.0, uu, 40.0 / 3.0), __builtin_fma(20.0, uu, -4.0)), g2 * __builtin_fma(-6.0, q6, 1.0));
+    const double G4 = __builtin_fma(-20.0 / 3.0 * ez, tau * tau, g2);
+    const double G5 = -__builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-20.0, uu, 8.0 / 3.0), 4.0 * uu), g2 * g2);
+    cF = __builtin_fma(-G1, iR, cF);
+    const double nG2 = -G2 * iR;                       // (-G2) iR : multiplies R.v to give -G2 E
+    // forward: W v_j
+    const double Rvj = __builtin_fma(Rz, vjz, pj);
+    const double cRj = __builtin_fma(G3, vjz, nG2 * Rvj) * iR2;
+    const double G4i = G4 * iR, G3i = G3 * iR;
+    const double cbj = __builtin_fma(G5, vjz, G4i * Rvj) * iR;
+    const double cj = cDj + cRj;
+    ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cj, dx, ui.x);
+    ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cj, dy, ui.y);
+    ui.z = __builtin_fma(cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
+    ui.z = __builtin_fma(cRj, Rz, ui.z); ui.z += cbj;
+    // transposed: W^T v_i  (f3 <-> f4)
+    const double Rvi = __builtin_fma(Rz, viz, pi);
+    const double cRi = __builtin_fma(G4, viz, nG2 * Rvi) * iR2;
+    const double cbi = __builtin_fma(G5, viz, G3i * Rvi) * iR;
+    const double ci = cDi + cRi;
+    tx = __builtin_fma(ci, dx, cF * vix);
+    ty = __builtin_fma(ci, dy, cF * viy);
+    tz = __builtin_fma(cRi, Rz, __builtin_fma(cDi, dz, __builtin_fma(cF, viz, cbi)));
+  }
+}
+
+__device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
+  // row-major over the upper triangle: row I holds (T - I) units
+  const double tt = 2.0 * T + 1.0;
+  long i = (long)((tt - sqrt(tt * tt - 8.0 * (double)u)) * 0.5);
+  if (i < 0) i = 0;
+  if (i > T - 1) i = T - 1;
+  while (i > 0 && i * T - i * (i - 1) / 2 > u) --i;
+  while ((i + 1) * T - (i + 1) * i / 2 <= u) ++i;
+  I = (int)i;
+  J = (int)(u - (i * T - i * (i - 1) / 2) + i);
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a) {
+  __shared__ double2 rec_all[kSymWaves][64 * 3];
+  __shared__ double accj_all[kSymWaves][3 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double2* rec = rec_all[wave];
+  double* accj = accj_all[wave];
+  const char* rec_bytes = reinterpret_cast<const char*>(rec);
+
+  for (;;) {
+    unsigned int u = 0;
+    if (lane == 0) u = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if ((long)u >= a.n_units) break;
+    int I, J;
+    unit_to_tiles((long)u, a.n_tiles, I, J);
+
+    // own blob i -> registers
+    const long i = 64L * I + lane;
+    const bool vi_ok = i < a.n;
+    double xi = 1e100, yi = 1e100, zi = 1.0, vix = 0, viy = 0, viz = 0;
+    if (vi_ok) {
+      const double4 p = a.pos[i];
+      xi = p.x; yi = p.y; zi = p.z;
+      vix = a.vec[3 * i] * p.w; viy = a.vec[3 * i + 1] * p.w; viz = a.vec[3 * i + 2] * p.w;
+    }
+    // tile J -> this wave's LDS slab (record l = blob 64 J + l), zero its accumulators
+    {
+      const long j = 64L * J + lane;
+      double xj = -1e100, yj = -1e100, zj = 1.0, vjx = 0, vjy = 0, vjz = 0;
+      if (j < a.n) {
+        const double4 p = a.pos[j];
+        xj = p.x; yj = p.y; zj = p.z;
+        vjx = a.vec[3 * j] * p.w; vjy = a.vec[3 * j + 1] * p.w; vjz = a.vec[3 * j + 2] * p.w;
+      }
+      rec[lane * 3 + 0] = make_double2(xj, yj);
+      rec[lane * 3 + 1] = make_double2(zj, vjx);
+      rec[lane * 3 + 2] = make_double2(vjy, vjz);
+      accj[lane] = 0.0; accj[64 + lane] = 0.0; accj[128 + lane] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    Vec3 ui = {0.0, 0.0, 0.0};
+    if (I != J) {
+      for (int k = 0; k < 64; ++k) {
+        const int jj = (lane + k) & 63;
+        const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
+        const double2 q0 = r[0], q1 = r[1], q2 = r[2];
+        double tx, ty, tz;
+        pair_tt_sym<WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi + q1.x, q1.x, vix, viy, viz, q1.y, q2.x, q2.y, ui,
+                          tx, ty, tz);
+        __hip_atomic_fetch_add(&accj[jj], tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[64 + jj], ty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[128 + jj], tz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    } else {
+      for (int k = 1; k < 64; ++k) {
+        const int jj = (lane + k) & 63;
+        const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
+        const double2 q0 = r[0], q1 = r[1], q2 = r[2];
+        pair_tt<WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi + q1.x, q1.x, q1.y, q2.x, q2.y, ui);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    if (vi_ok) {
+      __hip_atomic_fetch_add(&a.acc[i], ui.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ui.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], ui.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (I != J) {
+      const long j = 64L * J + lane;
+      if (j < a.n) {
+        __hip_atomic_fetch_add(&a.acc[j], accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + j], accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
+  }
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(256) void sym_tt_finalize_kernel(const SymArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
+  const double4 p = a.pos[i];
+  const double b = p.w;
+  self_term<KIND_TT, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
+  const double sc = a.prefactor * b;
+  a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
+}
+
+}  // namespace rmb

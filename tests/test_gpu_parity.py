@@ -218,6 +218,7 @@ def test_rfd_difference_is_resolved(mob, oracle):
 def test_context_chunk_count_does_not_change_result(Ctx):
   r, f, eta, a = d2_cloud(5000, seed=17)
   ctx = Ctx(0)
+  ctx.set_option("deterministic", 1)      # the chunked sweep kernel (the symmetric kernel has no chunks)
   ctx.set_positions(r, a, wall=True)
   outs = []
   for chunks in (1, 2, 7, 10):
@@ -248,6 +249,28 @@ def test_target_shards_equal_single_range(Ctx, G):
       assert parts[-1].shape == (3 * (e - b),)
     ctx.set_target_range(0, len(r))
     assert rel_err(np.concatenate(parts), full) < TOL_SHARD
+  ctx.close()
+
+
+@pytest.mark.parametrize("wall", [True, False])
+@pytest.mark.parametrize("N", [128, 1000, 4097, 20000])
+def test_symmetric_kernel_matches_deterministic_sweep(Ctx, oracle, wall, N):
+  """tt has two device paths: sym_tt_kernel (each unordered pair once, atomics) and sweep_kernel
+  (every ordered pair, atomic-free).  Both must agree to rounding and with the oracle."""
+  r, f, eta, a = d1_cloud(N, seed=30 + N) if N <= 4097 else d2_cloud(N, seed=30)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, wall=wall)
+  u_sym = ctx.matvec("tt", f, eta)
+  u_sym2 = ctx.matvec("tt", f, eta)
+  ctx.set_option("deterministic", 1)
+  u_det = ctx.matvec("tt", f, eta)
+  u_det2 = ctx.matvec("tt", f, eta)
+  assert np.array_equal(u_det, u_det2)              # sweep path is bit-reproducible
+  assert rel_err(u_sym, u_det) < 1e-13 and rel_err(u_sym2, u_det) < 1e-13
+  if N <= 4097:
+    pre = "single_wall" if wall else "no_wall"
+    ref = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(r, f, eta, a)
+    assert rel_err(u_sym, ref) < TOL_D1
   ctx.close()
 
 
