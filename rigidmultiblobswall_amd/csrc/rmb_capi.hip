@@ -63,13 +63,16 @@ struct rmb_ctx {
   DevBuf pos;      // double4[n]
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial;
-  DevBuf symbuf;   // [counter (256 B)] [acc 3 x n_pad doubles] for the symmetric tt kernel
+  DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
+  long symbuf_zeroed_for = -1;
   // options
   long opt_chunks = 0;
   long opt_timing = 0;
   long opt_symmetric = 1;      // use the symmetric (each unordered pair once) kernel where applicable
   long opt_deterministic = 0;  // force the atomic-free sweep kernel everywhere
   int last_path = 0;           // 0 = sweep, 1 = symmetric
+  long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
+  long opt_sym_pin = 1;        // pad dynamic LDS so residency is exactly that number
   // timing ring (events around the sweep kernel)
   std::vector<hipEvent_t> ev0, ev1;
   int ev_count = 0;  // events recorded since last reset (capped at ring size)
@@ -186,13 +189,15 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out) {
   const long tiles = (n + 63) / 64;
   const long n_pad = 64 * tiles;
   const size_t acc_bytes = (size_t)3 * n_pad * sizeof(double);
-  if (int rc = c->symbuf.reserve(256 + acc_bytes)) return rc;
-  RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, 256 + acc_bytes, c->stream));
+  if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
+    if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
+    RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));   // later calls: finalize re-zeroes
+    c->symbuf_zeroed_for = n_pad;
+  }
   rmb::SymArgs a;
   a.pos = (const double4*)c->pos.p;
   a.vec = v;
-  a.counter = (unsigned int*)c->symbuf.p;
-  a.acc = (double*)((char*)c->symbuf.p + 256);
+  a.acc = (double*)c->symbuf.p;
   a.out = out;
   a.n = n;
   a.n_pad = n_pad;
@@ -202,14 +207,25 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out) {
   a.k = make_pair_consts(c->a);
   static int occ[2] = {0, 0};
   const void* fn = c->wall ? (const void*)rmb::sym_tt_kernel<true> : (const void*)rmb::sym_tt_kernel<false>;
-  long blocks = 256L * resident_blocks(fn, &occ[c->wall ? 1 : 0]);
-  const long need = (a.n_units + rmb::kSymWaves - 1) / rmb::kSymWaves;
+  int wps = resident_blocks(fn, &occ[c->wall ? 1 : 0]);
+  if (c->opt_sym_wps > 0 && c->opt_sym_wps < wps) wps = (int)c->opt_sym_wps;
+  // dynamic LDS padding pins residency to exactly `wps` workgroups per CU, so that the static schedule
+  // (equal steps per wave) is also equal work per SIMD
+  size_t pad = 0;
+  if (c->opt_sym_pin) {
+    const size_t per_block = (size_t)(160 * 1024) / (size_t)wps;
+    const size_t stat = sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
+    if (per_block > stat + 1024) pad = per_block - stat - 512;
+    if (pad > 48 * 1024) RMB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+  }
+  long blocks = 256L * wps;
+  const long need = (a.n_units * 64 + 255) / 256;   // at least one step per wave
   if (blocks > need) blocks = need;
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  if (c->wall) hipLaunchKernelGGL(rmb::sym_tt_kernel<true>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
-  else         hipLaunchKernelGGL(rmb::sym_tt_kernel<false>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+  if (c->wall) hipLaunchKernelGGL(rmb::sym_tt_kernel<true>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
+  else         hipLaunchKernelGGL(rmb::sym_tt_kernel<false>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
   const dim3 fgrid((unsigned)((n + 255) / 256));
@@ -402,6 +418,8 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "timing")) { c->opt_timing = value; return 0; }
   if (!strcmp(key, "symmetric")) { c->opt_symmetric = value; return 0; }
   if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
+  if (!strcmp(key, "sym_wps")) { c->opt_sym_wps = value; return 0; }
+  if (!strcmp(key, "sym_pin")) { c->opt_sym_pin = value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
 }
 

@@ -18,10 +18,13 @@
 // ds_read_b128 (48-byte records: conflict-free).  Diagonal units (I == J) run forward-only over
 // k = 1..63 (every ordered pair exactly once).  After 64 steps u_i (registers) and u_J (LDS) are flushed
 // to global SoA accumulators with global_atomic_add_f64; finalize adds the self term and scales.
-// Units are handed out dynamically (one agent-scope atomic counter), so all SIMDs finish together
-// whatever the clocks of their XCDs.  Summation order is therefore not fixed: results agree with the
-// deterministic sweep_kernel to rounding (~1e-15 relative) but are not bit-reproducible; the
-// "deterministic" context option selects sweep_kernel instead.
+// Schedule: static and exactly balanced -- the n_units x 64 rotation steps are cut into equal contiguous
+// ranges, one per resident wave (a range may start/end inside a unit), so every SIMD gets the same number
+// of steps and no work counter is needed (a single dequeue word saturates at ~88 dequeues/us, which is
+// about the unit rate of this kernel at N = 1e4).  Consecutive units share the row tile I, whose
+// accumulator stays in registers until the row changes.  The order in which the atomics land is not
+// fixed: results agree with the deterministic sweep_kernel to rounding (~1e-15 relative) but are not
+// bit-reproducible; the "deterministic" context option selects sweep_kernel instead.
 #pragma once
 #include "pair_ops.h"
 
@@ -30,8 +33,7 @@ namespace rmb {
 struct SymArgs {
   const double4* pos;   // [n] packed positions
   const double* vec;    // [3n] source vector (AoS)
-  double* acc;          // [3][n_pad] global SoA accumulators, zeroed before launch
-  unsigned int* counter;  // work counter, zeroed before launch
+  double* acc;          // [3][n_pad] global SoA accumulators; zero on entry, re-zeroed by finalize
   double* out;          // [3n] final output (AoS)
   long n;
   long n_pad;           // 64 * n_tiles
@@ -135,22 +137,45 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
   double* accj = accj_all[wave];
   const char* rec_bytes = reinterpret_cast<const char*>(rec);
 
-  for (;;) {
-    unsigned int u = 0;
-    if (lane == 0) u = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u = __builtin_amdgcn_readfirstlane(u);
-    if ((long)u >= a.n_units) break;
-    int I, J;
-    unit_to_tiles((long)u, a.n_tiles, I, J);
+  // Static, exactly balanced schedule: the n_units * 64 rotation steps are cut into gridDim.x * 4 equal
+  // contiguous ranges, one per wave; a range may begin and end inside a unit.
+  const long n_waves = (long)gridDim.x * kSymWaves;
+  const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long s_total = a.n_units * 64;
+  long s = (long)(((__int128)s_total * w) / n_waves);
+  const long s_end = (long)(((__int128)s_total * (w + 1)) / n_waves);
 
-    // own blob i -> registers
-    const long i = 64L * I + lane;
-    const bool vi_ok = i < a.n;
-    double xi = 1e100, yi = 1e100, zi = 1.0, vix = 0, viy = 0, viz = 0;
-    if (vi_ok) {
-      const double4 p = a.pos[i];
-      xi = p.x; yi = p.y; zi = p.z;
-      vix = a.vec[3 * i] * p.w; viy = a.vec[3 * i + 1] * p.w; viz = a.vec[3 * i + 2] * p.w;
+  int I_cur = -1;
+  long i = 0;
+  bool vi_ok = false;
+  double xi = 0, yi = 0, zi = 1.0, vix = 0, viy = 0, viz = 0;
+  Vec3 ui = {0.0, 0.0, 0.0};
+
+  while (s < s_end) {
+    const long u = s >> 6;
+    const int k0 = (int)(s & 63);
+    const long left = s_end - s;
+    const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    s += k1 - k0;
+    int I, J;
+    unit_to_tiles(u, a.n_tiles, I, J);
+
+    if (I != I_cur) {
+      if (I_cur >= 0 && vi_ok) {   // flush the previous row's accumulator
+        __hip_atomic_fetch_add(&a.acc[i], ui.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ui.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], ui.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      I_cur = I;
+      i = 64L * I + lane;
+      vi_ok = i < a.n;
+      xi = 1e100; yi = 1e100; zi = 1.0; vix = 0; viy = 0; viz = 0;
+      if (vi_ok) {
+        const double4 p = a.pos[i];
+        xi = p.x; yi = p.y; zi = p.z;
+        vix = a.vec[3 * i] * p.w; viy = a.vec[3 * i + 1] * p.w; viz = a.vec[3 * i + 2] * p.w;
+      }
+      ui.x = 0.0; ui.y = 0.0; ui.z = 0.0;
     }
     // tile J -> this wave's LDS slab (record l = blob 64 J + l), zero its accumulators
     {
@@ -170,9 +195,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    Vec3 ui = {0.0, 0.0, 0.0};
     if (I != J) {
-      for (int k = 0; k < 64; ++k) {
+      for (int k = k0; k < k1; ++k) {
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -183,32 +207,30 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
         __hip_atomic_fetch_add(&accj[64 + jj], ty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __hip_atomic_fetch_add(&accj[128 + jj], tz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-    } else {
-      for (int k = 1; k < 64; ++k) {
-        const int jj = (lane + k) & 63;
-        const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
-        const double2 q0 = r[0], q1 = r[1], q2 = r[2];
-        pair_tt<WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi + q1.x, q1.x, q1.y, q2.x, q2.y, ui);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    if (vi_ok) {
-      __hip_atomic_fetch_add(&a.acc[i], ui.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ui.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], ui.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (I != J) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const long j = 64L * J + lane;
       if (j < a.n) {
         __hip_atomic_fetch_add(&a.acc[j], accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&a.acc[a.n_pad + j], accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    } else {
+      // diagonal unit: every ordered pair of the tile once, forward only; step 0 is the self pair (skipped)
+      for (int k = (k0 > 1 ? k0 : 1); k < k1; ++k) {
+        const int jj = (lane + k) & 63;
+        const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
+        const double2 q0 = r[0], q1 = r[1], q2 = r[2];
+        pair_tt<WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi + q1.x, q1.x, q1.y, q2.x, q2.y, ui);
+      }
     }
     __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
+  }
+  if (I_cur >= 0 && vi_ok) {
+    __hip_atomic_fetch_add(&a.acc[i], ui.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ui.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], ui.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -217,6 +239,7 @@ __global__ __launch_bounds__(256) void sym_tt_finalize_kernel(const SymArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
+  a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;   // ready for the next product
   const double4 p = a.pos[i];
   const double b = p.w;
   self_term<KIND_TT, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);

@@ -157,7 +157,7 @@ def test_inputs_not_mutated_flat_and_strided_inputs(mob, oracle):
   u = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a, step=3, update_PC=1)   # extra kwargs ignored
   assert np.array_equal(r, r0) and np.array_equal(f, f0)
   for other in (u_view, u_flat, u_f):
-    assert np.array_equal(u, other)
+    assert rel_err(other, u) < 1e-14      # default tt path accumulates with atomics: equal to rounding
   assert u.dtype == np.float64 and u.flags["C_CONTIGUOUS"] and u.flags["OWNDATA"]
 
 
