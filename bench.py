@@ -123,13 +123,30 @@ def main():
   flops = FLOPS_PER_PAIR["tt_wall"] * pairs_per_launch
   achieved_tf = flops / (res["kern_ms"] * 1e-3) / 1e12
   alg_bytes = 48.0 * N + 24.0 * res["n_local"]       # read r,f of all sources; write u of own targets
+  traffic = args.traffic_bytes
+  if traffic is None:
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    try:
+      with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+        tj = json.load(fh)
+      key = "sym_tt_wall_N%d" % N if res["launch"]["chunks"] == 0 else "sweep_tt_wall_N%d" % N
+      cand = [v for k, v in tj.items() if k.endswith(key)]
+      if cand and world == 1:
+        traffic = cand[-1]["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+      traffic = None
+  sym = res["launch"]["chunks"] == 0
   roofline = {
-      "bound": "valu_fp64", "kernel": "rmb::sweep_kernel<TT,wall>",
+      "bound": "valu_fp64",
+      "kernel": "rmb::sym_tt_kernel<wall> (each unordered pair once)" if sym else "rmb::sweep_kernel<TT,wall>",
+      "note": "achieved = ALGORITHMIC flops (211 per ordered pair, the reference's as-written count, SURVEY 8d) / measured "
+              "kernel time; the kernel executes ~58 (symmetric) or ~93 (sweep) fp64 VALU instructions per ordered pair, so "
+              "frac can exceed 1; measured fp64 issue ceiling of the chip: 479 G wave-instr/s (profiles/r1_ubench_*)",
       "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
       "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
       "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_per_launch,
       "kernel_ms_avg": round(res["kern_ms"], 5), "launch": res["launch"],
-      "traffic": args.traffic_bytes,
+      "traffic": traffic,
       "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
               "achieved": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
