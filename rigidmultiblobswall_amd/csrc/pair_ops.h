@@ -68,6 +68,50 @@ __device__ __forceinline__ double rcp_f64(double x) {
   return __builtin_fma(y, p, y);
 }
 
+
+// Wall-correction polynomials of the tt block.  With tau = a^2/R^2, u = e_z^2, g = z_j/|R| (= h e_z),
+// w = g (e_z - g), q6 = e_z (e_z - g):
+//   G1 = (1+2w) + tau [ (2/3)(1-3u) + tau (2/3)(5u-1) ]
+//   G2 = (1-6w) + tau [ 2(5u-1) + tau (10/3)(1-7u) ]
+//   G3 = 2g(1-6 q6) + 4 e_z tau [ (5u-1) + (5/3) tau (2-7u) ]
+//   G4 = 2g - (20/3) e_z tau^2
+//   G5 = -[ 4g^2 + 4 tau ( u + tau (2/3 - 5u) ) ]
+// and  W = -G1 iR I - G2 iR e e^T + G3 iR e z^T + G4 iR z e^T + G5 iR z z^T      (times 1/(8 pi eta)).
+// Every fma below has at most one non-inline constant, so the compiler needs no VGPR copies of
+// constants (v_mov_b64 + v_fmac) in the pair loop.
+struct WallTT { double iR, iR2, G1, G2, G3, G4, G5; };
+
+__device__ __forceinline__ WallTT wall_tt_factors(const PairConsts& k, double rho2, double Rz, double zj) {
+  WallTT W;
+  const double R2 = __builtin_fma(Rz, Rz, rho2);
+  W.iR = rsqrt_f64(R2);
+  W.iR2 = W.iR * W.iR;
+  const double tau = k.a2 * W.iR2;
+  const double ez = Rz * W.iR;
+  const double g = zj * W.iR;
+  const double uu = ez * ez;
+  const double dd = ez - g;
+  const double w = g * dd;
+  const double q6 = ez * dd;
+  const double tau23 = tau * (2.0 / 3.0);
+  const double tau53 = tau * (5.0 / 3.0);
+  const double tau2 = tau + tau;
+  const double tau4 = tau * 4.0;
+  const double p5 = __builtin_fma(uu, 5.0, -1.0);     // 5u - 1
+  const double p3 = __builtin_fma(uu, -3.0, 1.0);     // 1 - 3u
+  const double p7 = __builtin_fma(uu, -7.0, 1.0);     // 1 - 7u
+  const double p7b = p7 + 1.0;                        // 2 - 7u
+  const double g2 = g + g;
+  W.G1 = __builtin_fma(tau23, __builtin_fma(tau, p5, p3), __builtin_fma(w, 2.0, 1.0));
+  W.G2 = __builtin_fma(tau2, __builtin_fma(tau53, p7, p5), __builtin_fma(w, -6.0, 1.0));
+  const double e4 = ez * tau4;                        // 4 e_z tau
+  W.G3 = __builtin_fma(e4, __builtin_fma(tau53, p7b, p5), g2 * __builtin_fma(q6, -6.0, 1.0));
+  W.G4 = __builtin_fma(-e4, tau53, g2);
+  const double ut = uu * tau;
+  W.G5 = -__builtin_fma(tau4, __builtin_fma(ut, -5.0, tau23) + uu, g2 * g2);
+  return W;
+}
+
 // ---------------------------------------------------------------------------------------------
 // tt:  u += [RPY_tt(d) + W_tt(d_x, d_y, R_z; z_j)] f          (common prefactor 1/(8 pi eta))
 // ---------------------------------------------------------------------------------------------
@@ -96,27 +140,12 @@ __device__ __forceinline__ void pair_tt(const PairConsts& k, double dx, double d
     u.y = __builtin_fma(cF, fy, u.y); u.y = __builtin_fma(cD, dy, u.y);
     u.z = __builtin_fma(cF, fz, u.z); u.z = __builtin_fma(cD, dz, u.z);
   } else {
-    const double R2 = __builtin_fma(Rz, Rz, rho2);
-    const double iR = rsqrt_f64(R2);
-    const double iR2 = iR * iR;
-    const double tau = k.a2 * iR2;
-    const double ez = Rz * iR;
-    const double g = zj * iR;        // h e_z
-    const double uu = ez * ez;
-    const double dd = ez - g;
-    const double w = g * dd;         // h (1-h) e_z^2
-    const double q6 = ez * dd;       // (1-h) e_z^2
-    const double G1 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(10.0 / 3.0, uu, -2.0 / 3.0), __builtin_fma(-2.0, uu, 2.0 / 3.0)), __builtin_fma(2.0, w, 1.0));
-    const double G2 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-70.0 / 3.0, uu, 10.0 / 3.0), __builtin_fma(10.0, uu, -2.0)), __builtin_fma(-6.0, w, 1.0));
-    const double g2 = g + g;
-    const double G3 = __builtin_fma(ez * tau, __builtin_fma(tau, __builtin_fma(-140.0 / 3.0, uu, 40.0 / 3.0), __builtin_fma(20.0, uu, -4.0)), g2 * __builtin_fma(-6.0, q6, 1.0));
-    const double G4 = __builtin_fma(-20.0 / 3.0 * ez, tau * tau, g2);
-    const double G5 = -__builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-20.0, uu, 8.0 / 3.0), 4.0 * uu), g2 * g2);
-    const double Rf = __builtin_fma(Rz, fz, pxy);
-    const double E = iR * Rf;
-    const double cR = __builtin_fma(G3, fz, -G2 * E) * iR2;
-    const double cb = __builtin_fma(G5, fz, G4 * E) * iR;
-    cF = __builtin_fma(-G1, iR, cF);
+    const WallTT W = wall_tt_factors(k, rho2, Rz, zj);
+    const double E = W.iR * __builtin_fma(Rz, fz, pxy);      // e.f
+    // coefficient of R: iR^2 (G3 f_z - G2 e.f);  of z: iR (G5 f_z + G4 e.f)
+    const double cR = __builtin_fma(W.G3, fz, -W.G2 * E) * W.iR2;
+    const double cb = __builtin_fma(W.G5, fz, W.G4 * E) * W.iR;
+    cF = __builtin_fma(-W.G1, W.iR, cF);
     const double cDR = cD + cR;
     u.x = __builtin_fma(cF, fx, u.x); u.x = __builtin_fma(cDR, dx, u.x);
     u.y = __builtin_fma(cF, fy, u.y); u.y = __builtin_fma(cDR, dy, u.y);

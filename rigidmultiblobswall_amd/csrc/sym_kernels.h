@@ -76,29 +76,17 @@ __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, doub
     ty = __builtin_fma(cDi, dy, cF * viy);
     tz = __builtin_fma(cDi, dz, cF * viz);
   } else {
-    const double R2 = __builtin_fma(Rz, Rz, rho2);
-    const double iR = rsqrt_f64(R2);
-    const double iR2 = iR * iR;
-    const double tau = k.a2 * iR2;
-    const double ez = Rz * iR;
-    const double g = zj * iR;
-    const double uu = ez * ez;
-    const double dd = ez - g;
-    const double w = g * dd;
-    const double q6 = ez * dd;
-    const double G1 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(10.0 / 3.0, uu, -2.0 / 3.0), __builtin_fma(-2.0, uu, 2.0 / 3.0)), __builtin_fma(2.0, w, 1.0));
-    const double G2 = __builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-70.0 / 3.0, uu, 10.0 / 3.0), __builtin_fma(10.0, uu, -2.0)), __builtin_fma(-6.0, w, 1.0));
-    const double g2 = g + g;
-    const double G3 = __builtin_fma(ez * tau, __builtin_fma(tau, __builtin_fma(-140.0 / 3.0, uu, 40.0 / 3.0), __builtin_fma(20.0, uu, -4.0)), g2 * __builtin_fma(-6.0, q6, 1.0));
-    const double G4 = __builtin_fma(-20.0 / 3.0 * ez, tau * tau, g2);
-    const double G5 = -__builtin_fma(tau, __builtin_fma(tau, __builtin_fma(-20.0, uu, 8.0 / 3.0), 4.0 * uu), g2 * g2);
-    cF = __builtin_fma(-G1, iR, cF);
-    const double nG2 = -G2 * iR;                       // (-G2) iR : multiplies R.v to give -G2 E
+    const WallTT W = wall_tt_factors(k, rho2, Rz, zj);
+    const double iR3 = W.iR * W.iR2;
+    cF = __builtin_fma(-W.G1, W.iR, cF);
+    const double nG2 = -W.G2 * iR3;      // coefficient of (R.v) R
+    const double G3r = W.G3 * W.iR2;     // G3 iR^2 : v_z R (forward)  /  (R.v) z (transposed)
+    const double G4r = W.G4 * W.iR2;     // G4 iR^2 : (R.v) z (forward) /  v_z R (transposed)
+    const double G5r = W.G5 * W.iR;      // G5 iR   : v_z z
     // forward: W v_j
     const double Rvj = __builtin_fma(Rz, vjz, pj);
-    const double cRj = __builtin_fma(G3, vjz, nG2 * Rvj) * iR2;
-    const double G4i = G4 * iR, G3i = G3 * iR;
-    const double cbj = __builtin_fma(G5, vjz, G4i * Rvj) * iR;
+    const double cRj = __builtin_fma(G3r, vjz, nG2 * Rvj);
+    const double cbj = __builtin_fma(G5r, vjz, G4r * Rvj);
     const double cj = cDj + cRj;
     ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cj, dx, ui.x);
     ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cj, dy, ui.y);
@@ -106,8 +94,8 @@ __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, doub
     ui.z = __builtin_fma(cRj, Rz, ui.z); ui.z += cbj;
     // transposed: W^T v_i  (f3 <-> f4)
     const double Rvi = __builtin_fma(Rz, viz, pi);
-    const double cRi = __builtin_fma(G4, viz, nG2 * Rvi) * iR2;
-    const double cbi = __builtin_fma(G5, viz, G3i * Rvi) * iR;
+    const double cRi = __builtin_fma(G4r, viz, nG2 * Rvi);
+    const double cbi = __builtin_fma(G5r, viz, G3r * Rvi);
     const double ci = cDi + cRi;
     tx = __builtin_fma(ci, dx, cF * vix);
     ty = __builtin_fma(ci, dy, cF * viy);
