@@ -48,11 +48,20 @@ def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, de
   r, f, eta, a = d2_cloud(n_blobs, seed=0)
   b, e, _ = partition(n_blobs, world, rank)
   sm.set_local_positions(torch.as_tensor(r[b:e].reshape(-1), device=device), n_blobs, a, wall=True)
-  f_local = torch.as_tensor(f[b:e].reshape(-1), device=device)
-  out = torch.empty(3 * (e - b), dtype=torch.float64, device=device)
+  if world == 1:
+    f_local = torch.as_tensor(f[b:e].reshape(-1), device=device)
+    out = torch.empty(3 * (e - b), dtype=torch.float64, device=device)
 
-  def step():
-    sm.matvec_local("tt", f_local, eta, out=out)
+    def step():
+      sm.matvec_local("tt", f_local, eta, out=out)
+  else:
+    # replicated vectors: every rank holds f and receives u; unordered pairs are sharded over the
+    # ranks (each pair evaluated once, applied to both blobs) and u is all-reduced (RCCL)
+    f_full = torch.as_tensor(f.reshape(-1), device=device)
+    out = torch.empty(3 * n_blobs, dtype=torch.float64, device=device)
+
+    def step():
+      sm.matvec_replicated("tt", f_full, eta, out=out)
 
   for _ in range(warmup):
     step()
@@ -102,10 +111,15 @@ def main():
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-  device = torch.device("cuda:%d" % local_rank)
+  # rehearsal on a 1-GPU box: RMB_BENCH_BACKEND=gloo lets several ranks share cuda:0 (RCCL refuses that)
+  backend_name = os.environ.get("RMB_BENCH_BACKEND", "nccl")
+  device = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))
   torch.cuda.set_device(device)
   if world > 1:
-    dist.init_process_group("nccl", device_id=device)
+    if backend_name == "nccl":
+      dist.init_process_group("nccl", device_id=device)
+    else:
+      dist.init_process_group(backend_name)
   assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
   from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
@@ -118,8 +132,8 @@ def main():
   ms_per_step = 1e3 * res["dt"] / args.steps
   value = args.steps / res["dt"]
 
-  # roofline of the dominant kernel: this rank's launch covers n_local targets x N sources
-  pairs_per_launch = float(res["n_local"]) * N
+  # roofline of the dominant kernel: one rank's launch covers 1/world of the N x N ordered pairs
+  pairs_per_launch = float(N) * N / world
   flops = FLOPS_PER_PAIR["tt_wall"] * pairs_per_launch
   achieved_tf = flops / (res["kern_ms"] * 1e-3) / 1e12
   alg_bytes = 48.0 * N + 24.0 * res["n_local"]       # read r,f of all sources; write u of own targets
@@ -159,7 +173,10 @@ def main():
       "dtype": "f64", "data": "synthetic",
       "config": {"workload": "configs[1]: %d random blobs above a wall (D2 cloud, 5%% volume fraction, seed 0), fp64, "
                              "single_wall_mobility_trans_times_force; vectors resident in HBM" % N,
-                 "n_blobs": N, "parallelism": "targets sharded over %d rank(s), all-gather of f per matvec" % world},
+                 "n_blobs": N,
+                 "parallelism": ("single GPU" if world == 1 else
+                                 "unordered blob pairs sharded over %d ranks (each pair once, both blobs updated), "
+                                 "f replicated, one RCCL all-reduce of u per matvec" % world)},
       "roofline": roofline,
   }
 
@@ -190,7 +207,7 @@ def main():
     sweep = []
     for nb, st, wu in ((100000, 5, 1), (1000000, 2, 1) if world > 1 else (262144, 3, 1)):
       rs = run_config(torch, dist, sm, backend, nb, st, wu, world, rank, device)
-      pairs = float(rs["n_local"]) * nb
+      pairs = float(nb) * nb / world
       sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
                     "kernel_ms_avg": round(rs["kern_ms"], 3),
                     "valu_fp64_tflops": round(211.0 * pairs / (rs["kern_ms"] * 1e-3) / 1e12, 2),

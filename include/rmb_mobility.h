@@ -83,6 +83,14 @@ int rmb_matvec(rmb_ctx* ctx, int kind, int in_plane, const double* vec_host, con
 int rmb_matvec_device(rmb_ctx* ctx, int kind, int in_plane, const double* vec_dev, const double* vec2_dev,
                       double eta, double* out_dev);
 
+/* Multi-GPU, symmetric pair sharding (RMB_TT, non-periodic): the unordered blob pairs are cut into
+ * `nshards` equal parts; this call evaluates part `shard` (each pair once, applied to both blobs) and
+ * writes its contribution to ALL n targets (3n doubles).  The sum over shards is the full product; the
+ * self term of target i is added by the shard that owns i in the contiguous block partition.  The
+ * caller all-reduces (or reduce-scatters) the outputs.  No reference counterpart (single device). */
+int rmb_matvec_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_dev, double eta, double* out_dev,
+                                long shard, long nshards);
+
 /* Blob-blob soft repulsion on the resident positions (multi_bodies/forces_numba.py:12-55,
  * forces_pycuda.py:66-118): out (n_targets,3).  Uses the UNCLAMPED positions: call
  * rmb_set_positions with wall = 0 first (the reference passes raw r_vectors). */

@@ -104,6 +104,20 @@ class MobilityContext(object):
                                            float(eta), ctypes.c_void_p(out.data_ptr())))
     return out
 
+  def matvec_pairshard_device(self, kind, vec, eta, shard, nshards, out=None):
+    """Contribution of pair-shard `shard` of `nshards` to ALL targets (3n entries); tt, non-periodic."""
+    import torch
+    k = _lib.KINDS[kind] if isinstance(kind, str) else int(kind)
+    if not _is_torch_cuda(vec) or vec.numel() != 3 * self.n or not vec.is_contiguous():
+      raise ValueError("vec must be a contiguous CUDA float64 tensor with 3*n entries")
+    if out is None:
+      out = torch.empty(3 * self.n, dtype=torch.float64, device=vec.device)
+    elif not _is_torch_cuda(out) or out.numel() != 3 * self.n or not out.is_contiguous():
+      raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n entries")
+    _lib.check(self._lib.rmb_matvec_pairshard_device(self._h, k, ctypes.c_void_p(vec.data_ptr()), float(eta),
+                                                     ctypes.c_void_p(out.data_ptr()), int(shard), int(nshards)))
+    return out
+
   def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
     out = np.empty(3 * self.n_targets)
     _lib.check(self._lib.rmb_blob_blob_force(self._h, float(repulsion_strength), float(debye_length),

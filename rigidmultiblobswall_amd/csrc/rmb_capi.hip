@@ -184,7 +184,7 @@ int check_ready(rmb_ctx* c) {
   return 0;
 }
 
-int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out) {
+int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out, long shard = 0, long nshards = 1) {
   const long n = c->n;
   const long tiles = (n + 63) / 64;
   const long n_pad = 64 * tiles;
@@ -203,6 +203,14 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out) {
   a.n_pad = n_pad;
   a.n_tiles = (int)tiles;
   a.n_units = tiles * (tiles + 1) / 2;
+  {
+    const __int128 s_total = (__int128)a.n_units * 64;
+    a.step_begin = (long)(s_total * shard / nshards);
+    a.step_end = (long)(s_total * (shard + 1) / nshards);
+    const long block = (n + nshards - 1) / nshards;       // same block partition as distributed.partition()
+    a.self_begin = block * shard < n ? block * shard : n;
+    a.self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
+  }
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
   static int occ[2] = {0, 0};
@@ -219,7 +227,7 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out) {
     if (pad > 48 * 1024) RMB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
   }
   long blocks = 256L * wps;
-  const long need = (a.n_units * 64 + 255) / 256;   // at least one step per wave
+  const long need = (a.step_end - a.step_begin + 255) / 256 > 0 ? (a.step_end - a.step_begin + 255) / 256 : 1;   // >= 64 steps per wave
   if (blocks > need) blocks = need;
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   int slot;
@@ -457,6 +465,19 @@ int rmb_set_target_range(rmb_ctx* c, long begin, long end) {
 
 int rmb_matvec_device(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out) {
   return matvec_device_impl(c, kind, in_plane, v, v2, eta, out);
+}
+
+int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards) {
+  if (int rc = check_ready(c)) return rc;
+  if (kind != rmb::KIND_TT) return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT only");
+  if (c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0) return fail(RMB_ERR_ARG, "pair sharding needs periodic_length = 0");
+  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
+  if (c->n == 0) return 0;
+  if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  c->last_path = 1;
+  return sym_tt_device(c, v, eta, out, shard, nshards);
 }
 
 int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out) {

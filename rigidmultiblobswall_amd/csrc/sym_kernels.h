@@ -39,6 +39,8 @@ struct SymArgs {
   long n_pad;           // 64 * n_tiles
   int n_tiles;
   long n_units;         // n_tiles (n_tiles + 1) / 2
+  long step_begin, step_end;  // rotation steps [begin, end) of the n_units*64 this launch covers (pair shard)
+  long self_begin, self_end;  // targets whose self term this launch adds (exactly one shard per target)
   double prefactor;
   PairConsts k;
 };
@@ -129,9 +131,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
   // contiguous ranges, one per wave; a range may begin and end inside a unit.
   const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
-  const long s_total = a.n_units * 64;
-  long s = (long)(((__int128)s_total * w) / n_waves);
-  const long s_end = (long)(((__int128)s_total * (w + 1)) / n_waves);
+  const long s_total = a.step_end - a.step_begin;
+  long s = a.step_begin + (long)(((__int128)s_total * w) / n_waves);
+  const long s_end = a.step_begin + (long)(((__int128)s_total * (w + 1)) / n_waves);
 
   int I_cur = -1;
   long i = 0;
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(256) void sym_tt_finalize_kernel(const SymArgs a) {
   a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;   // ready for the next product
   const double4 p = a.pos[i];
   const double b = p.w;
-  self_term<KIND_TT, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
+  if (i >= a.self_begin && i < a.self_end)
+    self_term<KIND_TT, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
   const double sc = a.prefactor * b;
   a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
 }

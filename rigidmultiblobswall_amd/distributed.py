@@ -55,6 +55,12 @@ class HipBackend(object):
   def blob_blob_force(self, eps, b, a, out=None):
     return self.ctx.blob_blob_force_device(eps, b, a, out=out, device=self.device)
 
+  def supports_pairshard(self, kind, periodic):
+    return kind == "tt" and not periodic
+
+  def matvec_pairshard(self, kind, v_full, eta, shard, nshards, out=None):
+    return self.ctx.matvec_pairshard_device(kind, v_full, eta, shard, nshards, out=out)
+
 
 class ShardedMobility(object):
   """M.v with targets sharded over the ranks of a process group."""
@@ -69,6 +75,7 @@ class ShardedMobility(object):
     self.begin = self.end = self.block = 0
     self._gather_buf = None
     self._gather_buf2 = None
+    self._periodic = False
 
   # -- helpers ----------------------------------------------------------------------------------
   def _all_gather_blocks(self, local_flat, buf):
@@ -102,6 +109,7 @@ class ShardedMobility(object):
                        (self.rank, self.begin, self.end, r_local.numel()))
     r_full, _ = self._all_gather_blocks(r_local, None)
     L = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
+    self._periodic = bool(np.any(L > 0))
     self.backend.set_positions(r_full.clone(), a, L, wall)
     self.backend.set_target_range(self.begin, self.end)
 
@@ -130,6 +138,26 @@ class ShardedMobility(object):
     u_local = self.matvec_local(kind, v[lo:hi], eta, None if v2 is None else v2[lo:hi], in_plane)
     u_full, _ = self._all_gather_blocks(u_local.view(-1), None)
     return u_full.clone()
+
+  def matvec_replicated(self, kind, v_full, eta, vec2_full=None, in_plane=False, out=None):
+    """Every rank holds the full source vector and receives the full product (the layout a replicated
+    Krylov loop wants: its dot products / axpys on 3N-vectors are negligible next to the O(N^2) sweep).
+      * tt, non-periodic: SYMMETRIC PAIR SHARDING -- rank g evaluates the g-th slice of the unordered
+        pairs once each (rmb_matvec_pairshard_device) into a full-length partial, then ONE all-reduce
+        (sum) of 24 N bytes.  Half the arithmetic of target sharding.
+      * other kinds / periodic: target sharding on the rank's block, then all-gather of the blocks."""
+    v = self._to_dev(v_full)
+    periodic = bool(self._periodic)
+    if (vec2_full is None and not in_plane and hasattr(self.backend, "supports_pairshard")
+        and self.backend.supports_pairshard(kind, periodic)):
+      part = self.backend.matvec_pairshard(kind, v, eta, self.rank, self.world, out=out)
+      if self.world > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+      return part
+    v2 = self._to_dev(vec2_full) if vec2_full is not None else None
+    u_local = self.backend.matvec(kind, v, eta, vec2_full=v2, in_plane=in_plane)
+    u_full, _ = self._all_gather_blocks(u_local.view(-1), None)
+    return u_full if self.world == 1 else u_full.clone()
 
   def blob_blob_force_local(self, eps, b, a):
     return self.backend.blob_blob_force(eps, b, a)

@@ -32,6 +32,20 @@ class OracleBackend(object):
     b, e = self.range
     return torch.from_numpy(u[3 * b:3 * e].copy())
 
+  # pair-shard stand-in: "shard g" = the contribution of source block g to all targets (self terms of
+  # block g included).  Like the HIP kernel's slices of unordered pairs, the shards sum to M.v.
+  def supports_pairshard(self, kind, periodic):
+    return kind == "tt" and not periodic
+
+  def matvec_pairshard(self, kind, v_full, eta, shard, nshards, out=None):
+    n = len(self.r)
+    b, e, _ = partition(n, nshards, shard)
+    v = np.zeros(3 * n)
+    v[3 * b:3 * e] = v_full.cpu().numpy()[3 * b:3 * e]
+    pre = "single_wall" if self.wall else "no_wall"
+    u = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(self.r, v, eta, self.a, periodic_length=self.L)
+    return torch.from_numpy(u.copy())
+
 
 def main():
   dist.init_process_group("gloo")
@@ -48,6 +62,14 @@ def main():
     u_local = sm.matvec_local("tt", v[b:e].reshape(-1), eta)
     assert u_local.numel() == 3 * (e - b)
     u_full = sm.matvec("rr", v.reshape(-1), eta)
+    # replicated-vector API: tt goes through pair sharding + all-reduce, rr through target sharding + all-gather
+    ref_tt_all = oracle.single_wall_mobility_trans_times_force_oracle(r, v, eta, a)
+    ref_rr_all = oracle.single_wall_mobility_rot_times_torque_oracle(r, v, eta, a)
+    u_rep_tt = sm.matvec_replicated("tt", v.reshape(-1), eta).numpy()
+    u_rep_rr = sm.matvec_replicated("rr", v.reshape(-1), eta).numpy()
+    assert u_rep_tt.shape == (3 * N,) and u_rep_rr.shape == (3 * N,)
+    assert np.abs(u_rep_tt - ref_tt_all).max() <= 1e-13 * max(1.0, np.abs(ref_tt_all).max())
+    assert np.abs(u_rep_rr - ref_rr_all).max() <= 1e-13 * max(1.0, np.abs(ref_rr_all).max())
     if rank == 0:
       ref_tt = oracle.single_wall_mobility_trans_times_force_oracle(r, v, eta, a)
       ref_rr = oracle.single_wall_mobility_rot_times_torque_oracle(r, v, eta, a)

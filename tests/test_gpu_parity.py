@@ -274,6 +274,47 @@ def test_symmetric_kernel_matches_deterministic_sweep(Ctx, oracle, wall, N):
   ctx.close()
 
 
+@pytest.mark.parametrize("G", [2, 3, 8])
+@pytest.mark.parametrize("wall", [True, False])
+def test_pair_shards_sum_to_full_product(Ctx, oracle, G, wall):
+  """What the G ranks of a pair-sharded job compute (rmb_matvec_pairshard_device), summed as the
+  all-reduce would, equals the single-GPU product; each shard's output covers all targets."""
+  import torch
+  N = 3001
+  r, f, eta, a = d1_cloud(N, seed=40)
+  ctx = Ctx(0)
+  ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+  ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda"), a, wall=wall)
+  fd = torch.as_tensor(f.reshape(-1), device="cuda")
+  total = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
+  norms = []
+  for g in range(G):
+    part = ctx.matvec_pairshard_device("tt", fd, eta, g, G)
+    norms.append(float(part.norm()))
+    total += part
+  full = ctx.matvec_device("tt", fd, eta)
+  torch.cuda.synchronize()
+  pre = "single_wall" if wall else "no_wall"
+  ref = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(r, f, eta, a)
+  assert rel_err(total.cpu().numpy(), ref) < TOL_D1
+  assert rel_err(total.cpu().numpy(), full.cpu().numpy()) < 1e-13
+  assert all(x > 0 for x in norms)
+  ctx.close()
+
+
+def test_sharded_replicated_world1(oracle):
+  import torch
+  from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
+  r, f, eta, a = d2_cloud(2000, seed=41)
+  sm = ShardedMobility(HipBackend("cuda:0"), device="cuda:0")
+  sm.set_positions(r, a, wall=True)
+  for kind, stem in (("tt", "trans_times_force"), ("rr", "rot_times_torque")):
+    u = sm.matvec_replicated(kind, f, eta)
+    torch.cuda.synchronize()
+    ref = getattr(oracle, "single_wall_mobility_%s_oracle" % stem)(r, f, eta, a)
+    assert rel_err(u.cpu().numpy(), ref) < TOL_D2
+
+
 def test_device_resident_path_and_timing(Ctx, oracle):
   import torch
   r, f, eta, a = d2_cloud(3000, seed=19)
