@@ -91,6 +91,14 @@ int rmb_matvec_device(rmb_ctx* ctx, int kind, int in_plane, const double* vec_de
 int rmb_matvec_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_dev, double eta, double* out_dev,
                                 long shard, long nshards);
 
+/* Dense translation-translation mobility of each rigid body's own blobs (building block of the
+ * block-diagonal preconditioner, multi_bodies/multi_bodies.py:516-531; replaces body/body.py:186-191 ->
+ * mobility/mobility.py:1018-1116 / :967-1013 called once per body in Python).  All listed bodies have
+ * n_b contiguous blobs starting at first_blob[k]; out[k] is the (3 n_b x 3 n_b) row-major block
+ * B M(z_eff) B of body k.  Device pointers, asynchronous.  Non-periodic. */
+int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, long n_bodies, int n_b, double eta,
+                                   double* out_dev);
+
 /* Blob-blob soft repulsion on the resident positions (multi_bodies/forces_numba.py:12-55,
  * forces_pycuda.py:66-118): out (n_targets,3).  Uses the UNCLAMPED positions: call
  * rmb_set_positions with wall = 0 first (the reference passes raw r_vectors). */

@@ -33,6 +33,7 @@ SYMBOLS = {
     "rmb_matvec_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
     "rmb_matvec_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_long,
                                                    ctypes.c_long]),
+    "rmb_body_mobility_dense_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_double, _vp]),
     "rmb_blob_blob_force": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_blob_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_timing_collect": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),

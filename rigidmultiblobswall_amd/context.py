@@ -118,6 +118,19 @@ class MobilityContext(object):
                                                      ctypes.c_void_p(out.data_ptr()), int(shard), int(nshards)))
     return out
 
+  def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
+    """Dense (3 n_b x 3 n_b) tt mobility of every listed body (int64 CUDA tensor of first-blob indices)."""
+    import torch
+    if not (isinstance(first_blob, torch.Tensor) and first_blob.is_cuda and first_blob.dtype == torch.int64):
+      raise ValueError("first_blob must be a CUDA int64 tensor")
+    first_blob = first_blob.contiguous()
+    nb = first_blob.numel()
+    if out is None:
+      out = torch.empty((nb, 3 * n_b, 3 * n_b), dtype=torch.float64, device=first_blob.device)
+    _lib.check(self._lib.rmb_body_mobility_dense_device(self._h, ctypes.c_void_p(first_blob.data_ptr()), nb, int(n_b),
+                                                        float(eta), ctypes.c_void_p(out.data_ptr())))
+    return out
+
   def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
     out = np.empty(3 * self.n_targets)
     _lib.check(self._lib.rmb_blob_blob_force(self._h, float(repulsion_strength), float(debye_length),

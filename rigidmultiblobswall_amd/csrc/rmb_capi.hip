@@ -13,6 +13,7 @@
 
 #include "matvec_kernels.h"
 #include "sym_kernels.h"
+#include "dense_kernels.h"
 
 namespace {
 
@@ -478,6 +479,29 @@ int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double et
   RMB_HIP(hipSetDevice(c->device));
   c->last_path = 1;
   return sym_tt_device(c, v, eta, out, shard, nshards);
+}
+
+int rmb_body_mobility_dense_device(rmb_ctx* c, const long* first_blob_dev, long n_bodies, int n_b, double eta,
+                                   double* out_dev) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 0 || n_b < 1) return fail(RMB_ERR_ARG, "bad n_bodies / blobs per body");
+  if (n_bodies == 0) return 0;
+  if (!first_blob_dev || !out_dev) return fail(RMB_ERR_ARG, "null pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  if (c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0) return fail(RMB_ERR_ARG, "dense body blocks are non-periodic");
+  RMB_HIP(hipSetDevice(c->device));
+  rmb::DenseArgs a;
+  a.pos = (const double4*)c->pos.p;
+  a.first_blob = first_blob_dev;
+  a.out = out_dev;
+  a.n_b = n_b;
+  a.n_bodies = n_bodies;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.k = make_pair_consts(c->a);
+  if (c->wall) hipLaunchKernelGGL(rmb::body_dense_tt_kernel<true>, dim3((unsigned)n_bodies), dim3(256), 0, c->stream, a);
+  else         hipLaunchKernelGGL(rmb::body_dense_tt_kernel<false>, dim3((unsigned)n_bodies), dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
 }
 
 int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out) {

@@ -1,0 +1,252 @@
+"""Device-resident rigid-multiblob mobility solve.
+
+The caller side of the hot path: what multi_bodies/multi_bodies.py:424-471 (`linear_operator_rigid`),
+:474-618 (block-diagonal preconditioner) and
+quaternion_integrator/quaternion_integrator_multi_bodies.py:1441-1547 (`solve_mobility_problem`) do
+with numpy + scipy on the host, here with every vector resident in HBM:
+
+    |  M   -K | |lambda|   | slip |          lambda : constraint forces on the blobs (3 N_blobs)
+    | -K^T  0 | |  U   | = |  -F  |          U      : (v, omega) of each body      (6 N_bodies)
+
+  * M.lambda is the HIP pair sweep (rmb_matvec_device, symmetric kernel) -- the only O(N^2) piece;
+  * K.U / K^T.lambda are batched (3 n_b x 6) products per body shape (torch.bmm);
+  * the preconditioner solves each body alone: dense per-body blob mobility built on the device
+    (rmb_body_mobility_dense_device), batched Cholesky, N = (K^T M^-1 K)^-1 (multi_bodies.py:516-531,
+    :548-560);
+  * right-preconditioned restarted GMRES(60), relative tolerance on the true residual, RHS normalised
+    to 1 (general_application_utils.py:514-627, quaternion_integrator_multi_bodies.py:1518-1537).
+    Krylov vectors stay on the device; per iteration only the new Hessenberg column crosses PCIe.
+
+PyTorch is used for device memory and batched small dense algebra only.
+"""
+import numpy as np
+import torch
+
+from .context import MobilityContext
+
+
+def quaternion_rotation_matrix(q):
+  """Rotation matrix of a unit quaternion (s, p) -- same convention as
+  quaternion_integrator/quaternion.py:41-51.  q: (..., 4) -> (..., 3, 3)."""
+  q = np.asarray(q, dtype=np.float64)
+  s, p0, p1, p2 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+  d = s * s - 0.5
+  R = np.empty(q.shape[:-1] + (3, 3))
+  R[..., 0, 0] = p0 * p0 + d;       R[..., 0, 1] = p0 * p1 - s * p2;  R[..., 0, 2] = p0 * p2 + s * p1
+  R[..., 1, 0] = p1 * p0 + s * p2;  R[..., 1, 1] = p1 * p1 + d;       R[..., 1, 2] = p1 * p2 - s * p0
+  R[..., 2, 0] = p2 * p0 - s * p1;  R[..., 2, 1] = p2 * p1 + s * p0;  R[..., 2, 2] = p2 * p2 + d
+  return 2.0 * R
+
+
+def blob_positions(reference_configuration, location, quaternion):
+  """r = ref . R(q)^T + location   (body/body.py:64-78)."""
+  R = quaternion_rotation_matrix(quaternion)
+  return np.asarray(reference_configuration) @ R.T + np.asarray(location)
+
+
+class _Group(object):
+  """All bodies that share one reference configuration size n_b."""
+  __slots__ = ("n_b", "body_idx", "first_blob", "blob_idx3", "K", "Minv", "Nbody", "Lchol")
+
+
+class RigidSuspension(object):
+  """Rigid bodies made of blobs, on one GPU.
+
+  reference_configurations: list with one (n_b, 3) array per body (bodies may differ in shape);
+  locations (n_bodies, 3); quaternions (n_bodies, 4) as (s, p1, p2, p3).  Blobs are numbered body after
+  body, as multi_bodies.py:194-204 does.
+  """
+
+  def __init__(self, reference_configurations, locations, quaternions, a, eta, wall=True, periodic_length=None,
+               device="cuda:0", ctx=None):
+    self.device = torch.device(device)
+    self.a, self.eta, self.wall = float(a), float(eta), bool(wall)
+    self.L = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
+    locations = np.asarray(locations, dtype=np.float64).reshape(-1, 3)
+    quaternions = np.asarray(quaternions, dtype=np.float64).reshape(-1, 4)
+    self.n_bodies = len(locations)
+    refs = [np.asarray(c, dtype=np.float64).reshape(-1, 3) for c in reference_configurations]
+    assert len(refs) == self.n_bodies
+    sizes = np.array([len(c) for c in refs])
+    first = np.concatenate([[0], np.cumsum(sizes)])
+    self.n_blobs = int(first[-1])
+    self.first_blob = first[:-1]
+    # blob coordinates, body after body
+    R = quaternion_rotation_matrix(quaternions)
+    r = np.empty((self.n_blobs, 3))
+    rel = np.empty((self.n_blobs, 3))
+    for k in range(self.n_bodies):
+      rk = refs[k] @ R[k].T
+      rel[first[k]:first[k + 1]] = rk
+      r[first[k]:first[k + 1]] = rk + locations[k]
+    self.r_vectors = r
+    self.ctx = ctx if ctx is not None else MobilityContext(self.device.index or 0)
+    self._own_ctx = ctx is None
+    if self.device.type == "cuda":
+      self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+    self.r_dev = torch.as_tensor(r.reshape(-1), device=self.device)
+    self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
+    # groups of equal n_b; K = [I, rot] with rot x = -(r x x)  (body/body.py:81-115)
+    self.groups = []
+    for n_b in sorted(set(sizes.tolist())):
+      g = _Group()
+      g.n_b = int(n_b)
+      idx = np.nonzero(sizes == n_b)[0]
+      g.body_idx = torch.as_tensor(idx, device=self.device, dtype=torch.int64)
+      g.first_blob = torch.as_tensor(first[idx], device=self.device, dtype=torch.int64)
+      blob = first[idx][:, None] + np.arange(n_b)[None, :]                       # (nb_g, n_b)
+      comp = (3 * blob[:, :, None] + np.arange(3)[None, None, :]).reshape(len(idx), 3 * n_b)
+      g.blob_idx3 = torch.as_tensor(comp, device=self.device, dtype=torch.int64)
+      rr = rel[blob.reshape(-1)].reshape(len(idx), n_b, 3)
+      K = np.zeros((len(idx), n_b, 3, 6))
+      K[:, :, 0, 0] = K[:, :, 1, 1] = K[:, :, 2, 2] = 1.0
+      K[:, :, 0, 4] = rr[:, :, 2];  K[:, :, 0, 5] = -rr[:, :, 1]
+      K[:, :, 1, 3] = -rr[:, :, 2]; K[:, :, 1, 5] = rr[:, :, 0]
+      K[:, :, 2, 3] = rr[:, :, 1];  K[:, :, 2, 4] = -rr[:, :, 0]
+      g.K = torch.as_tensor(K.reshape(len(idx), 3 * n_b, 6), device=self.device)
+      g.Minv = g.Nbody = g.Lchol = None
+      self.groups.append(g)
+    self.size = 3 * self.n_blobs + 6 * self.n_bodies
+    self.matvec_count = 0
+
+  def close(self):
+    if self._own_ctx:
+      self.ctx.close()
+
+  # ---- pieces of the operator -------------------------------------------------------------------
+  def mobility_times_lambda(self, lam):
+    self.matvec_count += 1
+    return self.ctx.matvec_device("tt", lam.contiguous(), self.eta)
+
+  def K_times_U(self, U):
+    """U (6 n_bodies,) -> (3 n_blobs,)   (multi_bodies.py:327-349)."""
+    U = U.view(self.n_bodies, 6)
+    out = torch.empty(3 * self.n_blobs, dtype=torch.float64, device=self.device)
+    for g in self.groups:
+      KU = torch.bmm(g.K, U[g.body_idx].unsqueeze(-1)).squeeze(-1)
+      out[g.blob_idx3.reshape(-1)] = KU.reshape(-1)
+    return out
+
+  def KT_times_lambda(self, lam):
+    """lambda (3 n_blobs,) -> (6 n_bodies,)   (multi_bodies.py:352-375)."""
+    out = torch.empty((self.n_bodies, 6), dtype=torch.float64, device=self.device)
+    for g in self.groups:
+      lg = lam[g.blob_idx3.reshape(-1)].view(len(g.body_idx), 3 * g.n_b, 1)
+      out[g.body_idx] = torch.bmm(g.K.transpose(1, 2), lg).squeeze(-1)
+    return out.reshape(-1)
+
+  def apply_operator(self, x):
+    """[lambda; U] -> [M lambda - K U; -K^T lambda]   (multi_bodies.py:424-471, no constraints)."""
+    n3 = 3 * self.n_blobs
+    lam, U = x[:n3], x[n3:]
+    top = self.mobility_times_lambda(lam) - self.K_times_U(U)
+    return torch.cat([top, -self.KT_times_lambda(lam)])
+
+  # ---- block-diagonal preconditioner ------------------------------------------------------------
+  def build_preconditioner(self):
+    """Per body: M_b (dense, device kernel), Cholesky, N_b = (K^T M_b^-1 K)^-1 (multi_bodies.py:516-531)."""
+    for g in self.groups:
+      Mb = self.ctx.body_mobility_dense_device(g.first_blob, g.n_b, self.eta)
+      Mb = 0.5 * (Mb + Mb.transpose(1, 2))
+      g.Lchol = torch.linalg.cholesky(Mb)
+      MinvK = torch.cholesky_solve(g.K, g.Lchol)
+      g.Nbody = torch.linalg.pinv(torch.bmm(g.K.transpose(1, 2), MinvK))
+    return self
+
+  def apply_preconditioner(self, x):
+    """Solve every body alone (multi_bodies.py:548-560):
+       Lt = M^-1 slip;  Y = N (-F - K^T Lt);  lambda = M^-1 (slip + K Y);  U = Y."""
+    n3 = 3 * self.n_blobs
+    out = torch.empty_like(x)
+    F = x[n3:].view(self.n_bodies, 6)
+    outU = out[n3:].view(self.n_bodies, 6)
+    for g in self.groups:
+      flat = g.blob_idx3.reshape(-1)
+      slip = x[:n3][flat].view(len(g.body_idx), 3 * g.n_b, 1)
+      Lt = torch.cholesky_solve(slip, g.Lchol)
+      Y = torch.bmm(g.Nbody, -F[g.body_idx].unsqueeze(-1) - torch.bmm(g.K.transpose(1, 2), Lt))
+      lam = torch.cholesky_solve(slip + torch.bmm(g.K, Y), g.Lchol)
+      out[:n3][flat] = lam.reshape(-1)
+      outU[g.body_idx] = Y.squeeze(-1)
+    return out
+
+  # ---- solve ------------------------------------------------------------------------------------
+  def solve_mobility_problem(self, slip=None, force_torque=None, tol=1e-8, restart=60, maxiter=1000, x0=None):
+    """Returns (velocities (n_bodies, 6), lambda (n_blobs, 3), info).  RHS = [slip, -F]
+    (quaternion_integrator_multi_bodies.py:1458-1475), normalised to 1 before GMRES (:1518-1521)."""
+    n3 = 3 * self.n_blobs
+    rhs = torch.zeros(self.size, dtype=torch.float64, device=self.device)
+    if slip is not None:
+      rhs[:n3] = torch.as_tensor(np.asarray(slip, dtype=np.float64).reshape(-1), device=self.device)
+    if force_torque is not None:
+      rhs[n3:] = -torch.as_tensor(np.asarray(force_torque, dtype=np.float64).reshape(-1), device=self.device)
+    if self.groups[0].Lchol is None:
+      self.build_preconditioner()
+    nrm = float(torch.linalg.norm(rhs))
+    if nrm == 0.0:
+      z = torch.zeros(self.size, dtype=torch.float64, device=self.device)
+      return z[n3:].view(-1, 6).cpu().numpy(), z[:n3].view(-1, 3).cpu().numpy(), dict(iterations=0, residual=0.0)
+    sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
+                                           restart=restart, maxiter=maxiter)
+    sol = sol * nrm
+    return sol[n3:].view(-1, 6).cpu().numpy(), sol[:n3].view(-1, 3).cpu().numpy(), info
+
+
+def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000):
+  """Solve A x = b with x = Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
+  Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after maxiter iterations in total.
+  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host."""
+  dev = b.device
+  n = b.numel()
+  bnorm = float(torch.linalg.norm(b))
+  y = torch.zeros(n, dtype=torch.float64, device=dev)
+  r = b.clone()
+  beta = bnorm
+  its = 0
+  res = beta / bnorm if bnorm > 0 else 0.0
+  history = []
+  while its < maxiter and res > tol:
+    m = min(restart, maxiter - its)
+    V = torch.empty((m + 1, n), dtype=torch.float64, device=dev)
+    V[0] = r / beta
+    H = np.zeros((m + 1, m))
+    cs, sn = np.zeros(m), np.zeros(m)
+    g = np.zeros(m + 1)
+    g[0] = beta
+    k_used = 0
+    for j in range(m):
+      w = A(Minv(V[j]))
+      Vj = V[:j + 1]
+      h = Vj @ w
+      w = w - Vj.t() @ h
+      h2 = Vj @ w
+      w = w - Vj.t() @ h2
+      hn = torch.linalg.norm(w)
+      col = torch.cat([h + h2, hn.reshape(1)]).cpu().numpy()      # the one host transfer of the iteration
+      H[:j + 2, j] = col
+      if col[-1] > 0:
+        V[j + 1] = w / hn
+      for i in range(j):                                           # previous rotations
+        t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
+        H[i + 1, j] = -sn[i] * H[i, j] + cs[i] * H[i + 1, j]
+        H[i, j] = t
+      d = np.hypot(H[j, j], H[j + 1, j])
+      cs[j], sn[j] = (H[j, j] / d, H[j + 1, j] / d) if d > 0 else (1.0, 0.0)
+      H[j, j] = d
+      H[j + 1, j] = 0.0
+      g[j + 1] = -sn[j] * g[j]
+      g[j] = cs[j] * g[j]
+      its += 1
+      k_used = j + 1
+      res = abs(g[j + 1]) / bnorm
+      history.append(res)
+      if res <= tol or col[-1] == 0:
+        break
+    coef = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used]) if k_used > 0 else np.zeros(0)
+    y = y + V[:k_used].t() @ torch.as_tensor(coef, device=dev)
+    if res > tol and its < maxiter:                                # restart: true residual
+      r = b - A(Minv(y))
+      beta = float(torch.linalg.norm(r))
+      res = beta / bnorm
+  x = Minv(y)
+  return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history)
