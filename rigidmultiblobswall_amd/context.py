@@ -35,6 +35,8 @@ class MobilityContext(object):
     self.n_targets = 0
     self.target_range = (0, 0)
     self._keepalive = None
+    self._tstream = None       # torch.cuda.Stream our device-path kernels run on (created lazily)
+    self._user_stream = False  # True once set_stream() was called: the caller owns the ordering
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h.value:
@@ -49,7 +51,31 @@ class MobilityContext(object):
 
   # --- configuration ---------------------------------------------------------------------------
   def set_stream(self, stream_ptr):
+    """Enqueue on a caller-owned hipStream_t.  The caller is then responsible for ordering against the
+    producers/consumers of the device buffers it passes (see _enter for why stream 0 is not enough)."""
     _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+    self._user_stream = True
+
+  # Ordering of the device path against PyTorch.  Handing torch's "current stream" handle (0 for the
+  # default stream) to the C ABI is NOT sufficient: torch's stream 0 and this library's stream 0 are
+  # not the same queue on ROCm (measured: a GMRES loop mixing torch kernels and rmb_matvec_device on
+  # handle 0 raced).  So device-path calls run on a stream created by torch and are fenced with events
+  # on both sides (wait_stream) -- asynchronous, no host synchronisation.
+  def _enter(self):
+    if self._user_stream:
+      return None
+    import torch
+    dev = torch.device("cuda", self.device)
+    if self._tstream is None:
+      self._tstream = torch.cuda.Stream(device=dev)
+      _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(self._tstream.cuda_stream)))
+    self._tstream.wait_stream(torch.cuda.current_stream(dev))
+    return dev
+
+  def _exit(self, dev):
+    if dev is not None:
+      import torch
+      torch.cuda.current_stream(dev).wait_stream(self._tstream)
 
   def set_option(self, key, value):
     _lib.check(self._lib.rmb_ctx_set_option(self._h, key.encode(), int(value)))
@@ -60,8 +86,10 @@ class MobilityContext(object):
     if _is_torch_cuda(r_vectors):
       r = r_vectors.contiguous().view(-1)
       n = r.numel() // 3
+      dev = self._enter()
       _lib.check(self._lib.rmb_set_positions_device(self._h, ctypes.c_void_p(r.data_ptr()), n, float(a), _ptr(L),
                                                     int(bool(wall))))
+      self._exit(dev)
       self._keepalive = r
     else:
       r = _as_f64(r_vectors)
@@ -99,9 +127,11 @@ class MobilityContext(object):
       out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=vec.device)
     elif not _is_torch_cuda(out) or out.numel() != 3 * self.n_targets or not out.is_contiguous():
       raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n_targets entries")
+    dev = self._enter()
     _lib.check(self._lib.rmb_matvec_device(self._h, k, int(bool(in_plane)), ctypes.c_void_p(vec.data_ptr()),
                                            ctypes.c_void_p(vec2.data_ptr()) if vec2 is not None else None,
                                            float(eta), ctypes.c_void_p(out.data_ptr())))
+    self._exit(dev)
     return out
 
   def matvec_pairshard_device(self, kind, vec, eta, shard, nshards, out=None):
@@ -114,8 +144,10 @@ class MobilityContext(object):
       out = torch.empty(3 * self.n, dtype=torch.float64, device=vec.device)
     elif not _is_torch_cuda(out) or out.numel() != 3 * self.n or not out.is_contiguous():
       raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n entries")
+    dev = self._enter()
     _lib.check(self._lib.rmb_matvec_pairshard_device(self._h, k, ctypes.c_void_p(vec.data_ptr()), float(eta),
                                                      ctypes.c_void_p(out.data_ptr()), int(shard), int(nshards)))
+    self._exit(dev)
     return out
 
   def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
@@ -127,8 +159,10 @@ class MobilityContext(object):
     nb = first_blob.numel()
     if out is None:
       out = torch.empty((nb, 3 * n_b, 3 * n_b), dtype=torch.float64, device=first_blob.device)
+    dev = self._enter()
     _lib.check(self._lib.rmb_body_mobility_dense_device(self._h, ctypes.c_void_p(first_blob.data_ptr()), nb, int(n_b),
                                                         float(eta), ctypes.c_void_p(out.data_ptr())))
+    self._exit(dev)
     return out
 
   def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
@@ -141,8 +175,10 @@ class MobilityContext(object):
     import torch
     if out is None:
       out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=device or ("cuda:%d" % self.device))
+    dev = self._enter()
     _lib.check(self._lib.rmb_blob_blob_force_device(self._h, float(repulsion_strength), float(debye_length),
                                                     float(blob_radius), ctypes.c_void_p(out.data_ptr())))
+    self._exit(dev)
     return out
 
   # --- measurement -----------------------------------------------------------------------------

@@ -34,16 +34,15 @@ def partition(n, world_size, rank):
 
 
 class HipBackend(object):
-  """Per-rank compute on one MI355X through the C ABI; enqueues on torch's current stream."""
+  """Per-rank compute on one MI355X through the C ABI."""
 
   def __init__(self, device):
     self.device = torch.device(device)
     idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-    self.ctx = MobilityContext(idx)
-    self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+    self.ctx = MobilityContext(idx)   # device-path calls run on the context's own stream, event-fenced
+                                      # against torch's current stream (context.MobilityContext._enter)
 
   def set_positions(self, r_full, a, L, wall):
-    self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
     self.ctx.set_positions(r_full, a, L, wall)
 
   def set_target_range(self, begin, end):

@@ -82,8 +82,6 @@ class RigidSuspension(object):
     self.r_vectors = r
     self.ctx = ctx if ctx is not None else MobilityContext(self.device.index or 0)
     self._own_ctx = ctx is None
-    if self.device.type == "cuda":
-      self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
     self.r_dev = torch.as_tensor(r.reshape(-1), device=self.device)
     self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
     # groups of equal n_b; K = [I, rot] with rot x = -(r x x)  (body/body.py:81-115)

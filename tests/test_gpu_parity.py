@@ -283,7 +283,6 @@ def test_pair_shards_sum_to_full_product(Ctx, oracle, G, wall):
   N = 3001
   r, f, eta, a = d1_cloud(N, seed=40)
   ctx = Ctx(0)
-  ctx.set_stream(torch.cuda.current_stream().cuda_stream)
   ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda"), a, wall=wall)
   fd = torch.as_tensor(f.reshape(-1), device="cuda")
   total = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
@@ -319,7 +318,6 @@ def test_device_resident_path_and_timing(Ctx, oracle):
   import torch
   r, f, eta, a = d2_cloud(3000, seed=19)
   ctx = Ctx(0)
-  ctx.set_stream(torch.cuda.current_stream().cuda_stream)
   ctx.set_option("timing", 1)
   rd = torch.as_tensor(r, device="cuda")
   fd = torch.as_tensor(f.reshape(-1), device="cuda")
@@ -332,6 +330,26 @@ def test_device_resident_path_and_timing(Ctx, oracle):
   assert rel_err(out.cpu().numpy(), ref) < TOL_D2
   ms = ctx.timing_collect()
   assert len(ms) == 3 and np.all(ms > 0)
+  ctx.close()
+
+
+def test_device_path_is_ordered_against_torch_kernels(Ctx, oracle):
+  """Regression: torch kernels produce the input and consume the output of rmb_matvec_device with no
+  host synchronisation in between (what a device-resident Krylov loop does)."""
+  import torch
+  r, f, eta, a = d2_cloud(2500, seed=50)
+  ctx = Ctx(0)
+  ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda"), a, wall=True)
+  base = torch.as_tensor(f.reshape(-1), device="cuda")
+  acc = torch.zeros_like(base)
+  for k in range(20):
+    v = base * float(k + 1) + 0.0          # produced by a torch kernel right before the call
+    u = ctx.matvec_device("tt", v, eta)
+    acc += u / float(k + 1)                # consumed by a torch kernel right after
+    del v, u
+  torch.cuda.synchronize()
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  assert rel_err(acc.cpu().numpy() / 20.0, ref) < TOL_D2
   ctx.close()
 
 

@@ -9,7 +9,6 @@ from bench import d2_cloud
 def run(N, opts, reps=30):
   r, f, eta, a = d2_cloud(N)
   ctx = MobilityContext(0)
-  ctx.set_stream(torch.cuda.current_stream().cuda_stream)
   ctx.set_option("timing", 1)
   for k, v in opts.items():
     ctx.set_option(k, v)
