@@ -89,7 +89,9 @@ def test_config3_roller_shells_gmres(oracle, n_bodies):
   if n_bodies <= 30:
     # small case: dense direct solve with the oracle's M as ground truth
     N = rs.n_blobs
-    M = oracle.dense("tt", 1, rs.r_vectors, eta, a)
+    r_eff, bdiag, _ = oracle.wall_regularisation(rs.r_vectors, a)   # lowest blobs sit below z = a
+    B = np.repeat(bdiag, 3)
+    M = B[:, None] * oracle.dense("tt", 1, r_eff, eta, a) * B[None, :]
     K = np.zeros((3 * N, 6 * n_bodies))
     for k in range(n_bodies):
       K[36 * k:36 * (k + 1), 6 * k:6 * k + 6] = rs.groups[0].K[k].cpu().numpy()
