@@ -1,0 +1,97 @@
+"""Lanczos stochastic forcing  factor * M^{1/2} z, device resident.
+
+Same contract as stochastic_forcing/stochastic_forcing.py:112-264 (`stochastic_forcing_lanczos`): one
+M.v product per iteration, stop when the relative change of the noise estimate drops below
+`tolerance` (:239-255), return (noise, iterations); optional `L_mult` applied to the result.
+
+Differences in HOW:
+  * the Krylov basis lives in one pre-allocated device matrix (the reference grows it with
+    np.concatenate every iteration, :237) and is re-orthogonalised with two classical Gram-Schmidt
+    passes = two GEMVs (the reference loops over all previous rows in Python, :233-234);
+  * the noise estimate V^T (Q sqrt(L) Q^T e_1) |z| factor is NOT formed every iteration: with an
+    orthonormal basis, |noise_i - noise_{i-1}| equals the norm of the difference of the small
+    coefficient vectors, so the convergence test is O(i) host work on the (tiny) tridiagonal
+    eigen-problem and the 3N-vector is assembled once at the end (the reference does a dense `eigh`
+    plus a V^T product per iteration, :215-229);
+  * per iteration two scalars (h_ii, h_i+1,i) cross PCIe.
+"""
+import numpy as np
+import torch
+
+
+def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=None, mobility=None,
+                               mobility_mult=None, L_mult=None, z=None, print_residual=False, device=None):
+  """mobility_mult: callable(torch tensor (dim,)) -> torch tensor (dim,) on the same device
+  (e.g. lambda v: ctx.matvec_device('tt', v, eta)); or `mobility` = dense torch/numpy matrix.
+  z: numpy array or torch tensor; drawn from N(0,1) when None.  Returns (noise tensor, iterations)."""
+  if z is not None and dim is None:
+    dim = int(z.numel() if isinstance(z, torch.Tensor) else np.size(z))
+  if isinstance(z, torch.Tensor) and device is None:
+    device = z.device
+  if device is None:
+    device = mobility.device if isinstance(mobility, torch.Tensor) else torch.device("cpu")
+  device = torch.device(device)
+  if factor == 0.0:
+    return torch.zeros(dim, dtype=torch.float64, device=device), 0
+  if z is None:
+    z = torch.randn(dim, dtype=torch.float64, device=device)
+  z = torch.as_tensor(z, dtype=torch.float64, device=device).reshape(-1).clone()
+  if mobility is not None:
+    Mt = torch.as_tensor(mobility, dtype=torch.float64, device=device)
+    mobility_mult = lambda v: Mt @ v  # noqa: E731
+
+  cap = min(max_iter + 2, 64)
+  V = torch.empty((cap, dim), dtype=torch.float64, device=device)
+  v_norm = float(torch.linalg.norm(z))
+  V[0] = z / v_norm
+  h_diag, h_sup = [], []
+  coef_old = None
+  coef = None
+  its = max_iter
+  for i in range(max_iter + 1):
+    w = mobility_mult(V[i]).reshape(-1)
+    if i > 0:
+      w = w - h_sup[i - 1] * V[i - 1]
+    hd = torch.dot(w, V[i])
+    w = w - hd * V[i]
+    hs = torch.linalg.norm(w)
+    hd_f, hs_f = (float(x) for x in torch.stack([hd, hs]).cpu())
+    h_diag.append(hd_f)
+    h_sup.append(hs_f)
+    if hs_f > 0:
+      w = w / hs_f
+    else:
+      w = torch.zeros_like(w)
+      w[0] = 1.0
+    # small symmetric tridiagonal eigenproblem on the host (size i+1)
+    k = i + 1
+    H = np.diag(h_diag) + np.diag(h_sup[:k - 1], -1) + np.diag(h_sup[:k - 1], 1)
+    lam, Q = np.linalg.eigh(H)
+    coef = Q @ (np.sqrt(np.maximum(lam, 0.0)) * Q[0, :]) * (v_norm * factor)     # noise = V[:k]^T coef
+    # full re-orthogonalisation of the new basis vector (two classical Gram-Schmidt passes)
+    Vk = V[:k]
+    w = w - Vk.t() @ (Vk @ w)
+    w = w - Vk.t() @ (Vk @ w)
+    if k + 1 > cap:
+      cap = min(2 * cap, max_iter + 2)
+      Vn = torch.empty((cap, dim), dtype=torch.float64, device=device)
+      Vn[:k] = V[:k]
+      V = Vn
+    V[k] = w
+    if i > 0:
+      old = np.concatenate([coef_old, [0.0]])
+      old_norm = np.linalg.norm(old)
+      diff = np.linalg.norm(coef - old)
+      if print_residual:
+        if i == 1:
+          print('lanczos =  0 1')
+        print('lanczos = ', i, diff / old_norm)
+      if diff / max(old_norm, np.finfo(float).eps) < tolerance:
+        its = i
+        break
+    coef_old = coef
+  k = len(coef)
+  noise = V[:k].t() @ torch.as_tensor(coef, dtype=torch.float64, device=device)
+  if L_mult is not None:
+    noise = L_mult(noise).reshape(-1)
+  return noise, its

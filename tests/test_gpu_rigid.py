@@ -102,3 +102,43 @@ def test_config3_roller_shells_gmres(oracle, n_bodies):
     # rollers driven by a torque about +y translate along +x on average (the roller instability's base flow)
     assert U[:, 0].mean() > 0
   rs.close()
+
+
+def test_lanczos_golden_on_gpu():
+  """Reference Lanczos output (golden g6) with the HIP matvec as mobility_mult, vectors on the device."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  from rigidmultiblobswall_amd.stochastic import stochastic_forcing_lanczos
+  d = np.load(os.path.join(GOLDEN, "g6_lanczos.npz"))
+  eta, a = float(d["eta"]), float(d["a"])
+  ctx = MobilityContext(0)
+  ctx.set_positions(torch.as_tensor(d["r_vectors"].reshape(-1), device="cuda"), a, wall=True)
+  for tol in (1e-6, 1e-10):
+    noise, its = stochastic_forcing_lanczos(factor=0.7, tolerance=tol, z=torch.as_tensor(d["z"], device="cuda"),
+                                            mobility_mult=lambda v: ctx.matvec_device("tt", v.contiguous(), eta))
+    assert abs(its - int(d["iterations_tol%g" % tol])) <= 1
+    assert rel_err(noise.cpu().numpy(), d["noise_tol%g" % tol]) < 20 * tol
+  ctx.close()
+
+
+@pytest.mark.parametrize("N", [20000, 262144])
+def test_lanczos_large_covariance_identity(N):
+  """configs[4]-sized Brownian forcing (2.6e5 blobs): |M^1/2 z|^2 == z.M.z, the defining property."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  from test_gpu_parity import d2_cloud
+  r, _, eta, a = d2_cloud(N, seed=60)
+  ctx = MobilityContext(0)
+  ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda"), a, wall=True)
+  from rigidmultiblobswall_amd.stochastic import stochastic_forcing_lanczos
+  z = torch.randn(3 * N, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+  mult = lambda v: ctx.matvec_device("tt", v.contiguous(), eta)  # noqa: E731
+  t0 = time.time()
+  noise, its = stochastic_forcing_lanczos(factor=1.0, tolerance=1e-8, mobility_mult=mult, z=z)
+  torch.cuda.synchronize()
+  dt = time.time() - t0
+  zMz = float(torch.dot(z, mult(z)))
+  nn = float(torch.dot(noise, noise))
+  print("lanczos N=%d iterations=%d time=%.3fs  |M^1/2 z|^2 / z.M.z - 1 = %.2e" % (N, its, dt, nn / zMz - 1))
+  assert its < 60 and abs(nn / zMz - 1) < 1e-6
+  ctx.close()

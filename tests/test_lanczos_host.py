@@ -1,0 +1,41 @@
+"""Lanczos M^{1/2} z (row N2) on CPU tensors against the reference's own Lanczos output (golden g6:
+stochastic_forcing/stochastic_forcing.py run in the build container) and the exact square root."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+
+@pytest.fixture(scope="module")
+def g6():
+  d = np.load(os.path.join(GOLDEN, "g6_lanczos.npz"))
+  return {k: d[k] for k in d.files}
+
+
+@pytest.mark.parametrize("tol", [1e-6, 1e-10])
+def test_matches_reference_lanczos(g6, oracle, tol):
+  from rigidmultiblobswall_amd.stochastic import stochastic_forcing_lanczos
+  r, eta, a = g6["r_vectors"], float(g6["eta"]), float(g6["a"])
+  mult = lambda v: torch.from_numpy(oracle.single_wall_mobility_trans_times_force_oracle(r, v.numpy(), eta, a))  # noqa: E731
+  noise, its = stochastic_forcing_lanczos(factor=0.7, tolerance=tol, mobility_mult=mult, z=g6["z"])
+  ref_its = int(g6["iterations_tol%g" % tol])
+  assert abs(its - ref_its) <= 1, (its, ref_its)
+  assert rel_err(noise.numpy(), g6["noise_tol%g" % tol]) < 20 * tol
+  assert rel_err(noise.numpy(), g6["noise_exact"]) < 50 * tol
+
+
+def test_dense_matrix_argument_and_zero_factor(g6, oracle):
+  from rigidmultiblobswall_amd.stochastic import stochastic_forcing_lanczos
+  M = oracle.dense("tt", 1, g6["r_vectors"], float(g6["eta"]), float(g6["a"]))
+  noise, its = stochastic_forcing_lanczos(factor=0.7, tolerance=1e-9, mobility=M, z=g6["z"])
+  assert rel_err(noise.numpy(), g6["noise_exact"]) < 1e-7
+  zero, n0 = stochastic_forcing_lanczos(factor=0.0, dim=180, mobility=M)
+  assert n0 == 0 and float(zero.abs().max()) == 0.0
+  # covariance property: <(M^1/2 z)(M^1/2 z)^T> = M  ->  check  z1.M.z2 = (M^1/2 z1).(M^1/2 z2)
+  z2 = np.random.RandomState(2).randn(180)
+  n2, _ = stochastic_forcing_lanczos(factor=1.0, tolerance=1e-10, mobility=M, z=z2)
+  n1, _ = stochastic_forcing_lanczos(factor=1.0, tolerance=1e-10, mobility=M, z=g6["z"])
+  assert abs(float(n1 @ n2) - g6["z"] @ M @ z2) < 1e-7 * abs(g6["z"] @ M @ z2)
