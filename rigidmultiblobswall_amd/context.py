@@ -64,7 +64,12 @@ class MobilityContext(object):
   def _enter(self):
     if self._user_stream:
       return None
+    import os
     import torch
+    if os.environ.get("RMB_NO_FENCE") == "1":   # experiment switch: enqueue on torch's current stream handle, no events
+      dev = torch.device("cuda", self.device)
+      _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+      return None
     dev = torch.device("cuda", self.device)
     if self._tstream is None:
       self._tstream = torch.cuda.Stream(device=dev)

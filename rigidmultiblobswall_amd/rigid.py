@@ -11,8 +11,8 @@ with numpy + scipy on the host, here with every vector resident in HBM:
   * M.lambda is the HIP pair sweep (rmb_matvec_device, symmetric kernel) -- the only O(N^2) piece;
   * K.U / K^T.lambda are batched (3 n_b x 6) products per body shape (torch.bmm);
   * the preconditioner solves each body alone: dense per-body blob mobility built on the device
-    (rmb_body_mobility_dense_device), batched Cholesky, N = (K^T M^-1 K)^-1 (multi_bodies.py:516-531,
-    :548-560);
+    (rmb_body_mobility_dense_device), batched Cholesky -> explicit M_b^-1, N = (K^T M_b^-1 K)^-1
+    (multi_bodies.py:516-531), applied with batched GEMMs only (:548-560);
   * right-preconditioned restarted GMRES(60), relative tolerance on the true residual, RHS normalised
     to 1 (general_application_utils.py:514-627, quaternion_integrator_multi_bodies.py:1518-1537).
     Krylov vectors stay on the device; per iteration only the new Hessenberg column crosses PCIe.
@@ -147,8 +147,14 @@ class RigidSuspension(object):
       Mb = self.ctx.body_mobility_dense_device(g.first_blob, g.n_b, self.eta)
       Mb = 0.5 * (Mb + Mb.transpose(1, 2))
       g.Lchol = torch.linalg.cholesky(Mb)
-      MinvK = torch.cholesky_solve(g.K, g.Lchol)
-      g.Nbody = torch.linalg.pinv(torch.bmm(g.K.transpose(1, 2), MinvK))
+      # explicit inverse, as the reference stores it (mobility_inv_blobs, multi_bodies.py:524): applying
+      # the preconditioner is then pure batched GEMM.  (Back-to-back batched cholesky_solve calls inside
+      # the Krylov loop were observed to race on ROCm 7.0 torch; bmm does not.)
+      g.Minv = torch.cholesky_inverse(g.Lchol)
+      g.Minv = 0.5 * (g.Minv + g.Minv.transpose(1, 2))
+      g.Nbody = torch.linalg.pinv(torch.bmm(g.K.transpose(1, 2), torch.bmm(g.Minv, g.K)))
+    if self.device.type == "cuda":
+      torch.cuda.synchronize(self.device)
     return self
 
   def apply_preconditioner(self, x):
@@ -161,9 +167,9 @@ class RigidSuspension(object):
     for g in self.groups:
       flat = g.blob_idx3.reshape(-1)
       slip = x[:n3][flat].view(len(g.body_idx), 3 * g.n_b, 1)
-      Lt = torch.cholesky_solve(slip, g.Lchol)
+      Lt = torch.bmm(g.Minv, slip)
       Y = torch.bmm(g.Nbody, -F[g.body_idx].unsqueeze(-1) - torch.bmm(g.K.transpose(1, 2), Lt))
-      lam = torch.cholesky_solve(slip + torch.bmm(g.K, Y), g.Lchol)
+      lam = torch.bmm(g.Minv, slip + torch.bmm(g.K, Y))
       out[:n3][flat] = lam.reshape(-1)
       outU[g.body_idx] = Y.squeeze(-1)
     return out
