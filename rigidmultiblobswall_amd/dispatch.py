@@ -1,0 +1,50 @@
+"""String dispatch of the blob-level backends.
+
+The reference selects implementations by strings from the input deck:
+  mobility_vector_prod_implementation -> multi_bodies/multi_bodies.py:233-287
+  blob_blob_force_implementation      -> multi_bodies/multi_bodies_functions.py:249-278
+  mobility_blobs_implementation       -> multi_bodies/multi_bodies.py:207-230
+These functions add the `hip*` strings and return callables with the reference's signatures.  With
+`accept_reference_gpu_names=True` the reference's own GPU strings (`pycuda`, `pycuda_no_wall`) are
+served by the HIP engine too, so an existing deck runs unchanged.
+"""
+import numpy as np
+
+from . import forces as _forces
+from . import mobility as _mob
+
+
+def set_mobility_vector_prod(implementation, accept_reference_gpu_names=False, *args, **kwargs):
+  table = {
+      "hip": _mob.single_wall_mobility_trans_times_force_hip,
+      "hip_no_wall": _mob.no_wall_mobility_trans_times_force_hip,
+      "hip_in_plane": _mob.in_plane_mobility_trans_times_force_hip,
+  }
+  if accept_reference_gpu_names:
+    table["pycuda"] = table["hip"]
+    table["pycuda_no_wall"] = table["hip_no_wall"]
+  if implementation not in table:
+    raise ValueError("mobility_vector_prod_implementation %r is not served by the HIP engine (known: %s)" %
+                     (implementation, ", ".join(sorted(table))))
+  return table[implementation]
+
+
+def _zero_forces(r_vectors, *args, **kwargs):
+  return np.zeros((np.size(r_vectors) // 3, 3))
+
+
+def set_blob_blob_forces(implementation, accept_reference_gpu_names=False, *args, **kwargs):
+  table = {"None": _zero_forces, "hip": _forces.calc_blob_blob_forces_hip}
+  if accept_reference_gpu_names:
+    table["pycuda"] = table["hip"]
+  if implementation not in table:
+    raise ValueError("blob_blob_force_implementation %r is not served by the HIP engine" % (implementation,))
+  return table[implementation]
+
+
+def set_mobility_blobs(implementation, *args, **kwargs):
+  """Dense (3N x 3N) blob mobility builders f(r_vectors, eta, a) (mobility.py:1018-1116, :967-1013)."""
+  table = {"hip": _mob.single_wall_fluid_mobility_hip, "hip_no_wall": _mob.rotne_prager_tensor_hip}
+  if implementation not in table:
+    raise ValueError("mobility_blobs_implementation %r is not served by the HIP engine" % (implementation,))
+  return table[implementation]

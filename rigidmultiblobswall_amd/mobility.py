@@ -156,3 +156,31 @@ def single_wall_mobility_trans_times_force_torque_hip(r_vectors, force, torque, 
 def no_wall_mobility_trans_times_force_torque_hip(r_vectors, force, torque, eta, a, *args, **kwargs):
   '''u = M_tt f + M_tr tau, unbounded (mobility/mobility.py:413-424).'''
   return _product('tt_tr', False, False, r_vectors, force, eta, a, kwargs, vec2=torque)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense builders (used per body by the preconditioner / body_mobility scheme in the reference)
+# ---------------------------------------------------------------------------------------------
+def _dense(r_vectors, eta, a, wall):
+  import torch
+  r = np.ascontiguousarray(r_vectors, dtype=np.float64).reshape(-1, 3)
+  n = len(r)
+  ctx = MobilityContext(0)
+  try:
+    ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda:0"), a, None, wall)
+    first = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    M = ctx.body_mobility_dense_device(first, n, eta)[0].cpu().numpy()
+  finally:
+    ctx.close()
+  return M
+
+
+def single_wall_fluid_mobility_hip(r_vectors, eta, a, *args, **kwargs):
+  '''Dense 3N x 3N wall mobility B M(z_eff) B (mobility/mobility.py:1018-1116 builds M(z) without the
+  clamp; identical whenever every blob has z > a).'''
+  return _dense(r_vectors, eta, a, True)
+
+
+def rotne_prager_tensor_hip(r_vectors, eta, a, *args, **kwargs):
+  '''Dense 3N x 3N unbounded RPY mobility (mobility/mobility.py:967-1013).'''
+  return _dense(r_vectors, eta, a, False)

@@ -408,3 +408,17 @@ def test_forces_vs_oracle_and_newton_third_law(oracle):
     ref = oracle.calc_blob_blob_forces_oracle(r, **kw)
     assert rel_err(F, ref) < TOL_D2
     assert np.abs(F.sum(axis=0)).max() < 1e-9 * np.abs(F).sum()     # pairwise antisymmetric
+
+
+# ---------------------------------------------------------------------------------------------
+# 6. dense builders (mobility/mobility.py:967-1013, :1018-1116) against the reference's dense products
+# ---------------------------------------------------------------------------------------------
+def test_dense_builders_match_reference_dense_products(mob):
+  g = load_golden(golden_files("g3_wall_cloud_N200.npz")[0])
+  r, f, eta, a = g["r_vectors"], g["vector"].reshape(-1), float(g["eta"]), float(g["a"])
+  M = mob.single_wall_fluid_mobility_hip(r, eta, a)
+  assert M.shape == (600, 600)
+  assert rel_err(M @ f, g["dense_wall_tt"]) < 1e-13
+  assert np.abs(M - M.T).max() < 1e-13 * np.abs(M).max() and np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0
+  M0 = mob.rotne_prager_tensor_hip(r, eta, a)
+  assert rel_err(M0 @ f, g["dense_no_wall_tt"]) < 1e-13
