@@ -82,5 +82,53 @@ def main():
                       lambda_blobs=lam, velocities=U)
 
 
+
+
+def pair_active_rods():
+  """The reference's only pinned known-answer on this path: multi_bodies/examples/pair_active_rods
+  (README.md:37-44: velocities must match run_*_res.velocity.dat.reference to solver_tolerance 1e-8).
+  Inputs (structure, clones, slip from the example's slip_function.py, forces from force_*.dat) are
+  evaluated with the reference's own code; the expected output is the reference's data file."""
+  out_dir = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+  load_reference(REF)
+  warnings.simplefilter("ignore")
+  from body import body as ref_body
+  from read_input import read_vertex_file, read_clones_file
+  ex = os.path.join(REF, "multi_bodies", "examples", "pair_active_rods")
+  # slip_function.py mixes tabs and spaces (Python 2 era; TabError under Python 3): run it with tabs
+  # expanded the way Python 2 read them.  Nothing of it is written to disk.
+  import types
+  slip_function = types.ModuleType("slip_function")
+  src = open(os.path.join(ex, "slip_function.py")).read().expandtabs(8)
+  exec(compile(src, "slip_function.py", "exec"), slip_function.__dict__)
+  S = os.path.join(REF, "multi_bodies", "Structures")
+  cases = {"low": ("Cylinder_N_14_Lg_1_9295_Rg_0_18323", 0.183228708092682),
+           "mid": ("Cylinder_N_86_Lg_1_9384_Rg_0_1484", None),
+           "high": ("Cylinder_N_324_Lg_2_0299_Rg_0_1554", None)}
+  for res, (name, a) in cases.items():
+    deck = os.path.join(ex, "inputfile_%s_resolution.dat" % res)
+    opts = {}
+    for line in open(deck):
+      line = line.split("#", 1)[0].strip()
+      if line:
+        k, v = line.split(None, 1)
+        opts[k] = v
+    a = float(opts["blob_radius"])
+    eta = float(opts["eta"])
+    ref_conf = read_vertex_file.read_vertex_file(os.path.join(S, name + ".vertex"))
+    nb, locs, oris = read_clones_file.read_clones_file(os.path.join(S, name + ".clones"))
+    bodies = [ref_body.Body(locs[k], oris[k], ref_conf, a) for k in range(nb)]
+    slip = np.concatenate([slip_function.slip_extensile_rod(b) for b in bodies])
+    FT = np.loadtxt(os.path.join(ex, "force_%s_resolution.dat" % res)).reshape(nb, 6)
+    expected = np.loadtxt(os.path.join(ex, "run_%s_res.velocity.dat.reference" % res)).reshape(nb, 6)
+    r = np.concatenate([b.get_r_vectors() for b in bodies])
+    print("  rods %s: %d blobs, z_min/a = %.3f" % (res, len(r), r[:, 2].min() / a))
+    np.savez_compressed(os.path.join(out_dir, "g7_pair_active_rods_%s.npz" % res), reference_configuration=ref_conf,
+                        locations=locs, quaternions=np.array([o.entries for o in oris]), eta=eta, a=a, slip=slip,
+                        force_torque=FT, r_vectors=r, velocities_reference=expected,
+                        solver_tolerance=float(opts["solver_tolerance"]))
+
+
 if __name__ == "__main__":
   main()
+  pair_active_rods()

@@ -143,3 +143,19 @@ def test_lanczos_large_covariance_identity(N):
   print("lanczos N=%d iterations=%d time=%.3fs  |M^1/2 z|^2 / z.M.z - 1 = %.2e" % (N, its, dt, nn / zMz - 1))
   assert its < 300 and abs(nn / zMz - 1) < 10 * tol
   ctx.close()
+
+
+@pytest.mark.parametrize("res", ["low", "mid", "high"])
+def test_pair_active_rods_pinned_reference_velocities_gpu(res):
+  """multi_bodies/examples/pair_active_rods/run_<res>_res.velocity.dat.reference, through the HIP matvec."""
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  d = np.load(os.path.join(GOLDEN, "g7_pair_active_rods_%s.npz" % res))
+  nb = len(d["locations"])
+  rs = RigidSuspension([d["reference_configuration"]] * nb, d["locations"], d["quaternions"], float(d["a"]), float(d["eta"]))
+  U, lam, info = rs.solve_mobility_problem(slip=d["slip"], force_torque=d["force_torque"], tol=1e-10)
+  ref = d["velocities_reference"]
+  print("rods %s: %d blobs, %d iterations, max |U - U_ref| / max|U_ref| = %.2e, omega_z = %.9f (ref %.9f)" %
+        (res, rs.n_blobs, info["iterations"], np.abs(U - ref).max() / np.abs(ref).max(), U[0, 5], ref[0, 5]))
+  assert info["converged"]
+  assert np.abs(U - ref).max() < 2e-8 * np.abs(ref).max()
+  rs.close()

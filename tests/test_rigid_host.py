@@ -134,3 +134,22 @@ def test_structure_readers_and_shell(tmp_path):
   loc, q, L = st.roller_monolayer(100, seed=1)
   d = np.linalg.norm(loc[:, None, :2] - loc[None, :, :2], axis=-1) + np.eye(100) * 10
   assert d.min() > 2 * 1.0155 * 0.9 and loc[:, 2].min() > 1.0155
+
+
+@pytest.mark.parametrize("res", ["low", "mid"])
+def test_pair_active_rods_pinned_reference_velocities(oracle, res):
+  """The reference's only pinned known-answer for this path (multi_bodies/examples/pair_active_rods,
+  README.md:37-44): body velocities of two active rods near a wall must match
+  run_<res>_res.velocity.dat.reference to solver_tolerance (1e-8).  Oracle-backed matvec on CPU."""
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  d = np.load(os.path.join(GOLDEN, "g7_pair_active_rods_%s.npz" % res))
+  nb = len(d["locations"])
+  rs = RigidSuspension([d["reference_configuration"]] * nb, d["locations"], d["quaternions"], float(d["a"]),
+                       float(d["eta"]), device="cpu", ctx=OracleCtx(oracle))
+  assert np.abs(rs.r_vectors - d["r_vectors"]).max() < 1e-13
+  U, lam, info = rs.solve_mobility_problem(slip=d["slip"], force_torque=d["force_torque"], tol=1e-10)
+  assert info["converged"]
+  ref = d["velocities_reference"]
+  # the reference file holds 12 significant digits of a solve converged to 1e-8
+  assert np.abs(U - ref).max() < 2e-8 * np.abs(ref).max()
+  assert abs(U[0, 5] - 3.88202665409) < 1e-7 if res == "low" else True
