@@ -48,8 +48,10 @@ enum rmb_status {
  *   TR     mobility_numba.py:548        :440            / mobility_pycuda.py:1516, :1733
  *   RT     mobility_numba.py:938        :832            / mobility_pycuda.py:926, :1034
  *   RR     mobility_numba.py:1189       :1077           / mobility_pycuda.py:593, :703
- *   TT_TR  fused u = M_tt f + M_tr tau, pycuda only     / mobility_pycuda.py:1266, :1394   */
-enum rmb_kind { RMB_TT = 0, RMB_TR = 1, RMB_RT = 2, RMB_RR = 3, RMB_TT_TR = 4 };
+ *   TT_TR  fused u = M_tt f + M_tr tau, pycuda only     / mobility_pycuda.py:1266, :1394
+ *   TT_FREE_SURFACE  u = [RPY(d) + RPY(image) P] f above a stress-free surface at z = 0
+ *          mobility_numba.py:1770 / mobility_pycuda.py:2081; needs set_positions(wall = 0)   */
+enum rmb_kind { RMB_TT = 0, RMB_TR = 1, RMB_RT = 2, RMB_RR = 3, RMB_TT_TR = 4, RMB_TT_FREE_SURFACE = 5 };
 
 /* ---- library / device ------------------------------------------------------------------- */
 const char* rmb_version(void);

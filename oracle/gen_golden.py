@@ -57,6 +57,7 @@ KERNELS = [
     ("wall_rr", "single_wall_mobility_rot_times_torque_numba"),
     ("in_plane_tt", "in_plane_mobility_trans_times_force_numba"),
     ("in_plane_tr", "in_plane_mobility_trans_times_torque_numba"),
+    ("free_surface_tt", "free_surface_mobility_trans_times_force_numba"),
 ]
 
 
@@ -112,7 +113,7 @@ def main():
   run_case(mob, "g2_periodic_x_N64", r, f, eta, a, Lx, out_dir)
   Lxyz = np.array([1.7, 2.3, 1.9])
   run_case(mob, "g2_periodic_xyz_N24", r[:24], f[:24], eta, a, Lxyz, out_dir,
-           kernels=("no_wall_tt", "no_wall_tr", "no_wall_rt", "no_wall_rr"))
+           kernels=("no_wall_tt", "no_wall_tr", "no_wall_rt", "no_wall_rr", "free_surface_tt"))
 
   # G3a: well-separated wall cloud (D2-like: 5% volume fraction, z in [1.1a, 1.1a+Lbox))
   rng = np.random.RandomState(6)

@@ -59,6 +59,8 @@ def _lib(fast=False):
     lib.oracle_wall_regularisation.argtypes = [ctypes.c_long, _dp, ctypes.c_double, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_int)]
     lib.oracle_wall_regularisation.restype = ctypes.c_int
+    lib.oracle_free_surface_matvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp]
+    lib.oracle_free_surface_matvec.restype = ctypes.c_int
     lib.oracle_num_threads.restype = ctypes.c_int
     _LIBS[name] = lib
   return _LIBS[name]
@@ -190,6 +192,18 @@ def single_wall_mobility_trans_times_force_torque_oracle(r, f, t, eta, a, *args,
 
 def no_wall_mobility_trans_times_force_torque_oracle(r, f, t, eta, a, *args, **kw):
   return _wrapped("tt", 0, r, f, eta, a, **kw) + _wrapped("tr", 0, r, t, eta, a, **kw)
+
+
+def free_surface_mobility_trans_times_force_oracle(r, f, eta, a, *args, **kw):
+  """mobility/mobility.py:1390-1406 (no height clamp)."""
+  L = _c(kw.get("periodic_length", np.zeros(3))).reshape(3)
+  r = _c(r).reshape(-1)
+  f = _c(f).reshape(-1)
+  out = np.zeros(r.size)
+  rc = _lib(kw.get("fast", False)).oracle_free_surface_matvec(r.size // 3, _p(r), _p(f), float(eta), float(a), _p(L), _p(out))
+  if rc != 0:
+    raise RuntimeError("oracle_free_surface_matvec failed: %d" % rc)
+  return out
 
 
 def calc_blob_blob_forces_oracle(r_vectors, *args, **kwargs):

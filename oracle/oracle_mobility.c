@@ -414,6 +414,42 @@ int oracle_mobility_matvec_targets(int kind, int wall, long N, const double *r, 
   return 0;
 }
 
+/* Free (stress-free) surface at z = 0: M = RPY(d) + RPY(R) P, P = diag(1,1,-1), R = (d_x, d_y, z_i+z_j).
+ * mobility/mobility_numba.py:1770-1937: the image block is evaluated with the PAIR formula also for
+ * i == j (:1890-1912) and added with its z COLUMN negated (:1915-1923).  No height clamp. */
+int oracle_free_surface_matvec(long N, const double *r, const double *v, double eta, double a, const double *L,
+                               double *out) {
+  if (N < 0 || !out) return 1;
+  if (N == 0) return 0;
+  const double inva = 1.0 / a;
+  const double norm = 1.0 / (8.0 * ORACLE_PI * eta * a);
+  const int px = L[0] > 0, py = L[1] > 0, pz = L[2] > 0;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long i = 0; i < N; ++i) {
+    double ux = 0, uy = 0, uz = 0;
+    const double xi = r[3 * i], yi = r[3 * i + 1], zi = r[3 * i + 2];
+    for (int bx = -px; bx <= px; ++bx)
+      for (int by = -py; by <= py; ++by)
+        for (int bz = -pz; bz <= pz; ++bz)
+          for (long j = 0; j < N; ++j) {
+            double rx = xi - r[3 * j], ry = yi - r[3 * j + 1], rz = zi - r[3 * j + 2];
+            if (px) rx = wrap_nearest(rx, L[0]) + bx * L[0];
+            if (py) ry = wrap_nearest(ry, L[1]) + by * L[1];
+            if (pz) rz = wrap_nearest(rz, L[2]) + bz * L[2];
+            const int self = (i == j) && bx == 0 && by == 0 && bz == 0;
+            block3 B, I;
+            rpy_tt(rx * inva, ry * inva, rz * inva, self, &B);
+            rpy_tt(rx * inva, ry * inva, (zi + r[3 * j + 2]) * inva, 0, &I);
+            const double vx = v[3 * j], vy = v[3 * j + 1], vz = v[3 * j + 2];
+            ux += ((B.m[0] + I.m[0]) * vx + (B.m[1] + I.m[1]) * vy + (B.m[2] - I.m[2]) * vz) * norm;
+            uy += ((B.m[3] + I.m[3]) * vx + (B.m[4] + I.m[4]) * vy + (B.m[5] - I.m[5]) * vz) * norm;
+            uz += ((B.m[6] + I.m[6]) * vx + (B.m[7] + I.m[7]) * vy + (B.m[8] - I.m[8]) * vz) * norm;
+          }
+    out[3 * i] = ux; out[3 * i + 1] = uy; out[3 * i + 2] = uz;
+  }
+  return 0;
+}
+
 /* Dense 3N x 3N matrix of one kind (row-major), same blocks as the matvec.
  * Used to check symmetry / SPD properties and the dense builders
  * (mobility/mobility.py:967-1013 rotne_prager_tensor, :1018-1116

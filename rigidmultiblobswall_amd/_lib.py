@@ -14,8 +14,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p
 _lp = ctypes.POINTER(ctypes.c_long)
 
-KIND_TT, KIND_TR, KIND_RT, KIND_RR, KIND_TT_TR = 0, 1, 2, 3, 4
-KINDS = {"tt": KIND_TT, "tr": KIND_TR, "rt": KIND_RT, "rr": KIND_RR, "tt_tr": KIND_TT_TR}
+KIND_TT, KIND_TR, KIND_RT, KIND_RR, KIND_TT_TR, KIND_TT_FREE = 0, 1, 2, 3, 4, 5
+KINDS = {"tt": KIND_TT, "tr": KIND_TR, "rt": KIND_RT, "rr": KIND_RR, "tt_tr": KIND_TT_TR, "tt_free": KIND_TT_FREE}
 
 # every symbol include/rmb_mobility.h declares: (restype, argtypes)
 SYMBOLS = {

@@ -25,7 +25,7 @@
 
 namespace rmb {
 
-enum Kind : int { KIND_TT = 0, KIND_TR = 1, KIND_RT = 2, KIND_RR = 3, KIND_TT_TR = 4, KIND_COUNT = 5 };
+enum Kind : int { KIND_TT = 0, KIND_TR = 1, KIND_RT = 2, KIND_RR = 3, KIND_TT_TR = 4, KIND_TT_FREE = 5, KIND_COUNT = 6 };
 
 // Uniform constants (host-computed from the blob radius a; see make_pair_consts in rmb_capi.hip).
 struct PairConsts {
@@ -296,6 +296,12 @@ __device__ __forceinline__ void self_term(const PairConsts& k, double zi, double
     }
     u.x = __builtin_fma(sxx, vx, u.x); u.y = __builtin_fma(sxx, vy, u.y); u.z = __builtin_fma(szz, vz, u.z);
   }
+  if constexpr (KIND == KIND_TT_FREE) {
+    // self: 4/(3a) I plus the blob's own image, evaluated with the pair formula at R = (0, 0, 2 z_i)
+    u.x = __builtin_fma(k.tt_n0, vx, u.x); u.y = __builtin_fma(k.tt_n0, vy, u.y); u.z = __builtin_fma(k.tt_n0, vz, u.z);
+    const double two_z = zi + zi;
+    pair_tt<false>(k, 0.0, 0.0, two_z, two_z, zi, vx, vy, -vz, u);
+  }
   if constexpr (KIND == KIND_RR) {
     double sxx = k.rr_m0, szz = k.rr_m0;
     if constexpr (WALL) {
@@ -336,6 +342,12 @@ __device__ __forceinline__ void pair_apply(const PairConsts& k, double dx, doubl
   if constexpr (KIND == KIND_TT_TR) {
     pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
     pair_tr<WALL>(k, dx, dy, dz, Rz, zi, wx, wy, wz, u);
+  }
+  if constexpr (KIND == KIND_TT_FREE) {
+    // free (stress-free) surface at z = 0: RPY(d) f + RPY(R) (f_x, f_y, -f_z), R = (d_x, d_y, z_i + z_j)
+    // (mobility/mobility_numba.py:1846-1925; image block added with the z column negated, :1915-1923)
+    pair_tt<false>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+    pair_tt<false>(k, dx, dy, Rz, Rz, zj, vx, vy, -vz, u);
   }
 }
 

@@ -143,7 +143,8 @@ KernelEntry make_entry() {
 // [kind][wall][periodic]
 KernelEntry g_kernels[rmb::KIND_COUNT][2][2] = {
 #define RMB_ROW(K) {{make_entry<K, false, false>(), make_entry<K, false, true>()}, {make_entry<K, true, false>(), make_entry<K, true, true>()}}
-    RMB_ROW(rmb::KIND_TT), RMB_ROW(rmb::KIND_TR), RMB_ROW(rmb::KIND_RT), RMB_ROW(rmb::KIND_RR), RMB_ROW(rmb::KIND_TT_TR)
+    RMB_ROW(rmb::KIND_TT), RMB_ROW(rmb::KIND_TR), RMB_ROW(rmb::KIND_RT), RMB_ROW(rmb::KIND_RR), RMB_ROW(rmb::KIND_TT_TR),
+    RMB_ROW(rmb::KIND_TT_FREE)
 #undef RMB_ROW
 };
 
@@ -247,7 +248,9 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out, long sha
 int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta,
                        double* out) {
   if (int rc = check_ready(c)) return rc;
-  if (kind < 0 || kind >= rmb::KIND_COUNT) return fail(RMB_ERR_ARG, "kind must be 0..4");
+  if (kind < 0 || kind >= rmb::KIND_COUNT) return fail(RMB_ERR_ARG, "kind must be 0..5");
+  if (kind == rmb::KIND_TT_FREE && c->wall)
+    return fail(RMB_ERR_STATE, "RMB_TT_FREE_SURFACE uses raw heights: call rmb_set_positions with wall = 0");
   const long n_tgt = c->tgt_end - c->tgt_begin;
   if (n_tgt == 0) return 0;
   if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");

@@ -158,6 +158,12 @@ def no_wall_mobility_trans_times_force_torque_hip(r_vectors, force, torque, eta,
   return _product('tt_tr', False, False, r_vectors, force, eta, a, kwargs, vec2=torque)
 
 
+def free_surface_mobility_trans_times_force_hip(r_vectors, force, eta, a, *args, **kwargs):
+  '''u = M f above a stress-free surface at z = 0: RPY plus the mirrored image blob, no height clamp
+  (mobility/mobility.py:533-548, :1390-1406).'''
+  return _product('tt_free', False, False, r_vectors, force, eta, a, kwargs)
+
+
 # ---------------------------------------------------------------------------------------------
 # dense builders (used per body by the preconditioner / body_mobility scheme in the reference)
 # ---------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ KERNEL_KEYS = {
     "wall_rt": "single_wall_mobility_rot_times_force",
     "no_wall_rr": "no_wall_mobility_rot_times_torque",
     "wall_rr": "single_wall_mobility_rot_times_torque",
+    "free_surface_tt": "free_surface_mobility_trans_times_force",
 }
 
 
