@@ -318,6 +318,42 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   if (!(b > 0.0)) return fail(RMB_ERR_ARG, "debye_length must be positive");
   RMB_HIP(hipSetDevice(c->device));
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  c->last_path = 0;
+  if (c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
+    // symmetric path: each unordered pair once (F_ji = -F_ij)
+    const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
+    const size_t acc_bytes = (size_t)3 * n_pad * sizeof(double);
+    if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
+      if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
+      RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));
+      c->symbuf_zeroed_for = n_pad;
+    }
+    rmb::SymForceArgs a;
+    a.pos = (const double4*)c->pos.p;
+    a.acc = (double*)c->symbuf.p;
+    a.out = out;
+    a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+    a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+    a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+    a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+    a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+    a.eps_over_b = eps / b; a.inv_b = 1.0 / b; a.two_a = 2.0 * blob_radius;
+    static int socc[2] = {0, 0};
+    const void* fn = periodic ? (const void*)rmb::sym_force_kernel<true> : (const void*)rmb::sym_force_kernel<false>;
+    long blocks = 256L * resident_blocks(fn, &socc[periodic ? 1 : 0]);
+    const long need = (a.n_units * 64 + 255) / 256;
+    if (blocks > need) blocks = need;
+    c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+    int slot;
+    if (int rc = timing_begin(c, &slot)) return rc;
+    if (periodic) hipLaunchKernelGGL(rmb::sym_force_kernel<true>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+    else          hipLaunchKernelGGL(rmb::sym_force_kernel<false>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+    if (int rc = timing_end(c, slot)) return rc;
+    hipLaunchKernelGGL(rmb::sym_force_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+    return 0;
+  }
   static int force_occ[2] = {0, 0};
   const void* ffn = periodic ? (const void*)rmb::force_sweep_kernel<true> : (const void*)rmb::force_sweep_kernel<false>;
   const long slots = 256L * resident_blocks(ffn, &force_occ[periodic ? 1 : 0]);

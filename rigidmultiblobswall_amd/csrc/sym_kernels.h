@@ -238,4 +238,134 @@ __global__ __launch_bounds__(256) void sym_tt_finalize_kernel(const SymArgs a) {
   a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric blob-blob force sweep: F_ij = -F_ji, so each unordered pair is evaluated once
+// (one rsqrt + one exp) and applied with opposite signs.  Same tile-pair rotation, LDS accumulation
+// and static step schedule as sym_tt_kernel.  multi_bodies/forces_numba.py:12-55 semantics.
+// ---------------------------------------------------------------------------------------------
+struct SymForceArgs {
+  const double4* pos;
+  double* acc;          // [3][n_pad], zero on entry, re-zeroed by the finalize kernel
+  double* out;          // [n][3]
+  long n, n_pad;
+  int n_tiles;
+  long n_units;
+  double Lx, Ly, Lz, iLx, iLy, iLz;
+  double eps_over_b, inv_b, two_a;
+};
+
+__device__ __forceinline__ double wrap_nearest_sym(double r, double L, double invL) {
+  const double q = r * invL;
+  const double h = (r > 0.0) ? 0.5 : ((r < 0.0) ? -0.5 : 0.0);
+  return __builtin_fma(-__builtin_trunc(q + h), L, r);
+}
+
+// f0(r) dr for one pair; dr = r_j - r_i (minimal image).  Returns the force ON i; the force on j is minus it.
+template <bool PERIODIC>
+__device__ __forceinline__ void pair_force(const SymForceArgs& a, double dx, double dy, double dz, double& fx, double& fy,
+                                           double& fz) {
+  if constexpr (PERIODIC) {
+    if (a.Lx > 0) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
+    if (a.Ly > 0) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
+    if (a.Lz > 0) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+  }
+  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+  const double ir = rsqrt_f64(r2);
+  const double r = r2 * ir;
+  double f0;
+  if (r > a.two_a) f0 = -a.eps_over_b * exp(-(r - a.two_a) * a.inv_b) * ir;
+  else f0 = -a.eps_over_b / fmax(r, 1e-25);
+  fx = f0 * dx; fy = f0 * dy; fz = f0 * dz;
+}
+
+template <bool PERIODIC>
+__global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForceArgs a) {
+  __shared__ double4 rec_all[kSymWaves][64];
+  __shared__ double accj_all[kSymWaves][3 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double4* rec = rec_all[wave];
+  double* accj = accj_all[wave];
+  const long n_waves = (long)gridDim.x * kSymWaves;
+  const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long s_total = a.n_units * 64;
+  long s = (long)(((__int128)s_total * w) / n_waves);
+  const long s_end = (long)(((__int128)s_total * (w + 1)) / n_waves);
+  int I_cur = -1;
+  long i = 0;
+  bool vi_ok = false;
+  double xi = 0, yi = 0, zi = 0;
+  double ax = 0, ay = 0, az = 0;
+  while (s < s_end) {
+    const long u = s >> 6;
+    const int k0 = (int)(s & 63);
+    const long left = s_end - s;
+    const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    s += k1 - k0;
+    int I, J;
+    unit_to_tiles(u, a.n_tiles, I, J);
+    if (I != I_cur) {
+      if (I_cur >= 0 && vi_ok) {
+        __hip_atomic_fetch_add(&a.acc[i], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      I_cur = I;
+      i = 64L * I + lane;
+      vi_ok = i < a.n;
+      xi = 1e100; yi = 1e100; zi = 1e100;
+      if (vi_ok) { const double4 p = a.pos[i]; xi = p.x; yi = p.y; zi = p.z; }
+      ax = 0.0; ay = 0.0; az = 0.0;
+    }
+    {
+      const long j = 64L * J + lane;
+      double4 p = make_double4(-1e100, -1e100, -1e100, 0.0);
+      if (j < a.n) p = a.pos[j];
+      rec[lane] = p;
+      accj[lane] = 0.0; accj[64 + lane] = 0.0; accj[128 + lane] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool diag = (I == J);
+    for (int k = (diag && k0 < 1) ? 1 : k0; k < k1; ++k) {
+      const int jj = (lane + k) & 63;
+      const double4 q = rec[jj];
+      double fx, fy, fz;
+      pair_force<PERIODIC>(a, q.x - xi, q.y - yi, q.z - zi, fx, fy, fz);
+      ax += fx; ay += fy; az += fz;
+      if (!diag) {   // wave-uniform
+        __hip_atomic_fetch_add(&accj[jj], -fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[64 + jj], -fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[128 + jj], -fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    if (!diag) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long j = 64L * J + lane;
+      if (j < a.n) {
+        __hip_atomic_fetch_add(&a.acc[j], accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + j], accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (I_cur >= 0 && vi_ok) {
+    __hip_atomic_fetch_add(&a.acc[i], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void sym_force_finalize_kernel(const SymForceArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  a.out[3 * i] = a.acc[i]; a.out[3 * i + 1] = a.acc[a.n_pad + i]; a.out[3 * i + 2] = a.acc[2 * a.n_pad + i];
+  a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;
+}
+
 }  // namespace rmb

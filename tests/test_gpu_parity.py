@@ -422,3 +422,23 @@ def test_dense_builders_match_reference_dense_products(mob):
   assert np.abs(M - M.T).max() < 1e-13 * np.abs(M).max() and np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0
   M0 = mob.rotne_prager_tensor_hip(r, eta, a)
   assert rel_err(M0 @ f, g["dense_no_wall_tt"]) < 1e-13
+
+
+@pytest.mark.parametrize("L", [(0.0, 0.0, 0.0), (3.0, 3.5, 0.0)])
+def test_symmetric_force_kernel_matches_sweep_and_oracle(Ctx, oracle, L):
+  """K15 has two device paths too: sym_force_kernel (F_ji = -F_ij, each pair once) and force_sweep_kernel."""
+  rng = np.random.RandomState(70)
+  N, a, b, eps = 3000, 0.13, 0.01, 3.92
+  r = rng.rand(N, 3) * (N ** (1.0 / 3.0)) * 2.2 * a
+  L = np.array(L)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, L, wall=False)
+  F_sym = ctx.blob_blob_force(eps, b, a)
+  assert ctx.last_launch()["chunks"] == 0
+  ctx.set_option("deterministic", 1)
+  F_det = ctx.blob_blob_force(eps, b, a)
+  assert ctx.last_launch()["chunks"] >= 1
+  ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=L, repulsion_strength=eps, debye_length=b, blob_radius=a)
+  assert rel_err(F_det, ref) < TOL_D2 and rel_err(F_sym, ref) < TOL_D2
+  assert np.abs(F_sym.sum(axis=0)).max() < 1e-10 * np.abs(F_sym).sum()
+  ctx.close()
