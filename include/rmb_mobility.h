@@ -124,6 +124,18 @@ int rmb_mobility_oneshot(int kind, int wall, int in_plane, long n, const double*
 int rmb_forces_oneshot(long n, const double* r, const double* L, double repulsion_strength,
                        double debye_length, double blob_radius, double* out);
 
+/* ---- source -> target products with per-blob radii (K13) --------------------------------------
+ * u_t = sum_s M(x_t, a_t; y_s, a_s) f_s for nt targets and ns sources, each blob with its own radius
+ * (mobility/mobility_numba.py:1480-1658; CUDA twin mobility_pycuda.py:1974-2078; wrappers
+ * mobility.py:494-615: per-blob height clamp + B on both sides when wall != 0).  Stateless; the host
+ * variant is synchronous, the device variant enqueues on the context's stream. */
+int rmb_mobility_source_target(long ns, const double* src, const double* radius_src, long nt, const double* tgt,
+                               const double* radius_tgt, const double* force, double eta, const double* L, int wall,
+                               double* out);
+int rmb_mobility_source_target_device(rmb_ctx* ctx, long ns, const double* src_dev, const double* radius_src_dev,
+                                      long nt, const double* tgt_dev, const double* radius_tgt_dev,
+                                      const double* force_dev, double eta, const double* L, int wall, double* out_dev);
+
 #ifdef __cplusplus
 }
 #endif

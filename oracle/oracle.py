@@ -61,6 +61,9 @@ def _lib(fast=False):
     lib.oracle_wall_regularisation.restype = ctypes.c_int
     lib.oracle_free_surface_matvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp]
     lib.oracle_free_surface_matvec.restype = ctypes.c_int
+    lib.oracle_source_target_matvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_double,
+                                                _dp, ctypes.c_int, _dp]
+    lib.oracle_source_target_matvec.restype = ctypes.c_int
     lib.oracle_num_threads.restype = ctypes.c_int
     _LIBS[name] = lib
   return _LIBS[name]
@@ -204,6 +207,40 @@ def free_surface_mobility_trans_times_force_oracle(r, f, eta, a, *args, **kw):
   if rc != 0:
     raise RuntimeError("oracle_free_surface_matvec failed: %d" % rc)
   return out
+
+
+def _source_target(source, target, force, radius_source, radius_target, eta, wall, **kw):
+  """Wrapper semantics of mobility/mobility.py:551-615: per-blob height clamp + B on both sides when wall."""
+  L = _c(kw.get("periodic_length", np.zeros(3))).reshape(3)
+  src = _c(source).reshape(-1, 3).copy()
+  tgt = _c(target).reshape(-1, 3).copy()
+  rs = _c(radius_source).reshape(-1)
+  rt = _c(radius_target).reshape(-1)
+  f = _c(force).reshape(-1, 3).copy()
+  bt = np.ones(len(tgt))
+  if wall:
+    bs = np.where(src[:, 2] < rs, src[:, 2] / rs, 1.0)      # damping_matrix_B_different_radius, mobility.py:102-119
+    bt = np.where(tgt[:, 2] < rt, tgt[:, 2] / rt, 1.0)
+    src[:, 2] = np.where(src[:, 2] > rs, src[:, 2], rs)      # shift_heights_different_radius, mobility.py:87-99
+    tgt[:, 2] = np.where(tgt[:, 2] > rt, tgt[:, 2], rt)
+    f = f * bs[:, None]
+  out = np.zeros(3 * len(tgt))
+  src, tgt, f = _c(src).reshape(-1), _c(tgt).reshape(-1), _c(f).reshape(-1)
+  rc = _lib().oracle_source_target_matvec(len(rs), _p(src), _p(rs), len(rt), _p(tgt), _p(rt), _p(f), float(eta), _p(L),
+                                          int(wall), _p(out))
+  if rc != 0:
+    raise RuntimeError("oracle_source_target_matvec failed: %d" % rc)
+  return (out.reshape(-1, 3) * bt[:, None]).reshape(-1)
+
+
+def single_wall_mobility_trans_times_force_source_target_oracle(source, target, force, radius_source, radius_target, eta,
+                                                                *args, **kw):
+  return _source_target(source, target, force, radius_source, radius_target, eta, 1, **kw)
+
+
+def no_wall_mobility_trans_times_force_source_target_oracle(source, target, force, radius_source, radius_target, eta,
+                                                            *args, **kw):
+  return _source_target(source, target, force, radius_source, radius_target, eta, 0, **kw)
 
 
 def calc_blob_blob_forces_oracle(r_vectors, *args, **kwargs):

@@ -450,6 +450,119 @@ int oracle_free_surface_matvec(long N, const double *r, const double *v, double 
   return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Source -> target translation mobility with per-blob radii (K13).          */
+/* mobility/mobility_numba.py:1480-1658 (and its pure-python twin             */
+/* mobility/mobility.py:830-945): unbounded part after Zuk et al. (three       */
+/* regimes in r vs a_t + a_s and |a_t - a_s|), wall part = -T(R) P with        */
+/* P = diag(1,1,-1), R = target - image(source), T the sum of five tensors.    */
+/* Restated here with explicit 3x3 outer products (the reference writes out    */
+/* all 9 entries of every term by hand).  Heights already clamped by caller.   */
+/* ------------------------------------------------------------------------ */
+static void outer3(const double *u, const double *v, double c, double *T) {
+  for (int l = 0; l < 3; ++l)
+    for (int m = 0; m < 3; ++m) T[3 * l + m] += c * u[l] * v[m];
+}
+
+int oracle_source_target_matvec(long Ns, const double *src, const double *rad_s, long Nt, const double *tgt,
+                                const double *rad_t, const double *force, double eta, const double *L, int wall,
+                                double *out) {
+  if (Ns < 0 || Nt < 0 || !out) return 1;
+  const double pref = 1.0 / (8.0 * ORACLE_PI * eta);
+  const int px = L[0] > 0, py = L[1] > 0, pz = L[2] > 0;
+  static const double zhat[3] = {0.0, 0.0, 1.0};
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long i = 0; i < Nt; ++i) {
+    const double at = rad_t[i];
+    double u[3] = {0, 0, 0};
+    for (int bx = -px; bx <= px; ++bx)
+      for (int by = -py; by <= py; ++by)
+        for (int bz = -pz; bz <= pz; ++bz)
+          for (long j = 0; j < Ns; ++j) {
+            const double as = rad_s[j];
+            double d[3] = {tgt[3 * i] - src[3 * j], tgt[3 * i + 1] - src[3 * j + 1], tgt[3 * i + 2] - src[3 * j + 2]};
+            if (px) d[0] = wrap_nearest(d[0], L[0]) + bx * L[0];
+            if (py) d[1] = wrap_nearest(d[1], L[1]) + by * L[1];
+            if (pz) d[2] = wrap_nearest(d[2], L[2]) + bz * L[2];
+            double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            /* unbounded part, mobility_numba.py:1556-1578 */
+            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const double r = sqrt(r2);
+            double C1, C2;
+            if (r > at + as) {
+              C1 = (1 + (as * as + at * at) / (3 * r2)) / r;
+              C2 = ((1 - (as * as + at * at) / r2) / r2) / r;
+            } else if (r > fabs(as - at)) {
+              const double r3 = r2 * r, dm = (as - at) * (as - at);
+              C1 = ((16 * (as + at) * r3 - (dm + 3 * r2) * (dm + 3 * r2)) / (32 * r3)) * (4.0 / 3.0) / (as * at);
+              C2 = ((3 * (dm - r2) * (dm - r2) / (32 * r3)) / r2) * (4.0 / 3.0) / (as * at);
+            } else {
+              C1 = (4.0 / 3.0) / (at > as ? at : as);
+              C2 = 0;
+            }
+            M[0] = M[4] = M[8] = C1;
+            outer3(d, d, C2, M);
+            if (wall) {
+              /* mobility_numba.py:1591-1644 */
+              const double x3 = tgt[3 * i + 2], y3 = src[3 * j + 2];
+              const double R[3] = {d[0], d[1], x3 + y3};
+              const double R2 = R[0] * R[0] + R[1] * R[1] + R[2] * R[2];
+              const double Rn = sqrt(R2), R3 = R2 * Rn, R5 = R3 * R2, R7 = R5 * R2, R9 = R7 * R2;
+              const double a2 = at * at, b2 = as * as, rz = R[2];
+              double T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+              /* G_ab(R) */
+              for (int k = 0; k < 3; ++k) T[4 * k] += (1 + (b2 + a2) / (3.0 * R2)) / Rn;
+              outer3(R, R, (1 - (b2 + a2) / R2) / R2 / Rn, T);
+              /* 2 (-J/r - R x3^T/r3 - y3 R^T/r3 + x3 y3 (I/r3 - 3 R R^T/r5)) */
+              T[8] += -2.0 / Rn;
+              outer3(R, zhat, -2.0 * x3 / R3, T);
+              outer3(zhat, R, -2.0 * y3 / R3, T);
+              for (int k = 0; k < 3; ++k) T[4 * k] += 2.0 * x3 * y3 / R3;
+              outer3(R, R, -6.0 * x3 * y3 / R5, T);
+              /* (2 a2/3)(-J/r3 + 3 R Rz^T/r5 - y3 (3 rz I/r5 + 3 z R^T/r5 + 3 R z^T/r5 - 15 rz R R^T/r7)) */
+              {
+                const double c = 2.0 * a2 / 3.0;
+                T[8] += -c / R3;
+                outer3(R, zhat, c * 3.0 * rz / R5, T);
+                for (int k = 0; k < 3; ++k) T[4 * k] += -c * y3 * 3.0 * rz / R5;
+                outer3(zhat, R, -c * y3 * 3.0 / R5, T);
+                outer3(R, zhat, -c * y3 * 3.0 / R5, T);
+                outer3(R, R, c * y3 * 15.0 * rz / R7, T);
+              }
+              /* (2 b2/3)(-J/r3 + 3 Rz R^T/r5 - x3 (same bracket)) */
+              {
+                const double c = 2.0 * b2 / 3.0;
+                T[8] += -c / R3;
+                outer3(zhat, R, c * 3.0 * rz / R5, T);
+                for (int k = 0; k < 3; ++k) T[4 * k] += -c * x3 * 3.0 * rz / R5;
+                outer3(zhat, R, -c * x3 * 3.0 / R5, T);
+                outer3(R, zhat, -c * x3 * 3.0 / R5, T);
+                outer3(R, R, c * x3 * 15.0 * rz / R7, T);
+              }
+              /* (2 a2 b2/3)(-I/r5 + 5 rz^2 I/r7 - 2J/r5 + 10 rz z R^T/r7 + 10 rz R z^T/r7 + 5 R R^T/r7 - 35 rz^2 R R^T/r9) */
+              {
+                const double c = 2.0 * a2 * b2 / 3.0;
+                for (int k = 0; k < 3; ++k) T[4 * k] += c * (-1.0 / R5 + 5.0 * rz * rz / R7);
+                T[8] += -2.0 * c / R5;
+                outer3(zhat, R, c * 10.0 * rz / R7, T);
+                outer3(R, zhat, c * 10.0 * rz / R7, T);
+                outer3(R, R, c * (5.0 / R7 - 35.0 * rz * rz / R9), T);
+              }
+              /* M += -T P : columns x,y subtracted, column z added */
+              for (int l = 0; l < 3; ++l) {
+                M[3 * l] -= T[3 * l];
+                M[3 * l + 1] -= T[3 * l + 1];
+                M[3 * l + 2] += T[3 * l + 2];
+              }
+            }
+            const double *f = force + 3 * j;
+            for (int l = 0; l < 3; ++l) u[l] += (M[3 * l] * f[0] + M[3 * l + 1] * f[1] + M[3 * l + 2] * f[2]) * pref;
+          }
+    out[3 * i] = u[0]; out[3 * i + 1] = u[1]; out[3 * i + 2] = u[2];
+  }
+  return 0;
+}
+
 /* Dense 3N x 3N matrix of one kind (row-major), same blocks as the matvec.
  * Used to check symmetry / SPD properties and the dense builders
  * (mobility/mobility.py:967-1013 rotne_prager_tensor, :1018-1116

@@ -42,6 +42,10 @@ SYMBOLS = {
     "rmb_ctx_synchronize": (ctypes.c_int, [_vp]),
     "rmb_mobility_oneshot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp, _vp, _vp,
                                             ctypes.c_double, ctypes.c_double, _vp, _vp]),
+    "rmb_mobility_source_target": (ctypes.c_int, [ctypes.c_long, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_double, _vp,
+                                                  ctypes.c_int, _vp]),
+    "rmb_mobility_source_target_device": (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp, _vp, _vp,
+                                                         ctypes.c_double, _vp, ctypes.c_int, _vp]),
     "rmb_forces_oneshot": (ctypes.c_int, [ctypes.c_long, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_double, _vp]),
 }

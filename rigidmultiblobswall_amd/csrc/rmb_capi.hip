@@ -14,6 +14,7 @@
 #include "matvec_kernels.h"
 #include "sym_kernels.h"
 #include "dense_kernels.h"
+#include "st_kernels.h"
 
 namespace {
 
@@ -64,6 +65,7 @@ struct rmb_ctx {
   DevBuf pos;      // double4[n]
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial;
+  DevBuf st[8];    // scratch of the source->target entry point
   DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
   long symbuf_zeroed_for = -1;
   // options
@@ -447,7 +449,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
+  for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
   delete c;
@@ -580,6 +582,97 @@ int rmb_blob_blob_force(rmb_ctx* c, double eps, double b, double blob_radius, do
   if (int rc = c->out.reserve(ob)) return rc;
   if (int rc = force_device_impl(c, eps, b, blob_radius, (double*)c->out.p)) return rc;
   RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rmb_mobility_source_target_device(rmb_ctx* c, long ns, const double* src_dev, const double* rad_s_dev, long nt,
+                                      const double* tgt_dev, const double* rad_t_dev, const double* force_dev,
+                                      double eta, const double* L, int wall, double* out_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (ns < 0 || nt < 0) return fail(RMB_ERR_ARG, "negative size");
+  if (nt == 0) return 0;
+  if (!out_dev || !tgt_dev || !rad_t_dev) return fail(RMB_ERR_ARG, "null target pointer");
+  if (ns > 0 && (!src_dev || !rad_s_dev || !force_dev)) return fail(RMB_ERR_ARG, "null source pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  if (ns == 0) { RMB_HIP(hipMemsetAsync(out_dev, 0, (size_t)3 * nt * sizeof(double), c->stream)); return 0; }
+  if (int rc = c->st[0].reserve((size_t)ns * sizeof(double4))) return rc;
+  if (int rc = c->st[1].reserve((size_t)nt * sizeof(double4))) return rc;
+  hipLaunchKernelGGL(rmb::pack_positions_radii_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, src_dev,
+                     rad_s_dev, ns, wall ? 1 : 0, (double4*)c->st[0].p);
+  hipLaunchKernelGGL(rmb::pack_positions_radii_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, tgt_dev,
+                     rad_t_dev, nt, wall ? 1 : 0, (double4*)c->st[1].p);
+  RMB_HIP(hipGetLastError());
+  rmb::StArgs a;
+  a.src = (const double4*)c->st[0].p; a.rad_s = rad_s_dev; a.force = force_dev;
+  a.tgt = (const double4*)c->st[1].p; a.rad_t = rad_t_dev; a.out = out_dev; a.partial = nullptr;
+  a.ns = ns; a.nt = nt;
+  const long tiles = (nt + 63) / 64;
+  a.n_tgt_pad = 64 * tiles;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  const double Lx = L ? L[0] : 0.0, Ly = L ? L[1] : 0.0, Lz = L ? L[2] : 0.0;
+  a.Lx = Lx; a.Ly = Ly; a.Lz = Lz;
+  a.iLx = Lx > 0 ? 1.0 / Lx : 0.0; a.iLy = Ly > 0 ? 1.0 / Ly : 0.0; a.iLz = Lz > 0 ? 1.0 / Lz : 0.0;
+  const bool periodic = Lx > 0 || Ly > 0 || Lz > 0;
+  static int occ[2][2] = {{0, 0}, {0, 0}};
+  typedef void (*st_fn)(const rmb::StArgs);
+  st_fn fn = wall ? (periodic ? (st_fn)rmb::st_sweep_kernel<true, true> : (st_fn)rmb::st_sweep_kernel<true, false>)
+                  : (periodic ? (st_fn)rmb::st_sweep_kernel<false, true> : (st_fn)rmb::st_sweep_kernel<false, false>);
+  const long slots = 256L * resident_blocks((const void*)fn, &occ[wall ? 1 : 0][periodic ? 1 : 0]);
+  long n_chunks, chunk_len;
+  choose_chunks(nt, ns, c->opt_chunks, slots, &n_chunks, &chunk_len);
+  if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");
+  a.chunk_len = chunk_len; a.n_chunks = (int)n_chunks;
+  if (n_chunks > 1) {
+    if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
+    a.partial = (double*)c->partial.p;
+  }
+  c->last_path = 0; c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  hipLaunchKernelGGL(fn, dim3((unsigned)tiles, (unsigned)n_chunks), dim3(rmb::kBlock), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
+  if (n_chunks > 1) {
+    hipLaunchKernelGGL(rmb::st_finalize_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int rmb_mobility_source_target(long ns, const double* src, const double* rad_s, long nt, const double* tgt,
+                               const double* rad_t, const double* force, double eta, const double* L, int wall,
+                               double* out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default_ctx) {
+    if (int rc = rmb_ctx_create(0, &g_default_ctx)) return rc;
+  }
+  rmb_ctx* c = g_default_ctx;
+  if (ns < 0 || nt < 0) return fail(RMB_ERR_ARG, "negative size");
+  if (nt == 0) return 0;
+  if (!out || !tgt || !rad_t || (ns > 0 && (!src || !rad_s || !force))) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  const size_t bs3 = (size_t)3 * (ns > 0 ? ns : 1) * sizeof(double), bt3 = (size_t)3 * nt * sizeof(double);
+  const size_t bs1 = (size_t)(ns > 0 ? ns : 1) * sizeof(double), bt1 = (size_t)nt * sizeof(double);
+  if (int rc = c->st[2].reserve(bs3)) return rc;   // src
+  if (int rc = c->st[3].reserve(bs1)) return rc;   // rad_s
+  if (int rc = c->st[4].reserve(bt3)) return rc;   // tgt
+  if (int rc = c->st[5].reserve(bt1)) return rc;   // rad_t
+  if (int rc = c->st[6].reserve(bs3)) return rc;   // force
+  if (int rc = c->st[7].reserve(bt3)) return rc;   // out
+  if (ns > 0) {
+    RMB_HIP(hipMemcpyAsync(c->st[2].p, src, (size_t)3 * ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RMB_HIP(hipMemcpyAsync(c->st[3].p, rad_s, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RMB_HIP(hipMemcpyAsync(c->st[6].p, force, (size_t)3 * ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  RMB_HIP(hipMemcpyAsync(c->st[4].p, tgt, bt3, hipMemcpyHostToDevice, c->stream));
+  RMB_HIP(hipMemcpyAsync(c->st[5].p, rad_t, bt1, hipMemcpyHostToDevice, c->stream));
+  if (int rc = rmb_mobility_source_target_device(c, ns, (const double*)c->st[2].p, (const double*)c->st[3].p, nt,
+                                                 (const double*)c->st[4].p, (const double*)c->st[5].p,
+                                                 (const double*)c->st[6].p, eta, L, wall, (double*)c->st[7].p))
+    return rc;
+  RMB_HIP(hipMemcpyAsync(out, c->st[7].p, bt3, hipMemcpyDeviceToHost, c->stream));
   RMB_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }

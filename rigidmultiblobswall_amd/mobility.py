@@ -165,6 +165,45 @@ def free_surface_mobility_trans_times_force_hip(r_vectors, force, eta, a, *args,
 
 
 # ---------------------------------------------------------------------------------------------
+# source -> target products with per-blob radii (velocity fields, `radii_*` mobility modes)
+# ---------------------------------------------------------------------------------------------
+def _source_target(source, target, force, radius_source, radius_target, eta, wall, kwargs):
+  import ctypes
+  L = np.ascontiguousarray(kwargs.get('periodic_length', np.zeros(3)), dtype=np.float64).reshape(3)
+  src = np.ascontiguousarray(source, dtype=np.float64).reshape(-1)
+  tgt = np.ascontiguousarray(target, dtype=np.float64).reshape(-1)
+  f = np.ascontiguousarray(force, dtype=np.float64).reshape(-1)
+  ns, nt = src.size // 3, tgt.size // 3
+  rs = np.ascontiguousarray(np.broadcast_to(np.asarray(radius_source, dtype=np.float64).reshape(-1), (ns,)))
+  rt = np.ascontiguousarray(np.broadcast_to(np.asarray(radius_target, dtype=np.float64).reshape(-1), (nt,)))
+  if f.size != 3 * ns:
+    raise ValueError("force must have 3*N_source entries")
+  out = np.empty(3 * nt)
+  p = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+  _lib.check(_lib.load().rmb_mobility_source_target(ns, p(src), p(rs), nt, p(tgt), p(rt), p(f), float(eta), p(L),
+                                                    int(wall), p(out)))
+  return out
+
+
+def single_wall_mobility_trans_times_force_source_target_hip(source, target, force, radius_source, radius_target, eta,
+                                                             *args, **kwargs):
+  '''Velocity of targets (radii radius_target) due to forces on sources (radii radius_source) above a wall;
+  per-blob height clamp and B-damping on both sides (mobility/mobility.py:494-530, :551-590).'''
+  return _source_target(source, target, force, radius_source, radius_target, eta, True, kwargs)
+
+
+def no_wall_mobility_trans_times_force_source_target_hip(source, target, force, radius_source, radius_target, eta,
+                                                         *args, **kwargs):
+  '''Same in an unbounded domain (mobility/mobility.py:593-615).'''
+  return _source_target(source, target, force, radius_source, radius_target, eta, False, kwargs)
+
+
+def mobility_radii_trans_times_force(r_vectors, force, eta, a, radius_blobs, function, *args, **kwargs):
+  '''M.f for blobs with different radii: sources == targets (mobility/mobility.py:1369-1374).'''
+  return function(r_vectors, r_vectors, force, radius_blobs, radius_blobs, eta, *args, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
 # dense builders (used per body by the preconditioner / body_mobility scheme in the reference)
 # ---------------------------------------------------------------------------------------------
 def _dense(r_vectors, eta, a, wall):

@@ -442,3 +442,46 @@ def test_symmetric_force_kernel_matches_sweep_and_oracle(Ctx, oracle, L):
   assert rel_err(F_det, ref) < TOL_D2 and rel_err(F_sym, ref) < TOL_D2
   assert np.abs(F_sym.sum(axis=0)).max() < 1e-10 * np.abs(F_sym).sum()
   ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# 7. source -> target products with per-blob radii (K13)
+# ---------------------------------------------------------------------------------------------
+def test_source_target_golden(mob):
+  g = load_golden(golden_files("g4_source_target.npz")[0])
+  for name in ("small", "mixed", "periodic"):
+    args = [g[name + "_" + k] for k in ("source", "target", "force", "radius_source", "radius_target")]
+    for wall, fn in ((1, mob.single_wall_mobility_trans_times_force_source_target_hip),
+                     (0, mob.no_wall_mobility_trans_times_force_source_target_hip)):
+      u = fn(*args, float(g[name + "_eta"]), periodic_length=g[name + "_L"])
+      assert u.shape == (3 * len(args[1]),)
+      assert rel_err(u, g["%s_wall%d" % (name, wall)]) < TOL_D1, (name, wall, rel_err(u, g["%s_wall%d" % (name, wall)]))
+  u = mob.mobility_radii_trans_times_force(g["mixed_source"], g["mixed_force"], float(g["mixed_eta"]), 0.3, g["mixed_radius_source"],
+                                           mob.single_wall_mobility_trans_times_force_source_target_hip)
+  assert rel_err(u, g["mixed_radii_self_wall1"]) < TOL_D1
+
+
+@pytest.mark.parametrize("ns,nt", [(1, 1), (3, 700), (5000, 64), (4000, 3000)])
+def test_source_target_vs_oracle(mob, oracle, ns, nt):
+  rng = np.random.RandomState(ns + nt)
+  box = (max(ns, nt) ** (1.0 / 3.0)) * 1.2
+  src = rng.rand(ns, 3) * box
+  tgt = rng.rand(nt, 3) * box
+  rs = 0.1 + 0.4 * rng.rand(ns)
+  rt = 0.1 + 0.4 * rng.rand(nt)
+  f = rng.randn(ns, 3)
+  for wall in (True, False):
+    pre = "single_wall" if wall else "no_wall"
+    u = getattr(mob, pre + "_mobility_trans_times_force_source_target_hip")(src, tgt, f, rs, rt, 0.8)
+    ref = getattr(oracle, pre + "_mobility_trans_times_force_source_target_oracle")(src, tgt, f, rs, rt, 0.8)
+    assert np.all(np.isfinite(u))
+    assert rel_err(u, ref) < TOL_D1, rel_err(u, ref)
+
+
+def test_source_target_equal_radii_reduces_to_tt(mob):
+  """With one radius and sources == targets the K13 kernel must reproduce the single-radius tt product."""
+  r, f, eta, a = d2_cloud(1500, seed=80)
+  ones = np.full(len(r), a)
+  u13 = mob.mobility_radii_trans_times_force(r, f, eta, a, ones, mob.single_wall_mobility_trans_times_force_source_target_hip)
+  u1 = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
+  assert rel_err(u13, u1) < 1e-12

@@ -63,3 +63,20 @@ def test_dense_matches_matvec(oracle):
     for wall in (0, 1):
       M = oracle.dense(kind, wall, r, eta, a)
       assert rel_err(M @ f, oracle.raw_matvec(kind, wall, r, f, eta, a)) < 1e-13
+
+
+def test_source_target_matches_reference(oracle):
+  """K13 (per-blob radii, N_src != N_trg): mobility/mobility.py:551-615 over mobility_numba.py:1480-1658."""
+  from conftest import GOLDEN
+  import os
+  g = np.load(os.path.join(GOLDEN, "g4_source_target.npz"))
+  for name in ("small", "mixed", "periodic"):
+    args = [g[name + "_" + k] for k in ("source", "target", "force", "radius_source", "radius_target")]
+    for wall, fn in ((1, oracle.single_wall_mobility_trans_times_force_source_target_oracle),
+                     (0, oracle.no_wall_mobility_trans_times_force_source_target_oracle)):
+      u = fn(*args, float(g[name + "_eta"]), periodic_length=g[name + "_L"])
+      assert rel_err(u, g["%s_wall%d" % (name, wall)]) < TOL
+  c = "mixed"
+  u = oracle.single_wall_mobility_trans_times_force_source_target_oracle(
+      g[c + "_source"], g[c + "_source"], g[c + "_force"], g[c + "_radius_source"], g[c + "_radius_source"], float(g[c + "_eta"]))
+  assert rel_err(u, g["mixed_radii_self_wall1"]) < TOL
