@@ -188,7 +188,18 @@ int check_ready(rmb_ctx* c) {
   return 0;
 }
 
-int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out, long shard = 0, long nshards = 1) {
+typedef void (*sym_fn)(const rmb::SymArgs);
+struct SymEntry { sym_fn sweep; sym_fn fin; int occ; };
+template <int KIND, bool WALL> SymEntry make_sym_entry() { return SymEntry{rmb::sym_kernel<KIND, WALL>, rmb::sym_finalize_kernel<KIND, WALL>, 0}; }
+// [kind tt,tr,rt,rr][wall]
+SymEntry g_sym[4][2] = {
+    {make_sym_entry<rmb::KIND_TT, false>(), make_sym_entry<rmb::KIND_TT, true>()},
+    {make_sym_entry<rmb::KIND_TR, false>(), make_sym_entry<rmb::KIND_TR, true>()},
+    {make_sym_entry<rmb::KIND_RT, false>(), make_sym_entry<rmb::KIND_RT, true>()},
+    {make_sym_entry<rmb::KIND_RR, false>(), make_sym_entry<rmb::KIND_RR, true>()}};
+
+int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard = 0, long nshards = 1) {
+  SymEntry& se = g_sym[kind][c->wall ? 1 : 0];
   const long n = c->n;
   const long tiles = (n + 63) / 64;
   const long n_pad = 64 * tiles;
@@ -217,9 +228,8 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out, long sha
   }
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
-  static int occ[2] = {0, 0};
-  const void* fn = c->wall ? (const void*)rmb::sym_tt_kernel<true> : (const void*)rmb::sym_tt_kernel<false>;
-  int wps = resident_blocks(fn, &occ[c->wall ? 1 : 0]);
+  const void* fn = (const void*)se.sweep;
+  int wps = resident_blocks(fn, &se.occ);
   if (c->opt_sym_wps > 0 && c->opt_sym_wps < wps) wps = (int)c->opt_sym_wps;
   // dynamic LDS padding pins residency to exactly `wps` workgroups per CU, so that the static schedule
   // (equal steps per wave) is also equal work per SIMD
@@ -236,13 +246,11 @@ int sym_tt_device(rmb_ctx* c, const double* v, double eta, double* out, long sha
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  if (c->wall) hipLaunchKernelGGL(rmb::sym_tt_kernel<true>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
-  else         hipLaunchKernelGGL(rmb::sym_tt_kernel<false>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
+  hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
   const dim3 fgrid((unsigned)((n + 255) / 256));
-  if (c->wall) hipLaunchKernelGGL(rmb::sym_tt_finalize_kernel<true>, fgrid, dim3(256), 0, c->stream, a);
-  else         hipLaunchKernelGGL(rmb::sym_tt_finalize_kernel<false>, fgrid, dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(se.fin, fgrid, dim3(256), 0, c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
 }
@@ -262,10 +270,10 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
 
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (kind == rmb::KIND_TT && !periodic && !in_plane && c->opt_symmetric && !c->opt_deterministic &&
+  if (kind <= rmb::KIND_RR && !periodic && !in_plane && c->opt_symmetric && !c->opt_deterministic &&
       c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
     c->last_path = 1;
-    return sym_tt_device(c, v, eta, out);
+    return sym_device(c, kind, v, eta, out);
   }
   KernelEntry& ke = g_kernels[kind][c->wall ? 1 : 0][periodic ? 1 : 0];
   const long slots = 256L * resident_blocks((const void*)ke.sweep, &ke.blocks_per_cu);
@@ -511,7 +519,7 @@ int rmb_matvec_device(rmb_ctx* c, int kind, int in_plane, const double* v, const
 
 int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards) {
   if (int rc = check_ready(c)) return rc;
-  if (kind != rmb::KIND_TT) return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT only");
+  if (kind < 0 || kind > rmb::KIND_RR) return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT / TR / RT / RR");
   if (c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0) return fail(RMB_ERR_ARG, "pair sharding needs periodic_length = 0");
   if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
   if (c->n == 0) return 0;
@@ -519,7 +527,7 @@ int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double et
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   RMB_HIP(hipSetDevice(c->device));
   c->last_path = 1;
-  return sym_tt_device(c, v, eta, out, shard, nshards);
+  return sym_device(c, kind, v, eta, out, shard, nshards);
 }
 
 int rmb_body_mobility_dense_device(rmb_ctx* c, const long* first_blob_dev, long n_bodies, int n_b, double eta,

@@ -105,6 +105,142 @@ __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, doub
   }
 }
 
+
+// rr, both directions.  W_rr = f1 I + f2 e e^T + f3 z e^T + f4 Q (Q = xy block, symmetric), so W^T moves f3 to
+// e z^T:  (W v)_xy = iR3{(3.5-6u) v - (1.5E + 3E_par) e},        (W v)_z = iR3{(0.5-3u) v_z + 1.5 E e_z}
+//         (W^T v)_xy = iR3{(3.5-6u) v - (4.5E_par - 1.5 e_z v_z) e}, (W^T v)_z = iR3{0.5 v_z - 1.5 E e_z}.
+template <bool WALL>
+__device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, double dy, double dz, double Rz,
+                                            double vix, double viy, double viz, double vjx, double vjy, double vjz,
+                                            Vec3& ui, double& tx, double& ty, double& tz) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double ir = rsqrt_f64(r2);
+  const double ir2 = ir * ir;
+  const double ir3 = ir2 * ir;
+  double cF = -0.5 * ir3;
+  double cD = 1.5 * ir3 * ir2;
+  if (__builtin_expect(__any(r2 < k.four_a2), 0)) {
+    const double r = r2 * ir;
+    const double r3 = r2 * r;
+    const bool near = r2 < k.four_a2;
+    cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : cF;
+    cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * ir) : cD;
+  }
+  const double pj = __builtin_fma(dy, vjy, dx * vjx);
+  const double pi = __builtin_fma(dy, viy, dx * vix);
+  const double cDj = cD * __builtin_fma(dz, vjz, pj);
+  const double cDi = cD * __builtin_fma(dz, viz, pi);
+  if constexpr (!WALL) {
+    ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cDj, dx, ui.x);
+    ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cDj, dy, ui.y);
+    ui.z = __builtin_fma(cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
+    tx = __builtin_fma(cDi, dx, cF * vix);
+    ty = __builtin_fma(cDi, dy, cF * viy);
+    tz = __builtin_fma(cDi, dz, cF * viz);
+  } else {
+    const double R2 = __builtin_fma(Rz, Rz, rho2);
+    const double iR = rsqrt_f64(R2);
+    const double iR2 = iR * iR;
+    const double iR3 = iR2 * iR;
+    const double iR5 = iR3 * iR2;
+    const double uu = Rz * Rz * iR2;
+    const double cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, cF);
+    const double cFzj = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, cF);
+    const double cFzi = __builtin_fma(0.5, iR3, cF);
+    const double zvj = Rz * vjz, zvi = Rz * viz;
+    const double h5 = 1.5 * iR5;
+    // forward
+    const double Rvj = zvj + pj;
+    const double cj = __builtin_fma(-h5, __builtin_fma(2.0, pj, Rvj), cDj);       // cD (d.v) - iR5 (1.5 R.v + 3 p)
+    ui.x = __builtin_fma(cFxy, vjx, ui.x); ui.x = __builtin_fma(cj, dx, ui.x);
+    ui.y = __builtin_fma(cFxy, vjy, ui.y); ui.y = __builtin_fma(cj, dy, ui.y);
+    ui.z = __builtin_fma(cFzj, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
+    ui.z = __builtin_fma(h5 * Rvj, Rz, ui.z);
+    // transposed
+    const double Rvi = zvi + pi;
+    const double ci = __builtin_fma(-h5, __builtin_fma(3.0, pi, -zvi), cDi);      // cD (d.v) - iR5 (4.5 p - 1.5 Rz v_z)
+    tx = __builtin_fma(ci, dx, cFxy * vix);
+    ty = __builtin_fma(ci, dy, cFxy * viy);
+    tz = __builtin_fma(-h5 * Rvi, Rz, __builtin_fma(cDi, dz, cFzi * viz));
+  }
+}
+
+// Coupling blocks, both directions.  KIND_TR: u = M_tr tau, wall part anchored on the TARGET height of each
+// direction (z_i forward, z_j transposed); KIND_RT: w = M_rt f, anchored on the SOURCE height (z_j forward,
+// z_i transposed).  The two directions share both rsqrt, tau, e and differ only in g = z iR, which enters
+// p, s, f3 linearly.  The reversed pair sees e' = (-e_x, -e_y, e_z) and d' = -d.
+template <bool TR, bool WALL>
+__device__ __forceinline__ void pair_coupling_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                                  double vix, double viy, double viz, double vjx, double vjy, double vjz,
+                                                  Vec3& ui, double& tx, double& ty, double& tz) {
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double c = coupling_coeff(k, r2);
+  // c (v_j x d)  and  -c (v_i x d)
+  double ax = __builtin_fma(vjy, dz, -vjz * dy) * c, ay = __builtin_fma(vjz, dx, -vjx * dz) * c, az = __builtin_fma(vjx, dy, -vjy * dx) * c;
+  double bx = __builtin_fma(viz, dy, -viy * dz) * c, by = __builtin_fma(vix, dz, -viz * dx) * c, bz = __builtin_fma(viy, dx, -vix * dy) * c;
+  if constexpr (WALL) {
+    const double Rz = zi + zj;
+    const double R2 = __builtin_fma(Rz, Rz, rho2);
+    const double iR = rsqrt_f64(R2);
+    const double iR2 = iR * iR;
+    const double tau = k.a2 * iR2;
+    const double ez = Rz * iR, ex = dx * iR, ey = dy * iR;
+    const double uu = ez * ez;
+    const double eztau = ez * tau;
+    const double f1 = iR2;
+    const double p0 = iR2 * __builtin_fma(2.0, eztau, ez);                      // p = p0 - 2 iR2 g
+    const double s0 = iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, 1.0);   // s = s0 + 12 iR2 ez g
+    const double f30 = 10.0 * iR2 * eztau;                                      // f3 = f30 - 6 iR2 g
+    const double gF = (TR ? zi : zj) * iR;       // forward anchor
+    const double gT = (TR ? zj : zi) * iR;       // transposed anchor
+    const double m2 = -2.0 * iR2, e12 = 12.0 * iR2 * ez, m6 = -6.0 * iR2;
+    const double pF = __builtin_fma(m2, gF, p0), sF = __builtin_fma(e12, gF, s0), f3F = __builtin_fma(m6, gF, f30);
+    const double pT = __builtin_fma(m2, gT, p0), sT = __builtin_fma(e12, gT, s0), f3T = __builtin_fma(m6, gT, f30);
+    if constexpr (TR) {
+      // forward (pair_tr):  (-f3 ex c0 + p vy + f1 ey vz, -f3 ey c0 - p vx - f1 ex vz, (s + f3 ez) c0)
+      const double c0 = __builtin_fma(ex, vjy, -ey * vjx);
+      const double fc = f3F * c0;
+      ax += __builtin_fma(f1 * ey, vjz, __builtin_fma(pF, vjy, -fc * ex));
+      ay -= __builtin_fma(f1 * ex, vjz, __builtin_fma(pF, vjx, fc * ey));
+      az += __builtin_fma(f3F, ez, sF) * c0;
+      // reversed pair: (-f3 ex c0i + p viy - f1 ey viz, -f3 ey c0i - p vix + f1 ex viz, -(s + f3 ez) c0i)
+      const double c0i = __builtin_fma(ex, viy, -ey * vix);
+      const double gc = f3T * c0i;
+      bx += __builtin_fma(-f1 * ey, viz, __builtin_fma(pT, viy, -gc * ex));
+      by += __builtin_fma(f1 * ex, viz, -__builtin_fma(pT, vix, gc * ey));
+      bz -= __builtin_fma(f3T, ez, sT) * c0i;
+    } else {
+      // forward (pair_rt): (kap ey - p vy, -kap ex + p vx, f1 (ex vy - ey vx)), kap = f3 E + s vz
+      const double E = __builtin_fma(ez, vjz, __builtin_fma(ey, vjy, ex * vjx));
+      const double kap = __builtin_fma(f3F, E, sF * vjz);
+      ax += __builtin_fma(kap, ey, -pF * vjy);
+      ay += __builtin_fma(-kap, ex, pF * vjx);
+      az += f1 * __builtin_fma(ex, vjy, -ey * vjx);
+      // reversed pair: E' = -ex vix - ey viy + ez viz; (-kap' ey - p viy, kap' ex + p vix, -f1 (ex viy - ey vix))
+      const double Ei = __builtin_fma(ez, viz, -__builtin_fma(ey, viy, ex * vix));
+      const double kapi = __builtin_fma(f3T, Ei, sT * viz);
+      bx -= __builtin_fma(kapi, ey, pT * viy);
+      by += __builtin_fma(kapi, ex, pT * vix);
+      bz -= f1 * __builtin_fma(ex, viy, -ey * vix);
+    }
+  }
+  ui.x += ax; ui.y += ay; ui.z += az;
+  tx = bx; ty = by; tz = bz;
+}
+
+// dispatcher
+template <int KIND, bool WALL>
+__device__ __forceinline__ void pair_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                         double vix, double viy, double viz, double vjx, double vjy, double vjz,
+                                         Vec3& ui, double& tx, double& ty, double& tz) {
+  if constexpr (KIND == KIND_TT) pair_tt_sym<WALL>(k, dx, dy, dz, zi + zj, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_RR) pair_rr_sym<WALL>(k, dx, dy, dz, zi + zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_TR) pair_coupling_sym<true, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_RT) pair_coupling_sym<false, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+}
+
 __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
   // row-major over the upper triangle: row I holds (T - I) units
   const double tt = 2.0 * T + 1.0;
@@ -117,8 +253,8 @@ __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
   J = (int)(u - (i * T - i * (i - 1) / 2) + i);
 }
 
-template <bool WALL>
-__global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a) {
+template <int KIND, bool WALL>
+__global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
   __shared__ double2 rec_all[kSymWaves][64 * 3];
   __shared__ double accj_all[kSymWaves][3 * 64];
   const int lane = threadIdx.x & 63;
@@ -191,8 +327,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
         double tx, ty, tz;
-        pair_tt_sym<WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi + q1.x, q1.x, vix, viy, viz, q1.y, q2.x, q2.y, ui,
-                          tx, ty, tz);
+        pair_sym<KIND, WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi, q1.x, vix, viy, viz, q1.y, q2.x, q2.y, ui,
+                             tx, ty, tz);
         __hip_atomic_fetch_add(&accj[jj], tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __hip_atomic_fetch_add(&accj[64 + jj], ty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __hip_atomic_fetch_add(&accj[128 + jj], tz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -212,7 +348,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
-        pair_tt<WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi + q1.x, q1.x, q1.y, q2.x, q2.y, ui);
+        pair_apply<KIND, WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi, q1.x, q1.y, q2.x, q2.y, 0.0, 0.0, 0.0, ui);
       }
     }
     __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
@@ -224,8 +360,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_tt_kernel(const SymArgs a)
   }
 }
 
-template <bool WALL>
-__global__ __launch_bounds__(256) void sym_tt_finalize_kernel(const SymArgs a) {
+template <int KIND, bool WALL>
+__global__ __launch_bounds__(256) void sym_finalize_kernel(const SymArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
@@ -233,7 +369,7 @@ __global__ __launch_bounds__(256) void sym_tt_finalize_kernel(const SymArgs a) {
   const double4 p = a.pos[i];
   const double b = p.w;
   if (i >= a.self_begin && i < a.self_end)
-    self_term<KIND_TT, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
+    self_term<KIND, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
   const double sc = a.prefactor * b;
   a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
 }

@@ -252,31 +252,36 @@ def test_target_shards_equal_single_range(Ctx, G):
   ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["tt", "tr", "rt", "rr"])
 @pytest.mark.parametrize("wall", [True, False])
 @pytest.mark.parametrize("N", [128, 1000, 4097, 20000])
-def test_symmetric_kernel_matches_deterministic_sweep(Ctx, oracle, wall, N):
-  """tt has two device paths: sym_tt_kernel (each unordered pair once, atomics) and sweep_kernel
+def test_symmetric_kernel_matches_deterministic_sweep(Ctx, oracle, wall, N, kind):
+  """tt / tr / rt / rr have two device paths: sym_kernel (each unordered pair once, atomics) and sweep_kernel
   (every ordered pair, atomic-free).  Both must agree to rounding and with the oracle."""
   r, f, eta, a = d1_cloud(N, seed=30 + N) if N <= 4097 else d2_cloud(N, seed=30)
   ctx = Ctx(0)
   ctx.set_positions(r, a, wall=wall)
-  u_sym = ctx.matvec("tt", f, eta)
-  u_sym2 = ctx.matvec("tt", f, eta)
+  u_sym = ctx.matvec(kind, f, eta)
+  assert ctx.last_launch()["chunks"] == 0
+  u_sym2 = ctx.matvec(kind, f, eta)
   ctx.set_option("deterministic", 1)
-  u_det = ctx.matvec("tt", f, eta)
-  u_det2 = ctx.matvec("tt", f, eta)
+  u_det = ctx.matvec(kind, f, eta)
+  assert ctx.last_launch()["chunks"] >= 1
+  u_det2 = ctx.matvec(kind, f, eta)
   assert np.array_equal(u_det, u_det2)              # sweep path is bit-reproducible
   assert rel_err(u_sym, u_det) < 1e-13 and rel_err(u_sym2, u_det) < 1e-13
   if N <= 4097:
     pre = "single_wall" if wall else "no_wall"
-    ref = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(r, f, eta, a)
+    stem = {"tt": "trans_times_force", "tr": "trans_times_torque", "rt": "rot_times_force", "rr": "rot_times_torque"}[kind]
+    ref = getattr(oracle, "%s_mobility_%s_oracle" % (pre, stem))(r, f, eta, a)
     assert rel_err(u_sym, ref) < TOL_D1
   ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["tt", "tr", "rt", "rr"])
 @pytest.mark.parametrize("G", [2, 3, 8])
 @pytest.mark.parametrize("wall", [True, False])
-def test_pair_shards_sum_to_full_product(Ctx, oracle, G, wall):
+def test_pair_shards_sum_to_full_product(Ctx, oracle, G, wall, kind):
   """What the G ranks of a pair-sharded job compute (rmb_matvec_pairshard_device), summed as the
   all-reduce would, equals the single-GPU product; each shard's output covers all targets."""
   import torch
@@ -288,13 +293,14 @@ def test_pair_shards_sum_to_full_product(Ctx, oracle, G, wall):
   total = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
   norms = []
   for g in range(G):
-    part = ctx.matvec_pairshard_device("tt", fd, eta, g, G)
+    part = ctx.matvec_pairshard_device(kind, fd, eta, g, G)
     norms.append(float(part.norm()))
     total += part
-  full = ctx.matvec_device("tt", fd, eta)
+  full = ctx.matvec_device(kind, fd, eta)
   torch.cuda.synchronize()
   pre = "single_wall" if wall else "no_wall"
-  ref = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(r, f, eta, a)
+  stem = {"tt": "trans_times_force", "tr": "trans_times_torque", "rt": "rot_times_force", "rr": "rot_times_torque"}[kind]
+  ref = getattr(oracle, "%s_mobility_%s_oracle" % (pre, stem))(r, f, eta, a)
   assert rel_err(total.cpu().numpy(), ref) < TOL_D1
   assert rel_err(total.cpu().numpy(), full.cpu().numpy()) < 1e-13
   assert all(x > 0 for x in norms)
