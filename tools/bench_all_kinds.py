@@ -23,7 +23,7 @@ for N in (10000, 100000):
         continue
       reps = 20 if N <= 10000 else 5
       v2 = fd if kind == "tt_tr" else None
-      for det in ((0, 1) if kind == "tt" else (0,)):
+      for det in ((0, 1) if kind in ("tt", "tr", "rt", "rr") else (0,)):
         ctx.set_option("deterministic", det)
         for _ in range(2):
           ctx.matvec_device(kind, fd, eta, vec2=v2)
@@ -33,7 +33,7 @@ for N in (10000, 100000):
         torch.cuda.synchronize()
         ms = float(np.mean(ctx.timing_collect(reps)))
         tf = FLOPS[(kind, wall)] * float(N) * N / (ms * 1e-3) / 1e12
-        rows.append(dict(N=N, kind=kind, wall=wall, path="sweep" if (det or kind != "tt") else "symmetric", kernel_ms=round(ms, 4),
+        rows.append(dict(N=N, kind=kind, wall=wall, path="symmetric" if ctx.last_launch()["chunks"] == 0 else "sweep", kernel_ms=round(ms, 4),
                          flops_per_pair=FLOPS[(kind, wall)], alg_tflops=round(tf, 2), frac_fp64_peak=round(tf / 78.6, 3),
                          gpairs_per_s=round(float(N) * N / (ms * 1e-3) / 1e9, 1)))
         print(rows[-1], flush=True)
@@ -50,7 +50,7 @@ for N in (10000, 100000):
     ctx.blob_blob_force_device(3.92, 0.1 * a, a)
   torch.cuda.synchronize()
   ms = float(np.mean(ctx.timing_collect(reps)))
-  rows.append(dict(N=N, kind="forces", wall=False, path="sweep", kernel_ms=round(ms, 4), flops_per_pair=22,
+  rows.append(dict(N=N, kind="forces", wall=False, path="symmetric" if ctx.last_launch()["chunks"] == 0 else "sweep", kernel_ms=round(ms, 4), flops_per_pair=22,
                    alg_tflops=round(22 * float(N) * N / (ms * 1e-3) / 1e12, 2), gpairs_per_s=round(float(N) * N / (ms * 1e-3) / 1e9, 1)))
   print(rows[-1], flush=True)
   ctx.close()
