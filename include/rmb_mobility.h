@@ -85,7 +85,7 @@ int rmb_matvec(rmb_ctx* ctx, int kind, int in_plane, const double* vec_host, con
 int rmb_matvec_device(rmb_ctx* ctx, int kind, int in_plane, const double* vec_dev, const double* vec2_dev,
                       double eta, double* out_dev);
 
-/* Multi-GPU, symmetric pair sharding (RMB_TT / TR / RT / RR, non-periodic): the unordered blob pairs are cut into
+/* Multi-GPU, symmetric pair sharding (RMB_TT / TR / RT / RR): the unordered blob pairs are cut into
  * `nshards` equal parts; this call evaluates part `shard` (each pair once, applied to both blobs) and
  * writes its contribution to ALL n targets (3n doubles).  The sum over shards is the full product; the
  * self term of target i is added by the shard that owns i in the contiguous block partition.  The

@@ -190,16 +190,17 @@ int check_ready(rmb_ctx* c) {
 
 typedef void (*sym_fn)(const rmb::SymArgs);
 struct SymEntry { sym_fn sweep; sym_fn fin; int occ; };
-template <int KIND, bool WALL> SymEntry make_sym_entry() { return SymEntry{rmb::sym_kernel<KIND, WALL>, rmb::sym_finalize_kernel<KIND, WALL>, 0}; }
-// [kind tt,tr,rt,rr][wall]
-SymEntry g_sym[4][2] = {
-    {make_sym_entry<rmb::KIND_TT, false>(), make_sym_entry<rmb::KIND_TT, true>()},
-    {make_sym_entry<rmb::KIND_TR, false>(), make_sym_entry<rmb::KIND_TR, true>()},
-    {make_sym_entry<rmb::KIND_RT, false>(), make_sym_entry<rmb::KIND_RT, true>()},
-    {make_sym_entry<rmb::KIND_RR, false>(), make_sym_entry<rmb::KIND_RR, true>()}};
+template <int KIND, bool WALL, bool PER> SymEntry make_sym_entry() {
+  return SymEntry{rmb::sym_kernel<KIND, WALL, PER>, rmb::sym_finalize_kernel<KIND, WALL>, 0};
+}
+// [kind tt,tr,rt,rr][wall][periodic]
+#define RMB_SYM_ROW(K) {{make_sym_entry<K, false, false>(), make_sym_entry<K, false, true>()}, {make_sym_entry<K, true, false>(), make_sym_entry<K, true, true>()}}
+SymEntry g_sym[4][2][2] = {RMB_SYM_ROW(rmb::KIND_TT), RMB_SYM_ROW(rmb::KIND_TR), RMB_SYM_ROW(rmb::KIND_RT), RMB_SYM_ROW(rmb::KIND_RR)};
+#undef RMB_SYM_ROW
 
 int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard = 0, long nshards = 1) {
-  SymEntry& se = g_sym[kind][c->wall ? 1 : 0];
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  SymEntry& se = g_sym[kind][c->wall ? 1 : 0][periodic ? 1 : 0];
   const long n = c->n;
   const long tiles = (n + 63) / 64;
   const long n_pad = 64 * tiles;
@@ -226,6 +227,10 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
     a.self_begin = block * shard < n ? block * shard : n;
     a.self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
   }
+  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
   const void* fn = (const void*)se.sweep;
@@ -270,7 +275,7 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
 
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (kind <= rmb::KIND_RR && !periodic && !in_plane && c->opt_symmetric && !c->opt_deterministic &&
+  if (kind <= rmb::KIND_RR && !in_plane && c->opt_symmetric && !c->opt_deterministic &&
       c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
     c->last_path = 1;
     return sym_device(c, kind, v, eta, out);
@@ -520,7 +525,6 @@ int rmb_matvec_device(rmb_ctx* c, int kind, int in_plane, const double* v, const
 int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards) {
   if (int rc = check_ready(c)) return rc;
   if (kind < 0 || kind > rmb::KIND_RR) return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT / TR / RT / RR");
-  if (c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0) return fail(RMB_ERR_ARG, "pair sharding needs periodic_length = 0");
   if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
   if (c->n == 0) return 0;
   if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");

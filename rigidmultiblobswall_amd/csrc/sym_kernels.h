@@ -41,6 +41,7 @@ struct SymArgs {
   long n_units;         // n_tiles (n_tiles + 1) / 2
   long step_begin, step_end;  // rotation steps [begin, end) of the n_units*64 this launch covers (pair shard)
   long self_begin, self_end;  // targets whose self term this launch adds (exactly one shard per target)
+  double Lx, Ly, Lz, iLx, iLy, iLz;  // pseudo-periodic lengths (<= 0: open) and reciprocals
   double prefactor;
   PairConsts k;
 };
@@ -241,6 +242,12 @@ __device__ __forceinline__ void pair_sym(const PairConsts& k, double dx, double 
   if constexpr (KIND == KIND_RT) pair_coupling_sym<false, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
 }
 
+__device__ __forceinline__ double wrap_nearest_sym(double r, double L, double invL) {
+  const double q = r * invL;
+  const double h = (r > 0.0) ? 0.5 : ((r < 0.0) ? -0.5 : 0.0);
+  return __builtin_fma(-__builtin_trunc(q + h), L, r);
+}
+
 __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
   // row-major over the upper triangle: row I holds (T - I) units
   const double tt = 2.0 * T + 1.0;
@@ -253,7 +260,7 @@ __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
   J = (int)(u - (i * T - i * (i - 1) / 2) + i);
 }
 
-template <int KIND, bool WALL>
+template <int KIND, bool WALL, bool PERIODIC>
 __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
   __shared__ double2 rec_all[kSymWaves][64 * 3];
   __shared__ double accj_all[kSymWaves][3 * 64];
@@ -321,14 +328,33 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // Pseudo-periodic images (mobility_numba.py:170-197): nearest image once, then the 3^d neighbour boxes.
+    // M_ji(box b) = M_ij(box -b)^T and the boxes are summed symmetrically, so both directions of every image
+    // are still evaluated together.
+    const int px = PERIODIC && a.Lx > 0, py = PERIODIC && a.Ly > 0, pz = PERIODIC && a.Lz > 0;
     if (I != J) {
       for (int k = k0; k < k1; ++k) {
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
+        double dx = xi - q0.x, dy = yi - q0.y, dz = zi - q1.x;
         double tx, ty, tz;
-        pair_sym<KIND, WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi, q1.x, vix, viy, viz, q1.y, q2.x, q2.y, ui,
-                             tx, ty, tz);
+        if constexpr (!PERIODIC) {
+          pair_sym<KIND, WALL>(a.k, dx, dy, dz, zi, q1.x, vix, viy, viz, q1.y, q2.x, q2.y, ui, tx, ty, tz);
+        } else {
+          if (px) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
+          if (py) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
+          if (pz) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+          tx = 0.0; ty = 0.0; tz = 0.0;
+          for (int bx = -px; bx <= px; ++bx)
+            for (int by = -py; by <= py; ++by)
+              for (int bz = -pz; bz <= pz; ++bz) {
+                double sx, sy, sz;
+                pair_sym<KIND, WALL>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, q1.x, vix, viy, viz, q1.y, q2.x,
+                                     q2.y, ui, sx, sy, sz);
+                tx += sx; ty += sy; tz += sz;
+              }
+        }
         __hip_atomic_fetch_add(&accj[jj], tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __hip_atomic_fetch_add(&accj[64 + jj], ty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __hip_atomic_fetch_add(&accj[128 + jj], tz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -343,12 +369,27 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
         __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      // diagonal unit: every ordered pair of the tile once, forward only; step 0 is the self pair (skipped)
-      for (int k = (k0 > 1 ? k0 : 1); k < k1; ++k) {
+      // diagonal unit: every ordered pair of the tile once, forward only.  Step 0 is the blob itself: its
+      // central-box term is the self term (finalize); its periodic images use the pair formula.
+      for (int k = (PERIODIC || k0 > 1) ? k0 : 1; k < k1; ++k) {
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
-        pair_apply<KIND, WALL>(a.k, xi - q0.x, yi - q0.y, zi - q1.x, zi, q1.x, q1.y, q2.x, q2.y, 0.0, 0.0, 0.0, ui);
+        double dx = xi - q0.x, dy = yi - q0.y, dz = zi - q1.x;
+        if constexpr (!PERIODIC) {
+          pair_apply<KIND, WALL>(a.k, dx, dy, dz, zi, q1.x, q1.y, q2.x, q2.y, 0.0, 0.0, 0.0, ui);
+        } else {
+          if (px) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
+          if (py) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
+          if (pz) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+          for (int bx = -px; bx <= px; ++bx)
+            for (int by = -py; by <= py; ++by)
+              for (int bz = -pz; bz <= pz; ++bz) {
+                if (k == 0 && bx == 0 && by == 0 && bz == 0) continue;
+                pair_apply<KIND, WALL>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, q1.x, q1.y, q2.x, q2.y, 0.0, 0.0,
+                                       0.0, ui);
+              }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
@@ -390,12 +431,6 @@ struct SymForceArgs {
   double Lx, Ly, Lz, iLx, iLy, iLz;
   double eps_over_b, inv_b, two_a;
 };
-
-__device__ __forceinline__ double wrap_nearest_sym(double r, double L, double invL) {
-  const double q = r * invL;
-  const double h = (r > 0.0) ? 0.5 : ((r < 0.0) ? -0.5 : 0.0);
-  return __builtin_fma(-__builtin_trunc(q + h), L, r);
-}
 
 // f0(r) dr for one pair; dr = r_j - r_i (minimal image).  Returns the force ON i; the force on j is minus it.
 template <bool PERIODIC>

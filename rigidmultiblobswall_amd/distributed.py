@@ -54,7 +54,7 @@ class HipBackend(object):
     return self.ctx.blob_blob_force_device(eps, b, a, out=out, device=self.device)
 
   def supports_pairshard(self, kind, periodic):
-    return kind in ("tt", "tr", "rt", "rr") and not periodic
+    return kind in ("tt", "tr", "rt", "rr")
 
   def matvec_pairshard(self, kind, v_full, eta, shard, nshards, out=None):
     return self.ctx.matvec_pairshard_device(kind, v_full, eta, shard, nshards, out=out)

@@ -119,6 +119,24 @@ def test_pseudo_periodic(mob, oracle, stem, L):
   assert rel_err(u, ref) < TOL_D2, rel_err(u, ref)
 
 
+@pytest.mark.parametrize("kind", ["tt", "tr", "rt", "rr"])
+def test_periodic_symmetric_vs_sweep(Ctx, oracle, kind):
+  """Pseudo-periodic images through both device paths (N large enough for the symmetric kernel,
+  incl. a partial last tile and self-images)."""
+  r, f, eta, a = d2_cloud(1000, seed=90)
+  L = np.array([14.0, 16.0, 0.0])
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, L, wall=True)
+  u_sym = ctx.matvec(kind, f, eta)
+  assert ctx.last_launch()["chunks"] == 0
+  ctx.set_option("deterministic", 1)
+  u_det = ctx.matvec(kind, f, eta)
+  stem = {"tt": "trans_times_force", "tr": "trans_times_torque", "rt": "rot_times_force", "rr": "rot_times_torque"}[kind]
+  ref = getattr(oracle, "single_wall_mobility_%s_oracle" % stem)(r, f, eta, a, periodic_length=L)
+  assert rel_err(u_det, ref) < TOL_D2 and rel_err(u_sym, ref) < TOL_D2
+  ctx.close()
+
+
 def test_fully_periodic_no_wall(mob, oracle):
   r, v, eta, a = d2_cloud(200, seed=8)
   L = np.array([9.0, 10.0, 11.0])
