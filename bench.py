@@ -152,9 +152,9 @@ def main():
   sym = res["launch"]["chunks"] == 0
   roofline = {
       "bound": "valu_fp64",
-      "kernel": "rmb::sym_tt_kernel<wall> (each unordered pair once)" if sym else "rmb::sweep_kernel<TT,wall>",
+      "kernel": "rmb::sym_kernel<TT,wall> (each unordered pair once)" if sym else "rmb::sweep_kernel<TT,wall>",
       "note": "achieved = ALGORITHMIC flops (211 per ordered pair, the reference's as-written count, SURVEY 8d) / measured "
-              "kernel time; the kernel executes ~58 (symmetric) or ~93 (sweep) fp64 VALU instructions per ordered pair, so "
+              "kernel time; the kernel executes ~55 (symmetric) or ~93 (sweep) fp64 VALU instructions per ordered pair, so "
               "frac can exceed 1; measured fp64 issue ceiling of the chip: 479 G wave-instr/s (profiles/r1_ubench_*)",
       "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
       "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
@@ -205,7 +205,7 @@ def main():
 
   if not args.no_sweep:
     sweep = []
-    for nb, st, wu in ((100000, 5, 1), (1000000, 2, 1) if world > 1 else (262144, 3, 1)):
+    for nb, st, wu in ((100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
       rs = run_config(torch, dist, sm, backend, nb, st, wu, world, rank, device)
       pairs = float(nb) * nb / world
       sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
