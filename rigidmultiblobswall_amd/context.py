@@ -60,18 +60,14 @@ class MobilityContext(object):
   # torch kernels that produced its inputs and before those that consume its outputs -- no events, no
   # host synchronisation.  (Measured alternative: a private stream + wait_stream fences costs ~24 us per
   # call, 11 % of a 1e4-blob matvec.)
-  def _enter(self):
+  def _follow_torch_stream(self):
     if self._user_stream:
-      return None
+      return
     import torch
     h = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
     if h != self._stream_handle:
       _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(h)))
       self._stream_handle = h
-    return None
-
-  def _exit(self, dev):
-    return None
 
   def set_option(self, key, value):
     _lib.check(self._lib.rmb_ctx_set_option(self._h, key.encode(), int(value)))
@@ -82,10 +78,9 @@ class MobilityContext(object):
     if _is_torch_cuda(r_vectors):
       r = r_vectors.contiguous().view(-1)
       n = r.numel() // 3
-      dev = self._enter()
+      self._follow_torch_stream()
       _lib.check(self._lib.rmb_set_positions_device(self._h, ctypes.c_void_p(r.data_ptr()), n, float(a), _ptr(L),
                                                     int(bool(wall))))
-      self._exit(dev)
       self._keepalive = r
     else:
       r = _as_f64(r_vectors)
@@ -123,11 +118,10 @@ class MobilityContext(object):
       out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=vec.device)
     elif not _is_torch_cuda(out) or out.numel() != 3 * self.n_targets or not out.is_contiguous():
       raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n_targets entries")
-    dev = self._enter()
+    self._follow_torch_stream()
     _lib.check(self._lib.rmb_matvec_device(self._h, k, int(bool(in_plane)), ctypes.c_void_p(vec.data_ptr()),
                                            ctypes.c_void_p(vec2.data_ptr()) if vec2 is not None else None,
                                            float(eta), ctypes.c_void_p(out.data_ptr())))
-    self._exit(dev)
     return out
 
   def matvec_pairshard_device(self, kind, vec, eta, shard, nshards, out=None):
@@ -140,10 +134,9 @@ class MobilityContext(object):
       out = torch.empty(3 * self.n, dtype=torch.float64, device=vec.device)
     elif not _is_torch_cuda(out) or out.numel() != 3 * self.n or not out.is_contiguous():
       raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n entries")
-    dev = self._enter()
+    self._follow_torch_stream()
     _lib.check(self._lib.rmb_matvec_pairshard_device(self._h, k, ctypes.c_void_p(vec.data_ptr()), float(eta),
                                                      ctypes.c_void_p(out.data_ptr()), int(shard), int(nshards)))
-    self._exit(dev)
     return out
 
   def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
@@ -155,10 +148,9 @@ class MobilityContext(object):
     nb = first_blob.numel()
     if out is None:
       out = torch.empty((nb, 3 * n_b, 3 * n_b), dtype=torch.float64, device=first_blob.device)
-    dev = self._enter()
+    self._follow_torch_stream()
     _lib.check(self._lib.rmb_body_mobility_dense_device(self._h, ctypes.c_void_p(first_blob.data_ptr()), nb, int(n_b),
                                                         float(eta), ctypes.c_void_p(out.data_ptr())))
-    self._exit(dev)
     return out
 
   def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
@@ -171,10 +163,9 @@ class MobilityContext(object):
     import torch
     if out is None:
       out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=device or ("cuda:%d" % self.device))
-    dev = self._enter()
+    self._follow_torch_stream()
     _lib.check(self._lib.rmb_blob_blob_force_device(self._h, float(repulsion_strength), float(debye_length),
                                                     float(blob_radius), ctypes.c_void_p(out.data_ptr())))
-    self._exit(dev)
     return out
 
   # --- measurement -----------------------------------------------------------------------------

@@ -19,7 +19,8 @@
 // 30-instruction IEEE sqrt+divide sequence.  The near-field (r < 2a, overlapping blobs) RPY
 // branch is taken per wave only when some lane needs it.
 //
-// A pair costs ~90 fp64 VALU instructions for wall-tt (the reference's as-written count is 211).
+// A wall-tt pair costs ~93 fp64 VALU instructions here (sweep) and ~55 per ordered pair in the symmetric
+// kernel of sym_kernels.h; the reference's as-written count is 211 flops.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -59,15 +60,6 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
   double p = __builtin_fma(0.375, e, 0.5) * e;
   return __builtin_fma(y, p, y);
 }
-
-// 1/x: v_rcp_f64 seed + third-order correction (used only outside the pair loop).
-__device__ __forceinline__ double rcp_f64(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, y, 1.0);
-  double p = __builtin_fma(e, e, e);
-  return __builtin_fma(y, p, y);
-}
-
 
 // Wall-correction polynomials of the tt block.  With tau = a^2/R^2, u = e_z^2, g = z_j/|R| (= h e_z),
 // w = g (e_z - g), q6 = e_z (e_z - g):

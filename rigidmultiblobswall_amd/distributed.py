@@ -39,7 +39,7 @@ class HipBackend(object):
   def __init__(self, device):
     self.device = torch.device(device)
     idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-    self.ctx = MobilityContext(idx)   # device-path calls follow torch's current stream (context._enter)
+    self.ctx = MobilityContext(idx)   # device-path calls follow torch's current stream (context._follow_torch_stream)
 
   def set_positions(self, r_full, a, L, wall):
     self.ctx.set_positions(r_full, a, L, wall)
