@@ -113,6 +113,9 @@ int rmb_blob_blob_force_device(rmb_ctx* ctx, double repulsion_strength, double d
  * "timing" option is on.  Copies up to max_n most recent durations (ms) into ms[], returns count. */
 int rmb_timing_collect(rmb_ctx* ctx, double* ms, int max_n);
 int rmb_timing_reset(rmb_ctx* ctx);
+/* Schedule diagnostics: with option "wave_clock" = 1 the symmetric kernel stamps every wave's start and end
+ * (100 MHz wall clock); copies (start, end) pairs of the last launch into stamps[2*max_waves], returns count. */
+int rmb_wave_clock_collect(rmb_ctx* ctx, long long* stamps, long max_waves);
 /* launch geometry of the last sweep: target tiles, source chunks, workgroups */
 int rmb_last_launch(rmb_ctx* ctx, long* tiles, long* chunks, long* workgroups);
 int rmb_ctx_synchronize(rmb_ctx* ctx);

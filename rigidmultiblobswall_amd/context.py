@@ -176,6 +176,14 @@ class MobilityContext(object):
       _lib.check(n)
     return np.array(buf[:n])
 
+  def wave_clock_collect(self, max_waves=8192):
+    """(n_waves, 2) array of start/end wall-clock stamps (100 MHz ticks) of the last symmetric launch."""
+    buf = np.zeros((max_waves, 2), dtype=np.int64)
+    n = self._lib.rmb_wave_clock_collect(self._h, ctypes.c_void_p(buf.ctypes.data), max_waves)
+    if n < 0:
+      _lib.check(n)
+    return buf[:n]
+
   def timing_reset(self):
     _lib.check(self._lib.rmb_timing_reset(self._h))
 

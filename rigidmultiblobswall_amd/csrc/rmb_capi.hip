@@ -66,6 +66,9 @@ struct rmb_ctx {
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial;
   DevBuf st[8];    // scratch of the source->target entry point
+  DevBuf wave_clock;  // optional per-wave (start, end) wall-clock stamps of the symmetric kernel
+  long wave_clock_n = 0;
+  long opt_wave_clock = 0;
   DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
   long symbuf_zeroed_for = -1;
   // options
@@ -76,6 +79,8 @@ struct rmb_ctx {
   int last_path = 0;           // 0 = sweep, 1 = symmetric
   long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
   long opt_sym_pin = 1;        // pad dynamic LDS so residency is exactly that number
+  long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
+                               // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
   // timing ring (events around the sweep kernel)
   std::vector<hipEvent_t> ev0, ev1;
   int ev_count = 0;  // events recorded since last reset (capped at ring size)
@@ -245,10 +250,16 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
     if (per_block > stat + 1024) pad = per_block - stat - 512;
     if (pad > 48 * 1024) RMB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
   }
-  long blocks = 256L * wps;
+  long blocks = 256L * wps * c->opt_sym_oversub;
   const long need = (a.step_end - a.step_begin + 255) / 256 > 0 ? (a.step_end - a.step_begin + 255) / 256 : 1;   // >= 64 steps per wave
   if (blocks > need) blocks = need;
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+  a.wave_clock = nullptr;
+  if (c->opt_wave_clock) {
+    c->wave_clock_n = blocks * rmb::kSymWaves;
+    if (int rc = c->wave_clock.reserve((size_t)2 * c->wave_clock_n * sizeof(long long))) return rc;
+    a.wave_clock = (long long*)c->wave_clock.p;
+  }
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
   hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
@@ -355,7 +366,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     a.eps_over_b = eps / b; a.inv_b = 1.0 / b; a.two_a = 2.0 * blob_radius;
     static int socc[2] = {0, 0};
     const void* fn = periodic ? (const void*)rmb::sym_force_kernel<true> : (const void*)rmb::sym_force_kernel<false>;
-    long blocks = 256L * resident_blocks(fn, &socc[periodic ? 1 : 0]);
+    long blocks = 256L * resident_blocks(fn, &socc[periodic ? 1 : 0]) * c->opt_sym_oversub;
     const long need = (a.n_units * 64 + 255) / 256;
     if (blocks > need) blocks = need;
     c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
@@ -462,7 +473,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
+  c->wave_clock.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
   delete c;
@@ -482,7 +493,9 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "symmetric")) { c->opt_symmetric = value; return 0; }
   if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
   if (!strcmp(key, "sym_wps")) { c->opt_sym_wps = value; return 0; }
+  if (!strcmp(key, "wave_clock")) { c->opt_wave_clock = value; return 0; }
   if (!strcmp(key, "sym_pin")) { c->opt_sym_pin = value; return 0; }
+  if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
 }
 
@@ -703,6 +716,16 @@ int rmb_timing_collect(rmb_ctx* c, double* ms, int max_n) {
     ms[i] = (double)t;
   }
   return have;
+}
+
+int rmb_wave_clock_collect(rmb_ctx* c, long long* stamps, long max_waves) {
+  if (!c || !stamps || max_waves < 0) return fail(RMB_ERR_ARG, "bad wave_clock_collect arguments");
+  RMB_HIP(hipSetDevice(c->device));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  long n = c->wave_clock_n < max_waves ? c->wave_clock_n : max_waves;
+  if (n > 0 && c->wave_clock.p) RMB_HIP(hipMemcpy(stamps, c->wave_clock.p, (size_t)2 * n * sizeof(long long), hipMemcpyDeviceToHost));
+  else n = 0;
+  return (int)n;
 }
 
 int rmb_timing_reset(rmb_ctx* c) {

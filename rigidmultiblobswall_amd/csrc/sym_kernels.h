@@ -19,8 +19,8 @@
 // k = 1..63 (every ordered pair exactly once).  After 64 steps u_i (registers) and u_J (LDS) are flushed
 // to global SoA accumulators with global_atomic_add_f64; finalize adds the self term and scales.
 // Schedule: static and exactly balanced -- the n_units x 64 rotation steps are cut into equal contiguous
-// ranges, one per resident wave (a range may start/end inside a unit), so every SIMD gets the same number
-// of steps and no work counter is needed (a single dequeue word saturates at ~88 dequeues/us, which is
+// ranges, one per wave (a range may start/end inside a unit; >= 64 steps each; 8x more workgroups than are
+// resident at once), so every SIMD gets the same number of steps and no work counter is needed (a single dequeue word saturates at ~88 dequeues/us, which is
 // about the unit rate of this kernel at N = 1e4).  Consecutive units share the row tile I, whose
 // accumulator stays in registers until the row changes.  The order in which the atomics land is not
 // fixed: results agree with the deterministic sweep_kernel to rounding (~1e-15 relative) but are not
@@ -43,6 +43,7 @@ struct SymArgs {
   long self_begin, self_end;  // targets whose self term this launch adds (exactly one shard per target)
   double Lx, Ly, Lz, iLx, iLy, iLz;  // pseudo-periodic lengths (<= 0: open) and reciprocals
   double prefactor;
+  long long* wave_clock;  // optional [n_waves][2] wall-clock stamps (start, end | placement bits) for schedule diagnostics, or nullptr
   PairConsts k;
 };
 
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
   // contiguous ranges, one per wave; a range may begin and end inside a unit.
   const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long long t_start = a.wave_clock ? wall_clock64() : 0;
   const long s_total = a.step_end - a.step_begin;
   long s = a.step_begin + (long)(((__int128)s_total * w) / n_waves);
   const long s_end = a.step_begin + (long)(((__int128)s_total * (w + 1)) / n_waves);
@@ -398,6 +400,13 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
     __hip_atomic_fetch_add(&a.acc[i], ui.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ui.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], ui.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.wave_clock && lane == 0) {   // stamps go to a buffer nothing else reads
+    // placement: HW_ID (reg 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID (reg 20) in the top 24 bits
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+    a.wave_clock[2 * w] = t_start;
+    a.wave_clock[2 * w + 1] = (wall_clock64() & 0xffffffffffLL) | ((long long)(hw & 0xffff) << 40) | ((long long)(xcc & 0xf) << 56);
   }
 }
 
