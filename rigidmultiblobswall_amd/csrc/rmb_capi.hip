@@ -69,6 +69,7 @@ struct rmb_ctx {
   DevBuf wave_clock;  // optional per-wave (start, end) wall-clock stamps of the symmetric kernel
   long wave_clock_n = 0;
   long opt_wave_clock = 0;
+  long opt_skip_pairs = 0;
   DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
   long symbuf_zeroed_for = -1;
   // options
@@ -254,6 +255,11 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   const long need = (a.step_end - a.step_begin + 255) / 256 > 0 ? (a.step_end - a.step_begin + 255) / 256 : 1;   // >= 64 steps per wave
   if (blocks > need) blocks = need;
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+  {
+    const long waves = blocks * rmb::kSymWaves, total = a.step_end - a.step_begin;
+    a.steps_per_wave = (total + waves - 1) / waves;
+  }
+  a.skip_pairs = (int)c->opt_skip_pairs;
   a.wave_clock = nullptr;
   if (c->opt_wave_clock) {
     c->wave_clock_n = blocks * rmb::kSymWaves;
@@ -494,6 +500,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
   if (!strcmp(key, "sym_wps")) { c->opt_sym_wps = value; return 0; }
   if (!strcmp(key, "wave_clock")) { c->opt_wave_clock = value; return 0; }
+  if (!strcmp(key, "skip_pairs")) { c->opt_skip_pairs = value; return 0; }
   if (!strcmp(key, "sym_pin")) { c->opt_sym_pin = value; return 0; }
   if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);

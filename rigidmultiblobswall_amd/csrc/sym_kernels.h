@@ -40,9 +40,11 @@ struct SymArgs {
   int n_tiles;
   long n_units;         // n_tiles (n_tiles + 1) / 2
   long step_begin, step_end;  // rotation steps [begin, end) of the n_units*64 this launch covers (pair shard)
+  long steps_per_wave;        // ceil((step_end - step_begin) / waves): wave w takes [begin + w spw, +spw)
   long self_begin, self_end;  // targets whose self term this launch adds (exactly one shard per target)
   double Lx, Ly, Lz, iLx, iLy, iLz;  // pseudo-periodic lengths (<= 0: open) and reciprocals
   double prefactor;
+  int skip_pairs;         // diagnostics: run the schedule / loads / flushes but no pair arithmetic (timing only)
   long long* wave_clock;  // optional [n_waves][2] wall-clock stamps (start, end | placement bits) for schedule diagnostics, or nullptr
   PairConsts k;
 };
@@ -276,9 +278,13 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
   const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
   const long long t_start = a.wave_clock ? wall_clock64() : 0;
-  const long s_total = a.step_end - a.step_begin;
-  long s = a.step_begin + (long)(((__int128)s_total * w) / n_waves);
-  const long s_end = a.step_begin + (long)(((__int128)s_total * (w + 1)) / n_waves);
+  long s = a.step_begin + w * a.steps_per_wave;
+  long s_end = s + a.steps_per_wave;
+  if (s_end > a.step_end) s_end = a.step_end;
+  (void)n_waves;
+  // decode the first unit once (row-major upper triangle); later units follow by increment
+  int I = 0, J = 0;
+  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
 
   int I_cur = -1;
   long i = 0;
@@ -292,8 +298,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
-    int I, J;
-    unit_to_tiles(u, a.n_tiles, I, J);
+    (void)u;
 
     if (I != I_cur) {
       if (I_cur >= 0 && vi_ok) {   // flush the previous row's accumulator
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
     // are still evaluated together.
     const int px = PERIODIC && a.Lx > 0, py = PERIODIC && a.Ly > 0, pz = PERIODIC && a.Lz > 0;
     if (I != J) {
-      for (int k = k0; k < k1; ++k) {
+      for (int k = (a.skip_pairs & 1) ? k1 : k0; k < k1; ++k) {
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const long j = 64L * J + lane;
-      if (j < a.n) {
+      if (j < a.n && !(a.skip_pairs & 2)) {
         __hip_atomic_fetch_add(&a.acc[j], accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&a.acc[a.n_pad + j], accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
     } else {
       // diagonal unit: every ordered pair of the tile once, forward only.  Step 0 is the blob itself: its
       // central-box term is the self term (finalize); its periodic images use the pair formula.
-      for (int k = (PERIODIC || k0 > 1) ? k0 : 1; k < k1; ++k) {
+      for (int k = (a.skip_pairs & 1) ? k1 : ((PERIODIC || k0 > 1) ? k0 : 1); k < k1; ++k) {
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -395,6 +400,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
       }
     }
     __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
+    if (k1 == 64) {                    // next unit in row-major order
+      if (++J == a.n_tiles) { ++I; J = I; }
+    }
   }
   if (I_cur >= 0 && vi_ok) {
     __hip_atomic_fetch_add(&a.acc[i], ui.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -470,8 +478,12 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
   const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
   const long s_total = a.n_units * 64;
-  long s = (long)(((__int128)s_total * w) / n_waves);
-  const long s_end = (long)(((__int128)s_total * (w + 1)) / n_waves);
+  const long spw = (s_total + n_waves - 1) / n_waves;
+  long s = w * spw;
+  long s_end = s + spw;
+  if (s_end > s_total) s_end = s_total;
+  int I = 0, J = 0;
+  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
   int I_cur = -1;
   long i = 0;
   bool vi_ok = false;
@@ -483,8 +495,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
-    int I, J;
-    unit_to_tiles(u, a.n_tiles, I, J);
+    (void)u;
     if (I != I_cur) {
       if (I_cur >= 0 && vi_ok) {
         __hip_atomic_fetch_add(&a.acc[i], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -533,6 +544,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (k1 == 64) {
+      if (++J == a.n_tiles) { ++I; J = I; }
+    }
   }
   if (I_cur >= 0 && vi_ok) {
     __hip_atomic_fetch_add(&a.acc[i], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

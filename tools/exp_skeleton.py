@@ -1,0 +1,21 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rigidmultiblobswall_amd import MobilityContext
+from bench import d2_cloud
+for N in (10000,):
+  r, f, eta, a = d2_cloud(N)
+  rd = torch.as_tensor(r.reshape(-1), device="cuda"); fd = torch.as_tensor(f.reshape(-1), device="cuda")
+  for k in (1, 8):
+    for skip in (0, 1, 3):
+      ctx = MobilityContext(0); ctx.set_option("timing", 1); ctx.set_option("sym_oversub", k); ctx.set_option("skip_pairs", skip)
+      ctx.set_positions(rd, a, wall=True)
+      for _ in range(3):
+        ctx.matvec_device("tt", fd, eta)
+      torch.cuda.synchronize(); ctx.timing_reset()
+      for _ in range(30):
+        ctx.matvec_device("tt", fd, eta)
+      torch.cuda.synchronize()
+      ms = ctx.timing_collect(30)
+      print("N=%d oversub=%d skip_pairs=%d wgs=%d kernel avg %.4f min %.4f ms" % (N, k, skip, ctx.last_launch()["workgroups"], ms.mean(), ms.min()), flush=True)
+      ctx.close()
