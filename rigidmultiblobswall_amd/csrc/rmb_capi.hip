@@ -254,6 +254,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   long blocks = 256L * wps * c->opt_sym_oversub;
   const long need = (a.step_end - a.step_begin + 255) / 256 > 0 ? (a.step_end - a.step_begin + 255) / 256 : 1;   // >= 64 steps per wave
   if (blocks > need) blocks = need;
+  if (blocks > 256L * wps) blocks -= blocks % (256L * wps);   // whole rounds only: a partial last round is a tail
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   {
     const long waves = blocks * rmb::kSymWaves, total = a.step_end - a.step_begin;

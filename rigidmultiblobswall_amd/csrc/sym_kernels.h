@@ -264,7 +264,7 @@ __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
 }
 
 template <int KIND, bool WALL, bool PERIODIC>
-__global__ __launch_bounds__(64 * kSymWaves) void sym_kernel(const SymArgs a) {
+__global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void sym_kernel(const SymArgs a) {
   __shared__ double2 rec_all[kSymWaves][64 * 3];
   __shared__ double accj_all[kSymWaves][3 * 64];
   const int lane = threadIdx.x & 63;
