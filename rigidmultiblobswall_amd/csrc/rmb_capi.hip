@@ -80,6 +80,7 @@ struct rmb_ctx {
   int last_path = 0;           // 0 = sweep, 1 = symmetric
   long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
   long opt_sym_pin = 1;        // pad dynamic LDS so residency is exactly that number
+  long opt_sym_min_steps = 64; // floor on rotation steps per wave (a unit is 64 steps)
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
   // timing ring (events around the sweep kernel)
@@ -252,7 +253,8 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
     if (pad > 48 * 1024) RMB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
   }
   long blocks = 256L * wps * c->opt_sym_oversub;
-  const long need = (a.step_end - a.step_begin + 255) / 256 > 0 ? (a.step_end - a.step_begin + 255) / 256 : 1;   // >= 64 steps per wave
+  const long per_wg = rmb::kSymWaves * c->opt_sym_min_steps;
+  const long need = (a.step_end - a.step_begin + per_wg - 1) / per_wg > 0 ? (a.step_end - a.step_begin + per_wg - 1) / per_wg : 1;
   if (blocks > need) blocks = need;
   if (blocks > 256L * wps) blocks -= blocks % (256L * wps);   // whole rounds only: a partial last round is a tail
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
@@ -504,6 +506,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "skip_pairs")) { c->opt_skip_pairs = value; return 0; }
   if (!strcmp(key, "sym_pin")) { c->opt_sym_pin = value; return 0; }
   if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
+  if (!strcmp(key, "sym_min_steps")) { c->opt_sym_min_steps = value < 1 ? 1 : value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
 }
 
