@@ -214,6 +214,27 @@ def main():
                     "launch": rs["launch"]})
     line["sweep"] = sweep
 
+  if world == 1 and not args.no_sweep:
+    # BASELINE.json configs[2]: 2048 rollers x 12-blob shells, full GMRES mobility solve on 1 GPU (reported
+    # beside the headline, not part of `value`)
+    from rigidmultiblobswall_amd import structures as st
+    from rigidmultiblobswall_amd.rigid import RigidSuspension
+    R, eta3 = 1.0155, 0.957e-3
+    shell = st.icosahedron_shell(0.792079207921 * R)
+    a3 = st.min_blob_separation(shell) / 2
+    nb = 2048
+    loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
+    FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
+    rs = RigidSuspension([shell] * nb, loc, quat, a3, eta3, device=device)
+    rs.solve_mobility_problem(force_torque=FT, tol=1e-8)        # warm-up (library initialisation)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
+    torch.cuda.synchronize(device)
+    line["config3_gmres"] = {"bodies": nb, "blobs": rs.n_blobs, "tolerance": 1e-8, "iterations": info["iterations"],
+                             "residual": float(info["residual"]), "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3)}
+    rs.close()
+
   if rank == 0:
     print(json.dumps(line), flush=True)
   if world > 1:
