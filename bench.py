@@ -138,6 +138,7 @@ def main():
   achieved_tf = flops / (res["kern_ms"] * 1e-3) / 1e12
   alg_bytes = 48.0 * N + 24.0 * res["n_local"]       # read r,f of all sources; write u of own targets
   traffic = args.traffic_bytes
+  valu_instr = issue_ceiling = None
   if traffic is None:
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     try:
@@ -147,6 +148,8 @@ def main():
       cand = [v for k, v in tj.items() if k.endswith(key)]
       if cand and world == 1:
         traffic = cand[-1]["traffic_bytes"]
+        valu_instr = cand[-1].get("SQ_INSTS_VALU_per_launch")
+        issue_ceiling = tj.get("_fp64_issue_ceiling_G_wave_instr_per_s")
     except (OSError, ValueError, KeyError):
       traffic = None
   sym = res["launch"]["chunks"] == 0
@@ -161,6 +164,12 @@ def main():
       "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_per_launch,
       "kernel_ms_avg": round(res["kern_ms"], 5), "launch": res["launch"],
       "traffic": traffic,
+      # executed-instruction view (what the kernel actually issues vs what the chip can issue): SQ_INSTS_VALU per
+      # launch from the committed rocprofv3 --pmc pass of this command / live kernel time, against the fp64 VALU
+      # issue ceiling measured by tools/ubench.hip on the same chip family
+      "issue": None if not valu_instr else {
+          "valu_wave_instr_per_launch": valu_instr, "achieved": round(valu_instr / (res["kern_ms"] * 1e-3) / 1e9, 1),
+          "peak": issue_ceiling, "unit": "G wave-instr/s", "frac": round(valu_instr / (res["kern_ms"] * 1e-3) / 1e9 / issue_ceiling, 4)},
       "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
               "achieved": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
