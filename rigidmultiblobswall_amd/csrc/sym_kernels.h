@@ -275,13 +275,11 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
 
   // Static, exactly balanced schedule: the n_units * 64 rotation steps are cut into gridDim.x * 4 equal
   // contiguous ranges, one per wave; a range may begin and end inside a unit.
-  const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
   const long long t_start = a.wave_clock ? wall_clock64() : 0;
   long s = a.step_begin + w * a.steps_per_wave;
   long s_end = s + a.steps_per_wave;
   if (s_end > a.step_end) s_end = a.step_end;
-  (void)n_waves;
   // decode the first unit once (row-major upper triangle); later units follow by increment
   int I = 0, J = 0;
   if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
@@ -293,12 +291,10 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
   Vec3 ui = {0.0, 0.0, 0.0};
 
   while (s < s_end) {
-    const long u = s >> 6;
     const int k0 = (int)(s & 63);
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
-    (void)u;
 
     if (I != I_cur) {
       if (I_cur >= 0 && vi_ok) {   // flush the previous row's accumulator
@@ -490,12 +486,10 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
   double xi = 0, yi = 0, zi = 0;
   double ax = 0, ay = 0, az = 0;
   while (s < s_end) {
-    const long u = s >> 6;
     const int k0 = (int)(s & 63);
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
-    (void)u;
     if (I != I_cur) {
       if (I_cur >= 0 && vi_ok) {
         __hip_atomic_fetch_add(&a.acc[i], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
