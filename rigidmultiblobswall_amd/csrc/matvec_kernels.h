@@ -217,6 +217,7 @@ struct ForceArgs {
   int n_chunks;
   double Lx, Ly, Lz, iLx, iLy, iLz;
   double eps_over_b, inv_b, two_a;
+  ExpConsts ec;
 };
 
 template <bool PERIODIC>
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(kBlock) void force_sweep_kernel(const ForceArgs a) 
       const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
       const double ir = rsqrt_f64(r2);
       const double r = r2 * ir;
-      // far: -(eps/b) exp(-(r-2a)/b)/r ; near (r <= 2a): -(eps/b)/max(r,1e-25)
-      double f0;
-      if (r > a.two_a) f0 = -a.eps_over_b * exp(-(r - a.two_a) * a.inv_b) * ir;
-      else f0 = -a.eps_over_b / fmax(r, 1e-25);
+      // far: -(eps/b) exp(-(r-2a)/b)/r ; near (r <= 2a): -(eps/b)/max(r,1e-25) = -(eps/b) min(1/r, 1e25)
+      const bool far = r > a.two_a;
+      const double e = exp_nonpositive(a.ec, far ? (a.two_a - r) * a.inv_b : 0.0);
+      double f0 = -a.eps_over_b * (far ? e * ir : fmin(ir, 1e25));
       if (j0 + s == ti) f0 = 0.0;  // i == j (r2 = 0 -> ir = inf; select, do not multiply)
       if (j0 + s == ti) { dx = 0.0; dy = 0.0; dz = 0.0; }
       fx = __builtin_fma(f0, dx, fx); fy = __builtin_fma(f0, dy, fy); fz = __builtin_fma(f0, dz, fz);

@@ -343,4 +343,23 @@ __device__ __forceinline__ void pair_apply(const PairConsts& k, double dx, doubl
   }
 }
 
+// exp(x) for x <= 0 in fp64 without ocml: n = rint(x log2 e), t = x - n ln2 (two-piece ln2), degree-13 Taylor
+// polynomial in t (|t| <= ln2/2: truncation 4e-18), result = ldexp(p, n) (v_ldexp_f64 underflows gradually to 0).
+// The coefficients travel as kernel arguments (SGPRs) so that every Horner step is one v_fma_f64 with a scalar
+// addend; ocml's exp keeps them in VGPRs and pays a v_mov_b64 per step (seen in the ISA of the first version).
+struct ExpConsts { double log2e, ln2_hi, ln2_lo, c[12]; };   // c[k] = 1/(k+2)!, k = 0..11
+
+__device__ __forceinline__ double exp_nonpositive(const ExpConsts& e, double x) {
+  x = fmax(x, -750.0);
+  const double n = __builtin_rint(x * e.log2e);
+  double t = __builtin_fma(n, -e.ln2_hi, x);
+  t = __builtin_fma(n, -e.ln2_lo, t);
+  double p = e.c[11];
+#pragma unroll
+  for (int k = 10; k >= 0; --k) p = __builtin_fma(p, t, e.c[k]);
+  p = __builtin_fma(p, t, 1.0);      // 1 + t (1 + t q)
+  p = __builtin_fma(p, t, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 }  // namespace rmb

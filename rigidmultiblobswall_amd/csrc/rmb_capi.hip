@@ -345,6 +345,16 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
   return 0;
 }
 
+rmb::ExpConsts exp_consts() {
+  rmb::ExpConsts e;
+  e.log2e = 1.4426950408889634;
+  e.ln2_hi = 6.93147180369123816490e-01;  // ln2 in two pieces; the high one has 33 significant bits, so n * ln2_hi is exact
+  e.ln2_lo = 1.90821492927058770002e-10;
+  double f = 2.0;
+  for (int k = 0; k < 12; ++k) { e.c[k] = 1.0 / f; f *= (double)(k + 3); }
+  return e;
+}
+
 int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
   if (int rc = check_ready(c)) return rc;
   const long n_tgt = c->tgt_end - c->tgt_begin;
@@ -373,6 +383,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
     a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
     a.eps_over_b = eps / b; a.inv_b = 1.0 / b; a.two_a = 2.0 * blob_radius;
+    a.ec = exp_consts();
     static int socc[2] = {0, 0};
     const void* fn = periodic ? (const void*)rmb::sym_force_kernel<true> : (const void*)rmb::sym_force_kernel<false>;
     long blocks = 256L * resident_blocks(fn, &socc[periodic ? 1 : 0]) * c->opt_sym_oversub;
@@ -412,6 +423,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   a.eps_over_b = eps / b;
   a.inv_b = 1.0 / b;
   a.two_a = 2.0 * blob_radius;
+  a.ec = exp_consts();
   if (n_chunks > 1) {
     if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
     a.partial = (double*)c->partial.p;

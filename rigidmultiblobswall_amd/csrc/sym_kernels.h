@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void sym_finalize_kernel(const SymArgs a) {
 // (one rsqrt + one exp) and applied with opposite signs.  Same tile-pair rotation, LDS accumulation
 // and static step schedule as sym_tt_kernel.  multi_bodies/forces_numba.py:12-55 semantics.
 // ---------------------------------------------------------------------------------------------
+
 struct SymForceArgs {
   const double4* pos;
   double* acc;          // [3][n_pad], zero on entry, re-zeroed by the finalize kernel
@@ -443,6 +444,7 @@ struct SymForceArgs {
   long n_units;
   double Lx, Ly, Lz, iLx, iLy, iLz;
   double eps_over_b, inv_b, two_a;
+  ExpConsts ec;
 };
 
 // f0(r) dr for one pair; dr = r_j - r_i (minimal image).  Returns the force ON i; the force on j is minus it.
@@ -457,9 +459,11 @@ __device__ __forceinline__ void pair_force(const SymForceArgs& a, double dx, dou
   const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
   const double ir = rsqrt_f64(r2);
   const double r = r2 * ir;
-  double f0;
-  if (r > a.two_a) f0 = -a.eps_over_b * exp(-(r - a.two_a) * a.inv_b) * ir;
-  else f0 = -a.eps_over_b / fmax(r, 1e-25);
+  // far: -(eps/b) exp(-(r-2a)/b) / r ;  near (r <= 2a): -(eps/b) / max(r, 1e-25) = -(eps/b) min(1/r, 1e25)
+  const bool far = r > a.two_a;
+  const double x = far ? (a.two_a - r) * a.inv_b : 0.0;
+  const double e = exp_nonpositive(a.ec, x);
+  const double f0 = -a.eps_over_b * (far ? e * ir : fmin(ir, 1e25));
   fx = f0 * dx; fy = f0 * dy; fz = f0 * dz;
 }
 

@@ -468,6 +468,29 @@ def test_symmetric_force_kernel_matches_sweep_and_oracle(Ctx, oracle, L):
   ctx.close()
 
 
+def test_force_edge_separations_elementwise(Ctx, oracle):
+  """exp_nonpositive (pair_ops.h) over its whole range: gaps from r = 2a exactly up to (r - 2a)/b = 900
+  (exp underflows through the denormals to 0), a coincident pair (r = 0) and a pair closer than 1e-25
+  (forces_numba.py:44-47 clamps r there).  Compared per component, not in norm."""
+  a, b, eps = 0.13, 0.01, 3.92
+  n_line = 200
+  gaps = 2 * a + b * np.linspace(0.0, 900.0, n_line)
+  r = np.zeros((n_line + 4, 3))
+  r[:n_line, 0] = 50.0 + np.cumsum(gaps)
+  r[n_line] = r[n_line + 1] = (-40.0, 3.0, 1.0)                   # coincident
+  r[n_line + 2] = (0.0, 0.0, 0.0); r[n_line + 3] = (1e-30, 0.0, 0.0)  # r < 1e-25
+  ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=np.zeros(3), repulsion_strength=eps, debye_length=b,
+                                            blob_radius=a)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, np.zeros(3), wall=False)
+  for det in (0, 1):
+    ctx.set_option("deterministic", det)
+    F = ctx.blob_blob_force(eps, b, a)
+    assert np.all(np.isfinite(F))
+    assert np.all(np.abs(F - ref) <= 1e-12 * np.abs(ref) + 1e-290), np.abs(F - ref).max()
+  ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # 7. source -> target products with per-blob radii (K13)
 # ---------------------------------------------------------------------------------------------
