@@ -244,6 +244,44 @@ def main():
                              "residual": float(info["residual"]), "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3)}
     rs.close()
 
+  if not args.no_sweep:
+    # BASELINE.json configs[4] recipe: 2.6e5 single-blob rollers, Brownian Adams-Bashforth steps = forces kernel +
+    # M_tt F + M_tr T + Lanczos M^{1/2} z + 2 random-finite-difference products per step; physical parameters of
+    # multi_bodies/examples/rollers/inputfile_rollers.dat.  On N ranks the same replicated stepper runs on every
+    # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline.
+    from rigidmultiblobswall_amd import structures as st
+    from rigidmultiblobswall_amd.distributed import ReplicatedContext
+    from rigidmultiblobswall_amd.rollers import RollersIntegrator
+    n5, a5 = 262144, 0.656
+    loc5, _, _ = st.roller_monolayer(n5, radius=a5, seed=7)
+    integ = RollersIntegrator(loc5, "stochastic_adams_bashforth_rollers", a5, 1.0e-3, tolerance=1e-3, device=device,
+                              ctx=ReplicatedContext(sm), seed=11)
+    integ.kT, integ.g = 0.0041419464, 0.0024892
+    integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
+    integ.debye_length = integ.debye_length_wall = 0.0656
+    integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
+    integ.advance_time_step(0.016)      # warm-up (first step is forward Euler)
+    torch.cuda.synchronize(device)
+    if world > 1:
+      dist.barrier()
+    p0, l0, n5_steps = integ.mobility_products, integ.stoch_iterations_count, 2
+    t0 = time.perf_counter()
+    for _ in range(n5_steps):
+      integ.advance_time_step(0.016)
+    torch.cuda.synchronize(device)
+    if world > 1:
+      dist.barrier()
+    dt5 = time.perf_counter() - t0
+    if world > 1:
+      t = torch.tensor([dt5], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      dt5 = float(t.item())
+    line["config5_rollers"] = {"rollers": n5, "scheme": integ.scheme, "lanczos_tolerance": 1e-3, "steps": n5_steps,
+                               "s_per_step": round(dt5 / n5_steps, 4),
+                               "mobility_products_per_step": (integ.mobility_products - p0) / n5_steps,
+                               "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
+                               "rejected_steps": integ.invalid_configuration_count}
+
   if rank == 0:
     print(json.dumps(line), flush=True)
   if world > 1:

@@ -44,6 +44,7 @@ struct SymArgs {
   long self_begin, self_end;  // targets whose self term this launch adds (exactly one shard per target)
   double Lx, Ly, Lz, iLx, iLy, iLz;  // pseudo-periodic lengths (<= 0: open) and reciprocals
   double prefactor;
+  int accumulate;         // finalize adds to `out` instead of overwriting it (second pass of the fused tt+tr product)
   int skip_pairs;         // diagnostics: run the schedule / loads / flushes but no pair arithmetic (timing only)
   long long* wave_clock;  // optional [n_waves][2] wall-clock stamps (start, end | placement bits) for schedule diagnostics, or nullptr
   PairConsts k;
@@ -425,7 +426,11 @@ __global__ __launch_bounds__(256) void sym_finalize_kernel(const SymArgs a) {
   if (i >= a.self_begin && i < a.self_end)
     self_term<KIND, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
   const double sc = a.prefactor * b;
-  a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
+  if (a.accumulate) {
+    a.out[3 * i] += acc.x * sc; a.out[3 * i + 1] += acc.y * sc; a.out[3 * i + 2] += acc.z * sc;
+  } else {
+    a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
+  }
 }
 
 

@@ -159,3 +159,58 @@ class ShardedMobility(object):
 
   def blob_blob_force_local(self, eps, b, a):
     return self.backend.blob_blob_force(eps, b, a)
+
+  # -- replicated layout: every rank holds full vectors (Krylov loops, time steppers) ---------------
+  def set_replicated_positions(self, r_full, a, periodic_length=None, wall=True):
+    """Every rank already holds all N positions (a replicated time stepper): no exchange at all."""
+    r = self._to_dev(r_full)
+    self.n = r.numel() // 3
+    self.begin, self.end, self.block = partition(self.n, self.world, self.rank)
+    L = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
+    self._periodic = bool(np.any(L > 0))
+    self.backend.set_positions(r, a, L, wall)
+    self.backend.set_target_range(self.begin, self.end)
+
+  def blob_blob_force_replicated(self, eps, b, a):
+    """Forces on ALL blobs on every rank: each rank sweeps its own target block, blocks are all-gathered."""
+    f_local = self.backend.blob_blob_force(eps, b, a)
+    f_full, _ = self._all_gather_blocks(f_local.view(-1), None)
+    return f_full if self.world == 1 else f_full.clone()
+
+
+class ReplicatedContext(object):
+  """MobilityContext-shaped facade over ShardedMobility (set_positions / matvec_device /
+  blob_blob_force_device / body_mobility_dense_device with FULL vectors on every rank), so the
+  device-resident callers written against one GPU -- RigidSuspension (rigid.py), stochastic_forcing_lanczos
+  (stochastic.py), RollersIntegrator (rollers.py) -- run unchanged on G GPUs: every rank executes the same
+  O(N) host/Krylov logic on replicated vectors (identical on all ranks because all-reduce / all-gather
+  return the same bits everywhere) and only the O(N^2) pair sweeps are divided.  Random numbers must come
+  from identically seeded generators on every rank."""
+
+  def __init__(self, sharded):
+    self.sm = sharded
+    self.n = 0
+
+  def set_stream(self, stream_ptr):
+    ctx = getattr(self.sm.backend, "ctx", None)
+    if ctx is not None:
+      ctx.set_stream(stream_ptr)
+
+  def set_positions(self, r_vectors, a, periodic_length=None, wall=True):
+    self.sm.set_replicated_positions(r_vectors, a, periodic_length, wall)
+    self.n = self.sm.n
+
+  def matvec_device(self, kind, vec, eta, vec2=None, in_plane=False, out=None):
+    return self.sm.matvec_replicated(kind, vec, eta, vec2_full=vec2, in_plane=in_plane, out=out)
+
+  def blob_blob_force_device(self, repulsion_strength, debye_length, blob_radius, out=None, device=None):
+    return self.sm.blob_blob_force_replicated(repulsion_strength, debye_length, blob_radius)
+
+  def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
+    # O(n_bodies n_b^2): replicated, not worth an exchange
+    return self.sm.backend.ctx.body_mobility_dense_device(first_blob, n_b, eta, out=out)
+
+  def close(self):
+    ctx = getattr(self.sm.backend, "ctx", None)
+    if ctx is not None:
+      ctx.close()

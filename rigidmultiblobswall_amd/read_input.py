@@ -47,6 +47,20 @@ _OPTIONS = {
     "omega_one_roller": ("omega_one_roller", _vec, np.zeros(3)),
     "update_PC": ("update_PC", int, 1),
     "domain": ("domain", str, "single_wall"),
+    "free_kinematics": ("free_kinematics", str, "True"),
+    "hydro_interactions": ("hydro_interactions", int, 1),
+    "n_relaxation": ("n_relaxation", int, 0),
+    "tracer_radius": ("tracer_radius", float, 0.0),
+    "random_state": ("random_state", str, None),
+    "nonlinear_solver_tolerance": ("nonlinear_solver_tolerance", float, 1e-8),
+    "save_clones": ("save_clones", str, "one_file_per_step"),
+    "repulsion_strength_firm": ("repulsion_strength_firm", float, 0.0),
+    "firm_delta": ("firm_delta", float, 1e-2),
+    "Lub_Cut": ("Lub_Cut", float, 4.5),
+    "zmin": ("zmin", float, 0.0),
+    "zmax": ("zmax", float, 1e7),
+    "domType": ("domType", str, "RPB"),
+    "diffusion_coefficient": ("diffusion_coefficient", float, 1.0),
 }
 
 

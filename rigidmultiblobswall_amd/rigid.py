@@ -196,16 +196,20 @@ class RigidSuspension(object):
     return sol[n3:].view(-1, 6).cpu().numpy(), sol[:n3].view(-1, 3).cpu().numpy(), info
 
 
-def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000):
-  """Solve A x = b with x = Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
+def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None):
+  """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
   Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after maxiter iterations in total.
-  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host."""
+  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host.
+  x0: optional initial guess (the roller torque solve warm-starts from the previous step,
+  quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
   dev = b.device
   n = b.numel()
   bnorm = float(torch.linalg.norm(b))
   y = torch.zeros(n, dtype=torch.float64, device=dev)
+  if x0 is not None:
+    b = b - A(x0)
   r = b.clone()
-  beta = bnorm
+  beta = float(torch.linalg.norm(r))
   its = 0
   res = beta / bnorm if bnorm > 0 else 0.0
   history = []
@@ -253,4 +257,6 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000):
       beta = float(torch.linalg.norm(r))
       res = beta / bnorm
   x = Minv(y)
+  if x0 is not None:
+    x = x + x0
   return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history)

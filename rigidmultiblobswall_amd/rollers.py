@@ -1,0 +1,581 @@
+"""Device-resident time steppers for single-blob rollers (SURVEY.md section 8(f), row N4 tail; the
+config-5 recipe of section 3.3).
+
+Mirror of quaternion_integrator/quaternion_integrator_rollers.py (`QuaternionIntegratorRollers`): same
+scheme names, same attribute names (eta, a, kT, tolerance, rf_delta, omega_one_roller, free_kinematics,
+hydro_interactions, periodic_length, domain, counters), same order of random draws, so a run of the
+reference with `np.random.seed(s)` and a run of this class with `rng=np.random.RandomState(s)` walk the
+same trajectory (to solver tolerance).  What differs is WHERE things live:
+
+  * the reference keeps one Python `Body` per roller and loops over them for every update (:132-151);
+    here the locations are ONE (N,3) float64 tensor in HBM and every update is one fused tensor op;
+  * forces, the four mobility products, the Lanczos basis and the GMRES basis stay on the device; per
+    step only a handful of scalars (norms, the validity flag) cross PCIe;
+  * `M_tt F + M_tr T` is one fused pair sweep (kind tt_tr, K11), which the reference has but leaves
+    commented out (:71, :1116);
+  * the random finite difference and all Krylov products reuse the same MobilityContext, re-packing the
+    positions (an O(N) kernel) when they move.
+
+Schemes: deterministic_forward_euler (:119), stochastic_first_order (:154),
+deterministic_adams_bashforth (:199), stochastic_adams_bashforth (:251), stochastic_EM (:304),
+stochastic_GDC (:369), stochastic_mid_point (:495), stochastic_mid_point_version_2 (:577),
+stochastic_trapezoidal (:659).  The articulated schemes (:737-902) need the constraint solver and are
+out of scope (constraints are not on the path).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .context import MobilityContext
+from .rigid import gmres_right_preconditioned
+from .stochastic import stochastic_forcing_lanczos
+
+
+class RollersIntegrator(object):
+  """locations: (N,3) array-like or tensor.  `scheme` may carry the reference's `_rollers` suffix."""
+
+  def __init__(self, locations, scheme, a, eta, tolerance=None, domain="single_wall", device="cuda:0", ctx=None,
+               rng=None, seed=None):
+    self.device = torch.device(device)
+    self.location = torch.as_tensor(np.asarray(locations, dtype=np.float64) if not isinstance(locations, torch.Tensor)
+                                    else locations, dtype=torch.float64, device=self.device).reshape(-1, 3).clone()
+    self.Nblobs = self.location.shape[0]
+    self.scheme = scheme
+    self.a, self.eta = float(a), float(eta)
+    self.domain = domain
+    if domain not in ("single_wall", "no_wall", "in_plane"):
+      raise ValueError("domain must be single_wall, no_wall or in_plane")
+    # state and counters, names as quaternion_integrator_rollers.py:36-58
+    self.velocities_previous_step = None
+    self.deterministic_torque_previous_step = None
+    self.first_step = True
+    self.kT = 0.0
+    self.tolerance = 1e-08 if tolerance is None else float(tolerance)
+    self.rf_delta = 1e-03
+    self.invalid_configuration_count = 0
+    self.wall_overlaps = 0
+    self.omega_one_roller = np.zeros(3)
+    self.free_kinematics = "True"
+    self.hydro_interactions = 1
+    self.det_iterations_count = 0
+    self.stoch_iterations_count = 0
+    self.periodic_length = np.zeros(3)
+    self.print_residual = False
+    self.max_retries = 1000
+    # force parameters: multi_bodies.py:1326-1336 binds these with functools.partial
+    self.g = 0.0
+    self.blob_mass = 1.0
+    self.repulsion_strength_wall = 0.0
+    self.debye_length_wall = 1.0
+    self.repulsion_strength = 0.0
+    self.debye_length = 1.0
+    # replaceable hooks, as the reference's attributes of the same names; tensors (N,3) in and out
+    self.calc_one_blob_forces = self._one_blob_forces
+    self.calc_blob_blob_forces = self._blob_blob_forces
+    self.preprocess = lambda integrator: None
+    self.postprocess = lambda integrator: None
+    # random numbers: a numpy RandomState-like object (host draws, reference order) or a device generator
+    self.rng = rng
+    self._gen = None
+    if rng is None:
+      self._gen = torch.Generator(device=self.device)
+      self._gen.manual_seed(0 if seed is None else int(seed))
+    self.ctx = ctx if ctx is not None else MobilityContext(self.device.index or 0)
+    self._own_ctx = ctx is None
+    self.mobility_products = 0
+
+  def close(self):
+    if self._own_ctx:
+      self.ctx.close()
+
+  # ---- plumbing -------------------------------------------------------------------------------------
+  def _randn(self, n):
+    if self.rng is not None:
+      return torch.as_tensor(self.rng.randn(n), dtype=torch.float64, device=self.device)
+    return torch.randn(n, dtype=torch.float64, device=self.device, generator=self._gen)
+
+  def _bind(self, r, wall=None):
+    """Make r the configuration the context's products refer to (clamp + B happen on the device)."""
+    if wall is None:
+      wall = self.domain != "no_wall"
+    self.ctx.set_positions(r.contiguous().view(-1), self.a, self.periodic_length, wall)
+
+  def _product(self, kind, vec, vec2=None):
+    self.mobility_products += 1
+    in_plane = self.domain == "in_plane"
+    if in_plane and kind in ("rt", "rr"):
+      raise ValueError("domain in_plane has no rot products (quaternion_integrator_rollers.py:85-91)")
+    if vec2 is not None:
+      if in_plane:   # no fused in-plane kernel in the reference either: two sweeps
+        return (self.ctx.matvec_device("tt", vec.contiguous(), self.eta, in_plane=True) +
+                self.ctx.matvec_device("tr", vec2.contiguous(), self.eta, in_plane=True))
+      return self.ctx.matvec_device("tt_tr", vec.contiguous(), self.eta, vec2=vec2.contiguous())
+    return self.ctx.matvec_device(kind, vec.contiguous(), self.eta, in_plane=in_plane)
+
+  def mobility_trans_times_force(self, r, force):
+    self._bind(r)
+    return self._product("tt", force)
+
+  def mobility_trans_times_torque(self, r, torque):
+    self._bind(r)
+    return self._product("tr", torque)
+
+  def mobility_rot_times_force(self, r, force):
+    self._bind(r)
+    return self._product("rt", force)
+
+  def mobility_rot_times_torque(self, r, torque):
+    self._bind(r)
+    return self._product("rr", torque)
+
+  # ---- forces (multi_bodies_functions.py:153-188 and forces_numba.py:12-55) ---------------------------
+  def _one_blob_forces(self, r):
+    """Gravity + wall repulsion  f_z = -g m + (e_w/b_w) exp(-(h-a)/b_w) for h > a, e_w/b_w below."""
+    f = torch.zeros_like(r)
+    f[:, 2] = -self.g * self.blob_mass
+    if self.repulsion_strength_wall != 0.0:
+      h = r[:, 2]
+      e = self.repulsion_strength_wall / self.debye_length_wall
+      f[:, 2] += torch.where(h > self.a, e * torch.exp(-(h - self.a) / self.debye_length_wall),
+                             torch.full_like(h, e))
+    return f
+
+  def _blob_blob_forces(self, r):
+    if self.repulsion_strength == 0.0:
+      return torch.zeros_like(r)
+    self._bind(r, wall=False)    # forces act on the true heights, not the clamped ones
+    return self.ctx.blob_blob_force_device(self.repulsion_strength, self.debye_length, self.a).view(-1, 3)
+
+  def get_omega_one_roller(self):
+    return np.asarray(self.omega_one_roller, dtype=np.float64)
+
+  def get_torque(self):
+    """Free kinematics: constant torque 8 pi eta a^3 omega on every roller (:1586-1595)."""
+    t = torch.as_tensor(self.get_omega_one_roller() * (8.0 * math.pi * self.eta * self.a ** 3), device=self.device)
+    return t.repeat(self.Nblobs)
+
+  # ---- deterministic part ---------------------------------------------------------------------------
+  def compute_deterministic_velocity_and_torque(self):
+    """v = M_tt F + M_tr T with T prescribed (free kinematics) or solved from M_rr T = omega - M_rt F
+    (:905-982).  Returns (velocity (3N,), torque (3N,))."""
+    r = self.location
+    force = (self.calc_one_blob_forces(r) + self.calc_blob_blob_forces(r)).reshape(-1)
+    if self.free_kinematics == "False":
+      omega = torch.as_tensor(self.get_omega_one_roller(), device=self.device).repeat(self.Nblobs)
+      self._bind(r)
+      rhs = omega - self._product("rt", force)
+      nrm = float(torch.linalg.norm(rhs))
+      if nrm > 0:
+        rhs = rhs / nrm
+      sol, info = gmres_right_preconditioned(lambda x: self._product("rr", x), lambda x: x, rhs, tol=self.tolerance,
+                                             restart=20, maxiter=1000, x0=self.deterministic_torque_previous_step)
+      self.det_iterations_count += info["iterations"]
+      self.deterministic_torque_previous_step = sol
+      torque = sol * nrm if nrm > 0 else sol
+    else:
+      torque = self.get_torque()
+      self._bind(r)
+    if bool(torch.any(torque != 0)):
+      velocity = self._product("tt", force, vec2=torque)
+    else:
+      velocity = self._product("tt", force)
+    return velocity, torque
+
+  def _self_mobility_coefficients(self, r):
+    """Swan-Brady single-blob coefficients with the max(h/a,1) and damping artefacts (:1027-1047)."""
+    h_over_a = r[:, 2] / self.a
+    h = torch.clamp(h_over_a, min=1.0)
+    damping = torch.where(h_over_a < 0.0, torch.zeros_like(h), torch.where(h_over_a <= 1.0, h_over_a,
+                                                                           torch.ones_like(h)))
+    f_tt = 1.0 / (6 * math.pi * self.eta * self.a)
+    f_rr = 1.0 / (6 * math.pi * self.eta * self.a ** 3)
+    f_rt = 1.0 / (6 * math.pi * self.eta * self.a ** 2)
+    c = dict(h=h, damping=damping)
+    c["mu_rt_para"] = f_rt * (3 / (32 * h ** 4)) * damping
+    c["mu_tt_perp"] = f_tt * (1 - 9 / (8 * h) + 1 / (2 * h ** 3) - 1 / (8 * h ** 5)) * damping
+    c["mu_tt_para"] = f_tt * (1 - 9 / (16 * h) + 2 / (16 * h ** 3) - 1 / (16 * h ** 5)) * damping
+    c["dmu_tt_perp"] = f_tt * (9 / (8 * h ** 2) - 3 / (2 * h ** 4) + 5 / (8 * h ** 6)) * damping
+    c["mu_rr_perp"] = f_rr * (3.0 / 4 - 3 / (32 * h ** 3)) * damping
+    c["mu_rr_para"] = f_rr * (3.0 / 4 - 15 / (64 * h ** 3)) * damping
+    return c
+
+  def compute_deterministic_velocity_and_torque_uncorrelated(self):
+    """No hydrodynamic interactions: every roller sees only the wall (:985-1079); O(N) tensor ops."""
+    r = self.location
+    force = self.calc_one_blob_forces(r) + self.calc_blob_blob_forces(r)
+    c = self._self_mobility_coefficients(r)
+    if self.free_kinematics == "False":
+      omega = torch.as_tensor(self.get_omega_one_roller(), device=self.device).expand(self.Nblobs, 3)
+      torque = torch.empty_like(r)
+      torque[:, 0] = (omega[:, 0] + c["mu_rt_para"] * force[:, 1]) / c["mu_rr_para"]
+      torque[:, 1] = (omega[:, 1] - c["mu_rt_para"] * force[:, 0]) / c["mu_rr_para"]
+      torque[:, 2] = omega[:, 2] / c["mu_rr_perp"]
+    else:
+      torque = self.get_torque().view(-1, 3)
+    velocity = torch.empty_like(r)
+    velocity[:, 0] = c["mu_tt_para"] * force[:, 0] + c["mu_rt_para"] * torque[:, 1]
+    velocity[:, 1] = c["mu_tt_para"] * force[:, 1] - c["mu_rt_para"] * torque[:, 0]
+    velocity[:, 2] = c["mu_tt_perp"] * force[:, 2]
+    return velocity.reshape(-1), torque.reshape(-1)
+
+  # ---- stochastic part ------------------------------------------------------------------------------
+  def _lanczos(self, mult, dim, z, dt):
+    noise, its = stochastic_forcing_lanczos(factor=math.sqrt(2 * self.kT / dt), tolerance=self.tolerance, dim=dim,
+                                            mobility_mult=mult, z=z, print_residual=self.print_residual,
+                                            device=self.device)
+    self.stoch_iterations_count += its
+    return noise
+
+  def _random_finite_difference(self, kinds):
+    """(M(q + d/2 W) - M(q - d/2 W)) W for each product kind in `kinds`, one draw of W (:1138-1160)."""
+    r = self.location
+    dx = self._randn(3 * self.Nblobs)
+    half = dx.view(-1, 3) * (self.rf_delta * self.a * 0.5)
+    self._bind(r + half)
+    plus = [self._product(k, dx) for k in kinds]
+    self._bind(r - half)
+    return [p - self._product(k, dx) for k, p in zip(kinds, plus)]
+
+  def compute_stochastic_linear_velocity(self, dt):
+    """sqrt(2kT/dt) M_tt^{1/2} W + kT div(M_tt) by Lanczos + random finite difference (:1203-1260)."""
+    z = self._randn(3 * self.Nblobs)
+    self._bind(self.location)
+    noise = self._lanczos(lambda v: self._product("tt", v), 3 * self.Nblobs, z, dt)
+    if self.kT > 0.0 and self.domain != "no_wall":
+      (div_M_tt,) = self._random_finite_difference(("tt",))
+      return noise + (self.kT / (self.rf_delta * self.a)) * div_M_tt
+    return noise
+
+  def compute_stochastic_linear_velocity_without_drift(self, dt):
+    """sqrt(2kT/dt) M_tt^{1/2} W (:1315-1353)."""
+    z = self._randn(3 * self.Nblobs)
+    self._bind(self.location)
+    return self._lanczos(lambda v: self._product("tt", v), 3 * self.Nblobs, z, dt)
+
+  def compute_linear_thermal_drift(self):
+    """kT div(M_tt) by random finite difference (:1404-1434); zero without wall or at kT = 0."""
+    if self.kT > 0.0 and self.domain != "no_wall":
+      (div_M_tt,) = self._random_finite_difference(("tt",))
+      return (self.kT / (self.rf_delta * self.a)) * div_M_tt
+    return torch.zeros(3 * self.Nblobs, dtype=torch.float64, device=self.device)
+
+  def grand_mobility(self, force_torque):
+    """[v; w] = [[M_tt, M_tr], [M_rt, M_rr]] [F; T] on the bound configuration (:1114-1121): the top row is
+    one fused sweep."""
+    n3 = 3 * self.Nblobs
+    F, T = force_torque[:n3], force_torque[n3:]
+    v = self._product("tt", F, vec2=T)
+    w = self._product("rt", F) + self._product("rr", T)
+    return torch.cat([v, w])
+
+  def compute_stochastic_velocity(self, dt):
+    """Noise from the 6N grand mobility, stochastic torque solve for prescribed kinematics (:1082-1200)."""
+    n3 = 3 * self.Nblobs
+    z = self._randn(2 * n3)
+    self._bind(self.location)
+    noise = self._lanczos(self.grand_mobility, 2 * n3, z, dt)
+    if self.kT > 0.0 and self.domain != "no_wall":
+      div_M_rt, div_M_tt = self._random_finite_difference(("rt", "tt"))
+    else:
+      div_M_rt = torch.zeros(n3, dtype=torch.float64, device=self.device)
+      div_M_tt = torch.zeros(n3, dtype=torch.float64, device=self.device)
+    self._bind(self.location)
+    scale = self.kT / (self.rf_delta * self.a)
+    if self.free_kinematics == "False":
+      rhs = -noise[n3:] - div_M_rt * scale
+      nrm = float(torch.linalg.norm(rhs))
+      if nrm > 0:
+        rhs = rhs / nrm
+      sol, info = gmres_right_preconditioned(lambda x: self._product("rr", x), lambda x: x, rhs, tol=self.tolerance,
+                                             restart=20, maxiter=1000)
+      self.det_iterations_count += info["iterations"]
+      torque = sol * nrm if nrm > 0 else sol
+      v_stoch = self._product("tr", torque)
+    else:
+      v_stoch = torch.zeros(n3, dtype=torch.float64, device=self.device)
+    return v_stoch + noise[:n3] + scale * div_M_tt
+
+  def compute_stochastic_linear_velocity_uncorrelated(self, dt):
+    """Independent rollers: analytic M^{1/2} and drift (:1263-1312)."""
+    z = self._randn(3 * self.Nblobs).view(-1, 3)
+    c = self._self_mobility_coefficients(self.location)
+    fd = math.sqrt(2 * self.kT / dt)
+    v = torch.empty_like(z)
+    v[:, 0:2] = fd * torch.sqrt(c["mu_tt_para"]).unsqueeze(1) * z[:, 0:2]
+    v[:, 2] = fd * torch.sqrt(c["mu_tt_perp"]) * z[:, 2] + self.kT * c["dmu_tt_perp"]
+    return v.reshape(-1)
+
+  def compute_stochastic_linear_velocity_without_drift_uncorrelated(self, z, dt):
+    """(:1356-1401)"""
+    z = z.view(-1, 3)
+    c = self._self_mobility_coefficients(self.location)
+    fd = math.sqrt(2 * self.kT / dt)
+    v = torch.empty_like(z)
+    v[:, 0:2] = fd * torch.sqrt(c["mu_tt_para"]).unsqueeze(1) * z[:, 0:2]
+    v[:, 2] = fd * torch.sqrt(c["mu_tt_perp"]) * z[:, 2]
+    return v.reshape(-1)
+
+  # ---- step bookkeeping -----------------------------------------------------------------------------
+  def _valid(self, r):
+    """A configuration is rejected when any roller is below the wall plane (:137-142)."""
+    if self.domain != "single_wall":
+      return True
+    return not bool(torch.any(r[:, 2] < 0.0))
+
+  def _accept(self, r_new):
+    self.location = r_new
+    if self.domain == "single_wall":
+      self.wall_overlaps += int(torch.count_nonzero(r_new[:, 2] < self.a))
+
+  def _rejected(self):
+    self.invalid_configuration_count += 1
+    if self.invalid_configuration_count > self.max_retries:
+      raise RuntimeError("rollers: more than %d rejected steps" % self.max_retries)
+
+  def _det(self):
+    if self.hydro_interactions == 1:
+      return self.compute_deterministic_velocity_and_torque()
+    return self.compute_deterministic_velocity_and_torque_uncorrelated()
+
+  def advance_time_step(self, dt, *args, **kwargs):
+    return getattr(self, self.scheme.replace("_rollers", ""))(dt, *args, **kwargs)
+
+  # ---- schemes --------------------------------------------------------------------------------------
+  def deterministic_forward_euler(self, dt, *args, **kwargs):
+    while True:
+      det_velocity, _ = self._det()
+      r_new = self.location + dt * det_velocity.view(-1, 3)
+      if self._valid(r_new):
+        return self._accept(r_new)
+      self._rejected()
+
+  def stochastic_first_order(self, dt, *args, **kwargs):
+    while True:
+      det_velocity, _ = self._det()
+      if self.hydro_interactions == 1:
+        stoch_velocity = self.compute_stochastic_linear_velocity(dt)
+      else:
+        stoch_velocity = self.compute_stochastic_linear_velocity_uncorrelated(dt)
+      r_new = self.location + dt * (det_velocity + stoch_velocity).view(-1, 3)
+      if self._valid(r_new):
+        return self._accept(r_new)
+      self._rejected()
+
+  def deterministic_adams_bashforth(self, dt, *args, **kwargs):
+    while True:
+      det_velocity, _ = self._det()
+      if self.first_step is False:
+        velocity = 1.5 * det_velocity - 0.5 * self.velocities_previous_step
+      else:
+        velocity = det_velocity
+        self.first_step = False     # as the reference: cleared even if the step is then rejected (:221)
+      r_new = self.location + dt * velocity.view(-1, 3)
+      if self._valid(r_new):
+        self.velocities_previous_step = det_velocity
+        return self._accept(r_new)
+      self._rejected()
+
+  def stochastic_adams_bashforth(self, dt, *args, **kwargs):
+    """The config-5 recipe: one fused det sweep + Lanczos on M_tt + 2 RFD sweeps per step."""
+    while True:
+      det_velocity, _ = self._det()
+      if self.hydro_interactions == 1:
+        stoch_velocity = self.compute_stochastic_linear_velocity(dt)
+      else:
+        stoch_velocity = self.compute_stochastic_linear_velocity_uncorrelated(dt)
+      if self.first_step is False:
+        velocity = 1.5 * det_velocity - 0.5 * self.velocities_previous_step + stoch_velocity
+      else:
+        velocity = det_velocity + stoch_velocity
+        self.first_step = False
+      r_new = self.location + dt * velocity.view(-1, 3)
+      if self._valid(r_new):
+        self.velocities_previous_step = det_velocity
+        return self._accept(r_new)
+      self._rejected()
+
+  def stochastic_EM(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      W = self._randn(3 * self.Nblobs)
+      det_velocity, _ = self._det()
+      if self.hydro_interactions == 1:
+        stoch_velocity = self.compute_stochastic_linear_velocity_without_drift(dt)
+      else:
+        stoch_velocity = self.compute_stochastic_linear_velocity_without_drift_uncorrelated(W, dt)
+      r_new = self.location + dt * (det_velocity + stoch_velocity).view(-1, 3)
+      self.postprocess(self)
+      if self._valid(r_new):
+        self.first_step = False
+        self.velocities_previous_step = det_velocity
+        return self._accept(r_new)
+      self._rejected()
+
+  def stochastic_GDC(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      r_old = self.location
+      W = self._randn(3 * self.Nblobs)
+      hydro = self.hydro_interactions == 1
+
+      def brownian():
+        if hydro:
+          return self.compute_stochastic_linear_velocity_without_drift(dt)
+        return self.compute_stochastic_linear_velocity_without_drift_uncorrelated(W, dt)
+
+      stoch_n = brownian()
+      # divergence of the Brownian velocity by a finite difference along z only (:403-421)
+      shift = torch.zeros(3, dtype=torch.float64, device=self.device)
+      shift[2] = self.rf_delta * self.a
+      self.location = r_old + shift
+      stoch_fd = brownian()
+      dz = (stoch_fd.view(-1, 3)[:, 2] - stoch_n.view(-1, 3)[:, 2]) / (self.rf_delta * self.a)
+      correction = (1.0 + 0.5 * dt * dz.sum()) if hydro else (1.0 + 0.5 * dt * dz).unsqueeze(1)
+      self.location = r_old + stoch_n.view(-1, 3) * (dt / 2.0)
+      if not self._valid(self.location):
+        self.location = r_old
+        self._rejected()
+        continue
+      det_velocity, _ = self._det()
+      velocities_mid = (det_velocity + brownian()).view(-1, 3)
+      r_new = r_old + velocities_mid * dt * correction
+      self.location = r_old
+      self.postprocess(self)
+      if self._valid(r_new):
+        self.first_step = False
+        self.velocities_previous_step = det_velocity
+        return self._accept(r_new)
+      self._rejected()
+
+  def _two_stage(self, dt, version):
+    while True:
+      r_old = self.location
+      drift = self.compute_linear_thermal_drift()
+      det_1, _ = self.compute_deterministic_velocity_and_torque()
+      if version == "trapezoidal":
+        stoch_1 = self.compute_stochastic_linear_velocity_without_drift(dt)
+        stoch_2 = None
+        first = dt
+      else:
+        stoch_1 = self.compute_stochastic_linear_velocity_without_drift(0.5 * dt)
+        stoch_2 = self.compute_stochastic_linear_velocity_without_drift(0.5 * dt) if version == "mid_point_2" else None
+        first = 0.5 * dt
+      self.location = r_old + first * (det_1 + stoch_1).view(-1, 3)
+      if not self._valid(self.location):
+        self.location = r_old
+        self._rejected()
+        continue
+      det_2, _ = self.compute_deterministic_velocity_and_torque()
+      if version == "trapezoidal":
+        velocity = 0.5 * (det_1 + det_2) + drift + stoch_1
+      else:
+        if stoch_2 is None:
+          stoch_2 = self.compute_stochastic_linear_velocity_without_drift(0.5 * dt)
+        velocity = det_2 + drift + (stoch_1 + stoch_2) * 0.5
+      r_new = r_old + dt * velocity.view(-1, 3)
+      if not self._valid(r_new):
+        self.location = r_old
+        self._rejected()
+        continue
+      return self._accept(r_new)
+
+  def stochastic_mid_point(self, dt, *args, **kwargs):
+    """Predictor to t + dt/2 with W_1, corrector with W_1 and a second noise at the mid point (:495-574)."""
+    return self._two_stage(dt, "mid_point")
+
+  def stochastic_mid_point_version_2(self, dt, *args, **kwargs):
+    """As above with both noises generated at q^n (:577-656)."""
+    return self._two_stage(dt, "mid_point_2")
+
+  def stochastic_trapezoidal(self, dt, *args, **kwargs):
+    """Predictor-corrector average of the deterministic velocity, one noise (:659-734)."""
+    return self._two_stage(dt, "trapezoidal")
+
+
+# ---- driver: the reference's input deck -> integrator -> time loop ------------------------------------
+def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
+  """Wire a RollersIntegrator from a ReadInput deck exactly as multi_bodies/multi_bodies.py:1322-1339 and
+  :1379-1390 wire QuaternionIntegratorRollers.  Every `structure` must be a one-blob vertex file (the
+  reference's Structures/blob.vertex); its .clones file lists the rollers.  With `seed` in the deck the
+  random numbers are numpy's stream for that seed (the reference calls np.random.seed, :1157-1158)."""
+  from . import structures as st
+  locations = []
+  body_types = []
+  for vertex_file, clones_file in [s[:2] for s in read.structures]:
+    ref = st.read_vertex_file(read.resolve(vertex_file))
+    if len(ref) != 1:
+      raise ValueError("%s has %d blobs: the roller schemes are for single-blob bodies (use RigidSuspension)" %
+                       (vertex_file, len(ref)))
+    _n, loc, _quat = st.read_clones_file(read.resolve(clones_file))
+    locations.append(np.asarray(loc, dtype=np.float64).reshape(-1, 3) + ref[0])
+    body_types.append(len(locations[-1]))
+  if not locations:
+    raise ValueError("input deck lists no structure")
+  if rng is None and read.seed is not None:
+    rng = np.random.RandomState(int(read.seed))
+  integ = RollersIntegrator(np.concatenate(locations), read.scheme, read.blob_radius, read.eta,
+                            tolerance=read.solver_tolerance, domain=read.domain, device=device, ctx=ctx, rng=rng)
+  integ.kT = read.kT
+  integ.rf_delta = read.rf_delta
+  integ.g = read.g
+  integ.repulsion_strength_wall = read.repulsion_strength_wall
+  integ.debye_length_wall = read.debye_length_wall
+  if read.blob_blob_force_implementation != "None":
+    integ.repulsion_strength = read.repulsion_strength
+    integ.debye_length = read.debye_length
+  integ.periodic_length = np.asarray(read.periodic_length, dtype=np.float64)
+  integ.omega_one_roller = np.asarray(read.omega_one_roller, dtype=np.float64)
+  integ.free_kinematics = read.free_kinematics
+  integ.hydro_interactions = read.hydro_interactions
+  integ.body_types = body_types
+  integ.structures_ID = list(read.structures_ID)
+  return integ
+
+
+def _write_clones(fh, locations):
+  fh.write(str(len(locations)) + "\n")
+  for x in locations:
+    fh.write("%s %s %s %s %s %s %s\n" % (x[0], x[1], x[2], 1.0, 0.0, 0.0, 0.0))
+
+
+def run(read, integrator, output_name=None, n_steps=None, callback=None):
+  """Time loop of multi_bodies.py:1412-1530 for rollers: every n_save steps (and after the last one) the
+  locations go to `<output_name>.<ID>.<step>.clones` (save_clones one_file_per_step) or are appended to
+  `<output_name>.<ID>.config` (one_file), in the reference's text format; orientation is the identity
+  (rollers do not track it).  Returns the integrator."""
+  output_name = read.output_name if output_name is None else output_name
+  n_steps = read.n_steps if n_steps is None else n_steps
+  if read.save_clones not in ("one_file_per_step", "one_file"):
+    raise ValueError('save_clones = %s is not implemented; use "one_file_per_step" or "one_file"' % read.save_clones)
+  files = None
+  if read.save_clones == "one_file":
+    files = [open(output_name + "." + ID + ".config", "w") for ID in integrator.structures_ID]
+
+  def save(step):
+    loc = integrator.location.cpu().numpy()
+    offset = 0
+    for i, ID in enumerate(integrator.structures_ID):
+      block = loc[offset:offset + integrator.body_types[i]]
+      offset += integrator.body_types[i]
+      if files is not None:
+        _write_clones(files[i], block)
+      else:
+        with open(output_name + "." + ID + "." + str(step).zfill(8) + ".clones", "w") as fh:
+          _write_clones(fh, block)
+
+  try:
+    step = read.initial_step - 1
+    for step in range(read.initial_step, n_steps):
+      if step % read.n_save == 0 and step >= 0:
+        save(step)
+      integrator.advance_time_step(read.dt, step=step)
+      if callback is not None:
+        callback(step, integrator)
+    if (step + 1) % read.n_save == 0 and step >= 0:
+      save(step + 1)
+  finally:
+    if files is not None:
+      for fh in files:
+        fh.close()
+  return integrator

@@ -27,10 +27,20 @@ class OracleBackend(object):
   def matvec(self, kind, v_full, eta, vec2_full=None, in_plane=False, out=None):
     names = {"tt": "trans_times_force", "tr": "trans_times_torque", "rt": "rot_times_force", "rr": "rot_times_torque"}
     pre = "single_wall" if self.wall else "no_wall"
-    fn = getattr(oracle, "%s_mobility_%s_oracle" % (pre, names[kind]))
-    u = fn(self.r, v_full.cpu().numpy(), eta, self.a, periodic_length=self.L)
+    if kind == "tt_tr":
+      u = getattr(oracle, pre + "_mobility_trans_times_force_torque_oracle")(
+          self.r, v_full.cpu().numpy(), vec2_full.cpu().numpy(), eta, self.a, periodic_length=self.L)
+    else:
+      fn = getattr(oracle, "%s_mobility_%s_oracle" % (pre, names[kind]))
+      u = fn(self.r, v_full.cpu().numpy(), eta, self.a, periodic_length=self.L)
     b, e = self.range
     return torch.from_numpy(u[3 * b:3 * e].copy())
+
+  def blob_blob_force(self, eps, b, a, out=None):
+    F = oracle.calc_blob_blob_forces_oracle(self.r, periodic_length=self.L, repulsion_strength=eps, debye_length=b,
+                                            blob_radius=a)
+    lo, hi = self.range
+    return torch.from_numpy(np.ascontiguousarray(F[lo:hi]).reshape(-1))
 
   # pair-shard stand-in: "shard g" = the contribution of source block g to all targets (self terms of
   # block g included).  Like the HIP kernel's slices of unordered pairs, the shards sum to M.v.
@@ -45,6 +55,27 @@ class OracleBackend(object):
     pre = "single_wall" if self.wall else "no_wall"
     u = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(self.r, v, eta, self.a, periodic_length=self.L)
     return torch.from_numpy(u.copy())
+
+
+def rollers_replicated(rank, world, out_dir):
+  """A replicated time stepper over sharded sweeps: RollersIntegrator on a ReplicatedContext must walk the
+  reference trajectory (golden g8) on every rank, and all ranks must hold identical locations."""
+  from rigidmultiblobswall_amd.distributed import ReplicatedContext
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  from _rollers_common import integrator_from_golden, run_and_compare
+  for name in ("g8_rollers_stoch_ab", "g8_rollers_det_ab_periodic"):
+    d = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    g = {k: d[k] for k in d.files}
+    ctx = ReplicatedContext(ShardedMobility(OracleBackend(), device="cpu"))
+    integ = integrator_from_golden(g, ctx, "cpu")
+    worst = run_and_compare(g, integ)
+    assert worst < (1e-11 if float(g["kT"]) == 0.0 else 1e-7), (name, worst)
+    mine = integ.location.clone()
+    hi = mine.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert torch.equal(mine, hi), "ranks diverged"
+    if rank == 0:
+      np.save(os.path.join(out_dir, name + "_final.npy"), mine.numpy())
 
 
 def main():
@@ -81,6 +112,7 @@ def main():
     t = torch.tensor([err], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() < 1e-13, t.item()
+  rollers_replicated(rank, world, out_dir)
   dist.destroy_process_group()
 
 

@@ -1,0 +1,43 @@
+"""CPU stand-in for MobilityContext backed by the oracle -- TEST infrastructure only (lets the host logic of
+the callers run here without a GPU; the product never imports it)."""
+import numpy as np
+import torch
+
+
+class OracleContext(object):
+  def __init__(self, oracle):
+    self.o = oracle
+    self.n_set_positions = 0
+
+  def set_stream(self, s):
+    pass
+
+  def set_positions(self, r, a, L=None, wall=True):
+    self.r = (r.detach().cpu().numpy() if isinstance(r, torch.Tensor) else np.asarray(r)).reshape(-1, 3).copy()
+    self.a, self.wall = float(a), bool(wall)
+    self.L = np.zeros(3) if L is None else np.asarray(L, dtype=np.float64)
+    self.n = len(self.r)
+    self.n_set_positions += 1
+
+  def _wrapped(self, kind, v, eta, in_plane):
+    return self.o._wrapped(kind, int(self.wall), self.r, v.detach().cpu().numpy(), eta, self.a, in_plane=in_plane,
+                           periodic_length=self.L)
+
+  def matvec_device(self, kind, vec, eta, vec2=None, in_plane=False, out=None):
+    if kind == "tt_tr":
+      u = self._wrapped("tt", vec, eta, in_plane) + self._wrapped("tr", vec2, eta, in_plane)
+    else:
+      u = self._wrapped(kind, vec, eta, in_plane)
+    return torch.from_numpy(u)
+
+  def blob_blob_force_device(self, eps, b, a, out=None, device=None):
+    F = self.o.calc_blob_blob_forces_oracle(self.r, periodic_length=self.L, repulsion_strength=eps, debye_length=b,
+                                            blob_radius=a)
+    return torch.from_numpy(np.ascontiguousarray(F).reshape(-1))
+
+  def body_mobility_dense_device(self, first_blob, n_b, eta):
+    out = [self.o.dense("tt", int(self.wall), self.r[f:f + n_b], eta, self.a) for f in first_blob.tolist()]
+    return torch.from_numpy(np.array(out))
+
+  def close(self):
+    pass

@@ -30,3 +30,8 @@ def test_sharded_matches_single_process(tmp_path, world):
     d = np.load(os.path.join(str(tmp_path), "case%d.npz" % case))
     assert np.abs(d["u_full"] - d["ref_rr"]).max() <= 1e-13 * max(1.0, np.abs(d["ref_rr"]).max())
     assert np.abs(d["u_local0"] - d["ref_tt_local0"]).max() <= 1e-13 * max(1.0, np.abs(d["ref_tt_local0"]).max())
+    if case == 0:
+      for name in ("g8_rollers_stoch_ab", "g8_rollers_det_ab_periodic"):
+        final = np.load(os.path.join(str(tmp_path), name + "_final.npy"))
+        ref = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["trajectory"][-1]
+        assert np.abs(final - ref).max() < 1e-7

@@ -160,6 +160,32 @@ def test_fused_force_torque(mob, oracle, wall):
   assert rel_err(u, u2) < 1e-13
 
 
+@pytest.mark.parametrize("wall", [True, False])
+@pytest.mark.parametrize("L", [(0.0, 0.0, 0.0), (9.0, 8.0, 0.0)])
+def test_fused_force_torque_symmetric_two_pass(Ctx, oracle, wall, L):
+  """K11/K12 at N >= 128 run as two symmetric passes into one output (rmb_capi.hip); must equal the one-sided
+  fused sweep (option deterministic) and the oracle."""
+  import torch
+  r, f, eta, a = d2_cloud(1500, seed=31)
+  t = np.random.RandomState(32).randn(*f.shape)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, np.array(L), wall=wall)
+  u_sym = ctx.matvec("tt_tr", f, eta, vec2=t)
+  assert ctx.last_launch()["chunks"] == 0
+  ctx.set_option("deterministic", 1)
+  u_sweep = ctx.matvec("tt_tr", f, eta, vec2=t)
+  assert ctx.last_launch()["chunks"] >= 1
+  ctx.set_option("deterministic", 0)
+  ctx.set_option("fused_symmetric", 0)
+  u_off = ctx.matvec("tt_tr", f, eta, vec2=t)
+  assert ctx.last_launch()["chunks"] >= 1
+  pre = "single_wall" if wall else "no_wall"
+  ref = getattr(oracle, pre + "_mobility_trans_times_force_torque_oracle")(r, f, t, eta, a, periodic_length=np.array(L))
+  assert rel_err(u_sym, ref) < TOL_D2 and rel_err(u_sweep, ref) < TOL_D2 and rel_err(u_off, ref) < TOL_D2
+  assert rel_err(u_sym, u_sweep) < 1e-13
+  ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # 3. boundary behaviour the callers rely on (SURVEY 8b)
 # ---------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ for N in (10000, 100000):
         continue
       reps = 20 if N <= 10000 else 5
       v2 = fd if kind == "tt_tr" else None
-      for det in ((0, 1) if kind in ("tt", "tr", "rt", "rr") else (0,)):
+      for det in ((0, 1) if kind in ("tt", "tr", "rt", "rr", "tt_tr") else (0,)):
         ctx.set_option("deterministic", det)
         for _ in range(2):
           ctx.matvec_device(kind, fd, eta, vec2=v2)
@@ -31,7 +31,8 @@ for N in (10000, 100000):
         for _ in range(reps):
           ctx.matvec_device(kind, fd, eta, vec2=v2)
         torch.cuda.synchronize()
-        ms = float(np.mean(ctx.timing_collect(reps)))
+        # kernel time per PRODUCT: the symmetric tt+tr product is two timed launches
+        ms = float(np.sum(ctx.timing_collect(4 * reps))) / reps
         tf = FLOPS[(kind, wall)] * float(N) * N / (ms * 1e-3) / 1e12
         rows.append(dict(N=N, kind=kind, wall=wall, path="symmetric" if ctx.last_launch()["chunks"] == 0 else "sweep", kernel_ms=round(ms, 4),
                          flops_per_pair=FLOPS[(kind, wall)], alg_tflops=round(tf, 2), frac_fp64_peak=round(tf / 78.6, 3),
