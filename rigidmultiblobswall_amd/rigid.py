@@ -44,9 +44,34 @@ def blob_positions(reference_configuration, location, quaternion):
   return np.asarray(reference_configuration) @ R.T + np.asarray(location)
 
 
+def quaternion_rotation_matrix_torch(q):
+  """Batched rotation matrices, same formula as above, on whatever device q lives.  (n,4) -> (n,3,3)."""
+  s, p0, p1, p2 = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+  d = s * s - 0.5
+  R = torch.stack([p0 * p0 + d, p0 * p1 - s * p2, p0 * p2 + s * p1,
+                   p1 * p0 + s * p2, p1 * p1 + d, p1 * p2 - s * p0,
+                   p2 * p0 - s * p1, p2 * p1 + s * p0, p2 * p2 + d], dim=1)
+  return 2.0 * R.view(-1, 3, 3)
+
+
+def quaternion_from_rotation_torch(phi):
+  """Quaternion of the rotation vector phi = omega dt (quaternion_integrator/quaternion.py:17-27).  (n,3) -> (n,4)."""
+  n = torch.linalg.norm(phi, dim=1, keepdim=True)
+  safe = torch.where(n > 0, n, torch.ones_like(n))
+  return torch.cat([torch.cos(0.5 * n), torch.where(n > 0, torch.sin(0.5 * n) / safe, torch.zeros_like(n)) * phi], dim=1)
+
+
+def quaternion_multiply_torch(q, r):
+  """q * r with q the LEFT quaternion (quaternion.py:30-39).  (n,4),(n,4) -> (n,4)."""
+  qs, qp = q[:, 0:1], q[:, 1:4]
+  rs, rp = r[:, 0:1], r[:, 1:4]
+  return torch.cat([qs * rs - (qp * rp).sum(dim=1, keepdim=True), qs * rp + rs * qp + torch.cross(qp, rp, dim=1)], dim=1)
+
+
 class _Group(object):
   """All bodies that share one reference configuration size n_b."""
-  __slots__ = ("n_b", "body_idx", "first_blob", "blob_idx3", "K", "Minv", "Nbody", "Lchol")
+  __slots__ = ("n_b", "body_idx", "first_blob", "blob_idx", "blob_idx3", "ref", "rel", "K", "K_pc", "Minv", "Nbody", "Lchol",
+               "Linv")
 
 
 class RigidSuspension(object):
@@ -54,7 +79,9 @@ class RigidSuspension(object):
 
   reference_configurations: list with one (n_b, 3) array per body (bodies may differ in shape);
   locations (n_bodies, 3); quaternions (n_bodies, 4) as (s, p1, p2, p3).  Blobs are numbered body after
-  body, as multi_bodies.py:194-204 does.
+  body, as multi_bodies.py:194-204 does.  The configuration lives on the device: `set_configuration`
+  moves every body (rotation matrices, blob coordinates and K are batched tensor ops), which is what the
+  time integrators (rigid_integrator.py) call between solves.
   """
 
   def __init__(self, reference_configurations, locations, quaternions, a, eta, wall=True, periodic_length=None,
@@ -62,29 +89,16 @@ class RigidSuspension(object):
     self.device = torch.device(device)
     self.a, self.eta, self.wall = float(a), float(eta), bool(wall)
     self.L = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
-    locations = np.asarray(locations, dtype=np.float64).reshape(-1, 3)
-    quaternions = np.asarray(quaternions, dtype=np.float64).reshape(-1, 4)
-    self.n_bodies = len(locations)
-    refs = [np.asarray(c, dtype=np.float64).reshape(-1, 3) for c in reference_configurations]
-    assert len(refs) == self.n_bodies
+    refs = [np.asarray(c, dtype=np.float64).reshape(len(c), -1)[:, :3] for c in reference_configurations]
+    self.n_bodies = len(refs)
     sizes = np.array([len(c) for c in refs])
     first = np.concatenate([[0], np.cumsum(sizes)])
     self.n_blobs = int(first[-1])
     self.first_blob = first[:-1]
-    # blob coordinates, body after body
-    R = quaternion_rotation_matrix(quaternions)
-    r = np.empty((self.n_blobs, 3))
-    rel = np.empty((self.n_blobs, 3))
-    for k in range(self.n_bodies):
-      rk = refs[k] @ R[k].T
-      rel[first[k]:first[k + 1]] = rk
-      r[first[k]:first[k + 1]] = rk + locations[k]
-    self.r_vectors = r
+    self.body_sizes = sizes
     self.ctx = ctx if ctx is not None else MobilityContext(self.device.index or 0)
     self._own_ctx = ctx is None
-    self.r_dev = torch.as_tensor(r.reshape(-1), device=self.device)
-    self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
-    # groups of equal n_b; K = [I, rot] with rot x = -(r x x)  (body/body.py:81-115)
+    # groups of equal n_b
     self.groups = []
     for n_b in sorted(set(sizes.tolist())):
       g = _Group()
@@ -94,18 +108,54 @@ class RigidSuspension(object):
       g.first_blob = torch.as_tensor(first[idx], device=self.device, dtype=torch.int64)
       blob = first[idx][:, None] + np.arange(n_b)[None, :]                       # (nb_g, n_b)
       comp = (3 * blob[:, :, None] + np.arange(3)[None, None, :]).reshape(len(idx), 3 * n_b)
+      g.blob_idx = torch.as_tensor(blob, device=self.device, dtype=torch.int64)
       g.blob_idx3 = torch.as_tensor(comp, device=self.device, dtype=torch.int64)
-      rr = rel[blob.reshape(-1)].reshape(len(idx), n_b, 3)
-      K = np.zeros((len(idx), n_b, 3, 6))
-      K[:, :, 0, 0] = K[:, :, 1, 1] = K[:, :, 2, 2] = 1.0
-      K[:, :, 0, 4] = rr[:, :, 2];  K[:, :, 0, 5] = -rr[:, :, 1]
-      K[:, :, 1, 3] = -rr[:, :, 2]; K[:, :, 1, 5] = rr[:, :, 0]
-      K[:, :, 2, 3] = rr[:, :, 1];  K[:, :, 2, 4] = -rr[:, :, 0]
-      g.K = torch.as_tensor(K.reshape(len(idx), 3 * n_b, 6), device=self.device)
-      g.Minv = g.Nbody = g.Lchol = None
+      g.ref = torch.as_tensor(np.array([refs[k] for k in idx]), device=self.device)      # (nb_g, n_b, 3)
+      g.rel = g.K = g.K_pc = g.Minv = g.Nbody = g.Lchol = g.Linv = None
       self.groups.append(g)
     self.size = 3 * self.n_blobs + 6 * self.n_bodies
     self.matvec_count = 0
+    self.set_configuration(locations, quaternions)
+
+  # ---- configuration --------------------------------------------------------------------------------
+  def _as_dev(self, x, cols):
+    if isinstance(x, torch.Tensor):
+      return x.to(device=self.device, dtype=torch.float64).reshape(-1, cols)
+    return torch.as_tensor(np.asarray(x, dtype=np.float64).reshape(-1, cols), device=self.device)
+
+  def blob_positions_device(self, locations, quaternions):
+    """(n_blobs, 3) blob coordinates of a configuration, r = ref . R(q)^T + location (body/body.py:64-78);
+    also returns the per-group body-frame offsets.  Does not touch the bound configuration."""
+    loc, quat = self._as_dev(locations, 3), self._as_dev(quaternions, 4)
+    r = torch.empty((self.n_blobs, 3), dtype=torch.float64, device=self.device)
+    rels = []
+    for g in self.groups:
+      R = quaternion_rotation_matrix_torch(quat[g.body_idx])
+      rel = torch.bmm(g.ref, R.transpose(1, 2))
+      r[g.blob_idx.reshape(-1)] = (rel + loc[g.body_idx].unsqueeze(1)).reshape(-1, 3)
+      rels.append(rel)
+    return r, rels
+
+  def set_configuration(self, locations, quaternions):
+    """Move the bodies: new blob coordinates, new K = [I, rot] with rot x = -(rel x x) (body/body.py:81-115), and the
+    context's packed positions.  The preconditioner is NOT touched (the reference also keeps the one built at time
+    level n for the other solves of a step); call build_preconditioner() to refresh it."""
+    self.location, self.orientation = self._as_dev(locations, 3).clone(), self._as_dev(quaternions, 4).clone()
+    r, rels = self.blob_positions_device(self.location, self.orientation)
+    for g, rel in zip(self.groups, rels):
+      g.rel = rel
+      K = torch.zeros((rel.shape[0], g.n_b, 3, 6), dtype=torch.float64, device=self.device)
+      K[:, :, 0, 0] = 1.0; K[:, :, 1, 1] = 1.0; K[:, :, 2, 2] = 1.0
+      K[:, :, 0, 4] = rel[:, :, 2];  K[:, :, 0, 5] = -rel[:, :, 1]
+      K[:, :, 1, 3] = -rel[:, :, 2]; K[:, :, 1, 5] = rel[:, :, 0]
+      K[:, :, 2, 3] = rel[:, :, 1];  K[:, :, 2, 4] = -rel[:, :, 0]
+      g.K = K.reshape(rel.shape[0], 3 * g.n_b, 6)
+    self.r_dev = r.reshape(-1)
+    self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
+
+  @property
+  def r_vectors(self):
+    return self.r_dev.detach().cpu().numpy().reshape(-1, 3)
 
   def close(self):
     if self._own_ctx:
@@ -152,6 +202,8 @@ class RigidSuspension(object):
       # the Krylov loop were observed to race on ROCm 7.0 torch; bmm does not.)
       g.Minv = torch.cholesky_inverse(g.Lchol)
       g.Minv = 0.5 * (g.Minv + g.Minv.transpose(1, 2))
+      g.K_pc = g.K
+      g.Linv = None
       g.Nbody = torch.linalg.pinv(torch.bmm(g.K.transpose(1, 2), torch.bmm(g.Minv, g.K)))
     if self.device.type == "cuda":
       torch.cuda.synchronize(self.device)
@@ -168,32 +220,75 @@ class RigidSuspension(object):
       flat = g.blob_idx3.reshape(-1)
       slip = x[:n3][flat].view(len(g.body_idx), 3 * g.n_b, 1)
       Lt = torch.bmm(g.Minv, slip)
-      Y = torch.bmm(g.Nbody, -F[g.body_idx].unsqueeze(-1) - torch.bmm(g.K.transpose(1, 2), Lt))
-      lam = torch.bmm(g.Minv, slip + torch.bmm(g.K, Y))
+      Y = torch.bmm(g.Nbody, -F[g.body_idx].unsqueeze(-1) - torch.bmm(g.K_pc.transpose(1, 2), Lt))
+      lam = torch.bmm(g.Minv, slip + torch.bmm(g.K_pc, Y))
       out[:n3][flat] = lam.reshape(-1)
       outU[g.body_idx] = Y.squeeze(-1)
     return out
 
   # ---- solve ------------------------------------------------------------------------------------
+  def solve(self, rhs, tol=1e-8, restart=60, maxiter=1000):
+    """Device-level solve of [M -K; -K^T 0] x = rhs at the bound configuration with the stored preconditioner
+    (built on first use).  RHS normalised to 1 before GMRES (quaternion_integrator_multi_bodies.py:1518-1521).
+    Returns (x tensor, info)."""
+    if self.groups[0].Lchol is None:
+      self.build_preconditioner()
+    nrm = float(torch.linalg.norm(rhs))
+    if nrm == 0.0:
+      return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
+    sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
+                                           restart=restart, maxiter=maxiter)
+    return sol * nrm, info
+
   def solve_mobility_problem(self, slip=None, force_torque=None, tol=1e-8, restart=60, maxiter=1000, x0=None):
     """Returns (velocities (n_bodies, 6), lambda (n_blobs, 3), info).  RHS = [slip, -F]
-    (quaternion_integrator_multi_bodies.py:1458-1475), normalised to 1 before GMRES (:1518-1521)."""
+    (quaternion_integrator_multi_bodies.py:1458-1475)."""
     n3 = 3 * self.n_blobs
     rhs = torch.zeros(self.size, dtype=torch.float64, device=self.device)
     if slip is not None:
       rhs[:n3] = torch.as_tensor(np.asarray(slip, dtype=np.float64).reshape(-1), device=self.device)
     if force_torque is not None:
       rhs[n3:] = -torch.as_tensor(np.asarray(force_torque, dtype=np.float64).reshape(-1), device=self.device)
+    sol, info = self.solve(rhs, tol=tol, restart=restart, maxiter=maxiter)
+    return sol[n3:].view(-1, 6).cpu().numpy(), sol[:n3].view(-1, 3).cpu().numpy(), info
+
+  # ---- Brownian forcing with the block-diagonal stochastic preconditioner ----------------------------
+  def _stochastic_factors(self):
+    """Per body M_b = L L^T (the Cholesky factor of the preconditioner build) and L^-1, explicit, so applying them is
+    batched GEMM (multi_bodies.py:516-531 stores P = L^-T and P_inv = L the same way)."""
+    for g in self.groups:
+      if g.Linv is None:
+        eye = torch.eye(3 * g.n_b, dtype=torch.float64, device=self.device).expand(len(g.body_idx), -1, -1)
+        g.Linv = torch.linalg.solve_triangular(g.Lchol, eye, upper=False)
+
+  def _blockdiag(self, x, which, transpose=False):
+    out = torch.empty_like(x)
+    for g in self.groups:
+      flat = g.blob_idx3.reshape(-1)
+      A = g.Linv if which == "Linv" else g.Lchol
+      if transpose:
+        A = A.transpose(1, 2)
+      out[flat] = torch.bmm(A, x[flat].view(len(g.body_idx), 3 * g.n_b, 1)).reshape(-1)
+    return out
+
+  def stochastic_forcing(self, z, factor, tol=1e-8, print_residual=False):
+    """factor * P^-1 (P^T M P)^{1/2} z with P = blockdiag(L_b^-T): the preconditioned Lanczos of
+    quaternion_integrator_multi_bodies.py:966-973 / multi_bodies.py:590-614 (covariance factor^2 M; needs O(1)
+    iterations per decade because each body's own block is the identity).  Uses the preconditioner of the
+    configuration it was built at, and the mobility of the bound configuration.  Returns (noise, iterations)."""
+    from .stochastic import stochastic_forcing_lanczos
     if self.groups[0].Lchol is None:
       self.build_preconditioner()
-    nrm = float(torch.linalg.norm(rhs))
-    if nrm == 0.0:
-      z = torch.zeros(self.size, dtype=torch.float64, device=self.device)
-      return z[n3:].view(-1, 6).cpu().numpy(), z[:n3].view(-1, 3).cpu().numpy(), dict(iterations=0, residual=0.0)
-    sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
-                                           restart=restart, maxiter=maxiter)
-    sol = sol * nrm
-    return sol[n3:].view(-1, 6).cpu().numpy(), sol[:n3].view(-1, 3).cpu().numpy(), info
+    self._stochastic_factors()
+
+    def mobility_pc(w):
+      v = self._blockdiag(w, "Linv", transpose=True)          # P w
+      v = self.mobility_times_lambda(v)
+      return self._blockdiag(v, "Linv")                        # P^T (M P w)
+
+    return stochastic_forcing_lanczos(factor=factor, tolerance=tol, dim=3 * self.n_blobs, mobility_mult=mobility_pc,
+                                      L_mult=lambda x: self._blockdiag(x, "Lchol"), z=z, print_residual=print_residual,
+                                      device=self.device)
 
 
 def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None):

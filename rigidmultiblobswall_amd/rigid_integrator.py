@@ -1,0 +1,453 @@
+"""Device-resident time integrators for suspensions of rigid multiblobs (the callers of the callers of the
+hot path: BASELINE.json configs[4] = "GMRES + Lanczos M^{1/2} z + forces kernel" per time step).
+
+Mirror of quaternion_integrator/quaternion_integrator_multi_bodies.py (`QuaternionIntegrator`) for free
+rigid bodies: same scheme names, attribute names and random-draw order, so a run of the reference driver with
+`seed s` in the deck and a run of this class with `rng=np.random.RandomState(s)` walk the same trajectory up
+to solver tolerance (tests/golden/g9_*, recorded from the reference's own multi_bodies.py).
+
+  deterministic_forward_euler (:75)   deterministic_adams_bashforth (:142)   deterministic_midpoint (:188)
+  stochastic_first_order_RFD (:326)   stochastic_adams_bashforth (:431)
+  stochastic_Slip_Trapz (:925)        stochastic_Slip_Mid (:1214)
+
+Where things live: locations / quaternions are two tensors in HBM; a step is a sequence of
+`RigidSuspension.set_configuration` (batched rotation + K rebuild + position pack), saddle-point solves
+(`RigidSuspension.solve`: HIP pair sweeps + batched GEMMs), preconditioned Lanczos
+(`RigidSuspension.stochastic_forcing`) and the blob force kernel; the reference loops over Python `Body`
+objects for every one of those (e.g. :86-91, :1003-1007).
+
+Not built: articulated bodies / constraints, prescribed kinematics (obstacles), the dense-algebra variants
+(`*_dense_algebra`, `Fixman`, `*_DLA`: O(N^3) teaching versions) and the traction schemes.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .rigid import RigidSuspension, quaternion_from_rotation_torch, quaternion_multiply_torch
+
+
+class RigidIntegrator(object):
+  """reference_configurations: one (n_b, 3) array per body; locations (nb, 3); quaternions (nb, 4)."""
+
+  def __init__(self, reference_configurations, locations, quaternions, scheme, a, eta, tolerance=None,
+               domain="single_wall", periodic_length=None, device="cuda:0", ctx=None, rng=None, seed=None):
+    if domain not in ("single_wall", "no_wall"):
+      raise ValueError("domain must be single_wall or no_wall")
+    self.device = torch.device(device)
+    self.scheme = scheme
+    self.a, self.eta = float(a), float(eta)
+    self.domain = domain
+    self.periodic_length = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
+    self.susp = RigidSuspension(reference_configurations, locations, quaternions, a, eta, wall=(domain == "single_wall"),
+                                periodic_length=self.periodic_length, device=device, ctx=ctx)
+    self.location = self.susp.location.clone()
+    self.orientation = self.susp.orientation.clone()
+    self.Nblobs, self.Nbodies = self.susp.n_blobs, self.susp.n_bodies
+    # body_length = largest blob-blob distance + 2a (body/body.py:218-231), one value per body
+    lengths = np.empty(self.Nbodies)
+    cache = {}
+    for k, ref in enumerate(reference_configurations):
+      ref = np.asarray(ref, dtype=np.float64).reshape(len(ref), -1)[:, :3]
+      key = ref.tobytes()
+      if key not in cache:
+        if len(ref) > 2000:
+          cache[key] = 10.0
+        else:
+          d = np.linalg.norm(ref[:, None, :] - ref[None, :, :], axis=-1)
+          cache[key] = float(d.max()) + 2 * self.a
+      lengths[k] = cache[key]
+    self.body_length = torch.as_tensor(lengths, device=self.device)
+    # state and counters, names as quaternion_integrator_multi_bodies.py:41-55
+    self.velocities_previous_step = None
+    self.first_step = True
+    self.kT = 0.0
+    self.tolerance = 1e-08 if tolerance is None else float(tolerance)
+    self.rf_delta = 1e-03
+    self.invalid_configuration_count = 0
+    self.det_iterations_count = 0
+    self.stoch_iterations_count = 0
+    self.update_PC = 1
+    self.print_residual = False
+    self.max_retries = 1000
+    self._pc_built = False
+    # force model of multi_bodies_functions.py (gravity + wall repulsion per blob, blob-blob repulsion)
+    self.g = 0.0
+    self.blob_mass = 1.0
+    self.repulsion_strength_wall = 0.0
+    self.debye_length_wall = 1.0
+    self.repulsion_strength = 0.0
+    self.debye_length = 1.0
+    # hooks, as the reference's attributes of the same names (tensors in / out)
+    self.calc_slip = None                       # callable(integrator) -> (Nblobs, 3) tensor
+    self.slip_body_frame = None                 # (Nblobs, 3) tensor: constant active slip in the body frame (.slip files)
+    self.calc_blob_forces = self._blob_forces   # callable(r (N,3) tensor) -> (N,3) tensor
+    self.external_force_torque = None           # callable(integrator) -> (nb, 6) tensor added to the blob-derived one
+    self.preprocess = lambda integrator: None
+    self.postprocess = lambda integrator: None
+    self.rng = rng
+    self._gen = None
+    if rng is None:
+      self._gen = torch.Generator(device=self.device)
+      self._gen.manual_seed(0 if seed is None else int(seed))
+
+  def close(self):
+    self.susp.close()
+
+  # ---- plumbing -------------------------------------------------------------------------------------
+  def _normal(self, n):
+    if self.rng is not None:
+      return torch.as_tensor(self.rng.normal(0.0, 1.0, n), dtype=torch.float64, device=self.device)
+    return torch.randn(n, dtype=torch.float64, device=self.device, generator=self._gen)
+
+  def _move(self, location, orientation):
+    self.susp.set_configuration(location, orientation)
+
+  @staticmethod
+  def _advance(location, orientation, velocities, dt):
+    """x + v dt and quaternion(omega dt) * q (quaternion_integrator_multi_bodies.py:86-91).  dt may be a per-body
+    column for the translation (the RFD displacement is scaled by the body length)."""
+    U = velocities.view(-1, 6)
+    return location + U[:, 0:3] * dt, quaternion_multiply_torch(quaternion_from_rotation_torch(U[:, 3:6] * dt), orientation)
+
+  def _valid(self, location, orientation):
+    """body.check_function (body/body.py:118-140): no blob below the wall plane."""
+    if self.domain != "single_wall":
+      return True
+    r, _ = self.susp.blob_positions_device(location, orientation)
+    if bool(torch.any(r[:, 2] < 0.0)):
+      self.invalid_configuration_count += 1
+      if self.invalid_configuration_count > self.max_retries:
+        raise RuntimeError("rigid integrator: more than %d rejected configurations" % self.max_retries)
+      return False
+    return True
+
+  def _refresh_preconditioner(self, step):
+    """multi_bodies.py:502: rebuild when step % update_PC == 0 or nothing has been built yet."""
+    if (not self._pc_built) or step is None or (step % self.update_PC == 0):
+      self.susp.build_preconditioner()
+      self._pc_built = True
+
+  # ---- forces ---------------------------------------------------------------------------------------
+  def _blob_forces(self, r):
+    """One-blob forces (multi_bodies_functions.py:153-188) + blob-blob repulsion (forces_numba.py:12-55)."""
+    f = torch.zeros_like(r)
+    f[:, 2] = -self.g * self.blob_mass
+    if self.repulsion_strength_wall != 0.0:
+      h = r[:, 2]
+      e = self.repulsion_strength_wall / self.debye_length_wall
+      f[:, 2] += torch.where(h > self.a, e * torch.exp(-(h - self.a) / self.debye_length_wall), torch.full_like(h, e))
+    if self.repulsion_strength != 0.0:
+      ctx = self.susp.ctx
+      ctx.set_positions(r.contiguous().view(-1), self.a, self.periodic_length, False)   # true heights, no clamp
+      f = f + ctx.blob_blob_force_device(self.repulsion_strength, self.debye_length, self.a).view(-1, 3)
+      ctx.set_positions(self.susp.r_dev, self.a, self.periodic_length, self.susp.wall)  # back to the mobility view
+    return f
+
+  def force_torque_calculator(self):
+    """(nb, 6) force and torque on every body from the blob forces: F = sum f, T = sum rel x f = K^T f
+    (multi_bodies_functions.py:411-445), plus the optional external hook."""
+    f = self.calc_blob_forces(self.susp.r_dev.view(-1, 3))
+    FT = self.susp.KT_times_lambda(f.reshape(-1)).view(-1, 6)
+    if self.external_force_torque is not None:
+      FT = FT + self.external_force_torque(self)
+    return FT
+
+  def _slip(self):
+    n3 = 3 * self.Nblobs
+    if self.calc_slip is not None:
+      return self.calc_slip(self).reshape(-1)
+    if self.slip_body_frame is not None:
+      # lab-frame slip = R(q) slip_body for every blob of the body (multi_bodies_functions.py:123-140)
+      from .rigid import quaternion_rotation_matrix_torch
+      out = torch.empty(n3, dtype=torch.float64, device=self.device)
+      R = quaternion_rotation_matrix_torch(self.susp.orientation)
+      for g in self.susp.groups:
+        sb = self.slip_body_frame[g.blob_idx.reshape(-1)].view(len(g.body_idx), g.n_b, 3)
+        out[g.blob_idx3.reshape(-1)] = torch.bmm(sb, R[g.body_idx].transpose(1, 2)).reshape(-1)
+      return out
+    return torch.zeros(n3, dtype=torch.float64, device=self.device)
+
+  # ---- the rigid solve ------------------------------------------------------------------------------
+  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None):
+    """[M -K; -K^T 0][lambda; U] = [slip - noise; -(F + noise_FT)] at the bound configuration
+    (quaternion_integrator_multi_bodies.py:1441-1547).  Returns the full solution tensor."""
+    n3 = 3 * self.Nblobs
+    if RHS is None:
+      FT = self.force_torque_calculator()
+      if noise_FT is not None:
+        FT = FT + noise_FT.view(-1, 6)
+      RHS = torch.cat([self._slip(), -FT.reshape(-1)])
+    else:
+      RHS = RHS.clone()
+    if noise is not None:
+      RHS[:n3] -= noise
+    sol, info = self.susp.solve(RHS, tol=self.tolerance, restart=60, maxiter=1000)
+    self.det_iterations_count += info["iterations"]
+    return sol
+
+  def _velocities(self, sol):
+    return sol[3 * self.Nblobs:]
+
+  def _noise(self, z, factor):
+    noise, its = self.susp.stochastic_forcing(z, factor, tol=self.tolerance, print_residual=self.print_residual)
+    self.stoch_iterations_count += its
+    return noise
+
+  def advance_time_step(self, dt, *args, **kwargs):
+    return getattr(self, self.scheme)(dt, *args, **kwargs)
+
+  def _accept(self, location, orientation):
+    self.location, self.orientation = location, orientation
+    self._move(location, orientation)
+
+  # ---- deterministic schemes ------------------------------------------------------------------------
+  def deterministic_forward_euler(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      self._move(self.location, self.orientation)
+      self._refresh_preconditioner(kwargs.get("step"))
+      U = self._velocities(self.solve_mobility_problem())
+      new = self._advance(self.location, self.orientation, U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+
+  def deterministic_adams_bashforth(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      self._move(self.location, self.orientation)
+      self._refresh_preconditioner(kwargs.get("step"))
+      U = self._velocities(self.solve_mobility_problem())
+      if self.first_step is False:
+        new = self._advance(self.location, self.orientation, 1.5 * U - 0.5 * self.velocities_previous_step, dt)
+      else:
+        new = self._advance(self.location, self.orientation, U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        self.first_step = False
+        self.velocities_previous_step = U
+        return self._accept(*new)
+
+  def deterministic_midpoint(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      self._move(*old)
+      self._refresh_preconditioner(kwargs.get("step"))
+      U = self._velocities(self.solve_mobility_problem())
+      mid = self._advance(old[0], old[1], U, 0.5 * dt)
+      if not self._valid(*mid):
+        continue
+      self._move(*mid)
+      U_mid = self._velocities(self.solve_mobility_problem())
+      new = self._advance(old[0], old[1], U_mid, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
+
+  # ---- stochastic schemes ---------------------------------------------------------------------------
+  def _rfd_drift_velocity(self, old, rfd_noise):
+    """Thermal drift of the first-order RFD schemes (:371-407): solve with the bodies displaced by -delta/2 W, then
+    correct that solution at +delta/2 W with one more solve on the residual.  Returns the drift velocities
+    (to be scaled by kT / delta)."""
+    n3 = 3 * self.Nblobs
+    W = rfd_noise.view(-1, 6)
+    Lb = self.body_length.unsqueeze(1)
+    force_rfd = W.clone()
+    force_rfd[:, 0:3] /= Lb
+    rhs = torch.cat([torch.zeros(n3, dtype=torch.float64, device=self.device), -force_rfd.reshape(-1)])
+    half = self.rf_delta * 0.5
+    minus = (old[0] + W[:, 0:3] * (-half * Lb),
+             quaternion_multiply_torch(quaternion_from_rotation_torch(W[:, 3:6] * (-half)), old[1]))
+    self._move(*minus)
+    sol = self.solve_mobility_problem(RHS=rhs)
+    plus = (old[0] + W[:, 0:3] * (half * Lb),
+            quaternion_multiply_torch(quaternion_from_rotation_torch(W[:, 3:6] * half), old[1]))
+    self._move(*plus)
+    sol = self.solve_mobility_problem(RHS=rhs - self.susp.apply_operator(sol))
+    return self._velocities(sol)
+
+  def stochastic_first_order_RFD(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      rfd_noise = self._normal(6 * self.Nbodies)
+      self._move(*old)
+      self._refresh_preconditioner(kwargs.get("step"))
+      noise = self._noise(self._normal(3 * self.Nblobs), math.sqrt(2 * self.kT / dt))
+      U = self._velocities(self.solve_mobility_problem(noise=noise)).clone()
+      U = U + (self.kT / self.rf_delta) * self._rfd_drift_velocity(old, rfd_noise)
+      new = self._advance(old[0], old[1], U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
+
+  def stochastic_adams_bashforth(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      rfd_noise = self._normal(6 * self.Nbodies)
+      self._move(*old)
+      self._refresh_preconditioner(kwargs.get("step"))
+      noise = self._noise(self._normal(3 * self.Nblobs), math.sqrt(2 * self.kT / dt))
+      zero = torch.zeros(self.susp.size, dtype=torch.float64, device=self.device)
+      U_stoch = self._velocities(self.solve_mobility_problem(RHS=zero, noise=noise)).clone()
+      U_det = self._velocities(self.solve_mobility_problem()).clone()
+      U_stoch = U_stoch + (self.kT / self.rf_delta) * self._rfd_drift_velocity(old, rfd_noise)
+      if self.first_step is False:
+        new = self._advance(old[0], old[1], 1.5 * U_det - 0.5 * self.velocities_previous_step + U_stoch, dt)
+      else:
+        new = self._advance(old[0], old[1], U_det + U_stoch, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        self.first_step = False
+        self.velocities_previous_step = U_det
+        return self._accept(*new)
+      self._move(*old)
+
+  def _slip_scheme(self, dt, trapezoidal, step):
+    """Shared body of stochastic_Slip_Trapz (:925-1045) and stochastic_Slip_Mid (:1214-1343): predictor with the
+    Brownian slip, random finite difference on M and K^T along the displacement a rigid solve of W_slip produces,
+    corrector with the drift folded into slip and force."""
+    n3 = 3 * self.Nblobs
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      W1 = self._normal(n3)
+      W_slip = self._normal(n3)
+      Wcor = None if trapezoidal else W1 + self._normal(n3)
+      self._move(*old)
+      MxW = self.susp.mobility_times_lambda(W_slip)
+      KTxW = self.susp.KT_times_lambda(W_slip)
+      self._refresh_preconditioner(step)
+      if trapezoidal:
+        noise_W1 = self._noise(W1, math.sqrt(2 * self.kT / dt))
+      else:
+        noise_W1 = self._noise(W1, math.sqrt(4 * self.kT / dt))
+        noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))
+      U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1)).clone()
+      rhs = torch.cat([-W_slip, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
+      W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs))
+      self._move(*self._advance(old[0], old[1], W_RFD, self.rf_delta))
+      M_rfdxW = self.susp.mobility_times_lambda(W_slip)
+      KT_rfdxW = self.susp.KT_times_lambda(W_slip)
+      if trapezoidal:
+        rand_slip_cor = noise_W1 + (2.0 * self.kT / self.rf_delta) * (M_rfdxW - MxW)
+        rand_force_cor = -2.0 * (self.kT / self.rf_delta) * (KT_rfdxW - KTxW)
+        predictor = self._advance(old[0], old[1], U_1, dt)
+      else:
+        rand_slip_cor = noise_Wcor + (self.kT / self.rf_delta) * (M_rfdxW - MxW)
+        rand_force_cor = -1.0 * (self.kT / self.rf_delta) * (KT_rfdxW - KTxW)
+        predictor = self._advance(old[0], old[1], U_1, 0.5 * dt)
+      if not self._valid(*predictor):
+        self._move(*old)
+        continue
+      self._move(*predictor)
+      U_2 = self._velocities(self.solve_mobility_problem(noise=rand_slip_cor, noise_FT=rand_force_cor))
+      U_new = 0.5 * (U_1 + U_2) if trapezoidal else U_2
+      new = self._advance(old[0], old[1], U_new, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
+
+  def stochastic_Slip_Trapz(self, dt, *args, **kwargs):
+    """3 rigid solves + 1 Lanczos + 2 blob mobility products + 2 K^T products per step."""
+    return self._slip_scheme(dt, True, kwargs.get("step"))
+
+  def stochastic_Slip_Mid(self, dt, *args, **kwargs):
+    """3 rigid solves + 2 Lanczos + 2 blob mobility products + 2 K^T products per step."""
+    return self._slip_scheme(dt, False, kwargs.get("step"))
+
+
+# ---- driver: reference input deck -> integrator -> time loop ------------------------------------------
+def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
+  """Bodies and integrator from a ReadInput deck as multi_bodies/multi_bodies.py:1160-1212, :1319-1393 build them:
+  every `structure` line = vertex file + clones file (+ optional .slip file with one body-frame slip per blob)."""
+  from . import structures as st
+  refs, locs, quats, slips, body_types = [], [], [], [], []
+  any_slip = False
+  for structure in read.structures[:read.num_free_bodies]:
+    ref = st.read_vertex_file(read.resolve(structure[0]))[:, :3]
+    n, loc, quat = st.read_clones_file(read.resolve(structure[1]))
+    slip = None
+    for extra in structure[2:]:
+      if extra.endswith(".slip"):
+        slip = st.read_slip_file(read.resolve(extra))[:len(ref)]
+        any_slip = True
+    for k in range(n):
+      refs.append(ref)
+      slips.append(slip if slip is not None else np.zeros((len(ref), 3)))
+    locs.append(loc)
+    quats.append(quat)
+    body_types.append(n)
+  if len(read.structures) > read.num_free_bodies or read.articulated:
+    raise ValueError("obstacles / articulated bodies are not supported by RigidIntegrator")
+  if rng is None and read.seed is not None:
+    rng = np.random.RandomState(int(read.seed))
+  integ = RigidIntegrator(refs, np.concatenate(locs), np.concatenate(quats), read.scheme, read.blob_radius, read.eta,
+                          tolerance=read.solver_tolerance, domain=read.domain, periodic_length=read.periodic_length,
+                          device=device, ctx=ctx, rng=rng)
+  integ.kT = read.kT
+  integ.rf_delta = read.rf_delta
+  integ.update_PC = read.update_PC
+  integ.g = read.g
+  integ.repulsion_strength_wall = read.repulsion_strength_wall
+  integ.debye_length_wall = read.debye_length_wall
+  if read.blob_blob_force_implementation != "None":
+    integ.repulsion_strength = read.repulsion_strength
+    integ.debye_length = read.debye_length
+  if any_slip:
+    integ.slip_body_frame = torch.as_tensor(np.concatenate(slips), device=integ.device)
+  integ.body_types = body_types
+  integ.structures_ID = list(read.structures_ID[:read.num_free_bodies])
+  return integ
+
+
+def _write_clones(fh, locations, quaternions):
+  fh.write(str(len(locations)) + "\n")
+  for x, q in zip(locations, quaternions):
+    fh.write("%s %s %s %s %s %s %s\n" % (x[0], x[1], x[2], q[0], q[1], q[2], q[3]))
+
+
+def run(read, integrator, output_name=None, n_steps=None, callback=None):
+  """Time loop of multi_bodies.py:1412-1530: `.clones` per saved step or one `.config` per structure, reference text
+  format (location + quaternion per body)."""
+  output_name = read.output_name if output_name is None else output_name
+  n_steps = read.n_steps if n_steps is None else n_steps
+  if read.save_clones not in ("one_file_per_step", "one_file"):
+    raise ValueError('save_clones = %s is not implemented; use "one_file_per_step" or "one_file"' % read.save_clones)
+  files = None
+  if read.save_clones == "one_file":
+    files = [open(output_name + "." + ID + ".config", "w") for ID in integrator.structures_ID]
+
+  def save(step):
+    loc, quat = integrator.location.cpu().numpy(), integrator.orientation.cpu().numpy()
+    offset = 0
+    for i, ID in enumerate(integrator.structures_ID):
+      sl = slice(offset, offset + integrator.body_types[i])
+      offset += integrator.body_types[i]
+      if files is not None:
+        _write_clones(files[i], loc[sl], quat[sl])
+      else:
+        with open(output_name + "." + ID + "." + str(step).zfill(8) + ".clones", "w") as fh:
+          _write_clones(fh, loc[sl], quat[sl])
+
+  try:
+    step = read.initial_step - 1
+    for step in range(read.initial_step, n_steps):
+      if step % read.n_save == 0 and step >= 0:
+        save(step)
+      integrator.advance_time_step(read.dt, step=step)
+      if callback is not None:
+        callback(step, integrator)
+    if (step + 1) % read.n_save == 0 and step >= 0:
+      save(step + 1)
+  finally:
+    if files is not None:
+      for fh in files:
+        fh.close()
+  return integrator

@@ -41,6 +41,17 @@ def read_clones_file(path):
   return n, np.array(loc).reshape(-1, 3), np.array(quat).reshape(-1, 4)
 
 
+def read_slip_file(path):
+  """Active slip per blob in the body frame (read_input/read_slip_file.py:7-37): first data line = number of blobs,
+  then one `sx sy sz` row per blob.  -> (Nblobs, 3)."""
+  lines = list(_data_lines(path))
+  n = int(lines[0].split()[0])
+  slip = np.array([[float(x) for x in l.split()[:3]] for l in lines[1:]], dtype=np.float64).reshape(-1, 3)
+  if len(slip) < n:
+    raise ValueError("%s: header announces %d blobs, found %d" % (path, n, len(slip)))
+  return slip
+
+
 def icosahedron_shell(geometric_radius):
   """12-blob shell = vertices of a regular icosahedron with one vertex on +z, the model behind the
   reference's Structures/shell_N_12_*.vertex files (e.g. Rg = 0.7921 for hydrodynamic radius 1)."""

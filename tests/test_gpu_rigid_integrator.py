@@ -1,0 +1,83 @@
+"""Rigid-multiblob time integrators on the GPU: replay of the decks the reference's driver was run on
+(tests/golden/g9_*), and size-independent checks on a larger suspension."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden, rel_err
+from _rigid_common import replay
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_files("g9_rigid_*.npz")
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[9:-4] for p in CASES])
+def test_deck_replay_matches_reference_driver(tmp_path, path):
+  g = load_golden(path)
+  integ, worst_x, worst_q = replay(g, tmp_path, "cuda:0", None)
+  tol = 1e-7 if float(g["kT"]) == 0.0 else 1e-6
+  assert worst_x < tol and worst_q < tol, (worst_x, worst_q)
+  assert integ.invalid_configuration_count == 0
+  integ.close()
+
+
+def _suspension(nb, seed):
+  from rigidmultiblobswall_amd import structures as st
+  R = 1.0155
+  shell = st.icosahedron_shell(0.792079207921 * R)
+  a = st.min_blob_separation(shell) / 2
+  loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=seed)
+  return shell, a, loc, quat
+
+
+def test_brownian_slip_trapz_step_on_a_large_suspension():
+  """600 shells (7200 blobs), two stochastic_Slip_Trapz steps with the device generator: reproducible for a fixed
+  seed (atomics => round-off only), quaternions stay unit, nothing is rejected, every solve converged."""
+  from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+  nb = 600
+  shell, a, loc, quat = _suspension(nb, 3)
+  out = []
+  for _ in range(2):
+    integ = RigidIntegrator([shell] * nb, loc, quat, "stochastic_Slip_Trapz", a, 0.957e-3, tolerance=1e-6, device="cuda:0", seed=9)
+    integ.kT, integ.g = 0.0041419464, 0.0024892 * 12
+    integ.repulsion_strength_wall, integ.debye_length_wall = 0.0165677856, 0.0656
+    integ.repulsion_strength, integ.debye_length = 0.0165677856, 0.0656
+    for step in range(2):
+      integ.advance_time_step(0.01, step=step)
+    assert integ.invalid_configuration_count == 0 and integ.stoch_iterations_count > 0
+    assert integ.det_iterations_count < 2 * 3 * 40
+    q = integ.orientation
+    assert float((torch.linalg.norm(q, dim=1) - 1).abs().max()) < 1e-12
+    out.append((integ.location.cpu().numpy(), q.cpu().numpy()))
+    integ.close()
+  assert np.abs(out[0][0] - out[1][0]).max() < 1e-8 and np.abs(out[0][1] - out[1][1]).max() < 1e-8
+  assert np.abs(out[0][0] - loc).max() > 1e-5
+
+
+def test_deterministic_step_equals_solve_plus_update():
+  """deterministic_forward_euler == one RigidSuspension solve with the integrator's own force model + the
+  quaternion update formula, on 300 shells."""
+  from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+  from rigidmultiblobswall_amd.rigid import RigidSuspension, quaternion_rotation_matrix
+  nb = 300
+  shell, a, loc, quat = _suspension(nb, 4)
+  eta, dt = 0.957e-3, 0.02
+  integ = RigidIntegrator([shell] * nb, loc, quat, "deterministic_forward_euler", a, eta, tolerance=1e-10, device="cuda:0")
+  integ.g, integ.repulsion_strength_wall, integ.debye_length_wall = 0.03, 0.0165677856, 0.0656
+  FT = integ.force_torque_calculator().cpu().numpy()
+  integ.advance_time_step(dt, step=0)
+  rs = RigidSuspension([shell] * nb, loc, quat, a, eta)
+  U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-10)
+  assert rel_err(integ.location.cpu().numpy(), loc + dt * U[:, :3]) < 1e-12
+  # orientation: R_new = R(omega dt) R_old
+  w = U[:, 3:] * dt
+  n = np.linalg.norm(w, axis=1)
+  dq = np.concatenate([np.cos(n / 2)[:, None], np.sin(n / 2)[:, None] * w / n[:, None]], axis=1)
+  R_new = quaternion_rotation_matrix(integ.orientation.cpu().numpy())
+  R_ref = quaternion_rotation_matrix(dq) @ quaternion_rotation_matrix(quat)
+  assert np.abs(R_new - R_ref).max() < 1e-9
+  rs.close()
+  integ.close()
