@@ -282,6 +282,45 @@ def main():
                                "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
                                "rejected_steps": integ.invalid_configuration_count}
 
+    # The same config with rigid multiblobs instead of single-blob rollers: 21845 shells x 12 blobs = 262140 blobs,
+    # stochastic_Slip_Trapz (3 GMRES rigid solves + preconditioned Lanczos + forces kernel per step), parameters of
+    # multi_bodies/examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat (tolerance 1e-4, constant torque).
+    import math
+    from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+    R5, eta5, nb5 = 1.0155, 0.957e-3, 21845
+    shell5 = st.icosahedron_shell(0.792079207921 * R5)
+    a5b = st.min_blob_separation(shell5) / 2
+    loc5, quat5, _ = st.roller_monolayer(nb5, radius=R5, seed=5)
+    ri = RigidIntegrator([shell5] * nb5, loc5, quat5, "stochastic_Slip_Trapz", a5b, eta5, tolerance=1e-4, device=device,
+                         ctx=ReplicatedContext(sm), seed=1)
+    ri.kT, ri.g = 0.0040749841, 0.0303 / 12
+    ri.repulsion_strength_wall = ri.repulsion_strength = 0.0326
+    ri.debye_length_wall = ri.debye_length = 0.0406
+    FT5 = torch.zeros((nb5, 6), dtype=torch.float64, device=device)
+    FT5[:, 4] = 8 * math.pi * eta5 * R5 ** 3 * 62.8
+    ri.external_force_torque = lambda it: FT5
+    ri.advance_time_step(0.01, step=0)          # warm-up
+    torch.cuda.synchronize(device)
+    if world > 1:
+      dist.barrier()
+    d0, l0, m0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count
+    t0 = time.perf_counter()
+    ri.advance_time_step(0.01, step=1)
+    torch.cuda.synchronize(device)
+    if world > 1:
+      dist.barrier()
+    dt5 = time.perf_counter() - t0
+    if world > 1:
+      t = torch.tensor([dt5], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      dt5 = float(t.item())
+    line["config5_multiblob_brownian"] = {"bodies": nb5, "blobs": ri.Nblobs, "scheme": ri.scheme, "solver_tolerance": 1e-4,
+                                          "steps": 1, "s_per_step": round(dt5, 4),
+                                          "gmres_iterations_per_step": ri.det_iterations_count - d0,
+                                          "lanczos_iterations_per_step": ri.stoch_iterations_count - l0,
+                                          "pair_sweeps_per_step": ri.susp.matvec_count - m0,
+                                          "rejected_steps": ri.invalid_configuration_count}
+
   if rank == 0:
     print(json.dumps(line), flush=True)
   if world > 1:

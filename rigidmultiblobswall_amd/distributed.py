@@ -59,6 +59,9 @@ class HipBackend(object):
   def matvec_pairshard(self, kind, v_full, eta, shard, nshards, out=None):
     return self.ctx.matvec_pairshard_device(kind, v_full, eta, shard, nshards, out=out)
 
+  def body_mobility_dense(self, first_blob, n_b, eta, out=None):
+    return self.ctx.body_mobility_dense_device(first_blob, n_b, eta, out=out)
+
 
 class ShardedMobility(object):
   """M.v with targets sharded over the ranks of a process group."""
@@ -208,7 +211,7 @@ class ReplicatedContext(object):
 
   def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
     # O(n_bodies n_b^2): replicated, not worth an exchange
-    return self.sm.backend.ctx.body_mobility_dense_device(first_blob, n_b, eta, out=out)
+    return self.sm.backend.body_mobility_dense(first_blob, n_b, eta, out=out)
 
   def close(self):
     ctx = getattr(self.sm.backend, "ctx", None)

@@ -42,6 +42,10 @@ class OracleBackend(object):
     lo, hi = self.range
     return torch.from_numpy(np.ascontiguousarray(F[lo:hi]).reshape(-1))
 
+  def body_mobility_dense(self, first_blob, n_b, eta, out=None):
+    M = [oracle.dense("tt", int(self.wall), self.r[f:f + n_b], eta, self.a) for f in first_blob.tolist()]
+    return torch.from_numpy(np.array(M))
+
   # pair-shard stand-in: "shard g" = the contribution of source block g to all targets (self terms of
   # block g included).  Like the HIP kernel's slices of unordered pairs, the shards sum to M.v.
   def supports_pairshard(self, kind, periodic):
@@ -76,6 +80,24 @@ def rollers_replicated(rank, world, out_dir):
     assert torch.equal(mine, hi), "ranks diverged"
     if rank == 0:
       np.save(os.path.join(out_dir, name + "_final.npy"), mine.numpy())
+
+
+def rigid_replicated(rank, world, out_dir):
+  """RigidIntegrator (GMRES + preconditioned Lanczos + forces) on a ReplicatedContext: the deck the reference's
+  driver was run on (golden g9) must replay on every rank, bit-identically across ranks."""
+  import tempfile
+  from rigidmultiblobswall_amd.distributed import ReplicatedContext
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  from _rigid_common import replay
+  d = np.load(os.path.join(ROOT, "tests", "golden", "g9_rigid_stoch_slip_trapz.npz"))
+  g = {k: d[k] for k in d.files}
+  ctx = ReplicatedContext(ShardedMobility(OracleBackend(), device="cpu"))
+  integ, worst_x, worst_q = replay(g, tempfile.mkdtemp(prefix="rank%d_" % rank), "cpu", ctx)
+  assert worst_x < 1e-6 and worst_q < 1e-6, (worst_x, worst_q)
+  mine = torch.cat([integ.location.reshape(-1), integ.orientation.reshape(-1)])
+  hi = mine.clone()
+  dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+  assert torch.equal(mine, hi), "ranks diverged"
 
 
 def main():
@@ -113,6 +135,7 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() < 1e-13, t.item()
   rollers_replicated(rank, world, out_dir)
+  rigid_replicated(rank, world, out_dir)
   dist.destroy_process_group()
 
 
