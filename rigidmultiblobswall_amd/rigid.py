@@ -161,6 +161,30 @@ class RigidSuspension(object):
     if self._own_ctx:
       self.ctx.close()
 
+  # ---- per-group views: with one body shape (the common case) blobs of a group are the whole vector in order,
+  #      so gathers / scatters are reshapes and cost no kernel -----------------------------------------
+  def _blobs_of(self, x, g):
+    """(3 n_blobs,) -> (nb_g, 3 n_b)"""
+    if len(self.groups) == 1:
+      return x.reshape(self.n_bodies, 3 * g.n_b)
+    return x[g.blob_idx3.reshape(-1)].view(len(g.body_idx), 3 * g.n_b)
+
+  def _put_blobs(self, out, g, values):
+    if len(self.groups) == 1:
+      out.view(self.n_bodies, 3 * g.n_b).copy_(values.reshape(self.n_bodies, 3 * g.n_b))
+    else:
+      out[g.blob_idx3.reshape(-1)] = values.reshape(-1)
+
+  def _bodies_of(self, U, g):
+    """(n_bodies, 6) -> (nb_g, 6)"""
+    return U if len(self.groups) == 1 else U[g.body_idx]
+
+  def _put_bodies(self, out, g, values):
+    if len(self.groups) == 1:
+      out.copy_(values.reshape(self.n_bodies, -1))
+    else:
+      out[g.body_idx] = values.reshape(len(g.body_idx), -1)
+
   # ---- pieces of the operator -------------------------------------------------------------------
   def mobility_times_lambda(self, lam):
     self.matvec_count += 1
@@ -171,16 +195,14 @@ class RigidSuspension(object):
     U = U.view(self.n_bodies, 6)
     out = torch.empty(3 * self.n_blobs, dtype=torch.float64, device=self.device)
     for g in self.groups:
-      KU = torch.bmm(g.K, U[g.body_idx].unsqueeze(-1)).squeeze(-1)
-      out[g.blob_idx3.reshape(-1)] = KU.reshape(-1)
+      self._put_blobs(out, g, torch.bmm(g.K, self._bodies_of(U, g).unsqueeze(-1)))
     return out
 
   def KT_times_lambda(self, lam):
     """lambda (3 n_blobs,) -> (6 n_bodies,)   (multi_bodies.py:352-375)."""
     out = torch.empty((self.n_bodies, 6), dtype=torch.float64, device=self.device)
     for g in self.groups:
-      lg = lam[g.blob_idx3.reshape(-1)].view(len(g.body_idx), 3 * g.n_b, 1)
-      out[g.body_idx] = torch.bmm(g.K.transpose(1, 2), lg).squeeze(-1)
+      self._put_bodies(out, g, torch.bmm(g.K.transpose(1, 2), self._blobs_of(lam, g).unsqueeze(-1)))
     return out.reshape(-1)
 
   def apply_operator(self, x):
@@ -217,13 +239,12 @@ class RigidSuspension(object):
     F = x[n3:].view(self.n_bodies, 6)
     outU = out[n3:].view(self.n_bodies, 6)
     for g in self.groups:
-      flat = g.blob_idx3.reshape(-1)
-      slip = x[:n3][flat].view(len(g.body_idx), 3 * g.n_b, 1)
+      slip = self._blobs_of(x[:n3], g).unsqueeze(-1)
       Lt = torch.bmm(g.Minv, slip)
-      Y = torch.bmm(g.Nbody, -F[g.body_idx].unsqueeze(-1) - torch.bmm(g.K_pc.transpose(1, 2), Lt))
+      Y = torch.bmm(g.Nbody, -self._bodies_of(F, g).unsqueeze(-1) - torch.bmm(g.K_pc.transpose(1, 2), Lt))
       lam = torch.bmm(g.Minv, slip + torch.bmm(g.K_pc, Y))
-      out[:n3][flat] = lam.reshape(-1)
-      outU[g.body_idx] = Y.squeeze(-1)
+      self._put_blobs(out[:n3], g, lam)
+      self._put_bodies(outU, g, Y)
     return out
 
   # ---- solve ------------------------------------------------------------------------------------
@@ -264,11 +285,10 @@ class RigidSuspension(object):
   def _blockdiag(self, x, which, transpose=False):
     out = torch.empty_like(x)
     for g in self.groups:
-      flat = g.blob_idx3.reshape(-1)
       A = g.Linv if which == "Linv" else g.Lchol
       if transpose:
         A = A.transpose(1, 2)
-      out[flat] = torch.bmm(A, x[flat].view(len(g.body_idx), 3 * g.n_b, 1)).reshape(-1)
+      self._put_blobs(out, g, torch.bmm(A, self._blobs_of(x, g).unsqueeze(-1)))
     return out
 
   def stochastic_forcing(self, z, factor, tol=1e-8, print_residual=False):
