@@ -219,8 +219,9 @@ def _source_target(source, target, force, radius_source, radius_target, eta, wal
   f = _c(force).reshape(-1, 3).copy()
   bt = np.ones(len(tgt))
   if wall:
-    bs = np.where(src[:, 2] < rs, src[:, 2] / rs, 1.0)      # damping_matrix_B_different_radius, mobility.py:102-119
-    bt = np.where(tgt[:, 2] < rt, tgt[:, 2] / rt, 1.0)
+    # damping_matrix_B_different_radius, mobility.py:102-119 (tracers have radius 0: the quotient is never selected)
+    bs = np.where(src[:, 2] < rs, src[:, 2] / np.where(rs > 0, rs, 1.0), 1.0)
+    bt = np.where(tgt[:, 2] < rt, tgt[:, 2] / np.where(rt > 0, rt, 1.0), 1.0)
     src[:, 2] = np.where(src[:, 2] > rs, src[:, 2], rs)      # shift_heights_different_radius, mobility.py:87-99
     tgt[:, 2] = np.where(tgt[:, 2] > rt, tgt[:, 2], rt)
     f = f * bs[:, None]

@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256) void body_dense_tt_kernel(const DenseArgs a) {
   const int nb = a.n_b;
   const int ld = 3 * nb;
   double* M = a.out + body * (long)ld * ld;
-  for (int p = threadIdx.x; p < nb * nb; p += blockDim.x) {
-    const int i = p / nb, j = p - i * nb;
+  for (long p = (long)blockIdx.y * blockDim.x + threadIdx.x; p < (long)nb * nb; p += (long)blockDim.x * gridDim.y) {
+    const int i = (int)(p / nb), j = (int)(p - (long)i * nb);
     const double4 pi = a.pos[base + i];
     const double4 pj = a.pos[base + j];
     const double sc = a.prefactor * pi.w * pj.w;
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void body_dense_tt_kernel(const DenseArgs a) {
       Vec3 u = {0.0, 0.0, 0.0};
       if (i == j) self_term<KIND_TT, WALL>(a.k, pi.z, vx, vy, vz, 0, 0, 0, u);
       else pair_apply<KIND_TT, WALL>(a.k, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, pi.z, pj.z, vx, vy, vz, 0, 0, 0, u);
-      M[(3 * i + 0) * ld + 3 * j + c] = u.x * sc;
-      M[(3 * i + 1) * ld + 3 * j + c] = u.y * sc;
-      M[(3 * i + 2) * ld + 3 * j + c] = u.z * sc;
+      M[(long)(3 * i + 0) * ld + 3 * j + c] = u.x * sc;
+      M[(long)(3 * i + 1) * ld + 3 * j + c] = u.y * sc;
+      M[(long)(3 * i + 2) * ld + 3 * j + c] = u.z * sc;
     }
   }
 }

@@ -589,7 +589,8 @@ int rmb_body_mobility_dense_device(rmb_ctx* c, const long* first_blob_dev, long 
   if (n_bodies == 0) return 0;
   if (!first_blob_dev || !out_dev) return fail(RMB_ERR_ARG, "null pointer");
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
-  if (c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0) return fail(RMB_ERR_ARG, "dense body blocks are non-periodic");
+  // Periodic contexts are accepted: a body's own block never includes images (the reference's per-body
+  // b.calc_mobility_blobs, body/body.py:186-191, has no periodic_length either).
   RMB_HIP(hipSetDevice(c->device));
   rmb::DenseArgs a;
   a.pos = (const double4*)c->pos.p;
@@ -599,8 +600,13 @@ int rmb_body_mobility_dense_device(rmb_ctx* c, const long* first_blob_dev, long 
   a.n_bodies = n_bodies;
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
-  if (c->wall) hipLaunchKernelGGL(rmb::body_dense_tt_kernel<true>, dim3((unsigned)n_bodies), dim3(256), 0, c->stream, a);
-  else         hipLaunchKernelGGL(rmb::body_dense_tt_kernel<false>, dim3((unsigned)n_bodies), dim3(256), 0, c->stream, a);
+  // blockIdx.y splits the n_b^2 blob pairs of a body so that one big "body" (the dense builders) still fills the chip
+  long ysplit = ((long)n_b * n_b + 256L * 16 - 1) / (256L * 16);
+  if (ysplit < 1) ysplit = 1;
+  if (ysplit > 4096) ysplit = 4096;
+  const dim3 grid((unsigned)n_bodies, (unsigned)ysplit);
+  if (c->wall) hipLaunchKernelGGL(rmb::body_dense_tt_kernel<true>, grid, dim3(256), 0, c->stream, a);
+  else         hipLaunchKernelGGL(rmb::body_dense_tt_kernel<false>, grid, dim3(256), 0, c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
 }

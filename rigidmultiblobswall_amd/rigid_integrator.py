@@ -24,7 +24,19 @@ import math
 import numpy as np
 import torch
 
-from .rigid import RigidSuspension, quaternion_from_rotation_torch, quaternion_multiply_torch
+from .rigid import (RigidSuspension, quaternion_from_rotation_torch, quaternion_multiply_torch,
+                    quaternion_rotation_matrix_torch)
+
+
+def lab_frame_slip(susp, slip_body_frame):
+  """Active slip given per blob in the body frame (.slip files), rotated to the bodies' current orientation:
+  slip_lab = R(q) slip_body (multi_bodies_functions.py:123-140).  (Nblobs, 3) tensor -> (3 Nblobs,)."""
+  out = torch.empty(3 * susp.n_blobs, dtype=torch.float64, device=susp.device)
+  R = quaternion_rotation_matrix_torch(susp.orientation)
+  for g in susp.groups:
+    sb = slip_body_frame[g.blob_idx.reshape(-1)].view(len(g.body_idx), g.n_b, 3)
+    out[g.blob_idx3.reshape(-1)] = torch.bmm(sb, R[g.body_idx].transpose(1, 2)).reshape(-1)
+  return out
 
 
 class RigidIntegrator(object):
@@ -154,19 +166,11 @@ class RigidIntegrator(object):
     return FT
 
   def _slip(self):
-    n3 = 3 * self.Nblobs
     if self.calc_slip is not None:
       return self.calc_slip(self).reshape(-1)
     if self.slip_body_frame is not None:
-      # lab-frame slip = R(q) slip_body for every blob of the body (multi_bodies_functions.py:123-140)
-      from .rigid import quaternion_rotation_matrix_torch
-      out = torch.empty(n3, dtype=torch.float64, device=self.device)
-      R = quaternion_rotation_matrix_torch(self.susp.orientation)
-      for g in self.susp.groups:
-        sb = self.slip_body_frame[g.blob_idx.reshape(-1)].view(len(g.body_idx), g.n_b, 3)
-        out[g.blob_idx3.reshape(-1)] = torch.bmm(sb, R[g.body_idx].transpose(1, 2)).reshape(-1)
-      return out
-    return torch.zeros(n3, dtype=torch.float64, device=self.device)
+      return lab_frame_slip(self.susp, self.slip_body_frame)
+    return torch.zeros(3 * self.Nblobs, dtype=torch.float64, device=self.device)
 
   # ---- the rigid solve ------------------------------------------------------------------------------
   def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None):
@@ -364,12 +368,15 @@ class RigidIntegrator(object):
 
 
 # ---- driver: reference input deck -> integrator -> time loop ------------------------------------------
-def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
-  """Bodies and integrator from a ReadInput deck as multi_bodies/multi_bodies.py:1160-1212, :1319-1393 build them:
-  every `structure` line = vertex file + clones file (+ optional .slip file with one body-frame slip per blob)."""
+def bodies_from_input(read):
+  """Bodies of a deck as multi_bodies/multi_bodies.py:1160-1212 creates them: every `structure` line = vertex file +
+  clones file (+ optional .slip file with one body-frame slip per blob).  Returns a dict with one reference
+  configuration and one body-frame slip array per body, stacked locations / quaternions, and bodies per structure."""
   from . import structures as st
   refs, locs, quats, slips, body_types = [], [], [], [], []
   any_slip = False
+  if len(read.structures) > read.num_free_bodies or read.articulated:
+    raise ValueError("obstacles / articulated bodies are not supported")
   for structure in read.structures[:read.num_free_bodies]:
     ref = st.read_vertex_file(read.resolve(structure[0]))[:, :3]
     n, loc, quat = st.read_clones_file(read.resolve(structure[1]))
@@ -384,11 +391,20 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
     locs.append(loc)
     quats.append(quat)
     body_types.append(n)
-  if len(read.structures) > read.num_free_bodies or read.articulated:
-    raise ValueError("obstacles / articulated bodies are not supported by RigidIntegrator")
+  if not refs:
+    raise ValueError("input deck lists no structure")
+  return dict(refs=refs, locations=np.concatenate(locs), quaternions=np.concatenate(quats),
+              slips=np.concatenate(slips) if any_slip else None, body_types=body_types,
+              structures_ID=list(read.structures_ID[:read.num_free_bodies]))
+
+
+def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
+  """Integrator wired from a ReadInput deck as multi_bodies/multi_bodies.py:1319-1393 wires QuaternionIntegrator."""
+  b = bodies_from_input(read)
+  refs, body_types, any_slip = b["refs"], b["body_types"], b["slips"] is not None
   if rng is None and read.seed is not None:
     rng = np.random.RandomState(int(read.seed))
-  integ = RigidIntegrator(refs, np.concatenate(locs), np.concatenate(quats), read.scheme, read.blob_radius, read.eta,
+  integ = RigidIntegrator(refs, b["locations"], b["quaternions"], read.scheme, read.blob_radius, read.eta,
                           tolerance=read.solver_tolerance, domain=read.domain, periodic_length=read.periodic_length,
                           device=device, ctx=ctx, rng=rng)
   integ.kT = read.kT
@@ -401,9 +417,9 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
     integ.repulsion_strength = read.repulsion_strength
     integ.debye_length = read.debye_length
   if any_slip:
-    integ.slip_body_frame = torch.as_tensor(np.concatenate(slips), device=integ.device)
+    integ.slip_body_frame = torch.as_tensor(b["slips"], device=integ.device)
   integ.body_types = body_types
-  integ.structures_ID = list(read.structures_ID[:read.num_free_bodies])
+  integ.structures_ID = b["structures_ID"]
   return integ
 
 
