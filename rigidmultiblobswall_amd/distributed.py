@@ -156,6 +156,14 @@ class ShardedMobility(object):
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
     v2 = self._to_dev(vec2_full) if vec2_full is not None else None
+    if (kind == "tt_tr" and v2 is not None and not in_plane and self.world > 1
+        and hasattr(self.backend, "supports_pairshard") and self.backend.supports_pairshard("tt", periodic)
+        and self.backend.supports_pairshard("tr", periodic)):
+      # fused M_tt f + M_tr tau: two pair-sharded symmetric passes, ONE all-reduce of the summed partials
+      part = self.backend.matvec_pairshard("tt", v, eta, self.rank, self.world, out=out)
+      part += self.backend.matvec_pairshard("tr", v2, eta, self.rank, self.world)
+      dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+      return part
     u_local = self.backend.matvec(kind, v, eta, vec2_full=v2, in_plane=in_plane)
     u_full, _ = self._all_gather_blocks(u_local.view(-1), None)
     return u_full if self.world == 1 else u_full.clone()

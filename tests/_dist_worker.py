@@ -49,7 +49,7 @@ class OracleBackend(object):
   # pair-shard stand-in: "shard g" = the contribution of source block g to all targets (self terms of
   # block g included).  Like the HIP kernel's slices of unordered pairs, the shards sum to M.v.
   def supports_pairshard(self, kind, periodic):
-    return kind == "tt" and not periodic
+    return kind in ("tt", "tr") and not periodic
 
   def matvec_pairshard(self, kind, v_full, eta, shard, nshards, out=None):
     n = len(self.r)
@@ -57,7 +57,8 @@ class OracleBackend(object):
     v = np.zeros(3 * n)
     v[3 * b:3 * e] = v_full.cpu().numpy()[3 * b:3 * e]
     pre = "single_wall" if self.wall else "no_wall"
-    u = getattr(oracle, pre + "_mobility_trans_times_force_oracle")(self.r, v, eta, self.a, periodic_length=self.L)
+    name = {"tt": "trans_times_force", "tr": "trans_times_torque"}[kind]
+    u = getattr(oracle, "%s_mobility_%s_oracle" % (pre, name))(self.r, v, eta, self.a, periodic_length=self.L)
     return torch.from_numpy(u.copy())
 
 
