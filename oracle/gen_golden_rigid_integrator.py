@@ -188,6 +188,9 @@ def main():
       ("g9_rigid_stoch_ab", "stochastic_adams_bashforth", mixed(1, 3), 3, dict(kT=kT, seed=3)),
       ("g9_rigid_stoch_slip_trapz", "stochastic_Slip_Trapz", mixed(2, 3), 3, dict(kT=kT, seed=4)),
       ("g9_rigid_stoch_slip_mid", "stochastic_Slip_Mid", mixed(2, 3), 2, dict(kT=kT, seed=5)),
+      ("g9_rigid_stoch_EM", "stochastic_EM", mixed(1, 3), 2, dict(kT=kT, seed=7)),
+      ("g9_rigid_stoch_traction_EM", "stochastic_traction_EM", mixed(1, 3), 2, dict(kT=kT, seed=8)),
+      ("g9_rigid_stoch_traction_AB", "stochastic_traction_AB", mixed(1, 3), 3, dict(kT=kT, seed=9)),
       ("g9_rigid_stoch_slip_trapz_16shells", "stochastic_Slip_Trapz", mixed(0, 16), 2, dict(kT=kT, seed=6)),
   ]
   for name, scheme, bodies, n_steps, kw in cases:

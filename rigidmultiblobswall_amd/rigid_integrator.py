@@ -7,7 +7,8 @@ rigid bodies: same scheme names, attribute names and random-draw order, so a run
 to solver tolerance (tests/golden/g9_*, recorded from the reference's own multi_bodies.py).
 
   deterministic_forward_euler (:75)   deterministic_adams_bashforth (:142)   deterministic_midpoint (:188)
-  stochastic_first_order_RFD (:326)   stochastic_adams_bashforth (:431)
+  stochastic_EM (:262)                stochastic_first_order_RFD (:326)      stochastic_adams_bashforth (:431)
+  stochastic_traction_EM (:626)       stochastic_traction_AB (:803)
   stochastic_Slip_Trapz (:925)        stochastic_Slip_Mid (:1214)
 
 Where things live: locations / quaternions are two tensors in HBM; a step is a sequence of
@@ -17,7 +18,7 @@ Where things live: locations / quaternions are two tensors in HBM; a step is a s
 objects for every one of those (e.g. :86-91, :1003-1007).
 
 Not built: articulated bodies / constraints, prescribed kinematics (obstacles), the dense-algebra variants
-(`*_dense_algebra`, `Fixman`, `*_DLA`: O(N^3) teaching versions) and the traction schemes.
+(`*_dense_algebra`, `Fixman`, `*_DLA`: O(N^3) teaching versions) and `stochastic_GDC_RFD`.
 """
 import math
 
@@ -311,6 +312,75 @@ class RigidIntegrator(object):
         self.velocities_previous_step = U_det
         return self._accept(*new)
       self._move(*old)
+
+  def stochastic_EM(self, dt, *args, **kwargs):
+    """Euler-Maruyama without drift term (:262-323): Brownian slip + one rigid solve."""
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      self._move(*old)
+      self._refresh_preconditioner(kwargs.get("step"))
+      noise = self._noise(self._normal(3 * self.Nblobs), math.sqrt(2 * self.kT / dt))
+      U = self._velocities(self.solve_mobility_problem(noise=noise))
+      new = self._advance(old[0], old[1], U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+
+  def _traction_scheme(self, dt, adams_bashforth, step):
+    """stochastic_traction_EM (:626-735) and stochastic_traction_AB (:803-922): the thermal drift comes from a random
+    finite difference of M, K and K^T applied to the constraint forces / velocities of a rigid solve with random
+    force-torque W (2-3 rigid solves + 1 Lanczos + 2 blob products + 4 K products per step)."""
+    n3 = 3 * self.Nblobs
+    Lb = self.body_length.unsqueeze(1)
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      rfd_noise = self._normal(6 * self.Nbodies).view(-1, 6)
+      W = rfd_noise.clone()
+      W[:, 0:3] *= self.kT / Lb
+      W[:, 3:6] *= self.kT
+      self._move(*old)
+      self._refresh_preconditioner(step)
+      rhs = torch.cat([torch.zeros(n3, dtype=torch.float64, device=self.device), -W.reshape(-1)])
+      sol = self.solve_mobility_problem(RHS=rhs)
+      U_RFD, Lam = sol[n3:].contiguous(), sol[:n3].contiguous()
+      MxLam = self.susp.mobility_times_lambda(Lam)
+      KTxLam = self.susp.KT_times_lambda(Lam)
+      KxU = self.susp.K_times_U(U_RFD)
+      self._move(old[0] + rfd_noise[:, 0:3] * (self.rf_delta * Lb),
+                 quaternion_multiply_torch(quaternion_from_rotation_torch(rfd_noise[:, 3:6] * self.rf_delta), old[1]))
+      DxM = self.susp.mobility_times_lambda(Lam) - MxLam
+      DxKT = self.susp.KT_times_lambda(Lam) - KTxLam
+      DxK = self.susp.K_times_U(U_RFD) - KxU
+      self._move(*old)
+      slip_noise = self._noise(self._normal(n3), math.sqrt(2.0 * self.kT / dt))
+      rand_force = (-1.0 / self.rf_delta) * DxKT
+      if not adams_bashforth:
+        rand_slip = slip_noise + (1.0 / self.rf_delta) * (DxM - DxK)
+        U = self._velocities(self.solve_mobility_problem(noise=rand_slip, noise_FT=rand_force))
+      else:
+        rand_slip = (1.0 / self.rf_delta) * (DxM - DxK)
+        U_new = self._velocities(self.solve_mobility_problem(noise=rand_slip, noise_FT=rand_force)).clone()
+        rhs = torch.cat([-slip_noise, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
+        U_noise = self._velocities(self.solve_mobility_problem(RHS=rhs))
+        if self.first_step is False:
+          U = 1.5 * U_new + U_noise - 0.5 * self.velocities_previous_step
+        else:
+          U = U_new + U_noise
+      new = self._advance(old[0], old[1], U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        if adams_bashforth:
+          self.first_step = False
+          self.velocities_previous_step = U_new
+        return self._accept(*new)
+
+  def stochastic_traction_EM(self, dt, *args, **kwargs):
+    return self._traction_scheme(dt, False, kwargs.get("step"))
+
+  def stochastic_traction_AB(self, dt, *args, **kwargs):
+    return self._traction_scheme(dt, True, kwargs.get("step"))
 
   def _slip_scheme(self, dt, trapezoidal, step):
     """Shared body of stochastic_Slip_Trapz (:925-1045) and stochastic_Slip_Mid (:1214-1343): predictor with the
