@@ -96,7 +96,9 @@ def case(ref, out_dir, name, scheme, bodies, n_steps, kT=0.0, dt=0.01, seed=1, d
   work = tempfile.mkdtemp(prefix="ref_run_")
   lines = []
   data = {}
-  for ID, vertex, loc, quat in bodies:
+  obstacles = []
+  for entry in bodies:
+    ID, vertex, loc, quat = entry[:4]
     with open(os.path.join(work, ID + ".vertex"), "w") as fh:
       fh.write("%d\n" % len(vertex))
       for x in vertex:
@@ -105,7 +107,10 @@ def case(ref, out_dir, name, scheme, bodies, n_steps, kT=0.0, dt=0.01, seed=1, d
       fh.write("%d\n" % len(loc))
       for x, q in zip(loc, quat):
         fh.write("%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n" % (tuple(x) + tuple(q)))
-    line = "structure %s.vertex %s.clones" % (ID, ID)
+    keyword = "obstacle" if len(entry) > 4 and entry[4] == "obstacle" else "structure"
+    if keyword == "obstacle":
+      obstacles.append(ID)
+    line = "%s %s.vertex %s.clones" % (keyword, ID, ID)
     if slip is not None and ID in slip:
       with open(os.path.join(work, ID + ".slip"), "w") as fh:
         fh.write("%d\n" % len(slip[ID]))
@@ -135,7 +140,7 @@ def case(ref, out_dir, name, scheme, bodies, n_steps, kT=0.0, dt=0.01, seed=1, d
   finally:
     os.chdir(cwd)
     sys.argv = argv
-  for ID, _, _, _ in bodies:
+  for ID in [e[0] for e in bodies]:
     files = sorted(glob.glob(os.path.join(work, "run.%s.*.clones" % ID)))
     assert len(files) == n_steps + 1, files
     traj = [read_clones(f) for f in files]
@@ -144,7 +149,7 @@ def case(ref, out_dir, name, scheme, bodies, n_steps, kT=0.0, dt=0.01, seed=1, d
   with open(os.path.join(work, "run.info")) as fh:
     info = fh.read()
   np.savez_compressed(os.path.join(out_dir, name + ".npz"), deck=deck, IDs=np.array([b[0] for b in bodies]),
-                      scheme=scheme, n_steps=n_steps, seed=seed, kT=kT, info=info, **data)
+                      scheme=scheme, n_steps=n_steps, seed=seed, kT=kT, info=info, obstacles=np.array(obstacles), **data)
   shutil.rmtree(work)
   print("  %-40s %-30s steps=%d  %.1fs" % (name, scheme, n_steps, time.time() - t0), flush=True)
 
@@ -175,6 +180,12 @@ def main():
       out.append(("shell", shell, loc, random_quaternions(rng, nb_shell)))
     return out
 
+  def with_obstacle(nb_shell):
+    """free shells next to a fixed boomerang-shaped obstacle (an `obstacle` line: prescribed kinematics, U = 0)"""
+    free = mixed(0, nb_shell)
+    obst = ("fixed", boomerang, np.array([[0.8, 2.0, 1.6]]), random_quaternions(rng, 1), "obstacle")
+    return free + [obst]
+
   kT = 0.0041
   cases = [
       ("g9_rigid_det_euler", "deterministic_forward_euler", mixed(2, 3), 3, {}),
@@ -191,6 +202,8 @@ def main():
       ("g9_rigid_stoch_EM", "stochastic_EM", mixed(1, 3), 2, dict(kT=kT, seed=7)),
       ("g9_rigid_stoch_traction_EM", "stochastic_traction_EM", mixed(1, 3), 2, dict(kT=kT, seed=8)),
       ("g9_rigid_stoch_traction_AB", "stochastic_traction_AB", mixed(1, 3), 3, dict(kT=kT, seed=9)),
+      ("g9_rigid_obstacle_det_euler", "deterministic_forward_euler", with_obstacle(3), 3, {}),
+      ("g9_rigid_obstacle_slip_trapz", "stochastic_Slip_Trapz", with_obstacle(3), 2, dict(kT=kT, seed=10)),
       ("g9_rigid_stoch_slip_trapz_16shells", "stochastic_Slip_Trapz", mixed(0, 16), 2, dict(kT=kT, seed=6)),
   ]
   for name, scheme, bodies, n_steps, kw in cases:

@@ -28,13 +28,16 @@ def run_reference(ref, work, deck_text):
   os.chdir(work)
   try:
     sys.argv = ["multi_bodies_utilities.py", "--input-file", "deck.dat"]
+    # fresh module state per run: the preconditioner builders cache per-body blocks in function attributes
+    for m in [m for m in sys.modules if m.startswith("multi_bodies")]:
+      del sys.modules[m]
     runpy.run_path(os.path.join(ref, "multi_bodies", "multi_bodies_utilities.py"), run_name="__main__")
   finally:
     os.chdir(cwd)
     sys.argv = argv
 
 
-def write_structure(work, ID, vertex, loc, quat, slip=None):
+def write_structure(work, ID, vertex, loc, quat, slip=None, keyword="structure"):
   with open(os.path.join(work, ID + ".vertex"), "w") as fh:
     fh.write("%d\n" % len(vertex))
     for x in vertex:
@@ -43,7 +46,7 @@ def write_structure(work, ID, vertex, loc, quat, slip=None):
     fh.write("%d\n" % len(loc))
     for x, q in zip(loc, quat):
       fh.write("%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n" % (tuple(x) + tuple(q)))
-  line = "structure %s.vertex %s.clones" % (ID, ID)
+  line = "%s %s.vertex %s.clones" % (keyword, ID, ID)
   if slip is not None:
     with open(os.path.join(work, ID + ".slip"), "w") as fh:
       fh.write("%d\n" % len(slip))
@@ -123,6 +126,22 @@ def main():
                         velocity_file=U, **data)
     shutil.rmtree(work)
     print("  " + name, flush=True)
+
+
+  # --- an obstacle (prescribed kinematics, U = 0) next to free shells: scheme mobility -------------------------------
+  work = tempfile.mkdtemp(prefix="ref_util_")
+  loc_o, q_o = np.array([[0.8, 2.0, 1.6]]), random_quaternions(rng, 1)
+  lines = [write_structure(work, "shell", shell, loc_s, q_s),
+           write_structure(work, "fixed", boomerang, loc_o, q_o, keyword="obstacle")]
+  deck = "scheme                                   mobility\n" + common + "\n".join(lines) + "\n"
+  run_reference(ref, work, deck)
+  np.savez_compressed(os.path.join(out_dir, "g10_util_mobility_obstacle.npz"), deck=deck, IDs=np.array(["shell", "fixed"]),
+                      vertex_shell=shell, vertex_fixed=boomerang, locations_shell=loc_s, locations_fixed=loc_o,
+                      quaternions_shell=q_s, quaternions_fixed=q_o,
+                      velocity=np.loadtxt(os.path.join(work, "run.velocity.dat")),
+                      force=np.loadtxt(os.path.join(work, "run.force.dat")))
+  shutil.rmtree(work)
+  print("  g10_util_mobility_obstacle", flush=True)
 
 
 if __name__ == "__main__":

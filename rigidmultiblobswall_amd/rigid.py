@@ -85,7 +85,10 @@ class RigidSuspension(object):
   """
 
   def __init__(self, reference_configurations, locations, quaternions, a, eta, wall=True, periodic_length=None,
-               device="cuda:0", ctx=None):
+               device="cuda:0", ctx=None, prescribed=None, prescribed_velocity=None):
+    """prescribed: optional bool per body -- bodies with prescribed kinematics (the reference's `obstacle` structures,
+    multi_bodies.py:1201-1203): their velocity is given (prescribed_velocity, default 0) and the unknown in their U slot
+    is the force-torque that holds them (multi_bodies.py:457-462, :561-571)."""
     self.device = torch.device(device)
     self.a, self.eta, self.wall = float(a), float(eta), bool(wall)
     self.L = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
@@ -115,6 +118,12 @@ class RigidSuspension(object):
       self.groups.append(g)
     self.size = 3 * self.n_blobs + 6 * self.n_bodies
     self.matvec_count = 0
+    self.free = None            # (n_bodies, 1) 1.0 = free body, 0.0 = prescribed kinematics; None = all free
+    self.prescribed_velocity = None
+    if prescribed is not None and np.any(prescribed):
+      self.free = torch.as_tensor(1.0 - np.asarray(prescribed, dtype=np.float64).reshape(-1, 1), device=self.device)
+      pv = np.zeros((self.n_bodies, 6)) if prescribed_velocity is None else np.asarray(prescribed_velocity, dtype=np.float64)
+      self.prescribed_velocity = torch.as_tensor(pv.reshape(self.n_bodies, 6), device=self.device) * (1.0 - self.free)
     self.set_configuration(locations, quaternions)
 
   # ---- configuration --------------------------------------------------------------------------------
@@ -209,8 +218,34 @@ class RigidSuspension(object):
     """[lambda; U] -> [M lambda - K U; -K^T lambda]   (multi_bodies.py:424-471, no constraints)."""
     n3 = 3 * self.n_blobs
     lam, U = x[:n3], x[n3:]
-    top = self.mobility_times_lambda(lam) - self.K_times_U(U)
-    return torch.cat([top, -self.KT_times_lambda(lam)])
+    if self.free is None:
+      top = self.mobility_times_lambda(lam) - self.K_times_U(U)
+      return torch.cat([top, -self.KT_times_lambda(lam)])
+    # prescribed bodies: their slot holds F, which enters only the force balance  -K^T lambda + F = 0
+    U = U.view(self.n_bodies, 6)
+    top = self.mobility_times_lambda(lam) - self.K_times_U((U * self.free).reshape(-1))
+    bottom = -self.KT_times_lambda(lam).view(self.n_bodies, 6) + U * (1.0 - self.free)
+    return torch.cat([top, bottom.reshape(-1)])
+
+  def prescribe(self, rhs):
+    """RHS of a system whose bodies partly have prescribed kinematics (quaternion_integrator_multi_bodies.py:1478-1487):
+    slip += K U_prescribed on their blobs, and their force rows are zero."""
+    if self.free is None:
+      return rhs
+    n3 = 3 * self.n_blobs
+    rhs = rhs.clone()
+    rhs[:n3] += self.K_times_U(self.prescribed_velocity.reshape(-1))
+    rhs[n3:] = (rhs[n3:].view(self.n_bodies, 6) * self.free).reshape(-1)
+    return rhs
+
+  def impose_prescribed_velocity(self, sol):
+    """After a solve the velocity slots of prescribed bodies carry their known velocity (:1541-1544)."""
+    if self.free is None:
+      return sol
+    n3 = 3 * self.n_blobs
+    sol = sol.clone()
+    sol[n3:] = (sol[n3:].view(self.n_bodies, 6) * self.free + self.prescribed_velocity).reshape(-1)
+    return sol
 
   # ---- block-diagonal preconditioner ------------------------------------------------------------
   def build_preconditioner(self):
@@ -243,6 +278,12 @@ class RigidSuspension(object):
       Lt = torch.bmm(g.Minv, slip)
       Y = torch.bmm(g.Nbody, -self._bodies_of(F, g).unsqueeze(-1) - torch.bmm(g.K_pc.transpose(1, 2), Lt))
       lam = torch.bmm(g.Minv, slip + torch.bmm(g.K_pc, Y))
+      if self.free is not None:
+        # prescribed kinematics (multi_bodies.py:561-571): lambda = M^-1 (slip + K U) with the RHS already holding
+        # slip + K U, and the slot returns F = K^T lambda
+        fr = self._bodies_of(self.free, g).unsqueeze(-1)
+        lam = fr * lam + (1.0 - fr) * Lt
+        Y = fr * Y + (1.0 - fr) * torch.bmm(g.K_pc.transpose(1, 2), Lt)
       self._put_blobs(out[:n3], g, lam)
       self._put_bodies(outU, g, Y)
     return out

@@ -44,7 +44,8 @@ class RigidIntegrator(object):
   """reference_configurations: one (n_b, 3) array per body; locations (nb, 3); quaternions (nb, 4)."""
 
   def __init__(self, reference_configurations, locations, quaternions, scheme, a, eta, tolerance=None,
-               domain="single_wall", periodic_length=None, device="cuda:0", ctx=None, rng=None, seed=None):
+               domain="single_wall", periodic_length=None, device="cuda:0", ctx=None, rng=None, seed=None,
+               prescribed=None, prescribed_velocity=None):
     if domain not in ("single_wall", "no_wall"):
       raise ValueError("domain must be single_wall or no_wall")
     self.device = torch.device(device)
@@ -53,7 +54,8 @@ class RigidIntegrator(object):
     self.domain = domain
     self.periodic_length = np.zeros(3) if periodic_length is None else np.asarray(periodic_length, dtype=np.float64)
     self.susp = RigidSuspension(reference_configurations, locations, quaternions, a, eta, wall=(domain == "single_wall"),
-                                periodic_length=self.periodic_length, device=device, ctx=ctx)
+                                periodic_length=self.periodic_length, device=device, ctx=ctx, prescribed=prescribed,
+                                prescribed_velocity=prescribed_velocity)
     self.location = self.susp.location.clone()
     self.orientation = self.susp.orientation.clone()
     self.Nblobs, self.Nbodies = self.susp.n_blobs, self.susp.n_bodies
@@ -182,14 +184,14 @@ class RigidIntegrator(object):
       FT = self.force_torque_calculator()
       if noise_FT is not None:
         FT = FT + noise_FT.view(-1, 6)
-      RHS = torch.cat([self._slip(), -FT.reshape(-1)])
+      RHS = self.susp.prescribe(torch.cat([self._slip(), -FT.reshape(-1)]))
     else:
       RHS = RHS.clone()
     if noise is not None:
       RHS[:n3] -= noise
     sol, info = self.susp.solve(RHS, tol=self.tolerance, restart=60, maxiter=1000)
     self.det_iterations_count += info["iterations"]
-    return sol
+    return self.susp.impose_prescribed_velocity(sol)
 
   def _velocities(self, sol):
     return sol[3 * self.Nblobs:]
@@ -445,9 +447,10 @@ def bodies_from_input(read):
   from . import structures as st
   refs, locs, quats, slips, body_types = [], [], [], [], []
   any_slip = False
-  if len(read.structures) > read.num_free_bodies or read.articulated:
-    raise ValueError("obstacles / articulated bodies are not supported")
-  for structure in read.structures[:read.num_free_bodies]:
+  if read.articulated:
+    raise ValueError("articulated bodies are not supported")
+  prescribed = []
+  for sid, structure in enumerate(read.structures):
     ref = st.read_vertex_file(read.resolve(structure[0]))[:, :3]
     n, loc, quat = st.read_clones_file(read.resolve(structure[1]))
     slip = None
@@ -458,6 +461,7 @@ def bodies_from_input(read):
     for k in range(n):
       refs.append(ref)
       slips.append(slip if slip is not None else np.zeros((len(ref), 3)))
+      prescribed.append(sid >= read.num_free_bodies)      # `obstacle` lines follow the `structure` lines
     locs.append(loc)
     quats.append(quat)
     body_types.append(n)
@@ -465,7 +469,7 @@ def bodies_from_input(read):
     raise ValueError("input deck lists no structure")
   return dict(refs=refs, locations=np.concatenate(locs), quaternions=np.concatenate(quats),
               slips=np.concatenate(slips) if any_slip else None, body_types=body_types,
-              structures_ID=list(read.structures_ID[:read.num_free_bodies]))
+              structures_ID=list(read.structures_ID), prescribed=np.array(prescribed, dtype=bool))
 
 
 def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
@@ -476,7 +480,7 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
     rng = np.random.RandomState(int(read.seed))
   integ = RigidIntegrator(refs, b["locations"], b["quaternions"], read.scheme, read.blob_radius, read.eta,
                           tolerance=read.solver_tolerance, domain=read.domain, periodic_length=read.periodic_length,
-                          device=device, ctx=ctx, rng=rng)
+                          device=device, ctx=ctx, rng=rng, prescribed=b["prescribed"])
   integ.kT = read.kT
   integ.rf_delta = read.rf_delta
   integ.update_PC = read.update_PC

@@ -48,7 +48,7 @@ def run(read, device="cuda:0", ctx=None, write=True):
   if scheme == "mobility":
     integ = RigidIntegrator(b["refs"], b["locations"], b["quaternions"], "deterministic_forward_euler", read.blob_radius,
                             read.eta, tolerance=read.solver_tolerance, domain="single_wall" if wall else "no_wall",
-                            periodic_length=read.periodic_length, device=device, ctx=ctx)
+                            periodic_length=read.periodic_length, device=device, ctx=ctx, prescribed=b["prescribed"])
     rs = integ.susp
     if b["slips"] is not None:
       integ.slip_body_frame = torch.as_tensor(b["slips"], device=rs.device)
@@ -61,8 +61,9 @@ def run(read, device="cuda:0", ctx=None, write=True):
       if read.blob_blob_force_implementation != "None":
         integ.repulsion_strength, integ.debye_length = read.repulsion_strength, read.debye_length
       FT = integ.force_torque_calculator()
-    rhs = torch.cat([slip, -FT.reshape(-1)])
+    rhs = rs.prescribe(torch.cat([slip, -FT.reshape(-1)]))
     sol, info = rs.solve(rhs, tol=read.solver_tolerance, restart=60, maxiter=1000)
+    sol = rs.impose_prescribed_velocity(sol)
     n3 = 3 * rs.n_blobs
     out["velocity"] = sol[n3:].view(nb, 6).cpu().numpy()
     out["lambda_blobs"] = sol[:n3].view(-1, 3).cpu().numpy()
