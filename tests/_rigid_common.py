@@ -47,3 +47,9 @@ def replay(g, tmp_path, device, ctx):
       worst_x = max(worst_x, np.abs(loc - tl[step]).max() / scale)
       worst_q = max(worst_q, np.abs(quat - tq[step]).max())
   return integ, worst_x, worst_q
+
+
+def reference_counters(g):
+  """The reference driver's `.info` file: invalid configurations, GMRES and Lanczos iteration totals of the run."""
+  d = dict(line.split("=") for line in str(g["info"]).strip().split("\n"))
+  return {k.strip(): int(v) for k, v in d.items()}

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import golden_files, load_golden, rel_err
-from _rigid_common import replay
+from _rigid_common import replay, reference_counters
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,10 @@ def test_deck_replay_matches_reference_driver(tmp_path, path):
   integ, worst_x, worst_q = replay(g, tmp_path, "cuda:0", None)
   tol = 1e-7 if float(g["kT"]) == 0.0 else 1e-6
   assert worst_x < tol and worst_q < tol, (worst_x, worst_q)
-  assert integ.invalid_configuration_count == 0
+  ref = reference_counters(g)
+  assert integ.invalid_configuration_count == ref["invalid_configuration_count"] == 0
+  assert abs(integ.det_iterations_count - ref["deterministic_iterations_count"]) <= 2     # atomics: round-off level
+  assert integ.stoch_iterations_count == ref["stochastic_iterations_count"]
   integ.close()
 
 
