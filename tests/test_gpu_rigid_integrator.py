@@ -84,3 +84,26 @@ def test_deterministic_step_equals_solve_plus_update():
   assert np.abs(R_new - R_ref).max() < 1e-9
   rs.close()
   integ.close()
+
+
+def test_command_line_runs_a_reference_deck(tmp_path):
+  """`python -m rigidmultiblobswall_amd --input-file deck` = the reference's `python multi_bodies.py --input-file deck`:
+  same deck, same output files (.clones per step, .bodies_info, .info with the same iteration totals)."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  from _rigid_common import write_case
+  from rigidmultiblobswall_amd import structures
+  g = load_golden([p for p in CASES if p.endswith("g9_rigid_stoch_slip_trapz.npz")][0])
+  deck = write_case(g, str(tmp_path))
+  res = subprocess.run([sys.executable, "-m", "rigidmultiblobswall_amd", "--input-file", deck], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+  for ID in [str(x) for x in g["IDs"]]:
+    tl = g["trajectory_locations_" + ID]
+    n, loc, quat = structures.read_clones_file(os.path.join(str(tmp_path), "run.%s.%08d.clones" % (ID, len(tl) - 1)))
+    assert np.abs(loc - tl[-1]).max() < 1e-6 * np.abs(tl[-1] - tl[0]).max()
+  info = open(os.path.join(str(tmp_path), "run.info")).read()
+  ref = reference_counters(g)
+  assert "stochastic_iterations_count    = %d" % ref["stochastic_iterations_count"] in info
+  assert "num_blobs          %d" % (15 * 2 + 12 * 3) in open(os.path.join(str(tmp_path), "run.bodies_info")).read()
