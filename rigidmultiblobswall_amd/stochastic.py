@@ -95,3 +95,32 @@ def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=No
   if L_mult is not None:
     noise = L_mult(noise).reshape(-1)
   return noise, its
+
+
+# ---- dense forcings (stochastic_forcing/stochastic_forcing.py:7-109): O(n^3), for small systems and as checks --------
+def _dense(mobility, z, device):
+  M = torch.as_tensor(np.asarray(mobility, dtype=np.float64) if not isinstance(mobility, torch.Tensor) else mobility,
+                      dtype=torch.float64, device=device)
+  if z is None:
+    z = torch.randn(M.shape[0], dtype=torch.float64, device=M.device)
+  return M, torch.as_tensor(z, dtype=torch.float64, device=M.device).reshape(-1)
+
+
+def stochastic_forcing_eig(mobility, factor=1.0, z=None, device=None):
+  """factor V S^{1/2} z with M = V S V^T (negative eigenvalues clipped to 0), :7-41."""
+  M, z = _dense(mobility, z, device)
+  lam, V = torch.linalg.eigh(M)
+  return factor * (V @ (torch.sqrt(torch.clamp(lam, min=0.0)) * z))
+
+
+def stochastic_forcing_eig_symm(mobility, factor=1.0, z=None, device=None):
+  """factor V S^{1/2} V^T z -- the symmetric square root, what Lanczos converges to, :44-82."""
+  M, z = _dense(mobility, z, device)
+  lam, V = torch.linalg.eigh(M)
+  return factor * (V @ (torch.sqrt(torch.clamp(lam, min=0.0)) * (V.t() @ z)))
+
+
+def stochastic_forcing_cholesky(mobility, factor=1.0, z=None, device=None):
+  """factor L z with M = L L^T, :85-109."""
+  M, z = _dense(mobility, z, device)
+  return factor * (torch.linalg.cholesky(M) @ z)

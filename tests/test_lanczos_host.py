@@ -39,3 +39,19 @@ def test_dense_matrix_argument_and_zero_factor(g6, oracle):
   n2, _ = stochastic_forcing_lanczos(factor=1.0, tolerance=1e-10, mobility=M, z=z2)
   n1, _ = stochastic_forcing_lanczos(factor=1.0, tolerance=1e-10, mobility=M, z=g6["z"])
   assert abs(float(n1 @ n2) - g6["z"] @ M @ z2) < 1e-7 * abs(g6["z"] @ M @ z2)
+
+
+def test_dense_forcings(g6, oracle):
+  """stochastic_forcing_eig / eig_symm / cholesky (stochastic_forcing.py:7-109): the symmetric root equals the
+  reference's eig_symm output (golden noise_exact); all three have covariance factor^2 M."""
+  from rigidmultiblobswall_amd.stochastic import (stochastic_forcing_eig, stochastic_forcing_eig_symm,
+                                                  stochastic_forcing_cholesky)
+  M = oracle.dense("tt", 1, g6["r_vectors"], float(g6["eta"]), float(g6["a"]))
+  w = stochastic_forcing_eig_symm(M, factor=0.7, z=g6["z"]).numpy()
+  assert rel_err(w, g6["noise_exact"]) < 1e-12
+  n = M.shape[0]
+  eye = np.eye(n)
+  for fn in (stochastic_forcing_eig, stochastic_forcing_eig_symm, stochastic_forcing_cholesky):
+    G = np.array([fn(M, factor=1.0, z=eye[k]).numpy() for k in range(n)]).T       # G = the root itself
+    assert np.abs(G @ G.T - M).max() < 1e-12 * np.abs(M).max()
+  assert stochastic_forcing_eig(M).shape == (n,)
