@@ -153,3 +153,17 @@ def test_pair_active_rods_pinned_reference_velocities(oracle, res):
   # the reference file holds 12 significant digits of a solve converged to 1e-8
   assert np.abs(U - ref).max() < 2e-8 * np.abs(ref).max()
   assert abs(U[0, 5] - 3.88202665409) < 1e-7 if res == "low" else True
+
+
+def test_body_mobility_from_resistance_matches_pinv():
+  from rigidmultiblobswall_amd.rigid import _body_mobility_from_resistance
+  rng = np.random.RandomState(4)
+  B = rng.randn(7, 6, 6)
+  A = torch.from_numpy(B @ B.transpose(0, 2, 1) + 0.1 * np.eye(6))
+  assert torch.allclose(_body_mobility_from_resistance(A), torch.linalg.pinv(A), rtol=1e-9, atol=1e-12)
+  # a rank-5 resistance (collinear rod: no resistance to spinning about its axis) must take the pseudo-inverse route
+  v = rng.randn(6, 5)
+  S = torch.from_numpy(np.stack([v @ v.T, B[0] @ B[0].T + np.eye(6)]))
+  N = _body_mobility_from_resistance(S)
+  assert torch.allclose(N, torch.linalg.pinv(S), rtol=1e-9, atol=1e-10)
+  assert float(N[0].abs().max()) < 1e3
