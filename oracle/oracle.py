@@ -65,6 +65,8 @@ def _lib(fast=False):
                                                 _dp, ctypes.c_int, _dp]
     lib.oracle_source_target_matvec.restype = ctypes.c_int
     lib.oracle_num_threads.restype = ctypes.c_int
+    lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
+    lib.oracle_set_num_threads.restype = None
     _LIBS[name] = lib
   return _LIBS[name]
 
@@ -79,6 +81,32 @@ def _p(x):
 
 def num_threads():
   return int(_lib().oracle_num_threads())
+
+
+def usable_cpus():
+  """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota (v2 cpu.max, v1 cfs quota)."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+  try:
+    with open("/sys/fs/cgroup/cpu.max") as fh:
+      quota, period = fh.read().split()[:2]
+    if quota != "max":
+      n = min(n, max(1, int(round(float(quota) / float(period)))))
+  except (OSError, ValueError):
+    try:
+      with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+        quota = int(fh.read())
+      with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+        period = int(fh.read())
+      if quota > 0:
+        n = min(n, max(1, int(round(quota / period))))
+    except (OSError, ValueError):
+      pass
+  return n
+
+
+def set_num_threads(n):
+  for fast in (False, True):
+    _lib(fast).oracle_set_num_threads(int(n))
 
 
 def raw_matvec(kind, wall, r, v, eta, a, L=None, in_plane=False, fast=False):

@@ -634,6 +634,16 @@ int oracle_wall_regularisation(long N, const double *r, double a, double *r_eff,
   return 0;
 }
 
+/* Cap the OpenMP team (the GPU box exposes every hardware thread of the host but grants a CPU share of a few cores:
+   an oversubscribed team makes the baseline slower than it is). */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
