@@ -5,7 +5,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from conftest import golden_files, load_golden, rel_err
 from _oracle_ctx import OracleContext

@@ -6,7 +6,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rigidmultiblobswall_amd import MobilityContext, mobility as mob
-from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip
 from bench import d2_cloud
 
 FLOPS = {("tt", True): 211, ("tt", False): 62, ("tr", True): 110, ("tr", False): 38, ("rt", True): 110, ("rt", False): 38,
