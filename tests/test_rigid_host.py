@@ -20,31 +20,7 @@ def _refs(g7):
   return [g7["shell"] if s else g7["boomerang"] for s in g7["body_is_shell"]]
 
 
-class OracleCtx(object):
-  """Stand-in for MobilityContext on CPU tensors (tests may use the oracle)."""
-
-  def __init__(self, oracle):
-    self.o = oracle
-
-  def set_stream(self, s):
-    pass
-
-  def set_positions(self, r, a, L, wall):
-    self.r = r.cpu().numpy().reshape(-1, 3).copy()
-    self.a, self.wall = a, wall
-
-  def matvec_device(self, kind, v, eta):
-    fn = self.o.single_wall_mobility_trans_times_force_oracle if self.wall else self.o.no_wall_mobility_trans_times_force_oracle
-    return torch.from_numpy(fn(self.r, v.cpu().numpy(), eta, self.a))
-
-  def body_mobility_dense_device(self, first_blob, n_b, eta):
-    out = []
-    for f in first_blob.tolist():
-      out.append(self.o.dense("tt", int(self.wall), self.r[f:f + n_b], eta, self.a))
-    return torch.from_numpy(np.array(out))
-
-  def close(self):
-    pass
+from _oracle_ctx import OracleContext as OracleCtx  # noqa: E402
 
 
 def test_blob_positions_and_K_match_reference_body(g7):
