@@ -334,17 +334,18 @@ class RigidSuspension(object):
     return out
 
   # ---- solve ------------------------------------------------------------------------------------
-  def solve(self, rhs, tol=1e-8, restart=60, maxiter=1000):
+  def solve(self, rhs, tol=1e-8, restart=60, maxiter=1000, x0=None):
     """Device-level solve of [M -K; -K^T 0] x = rhs at the bound configuration with the stored preconditioner
     (built on first use).  RHS normalised to 1 before GMRES (quaternion_integrator_multi_bodies.py:1518-1521).
-    Returns (x tensor, info)."""
+    x0: optional initial guess in the units of x.  Returns (x tensor, info)."""
     if self.groups[0].Lchol is None:
       self.build_preconditioner()
     nrm = float(torch.linalg.norm(rhs))
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
     sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
-                                           restart=restart, maxiter=maxiter)
+                                           restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm)
+    info["rhs_norm"] = nrm
     return sol * nrm, info
 
   def solve_mobility_problem(self, slip=None, force_torque=None, tol=1e-8, restart=60, maxiter=1000, x0=None):

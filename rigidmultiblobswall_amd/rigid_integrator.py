@@ -83,6 +83,8 @@ class RigidIntegrator(object):
     self.det_iterations_count = 0
     self.stoch_iterations_count = 0
     self.update_PC = 1
+    self.warm_start = False
+    self.first_guess = None
     self.print_residual = False
     self.max_retries = 1000
     self._pc_built = False
@@ -176,9 +178,13 @@ class RigidIntegrator(object):
     return torch.zeros(3 * self.Nblobs, dtype=torch.float64, device=self.device)
 
   # ---- the rigid solve ------------------------------------------------------------------------------
-  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None):
+  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None, guess=False):
     """[M -K; -K^T 0][lambda; U] = [slip - noise; -(F + noise_FT)] at the bound configuration
-    (quaternion_integrator_multi_bodies.py:1441-1547).  Returns the full solution tensor."""
+    (quaternion_integrator_multi_bodies.py:1441-1547).  Returns the full solution tensor.
+    guess=True marks the calls the reference makes with `x0 = self.first_guess, save_first_guess = True`.  There the
+    guess is silently dropped (general_application_utils.gmres passes x0=None on the right-preconditioned path, :627), so
+    by default it is not used here either and the iteration counts equal the reference's; with `warm_start = True` the
+    previous (normalised) solution does seed GMRES, which pays in slowly varying deterministic runs."""
     n3 = 3 * self.Nblobs
     if RHS is None:
       FT = self.force_torque_calculator()
@@ -189,8 +195,13 @@ class RigidIntegrator(object):
       RHS = RHS.clone()
     if noise is not None:
       RHS[:n3] -= noise
-    sol, info = self.susp.solve(RHS, tol=self.tolerance, restart=60, maxiter=1000)
+    x0 = None
+    if guess and self.warm_start and self.first_guess is not None:
+      x0 = self.first_guess * float(torch.linalg.norm(RHS))
+    sol, info = self.susp.solve(RHS, tol=self.tolerance, restart=60, maxiter=1000, x0=x0)
     self.det_iterations_count += info["iterations"]
+    if guess and info.get("rhs_norm", 0.0) > 0:
+      self.first_guess = sol / info["rhs_norm"]
     return self.susp.impose_prescribed_velocity(sol)
 
   def _velocities(self, sol):
@@ -214,7 +225,7 @@ class RigidIntegrator(object):
       self.preprocess(self)
       self._move(self.location, self.orientation)
       self._refresh_preconditioner(kwargs.get("step"))
-      U = self._velocities(self.solve_mobility_problem())
+      U = self._velocities(self.solve_mobility_problem(guess=True))
       new = self._advance(self.location, self.orientation, U, dt)
       self.postprocess(self)
       if self._valid(*new):
@@ -225,7 +236,7 @@ class RigidIntegrator(object):
       self.preprocess(self)
       self._move(self.location, self.orientation)
       self._refresh_preconditioner(kwargs.get("step"))
-      U = self._velocities(self.solve_mobility_problem())
+      U = self._velocities(self.solve_mobility_problem(guess=True))
       if self.first_step is False:
         new = self._advance(self.location, self.orientation, 1.5 * U - 0.5 * self.velocities_previous_step, dt)
       else:
@@ -242,12 +253,12 @@ class RigidIntegrator(object):
       old = (self.location, self.orientation)
       self._move(*old)
       self._refresh_preconditioner(kwargs.get("step"))
-      U = self._velocities(self.solve_mobility_problem())
+      U = self._velocities(self.solve_mobility_problem(guess=True))
       mid = self._advance(old[0], old[1], U, 0.5 * dt)
       if not self._valid(*mid):
         continue
       self._move(*mid)
-      U_mid = self._velocities(self.solve_mobility_problem())
+      U_mid = self._velocities(self.solve_mobility_problem(guess=True))
       new = self._advance(old[0], old[1], U_mid, dt)
       self.postprocess(self)
       if self._valid(*new):
@@ -284,7 +295,7 @@ class RigidIntegrator(object):
       self._move(*old)
       self._refresh_preconditioner(kwargs.get("step"))
       noise = self._noise(self._normal(3 * self.Nblobs), math.sqrt(2 * self.kT / dt))
-      U = self._velocities(self.solve_mobility_problem(noise=noise)).clone()
+      U = self._velocities(self.solve_mobility_problem(noise=noise, guess=True)).clone()
       U = U + (self.kT / self.rf_delta) * self._rfd_drift_velocity(old, rfd_noise)
       new = self._advance(old[0], old[1], U, dt)
       self.postprocess(self)
@@ -302,7 +313,7 @@ class RigidIntegrator(object):
       noise = self._noise(self._normal(3 * self.Nblobs), math.sqrt(2 * self.kT / dt))
       zero = torch.zeros(self.susp.size, dtype=torch.float64, device=self.device)
       U_stoch = self._velocities(self.solve_mobility_problem(RHS=zero, noise=noise)).clone()
-      U_det = self._velocities(self.solve_mobility_problem()).clone()
+      U_det = self._velocities(self.solve_mobility_problem(guess=True)).clone()
       U_stoch = U_stoch + (self.kT / self.rf_delta) * self._rfd_drift_velocity(old, rfd_noise)
       if self.first_step is False:
         new = self._advance(old[0], old[1], 1.5 * U_det - 0.5 * self.velocities_previous_step + U_stoch, dt)
@@ -323,7 +334,7 @@ class RigidIntegrator(object):
       self._move(*old)
       self._refresh_preconditioner(kwargs.get("step"))
       noise = self._noise(self._normal(3 * self.Nblobs), math.sqrt(2 * self.kT / dt))
-      U = self._velocities(self.solve_mobility_problem(noise=noise))
+      U = self._velocities(self.solve_mobility_problem(noise=noise, guess=True))
       new = self._advance(old[0], old[1], U, dt)
       self.postprocess(self)
       if self._valid(*new):
@@ -360,10 +371,10 @@ class RigidIntegrator(object):
       rand_force = (-1.0 / self.rf_delta) * DxKT
       if not adams_bashforth:
         rand_slip = slip_noise + (1.0 / self.rf_delta) * (DxM - DxK)
-        U = self._velocities(self.solve_mobility_problem(noise=rand_slip, noise_FT=rand_force))
+        U = self._velocities(self.solve_mobility_problem(noise=rand_slip, noise_FT=rand_force, guess=True))
       else:
         rand_slip = (1.0 / self.rf_delta) * (DxM - DxK)
-        U_new = self._velocities(self.solve_mobility_problem(noise=rand_slip, noise_FT=rand_force)).clone()
+        U_new = self._velocities(self.solve_mobility_problem(noise=rand_slip, noise_FT=rand_force, guess=True)).clone()
         rhs = torch.cat([-slip_noise, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
         U_noise = self._velocities(self.solve_mobility_problem(RHS=rhs))
         if self.first_step is False:
@@ -404,7 +415,7 @@ class RigidIntegrator(object):
       else:
         noise_W1 = self._noise(W1, math.sqrt(4 * self.kT / dt))
         noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))
-      U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1)).clone()
+      U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1, guess=True)).clone()
       rhs = torch.cat([-W_slip, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
       W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs))
       self._move(*self._advance(old[0], old[1], W_RFD, self.rf_delta))
@@ -422,7 +433,7 @@ class RigidIntegrator(object):
         self._move(*old)
         continue
       self._move(*predictor)
-      U_2 = self._velocities(self.solve_mobility_problem(noise=rand_slip_cor, noise_FT=rand_force_cor))
+      U_2 = self._velocities(self.solve_mobility_problem(noise=rand_slip_cor, noise_FT=rand_force_cor, guess=True))
       U_new = 0.5 * (U_1 + U_2) if trapezoidal else U_2
       new = self._advance(old[0], old[1], U_new, dt)
       self.postprocess(self)

@@ -80,3 +80,23 @@ def test_stochastic_forcing_has_the_covariance_square_root_property(oracle):
     G[:, k] = rs.stochastic_forcing(e, 1.0, tol=1e-12)[0].numpy()
   M = oracle.dense("tt", 1, rs.r_vectors, 1.1, 0.25)
   assert np.abs(G @ G.T - M).max() < 1e-8 * np.abs(M).max()
+
+
+def test_warm_start_saves_iterations_and_keeps_the_trajectory(oracle, tmp_path):
+  """warm_start = True seeds GMRES with the previous normalised solution (what the reference's `x0 = self.first_guess`
+  intends): same trajectory to solver tolerance, fewer iterations in a deterministic run."""
+  from rigidmultiblobswall_amd.read_input import ReadInput
+  from rigidmultiblobswall_amd import rigid_integrator
+  from _rigid_common import write_case
+  g = load_golden(golden_files("g9_rigid_det_ab.npz")[0])
+  read = ReadInput(write_case(g, str(tmp_path)))
+  counts, finals = [], []
+  for warm in (False, True):
+    integ = rigid_integrator.integrator_from_input(read, device="cpu", ctx=OracleContext(oracle))
+    integ.warm_start = warm
+    for step in range(read.n_steps):
+      integ.advance_time_step(read.dt, step=step)
+    counts.append(integ.det_iterations_count)
+    finals.append(torch.cat([integ.location.reshape(-1), integ.orientation.reshape(-1)]).numpy())
+  assert counts[1] < counts[0], counts
+  assert np.abs(finals[0] - finals[1]).max() < 1e-8
