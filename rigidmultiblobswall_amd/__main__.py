@@ -28,7 +28,7 @@ def main(argv=None):
       from . import rollers as engine
     else:
       from . import rigid_integrator as engine
-    integ = engine.integrator_from_input(read, device=args.device)
+    integ = engine.integrator_from_input(read, device=args.device, rng=read.random_generator(save=True))
     integ.print_residual = args.print_residual
     with open(read.output_name + ".bodies_info", "w") as fh:
       fh.write("num_of_body_types  %d\n" % len(integ.body_types))

@@ -64,6 +64,11 @@ _OPTIONS = {
 }
 
 
+_NO_OBSTACLES = ("deterministic_forward_euler_dense_algebra", "stochastic_first_order_RFD", "stochastic_adams_bashforth",
+                 "stochastic_first_order_RFD_dense_algebra", "stochastic_traction_EM", "Fixman", "stochastic_traction_AB",
+                 "stochastic_Slip_Mid_DLA")
+
+
 class ReadInput(object):
   def __init__(self, input_file):
     self.input_file = input_file
@@ -88,6 +93,31 @@ class ReadInput(object):
     self.articulated = [self.options["articulated%d" % i].split() for i in range(counts["articulated"])]
     self.num_free_bodies = counts["structure"]
     self.structures_ID = [os.path.basename(s[1])[:-len(".clones")] for s in self.structures]
+    self.num_obstacles = counts["obstacle"]
+    # restart (read_input.py:139-144): with initial_step > 0 the bodies start from the .clones files the run saved
+    if self.initial_step > 0:
+      for k, struct in enumerate(self.structures):
+        struct[1] = self.output_name + "." + self.structures_ID[k] + "." + str(self.initial_step).zfill(8) + ".clones"
+    # schemes whose reference implementation ignores prescribed kinematics refuse obstacles (read_input.py:146-157)
+    if self.num_obstacles > 0 and self.scheme in _NO_OBSTACLES:
+      raise ValueError("Obstacles are not implemented for scheme: %s" % self.scheme)
+
+  def random_generator(self, save=True):
+    """numpy RandomState of the run as multi_bodies.py:1150-1162 sets it up: restored from the pickled state named by
+    `random_state`, else seeded with `seed`, else None (callers then use a device generator); the state at the start of the
+    run is pickled to `<output_name>.random_state` so that a run can be repeated or resumed."""
+    import pickle
+    rng = None
+    if self.random_state is not None:
+      rng = np.random.RandomState()
+      with open(self.resolve(self.random_state), "rb") as fh:
+        rng.set_state(pickle.load(fh))
+    elif self.seed is not None:
+      rng = np.random.RandomState(int(self.seed))
+    if rng is not None and save:
+      with open(self.output_name + ".random_state", "wb") as fh:
+        pickle.dump(rng.get_state(), fh)
+    return rng
 
   def resolve(self, path):
     """Structure paths are relative to the directory the deck is run from; fall back to the deck's own."""

@@ -487,8 +487,8 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
   """Integrator wired from a ReadInput deck as multi_bodies/multi_bodies.py:1319-1393 wires QuaternionIntegrator."""
   b = bodies_from_input(read)
   refs, body_types, any_slip = b["refs"], b["body_types"], b["slips"] is not None
-  if rng is None and read.seed is not None:
-    rng = np.random.RandomState(int(read.seed))
+  if rng is None:
+    rng = read.random_generator(save=False)
   integ = RigidIntegrator(refs, b["locations"], b["quaternions"], read.scheme, read.blob_radius, read.eta,
                           tolerance=read.solver_tolerance, domain=read.domain, periodic_length=read.periodic_length,
                           device=device, ctx=ctx, rng=rng, prescribed=b["prescribed"])

@@ -512,8 +512,8 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
     body_types.append(len(locations[-1]))
   if not locations:
     raise ValueError("input deck lists no structure")
-  if rng is None and read.seed is not None:
-    rng = np.random.RandomState(int(read.seed))
+  if rng is None:
+    rng = read.random_generator(save=False)
   integ = RollersIntegrator(np.concatenate(locations), read.scheme, read.blob_radius, read.eta,
                             tolerance=read.solver_tolerance, domain=read.domain, device=device, ctx=ctx, rng=rng)
   integ.kT = read.kT

@@ -100,3 +100,49 @@ def test_warm_start_saves_iterations_and_keeps_the_trajectory(oracle, tmp_path):
     finals.append(torch.cat([integ.location.reshape(-1), integ.orientation.reshape(-1)]).numpy())
   assert counts[1] < counts[0], counts
   assert np.abs(finals[0] - finals[1]).max() < 1e-8
+
+
+def test_restart_from_saved_clones_and_random_state(oracle, tmp_path):
+  """initial_step > 0 restarts from <output>.<ID>.<step>.clones (read_input.py:139-144); `random_state` restores the
+  pickled numpy state written at the start of a run (multi_bodies.py:1150-1162)."""
+  import os
+  import pickle
+  from rigidmultiblobswall_amd.read_input import ReadInput
+  from rigidmultiblobswall_amd import rigid_integrator, structures
+  from _rigid_common import write_case
+  g = load_golden(golden_files("g9_rigid_det_euler.npz")[0])
+  deck = write_case(g, str(tmp_path))
+  text = open(deck).read().replace("n_steps                                  3", "n_steps                                  4")
+  open(deck, "w").write(text)
+  read = ReadInput(deck)
+  rigid_integrator.run(read, rigid_integrator.integrator_from_input(read, device="cpu", ctx=OracleContext(oracle)))
+  straight = {ID: structures.read_clones_file(os.path.join(str(tmp_path), "run.%s.00000004.clones" % ID)) for ID in read.structures_ID}
+  for ID in read.structures_ID:
+    os.remove(os.path.join(str(tmp_path), "run.%s.00000004.clones" % ID))
+  open(deck, "w").write(text + "initial_step 2\n")
+  again = ReadInput(deck)
+  assert all(s[1].endswith(".00000002.clones") for s in again.structures)
+  rigid_integrator.run(again, rigid_integrator.integrator_from_input(again, device="cpu", ctx=OracleContext(oracle)))
+  for ID in read.structures_ID:
+    n, loc, quat = structures.read_clones_file(os.path.join(str(tmp_path), "run.%s.00000004.clones" % ID))
+    assert np.abs(loc - straight[ID][1]).max() < 1e-12 and np.abs(quat - straight[ID][2]).max() < 1e-12
+  # random state: saved at the start, reloadable
+  rng = read.random_generator(save=True)
+  first = rng.normal(0.0, 1.0, 5)
+  assert os.path.exists(read.output_name + ".random_state")
+  open(deck, "w").write(text + "random_state %s\n" % (read.output_name + ".random_state"))
+  again = ReadInput(deck)
+  assert np.array_equal(again.random_generator(save=False).normal(0.0, 1.0, 5), first)
+  with open(read.output_name + ".random_state", "rb") as fh:
+    assert pickle.load(fh)[0] == "MT19937"
+
+
+def test_obstacles_are_refused_where_the_reference_refuses_them(tmp_path):
+  from rigidmultiblobswall_amd.read_input import ReadInput
+  g = load_golden(golden_files("g9_rigid_obstacle_det_euler.npz")[0])
+  from _rigid_common import write_case
+  deck = write_case(g, str(tmp_path))
+  text = open(deck).read().replace("deterministic_forward_euler", "stochastic_traction_AB")
+  open(deck, "w").write(text)
+  with pytest.raises(ValueError):
+    ReadInput(deck)
