@@ -259,6 +259,15 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   const long need = (a.step_end - a.step_begin + per_wg - 1) / per_wg > 0 ? (a.step_end - a.step_begin + per_wg - 1) / per_wg : 1;
   if (blocks > need) blocks = need;
   if (blocks > 256L * wps) blocks -= blocks % (256L * wps);   // whole rounds only: a partial last round is a tail
+  if (blocks < 256L * wps) {
+    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): filling the round with
+    // shorter waves (down to 16 steps) beats leaving SIMDs with one or two waves and no latency hiding
+    // (1/4 shard of 1e4 blobs: 68.9 -> 60.3 us; tools/exp_pairshard.py)
+    const long per_wg_fine = rmb::kSymWaves * 16L;
+    long fine = (a.step_end - a.step_begin + per_wg_fine - 1) / per_wg_fine;
+    if (fine > 256L * wps) fine = 256L * wps;
+    if (fine > blocks) blocks = fine;
+  }
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   {
     const long waves = blocks * rmb::kSymWaves, total = a.step_end - a.step_begin;
