@@ -447,6 +447,30 @@ def test_large_linearity_symmetry_and_spot_check(Ctx, oracle, N):
   ctx.close()
 
 
+@pytest.mark.parametrize("N", [262144, 1000000])
+def test_baseline_full_sizes_spot_check_and_symmetry(Ctx, oracle, N):
+  """BASELINE.json configs[4] / configs[3] sizes on one GPU: oracle on a sample of targets (all N sources each),
+  reciprocity g.Mf = f.Mg, and the symmetric path against the one-sided sweep on the same sample."""
+  import torch
+  r, f, eta, a = d2_cloud(N, seed=31)
+  g = np.random.RandomState(32).randn(*f.shape)
+  ctx = Ctx(0)
+  rd = torch.as_tensor(r.reshape(-1), device="cuda")
+  fd, gd = torch.as_tensor(f.reshape(-1), device="cuda"), torch.as_tensor(g.reshape(-1), device="cuda")
+  ctx.set_positions(rd, a, wall=True)
+  Mf = ctx.matvec_device("tt", fd, eta)
+  assert ctx.last_launch()["chunks"] == 0
+  Mg = ctx.matvec_device("tt", gd, eta)
+  gMf, fMg = float(torch.dot(gd, Mf)), float(torch.dot(fd, Mg))
+  assert abs(gMf - fMg) < 1e-11 * float(torch.linalg.norm(gd) * torch.linalg.norm(Mf))
+  tg = np.random.RandomState(33).choice(N, 32, replace=False)
+  r_eff, b, _ = oracle.wall_regularisation(r, a)
+  ref = oracle.raw_matvec_targets("tt", 1, r_eff, f, eta, a, tg)
+  got = Mf.cpu().numpy().reshape(-1, 3)[tg].reshape(-1)
+  assert rel_err(got, ref) < TOL_D2
+  ctx.close()
+
+
 def test_forces_vs_oracle_and_newton_third_law(oracle):
   from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip
   rng = np.random.RandomState(24)
