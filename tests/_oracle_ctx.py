@@ -35,9 +35,20 @@ class OracleContext(object):
                                             blob_radius=a)
     return torch.from_numpy(np.ascontiguousarray(F).reshape(-1))
 
-  def body_mobility_dense_device(self, first_blob, n_b, eta):
-    out = [self.o.dense("tt", int(self.wall), self.r[f:f + n_b], eta, self.a) for f in first_blob.tolist()]
-    return torch.from_numpy(np.array(out))
+  def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
+    """Per-body dense blocks with the same wall regularisation as the products (height clamp + B on both sides), which
+    is what body_dense_tt_kernel builds; equal to the reference's unclamped single_wall_fluid_mobility whenever every
+    blob sits above z = a."""
+    blocks = []
+    for f in first_blob.tolist():
+      rk = self.r[f:f + n_b]
+      if self.wall:
+        r_eff, b, _ = self.o.wall_regularisation(rk, self.a)
+        B = np.repeat(b, 3)
+        blocks.append(B[:, None] * self.o.dense("tt", 1, r_eff, eta, self.a) * B[None, :])
+      else:
+        blocks.append(self.o.dense("tt", 0, rk, eta, self.a))
+    return torch.from_numpy(np.array(blocks))
 
   def close(self):
     pass

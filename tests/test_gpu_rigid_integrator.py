@@ -107,3 +107,28 @@ def test_command_line_runs_a_reference_deck(tmp_path):
   ref = reference_counters(g)
   assert "stochastic_iterations_count    = %d" % ref["stochastic_iterations_count"] in info
   assert "num_blobs          %d" % (15 * 2 + 12 * 3) in open(os.path.join(str(tmp_path), "run.bodies_info")).read()
+
+
+def test_gpu_stack_equals_oracle_backed_stack_on_a_mid_size_suspension(oracle):
+  """250 shells (3000 blobs), one stochastic_Slip_Trapz step with the same numpy stream: the whole stack on the GPU
+  (symmetric kernels, device GMRES / Lanczos) against the same integrator driven by the oracle-backed CPU context."""
+  from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+  from _oracle_ctx import OracleContext
+  nb = 250
+  shell, a, loc, quat = _suspension(nb, 6)
+  res = []
+  for device, ctx in (("cuda:0", None), ("cpu", OracleContext(oracle))):
+    integ = RigidIntegrator([shell] * nb, loc, quat, "stochastic_Slip_Trapz", a, 0.957e-3, tolerance=1e-9, device=device,
+                            ctx=ctx, rng=np.random.RandomState(12))
+    integ.kT, integ.g = 0.0041419464, 0.03
+    integ.repulsion_strength_wall, integ.debye_length_wall = 0.0165677856, 0.0656
+    integ.repulsion_strength, integ.debye_length = 0.0165677856, 0.0656
+    integ.advance_time_step(0.01, step=0)
+    res.append((integ.location.cpu().numpy(), integ.orientation.cpu().numpy(), integ.det_iterations_count,
+                integ.stoch_iterations_count))
+    if ctx is None:
+      integ.close()
+  scale = np.abs(res[1][0] - loc).max()
+  assert np.abs(res[0][0] - res[1][0]).max() < 1e-6 * scale
+  assert np.abs(res[0][1] - res[1][1]).max() < 1e-7
+  assert abs(res[0][2] - res[1][2]) <= 2 and res[0][3] == res[1][3]
