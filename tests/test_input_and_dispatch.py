@@ -41,3 +41,19 @@ def test_dispatch_strings():
     dispatch.set_mobility_vector_prod("numba")      # CPU backends are the reference's, not ours
   with pytest.raises(ValueError):
     dispatch.set_mobility_vector_prod("pycuda")
+  assert dispatch.set_mobility_vector_prod("hip_free_surface") is mobility.free_surface_mobility_trans_times_force_hip
+  assert dispatch.set_mobility_vector_prod("pycuda_free_surface", accept_reference_gpu_names=True) is \
+      mobility.free_surface_mobility_trans_times_force_hip
+  # blobs of different radii: the partial carries the radii and the source->target function (multi_bodies.py:266-286)
+
+  class Body(object):
+    def __init__(self, radii):
+      self.blobs_radius = np.asarray(radii)
+  fn = dispatch.set_mobility_vector_prod("radii_hip", bodies=[Body([0.1, 0.2]), Body([0.3])])
+  assert fn.func is mobility.mobility_radii_trans_times_force
+  assert np.array_equal(fn.keywords["radius_blobs"], [0.1, 0.2, 0.3])
+  assert fn.keywords["function"] is mobility.single_wall_mobility_trans_times_force_source_target_hip
+  fn = dispatch.set_mobility_vector_prod("radii_hip_no_wall", radius_blobs=[0.5, 0.5])
+  assert fn.keywords["function"] is mobility.no_wall_mobility_trans_times_force_source_target_hip
+  with pytest.raises(ValueError):
+    dispatch.set_mobility_vector_prod("radii_hip")
