@@ -225,6 +225,7 @@ def main():
       sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
                     "kernel_ms_avg": round(rs["kern_ms"], 3),
                     "valu_fp64_tflops": round(211.0 * pairs / (rs["kern_ms"] * 1e-3) / 1e12, 2),
+                    "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4),
                     "launch": rs["launch"]})
     line["sweep"] = sweep
 
