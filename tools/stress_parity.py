@@ -1,0 +1,84 @@
+"""Randomised differential test: symmetric path, one-sided sweep and the oracle on random sizes, kinds, wall modes,
+periodic boxes and blob clouds (dilute / dense overlapping / partly below the wall).  Prints the worst relative error."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle
+from rigidmultiblobswall_amd import MobilityContext
+oracle.build()
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+names = {"tt": "trans_times_force", "tr": "trans_times_torque", "rt": "rot_times_force", "rr": "rot_times_torque"}
+worst = 0.0
+ctx = MobilityContext(0)
+for case in range(n_cases):
+  N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 511, 777, 1500, 2500]))
+  kind = str(rng.choice(["tt", "tr", "rt", "rr"]))
+  wall = bool(rng.rand() < 0.7)
+  a = float(0.1 + rng.rand())
+  eta = float(0.5 + rng.rand())
+  style = int(rng.randint(3))
+  box = a * (N ** (1.0 / 3.0)) * [6.0, 2.2, 3.0][style]
+  r = rng.rand(N, 3) * box
+  if style == 2:
+    r[:, 2] -= 0.15 * box                     # some blobs below the wall / below z = a
+  elif wall:
+    r[:, 2] += 1.05 * a
+  periodic = rng.rand() < 0.35
+  L = np.zeros(3)
+  if periodic:
+    L[0] = box * (1.0 + rng.rand())
+    if rng.rand() < 0.5:
+      L[1] = box * (1.0 + rng.rand())
+    if not wall and rng.rand() < 0.3:
+      L[2] = box * (1.0 + rng.rand())
+  v = rng.randn(N, 3)
+  pre = "single_wall" if wall else "no_wall"
+  ref = getattr(oracle, "%s_mobility_%s_oracle" % (pre, names[kind]))(r, v, eta, a, periodic_length=L)
+  ctx.set_positions(r, a, L, wall=wall)
+  res = {}
+  for det in (0, 1):
+    ctx.set_option("deterministic", det)
+    res[det] = ctx.matvec(kind, v, eta)
+  ctx.set_option("deterministic", 0)
+  nrm = np.linalg.norm(ref)
+  if not np.isfinite(nrm):
+    continue
+  errs = [np.linalg.norm(res[d] - ref) / max(nrm, 1e-300) for d in (0, 1)]
+  worst = max(worst, max(errs))
+  if max(errs) > 1e-10:
+    print("CASE %d N=%d kind=%s wall=%s style=%d L=%s errs=%s" % (case, N, kind, wall, style, L, errs), flush=True)
+print("cases %d, worst relative error %.3e" % (n_cases, worst))
+ctx.close()
+
+# --- forces, fused tt+tr, source->target --------------------------------------------------------------------
+from rigidmultiblobswall_amd import mobility as mob
+from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip
+worst2 = 0.0
+for case in range(n_cases // 3):
+  N = int(rng.choice([2, 64, 129, 300, 1000, 2000]))
+  a = float(0.1 + rng.rand()); eta = float(0.5 + rng.rand())
+  box = a * (N ** (1.0 / 3.0)) * float(rng.choice([2.2, 5.0]))
+  r = rng.rand(N, 3) * box; r[:, 2] += 0.5 * a
+  L = np.zeros(3)
+  if rng.rand() < 0.4:
+    L[:2] = box * (1.0 + rng.rand(2))
+  f, t = rng.randn(N, 3), rng.randn(N, 3)
+  kw = dict(periodic_length=L, repulsion_strength=float(rng.rand() * 4), debye_length=float(a * (0.05 + rng.rand())), blob_radius=a)
+  F, Fr = calc_blob_blob_forces_hip(r, **kw), oracle.calc_blob_blob_forces_oracle(r, **kw)
+  e1 = np.linalg.norm(F - Fr) / max(np.linalg.norm(Fr), 1e-300)
+  u = mob.single_wall_mobility_trans_times_force_torque_hip(r, f, t, eta, a, periodic_length=L)
+  ur = oracle.single_wall_mobility_trans_times_force_torque_oracle(r, f, t, eta, a, periodic_length=L)
+  e2 = np.linalg.norm(u - ur) / np.linalg.norm(ur)
+  nt = int(rng.choice([1, 70, 400]))
+  tgt = rng.rand(nt, 3) * box; tgt[:, 2] += 0.2 * a
+  rs, rt = a * (0.3 + rng.rand(N)), a * rng.rand(nt) * (rng.rand() < 0.7)
+  w = bool(rng.rand() < 0.6)
+  fn = mob.single_wall_mobility_trans_times_force_source_target_hip if w else mob.no_wall_mobility_trans_times_force_source_target_hip
+  fo = oracle.single_wall_mobility_trans_times_force_source_target_oracle if w else oracle.no_wall_mobility_trans_times_force_source_target_oracle
+  s, sr = fn(r, tgt, f, rs, rt, eta), fo(r, tgt, f, rs, rt, eta)
+  e3 = np.linalg.norm(s - sr) / np.linalg.norm(sr)
+  worst2 = max(worst2, e1, e2, e3)
+  if max(e1, e2, e3) > 1e-10:
+    print("CASE2 %d N=%d L=%s forces %.2e fused %.2e source_target %.2e" % (case, N, L, e1, e2, e3), flush=True)
+print("forces / fused / source-target: %d cases, worst relative error %.3e" % (n_cases // 3, worst2))
