@@ -130,8 +130,10 @@ int rmb_forces_oneshot(long n, const double* r, const double* L, double repulsio
 /* ---- source -> target products with per-blob radii (K13) --------------------------------------
  * u_t = sum_s M(x_t, a_t; y_s, a_s) f_s for nt targets and ns sources, each blob with its own radius
  * (mobility/mobility_numba.py:1480-1658; CUDA twin mobility_pycuda.py:1974-2078; wrappers
- * mobility.py:494-615: per-blob height clamp + B on both sides when wall != 0).  Stateless; the host
- * variant is synchronous, the device variant enqueues on the context's stream. */
+ * mobility.py:494-615: per-blob height clamp + B on both sides when wall == 1).  wall == 2 selects the
+ * stress-free surface at z = 0 instead (mobility_numba.py:1941-2091, wrapper mobility.py:1409-1429: mirror image
+ * with the z column negated, raw heights, no clamp).  Stateless; the host variant is synchronous, the device
+ * variant enqueues on the context's stream. */
 int rmb_mobility_source_target(long ns, const double* src, const double* radius_src, long nt, const double* tgt,
                                const double* radius_tgt, const double* force, double eta, const double* L, int wall,
                                double* out);

@@ -33,7 +33,8 @@ def main():
   out = {}
   for name, c in cases.items():
     for wall, fn in ((1, mob.single_wall_mobility_trans_times_force_source_target_numba),
-                     (0, mob.no_wall_mobility_trans_times_force_source_target_numba)):
+                     (0, mob.no_wall_mobility_trans_times_force_source_target_numba),
+                     (2, mob.free_surface_mobility_trans_times_force_source_target_numba)):   # stress-free surface
       u = fn(c["source"], c["target"], c["force"], c["radius_source"], c["radius_target"], c["eta"], periodic_length=c["L"])
       out["%s_wall%d" % (name, wall)] = np.asarray(u).reshape(-1)
     for k, v in c.items():

@@ -246,7 +246,7 @@ def _source_target(source, target, force, radius_source, radius_target, eta, wal
   rt = _c(radius_target).reshape(-1)
   f = _c(force).reshape(-1, 3).copy()
   bt = np.ones(len(tgt))
-  if wall:
+  if wall == 1:
     # damping_matrix_B_different_radius, mobility.py:102-119 (tracers have radius 0: the quotient is never selected)
     bs = np.where(src[:, 2] < rs, src[:, 2] / np.where(rs > 0, rs, 1.0), 1.0)
     bt = np.where(tgt[:, 2] < rt, tgt[:, 2] / np.where(rt > 0, rt, 1.0), 1.0)
@@ -270,6 +270,11 @@ def single_wall_mobility_trans_times_force_source_target_oracle(source, target, 
 def no_wall_mobility_trans_times_force_source_target_oracle(source, target, force, radius_source, radius_target, eta,
                                                             *args, **kw):
   return _source_target(source, target, force, radius_source, radius_target, eta, 0, **kw)
+
+
+def free_surface_mobility_trans_times_force_source_target_oracle(source, target, force, radius_source, radius_target, eta,
+                                                                 *args, **kw):
+  return _source_target(source, target, force, radius_source, radius_target, eta, 2, **kw)
 
 
 def calc_blob_blob_forces_oracle(r_vectors, *args, **kwargs):

@@ -502,7 +502,32 @@ int oracle_source_target_matvec(long Ns, const double *src, const double *rad_s,
             }
             M[0] = M[4] = M[8] = C1;
             outer3(d, d, C2, M);
-            if (wall) {
+            if (wall == 2) {
+              /* stress-free surface at z = 0 (mobility_numba.py:2040-2079): the same three-regime tensor evaluated at the
+               * mirror image R = (dx, dy, z_t + z_s) -- raw heights, not wrapped in z -- added with its z column negated */
+              const double Rv[3] = {d[0], d[1], tgt[3 * i + 2] + src[3 * j + 2]};
+              const double q2 = Rv[0] * Rv[0] + Rv[1] * Rv[1] + Rv[2] * Rv[2];
+              const double q = sqrt(q2);
+              double D1, D2;
+              if (q > at + as) {
+                D1 = (1 + (as * as + at * at) / (3 * q2)) / q;
+                D2 = ((1 - (as * as + at * at) / q2) / q2) / q;
+              } else if (q > fabs(as - at)) {
+                const double q3 = q2 * q, dm = (as - at) * (as - at);
+                D1 = ((16 * (as + at) * q3 - (dm + 3 * q2) * (dm + 3 * q2)) / (32 * q3)) * (4.0 / 3.0) / (as * at);
+                D2 = ((3 * (dm - q2) * (dm - q2) / (32 * q3)) / q2) * (4.0 / 3.0) / (as * at);
+              } else {
+                D1 = (4.0 / 3.0) / (at > as ? at : as);
+                D2 = 0;
+              }
+              double T[9] = {D1, 0, 0, 0, D1, 0, 0, 0, D1};
+              outer3(Rv, Rv, D2, T);
+              for (int l = 0; l < 3; ++l) {
+                M[3 * l] += T[3 * l];
+                M[3 * l + 1] += T[3 * l + 1];
+                M[3 * l + 2] -= T[3 * l + 2];
+              }
+            } else if (wall) {
               /* mobility_numba.py:1591-1644 */
               const double x3 = tgt[3 * i + 2], y3 = src[3 * j + 2];
               const double R[3] = {d[0], d[1], x3 + y3};

@@ -675,9 +675,9 @@ int rmb_mobility_source_target_device(rmb_ctx* c, long ns, const double* src_dev
   if (int rc = c->st[0].reserve((size_t)ns * sizeof(double4))) return rc;
   if (int rc = c->st[1].reserve((size_t)nt * sizeof(double4))) return rc;
   hipLaunchKernelGGL(rmb::pack_positions_radii_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, src_dev,
-                     rad_s_dev, ns, wall ? 1 : 0, (double4*)c->st[0].p);
+                     rad_s_dev, ns, wall == 1 ? 1 : 0, (double4*)c->st[0].p);
   hipLaunchKernelGGL(rmb::pack_positions_radii_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, tgt_dev,
-                     rad_t_dev, nt, wall ? 1 : 0, (double4*)c->st[1].p);
+                     rad_t_dev, nt, wall == 1 ? 1 : 0, (double4*)c->st[1].p);
   RMB_HIP(hipGetLastError());
   rmb::StArgs a;
   a.src = (const double4*)c->st[0].p; a.rad_s = rad_s_dev; a.force = force_dev;
@@ -690,11 +690,12 @@ int rmb_mobility_source_target_device(rmb_ctx* c, long ns, const double* src_dev
   a.Lx = Lx; a.Ly = Ly; a.Lz = Lz;
   a.iLx = Lx > 0 ? 1.0 / Lx : 0.0; a.iLy = Ly > 0 ? 1.0 / Ly : 0.0; a.iLz = Lz > 0 ? 1.0 / Lz : 0.0;
   const bool periodic = Lx > 0 || Ly > 0 || Lz > 0;
-  static int occ[2][2] = {{0, 0}, {0, 0}};
+  static int occ[3][2] = {{0, 0}, {0, 0}, {0, 0}};
   typedef void (*st_fn)(const rmb::StArgs);
-  st_fn fn = wall ? (periodic ? (st_fn)rmb::st_sweep_kernel<true, true> : (st_fn)rmb::st_sweep_kernel<true, false>)
-                  : (periodic ? (st_fn)rmb::st_sweep_kernel<false, true> : (st_fn)rmb::st_sweep_kernel<false, false>);
-  const long slots = 256L * resident_blocks((const void*)fn, &occ[wall ? 1 : 0][periodic ? 1 : 0]);
+  st_fn fn = wall == 2 ? (periodic ? (st_fn)rmb::st_sweep_kernel<2, true> : (st_fn)rmb::st_sweep_kernel<2, false>)
+           : wall      ? (periodic ? (st_fn)rmb::st_sweep_kernel<1, true> : (st_fn)rmb::st_sweep_kernel<1, false>)
+                       : (periodic ? (st_fn)rmb::st_sweep_kernel<0, true> : (st_fn)rmb::st_sweep_kernel<0, false>);
+  const long slots = 256L * resident_blocks((const void*)fn, &occ[wall == 2 ? 2 : (wall ? 1 : 0)][periodic ? 1 : 0]);
   long n_chunks, chunk_len;
   choose_chunks(nt, ns, c->opt_chunks, slots, &n_chunks, &chunk_len);
   if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");

@@ -112,7 +112,17 @@ __device__ __forceinline__ void pair_st(double dx, double dy, double dz, double 
   }
 }
 
-template <bool WALL, bool PERIODIC>
+// MODE 0: unbounded, 1: no-slip wall at z = 0 (Swan-Brady image system), 2: stress-free surface at z = 0
+// (mobility_numba.py:1941-2091: the unbounded tensor of the mirror image R = (dx, dy, z_t + z_s), raw heights,
+// added with its z column negated  =>  second pair_st<false> call with (fx, fy, -fz)).
+template <int MODE>
+__device__ __forceinline__ void pair_st_mode(double dx, double dy, double dz, double zt, double zs, double at, double as,
+                                             double fx, double fy, double fz, Vec3& u) {
+  pair_st<MODE == 1>(dx, dy, dz, zt, zs, at, as, fx, fy, fz, u);
+  if constexpr (MODE == 2) pair_st<false>(dx, dy, zt + zs, zt, zs, at, as, fx, fy, -fz, u);
+}
+
+template <int MODE, bool PERIODIC>
 __global__ __launch_bounds__(kBlock) void st_sweep_kernel(const StArgs a) {
   __shared__ double2 tile[kTile * 4];
   __shared__ double red[(kWaves - 1) * 3 * 64];
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void st_sweep_kernel(const StArgs a) {
       const double2 q0 = tile[s * 4 + 0], q1 = tile[s * 4 + 1], q2 = tile[s * 4 + 2], q3 = tile[s * 4 + 3];
       double dx = tp.x - q0.x, dy = tp.y - q0.y, dz = tp.z - q1.x;
       if constexpr (!PERIODIC) {
-        pair_st<WALL>(dx, dy, dz, tp.z, q1.x, at, q1.y, q2.x, q2.y, q3.x, acc);
+        pair_st_mode<MODE>(dx, dy, dz, tp.z, q1.x, at, q1.y, q2.x, q2.y, q3.x, acc);
       } else {
         const int px = a.Lx > 0, py = a.Ly > 0, pz = a.Lz > 0;
         if (px) dx = wrap_nearest(dx, a.Lx, a.iLx);
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void st_sweep_kernel(const StArgs a) {
         for (int bx = -px; bx <= px; ++bx)
           for (int by = -py; by <= py; ++by)
             for (int bz = -pz; bz <= pz; ++bz)
-              pair_st<WALL>(dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, tp.z, q1.x, at, q1.y, q2.x, q2.y, q3.x, acc);
+              pair_st_mode<MODE>(dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, tp.z, q1.x, at, q1.y, q2.x, q2.y, q3.x, acc);
       }
     }
   }

@@ -33,7 +33,8 @@ def set_mobility_vector_prod(implementation, accept_reference_gpu_names=False, *
       "hip_free_surface": _mob.free_surface_mobility_trans_times_force_hip,
   }
   radii = {"radii_hip": _mob.single_wall_mobility_trans_times_force_source_target_hip,
-           "radii_hip_no_wall": _mob.no_wall_mobility_trans_times_force_source_target_hip}
+           "radii_hip_no_wall": _mob.no_wall_mobility_trans_times_force_source_target_hip,
+           "radii_hip_free_surface": _mob.free_surface_mobility_trans_times_force_source_target_hip}
   if accept_reference_gpu_names:
     table["pycuda"] = table["hip"]
     table["pycuda_no_wall"] = table["hip_no_wall"]

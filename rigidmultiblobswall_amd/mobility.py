@@ -198,6 +198,13 @@ def no_wall_mobility_trans_times_force_source_target_hip(source, target, force, 
   return _source_target(source, target, force, radius_source, radius_target, eta, False, kwargs)
 
 
+def free_surface_mobility_trans_times_force_source_target_hip(source, target, force, radius_source, radius_target, eta,
+                                                              *args, **kwargs):
+  '''Same below a stress-free surface at z = 0 (mobility/mobility.py:1409-1429, kernel mobility_numba.py:1941-2091):
+  no height clamp, mirror image with the z column negated.'''
+  return _source_target(source, target, force, radius_source, radius_target, eta, 2, kwargs)
+
+
 def mobility_radii_trans_times_force(r_vectors, force, eta, a, radius_blobs, function, *args, **kwargs):
   '''M.f for blobs with different radii: sources == targets (mobility/mobility.py:1369-1374).'''
   return function(r_vectors, r_vectors, force, radius_blobs, radius_blobs, eta, *args, **kwargs)

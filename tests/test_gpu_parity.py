@@ -549,7 +549,8 @@ def test_source_target_golden(mob):
   for name in ("small", "mixed", "periodic"):
     args = [g[name + "_" + k] for k in ("source", "target", "force", "radius_source", "radius_target")]
     for wall, fn in ((1, mob.single_wall_mobility_trans_times_force_source_target_hip),
-                     (0, mob.no_wall_mobility_trans_times_force_source_target_hip)):
+                     (0, mob.no_wall_mobility_trans_times_force_source_target_hip),
+                     (2, mob.free_surface_mobility_trans_times_force_source_target_hip)):
       u = fn(*args, float(g[name + "_eta"]), periodic_length=g[name + "_L"])
       assert u.shape == (3 * len(args[1]),)
       assert rel_err(u, g["%s_wall%d" % (name, wall)]) < TOL_D1, (name, wall, rel_err(u, g["%s_wall%d" % (name, wall)]))
@@ -567,8 +568,7 @@ def test_source_target_vs_oracle(mob, oracle, ns, nt):
   rs = 0.1 + 0.4 * rng.rand(ns)
   rt = 0.1 + 0.4 * rng.rand(nt)
   f = rng.randn(ns, 3)
-  for wall in (True, False):
-    pre = "single_wall" if wall else "no_wall"
+  for pre in ("single_wall", "no_wall", "free_surface"):
     u = getattr(mob, pre + "_mobility_trans_times_force_source_target_hip")(src, tgt, f, rs, rt, 0.8)
     ref = getattr(oracle, pre + "_mobility_trans_times_force_source_target_oracle")(src, tgt, f, rs, rt, 0.8)
     assert np.all(np.isfinite(u))

@@ -55,5 +55,7 @@ def test_dispatch_strings():
   assert fn.keywords["function"] is mobility.single_wall_mobility_trans_times_force_source_target_hip
   fn = dispatch.set_mobility_vector_prod("radii_hip_no_wall", radius_blobs=[0.5, 0.5])
   assert fn.keywords["function"] is mobility.no_wall_mobility_trans_times_force_source_target_hip
+  fn = dispatch.set_mobility_vector_prod("radii_hip_free_surface", radius_blobs=[0.5])
+  assert fn.keywords["function"] is mobility.free_surface_mobility_trans_times_force_source_target_hip
   with pytest.raises(ValueError):
     dispatch.set_mobility_vector_prod("radii_hip")

@@ -73,7 +73,8 @@ def test_source_target_matches_reference(oracle):
   for name in ("small", "mixed", "periodic"):
     args = [g[name + "_" + k] for k in ("source", "target", "force", "radius_source", "radius_target")]
     for wall, fn in ((1, oracle.single_wall_mobility_trans_times_force_source_target_oracle),
-                     (0, oracle.no_wall_mobility_trans_times_force_source_target_oracle)):
+                     (0, oracle.no_wall_mobility_trans_times_force_source_target_oracle),
+                     (2, oracle.free_surface_mobility_trans_times_force_source_target_oracle)):   # mobility_numba.py:1941
       u = fn(*args, float(g[name + "_eta"]), periodic_length=g[name + "_L"])
       assert rel_err(u, g["%s_wall%d" % (name, wall)]) < TOL
   c = "mixed"
