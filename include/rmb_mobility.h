@@ -108,6 +108,12 @@ int rmb_blob_blob_force(rmb_ctx* ctx, double repulsion_strength, double debye_le
                         double* out_host);
 int rmb_blob_blob_force_device(rmb_ctx* ctx, double repulsion_strength, double debye_length,
                                double blob_radius, double* out_dev);
+/* Same with one radius per blob: contact distance a_i + a_j instead of 2a (multi_bodies/forces_numba.py:73-137,
+ * `blob_blob_force_implementation radii_numba`).  radii: double[n], host / device. */
+int rmb_blob_blob_force_radii(rmb_ctx* ctx, const double* radii, double repulsion_strength, double debye_length,
+                              double* out);
+int rmb_blob_blob_force_radii_device(rmb_ctx* ctx, const double* radii_dev, double repulsion_strength,
+                                     double debye_length, double* out_dev);
 
 /* Timing of the dominant (sweep) kernel, measured with HIP events on the context's stream when the
  * "timing" option is on.  Copies up to max_n most recent durations (ms) into ms[], returns count. */

@@ -143,6 +143,14 @@ def main():
     np.savez_compressed(os.path.join(out_dir, nm + ".npz"), r_vectors=r, periodic_length=L,
                         repulsion_strength=eps, debye_length=b, blob_radius=af, force=F)
     print("  %s" % nm, flush=True)
+  # one radius per blob (forces_numba.py:125-137)
+  radii = af * (0.5 + rng.rand(N))
+  for nm, L in (("g5_forces_radii_N100", np.zeros(3)), ("g5_forces_radii_periodic_N100", np.array([2.5, 3.0, 0.0]))):
+    F = forces_numba.calc_blob_blob_forces_radii_numba(r, radii, periodic_length=L, repulsion_strength=eps,
+                                                       debye_length=b, blob_radius=af)
+    np.savez_compressed(os.path.join(out_dir, nm + ".npz"), r_vectors=r, radius_blobs=radii, periodic_length=L,
+                        repulsion_strength=eps, debye_length=b, blob_radius=af, force=F)
+    print("  %s" % nm, flush=True)
 
 
 if __name__ == "__main__":

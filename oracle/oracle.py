@@ -56,6 +56,8 @@ def _lib(fast=False):
     lib.oracle_blob_blob_force.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, _dp]
     lib.oracle_blob_blob_force.restype = ctypes.c_int
+    lib.oracle_blob_blob_force_radii.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp]
+    lib.oracle_blob_blob_force_radii.restype = ctypes.c_int
     lib.oracle_wall_regularisation.argtypes = [ctypes.c_long, _dp, ctypes.c_double, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_int)]
     lib.oracle_wall_regularisation.restype = ctypes.c_int
@@ -289,4 +291,18 @@ def calc_blob_blob_forces_oracle(r_vectors, *args, **kwargs):
   rc = _lib(kwargs.get("_fast", False)).oracle_blob_blob_force(N, _p(r), _p(L), eps, b, a, _p(out))
   if rc != 0:
     raise RuntimeError("oracle_blob_blob_force failed: %d" % rc)
+  return out.reshape(N, 3)
+
+
+def calc_blob_blob_forces_radii_oracle(r_vectors, radius_blobs, *args, **kwargs):
+  """multi_bodies/forces_numba.py:125-137 (`radii_numba`): one radius per blob, contact distance a_i + a_j."""
+  r = _c(r_vectors).reshape(-1)
+  N = r.size // 3
+  rad = _c(radius_blobs).reshape(-1)
+  L = _c(kwargs.get("periodic_length", np.zeros(3)) if kwargs.get("periodic_length") is not None else np.zeros(3)).reshape(3)
+  out = np.zeros(3 * N)
+  rc = _lib().oracle_blob_blob_force_radii(N, _p(r), _p(rad), _p(L), float(kwargs.get("repulsion_strength")),
+                                           float(kwargs.get("debye_length")), _p(out))
+  if rc != 0:
+    raise RuntimeError("oracle_blob_blob_force_radii failed: %d" % rc)
   return out.reshape(N, 3)

@@ -641,6 +641,32 @@ int oracle_blob_blob_force(long N, const double *r, const double *L, double eps,
   return 0;
 }
 
+/* One radius per blob: contact distance a_i + a_j (multi_bodies/forces_numba.py:73-122). */
+int oracle_blob_blob_force_radii(long N, const double *r, const double *radii, const double *L, double eps, double b,
+                                 double *out) {
+  if (N < 0 || !out || !radii) return 1;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long i = 0; i < N; ++i) {
+    double fx = 0, fy = 0, fz = 0;
+    for (long j = 0; j < N; ++j) {
+      if (i == j) continue;
+      double dr[3];
+      for (int k = 0; k < 3; ++k) {
+        dr[k] = r[3 * j + k] - r[3 * i + k];
+        if (L[k] > 0) dr[k] = wrap_nearest(dr[k], L[k]);
+      }
+      const double a = (radii[i] + radii[j]) * 0.5;
+      double rn = sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+      double f0;
+      if (rn > 2 * a) f0 = -((eps / b) * exp(-(rn - 2.0 * a) / b) / rn);
+      else f0 = -((eps / b) / fmax(rn, 1e-25));
+      fx += f0 * dr[0]; fy += f0 * dr[1]; fz += f0 * dr[2];
+    }
+    out[3 * i] = fx; out[3 * i + 1] = fy; out[3 * i + 2] = fz;
+  }
+  return 0;
+}
+
 /* Height clamp + damping diagonal of the Python wrappers
  * (mobility/mobility.py:52-64 shift_heights uses `<=`, :67-84
  * damping_matrix_B uses `<`).  r_eff gets the clamped copy, bdiag (N entries)

@@ -36,6 +36,8 @@ SYMBOLS = {
     "rmb_body_mobility_dense_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_double, _vp]),
     "rmb_blob_blob_force": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_blob_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_blob_blob_force_radii": (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_blob_blob_force_radii_device": (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_timing_collect": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
     "rmb_timing_reset": (ctypes.c_int, [_vp]),
     "rmb_wave_clock_collect": (ctypes.c_int, [_vp, _vp, ctypes.c_long]),

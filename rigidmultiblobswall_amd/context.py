@@ -159,6 +159,26 @@ class MobilityContext(object):
                                              float(blob_radius), _ptr(out)))
     return out.reshape(self.n_targets, 3)
 
+  def blob_blob_force_radii(self, radius_blobs, repulsion_strength, debye_length):
+    """One radius per blob (contact distance a_i + a_j, forces_numba.py:73-137); host arrays."""
+    rad = _as_f64(radius_blobs, self.n)
+    out = np.empty(3 * self.n_targets)
+    _lib.check(self._lib.rmb_blob_blob_force_radii(self._h, _ptr(rad), float(repulsion_strength), float(debye_length),
+                                                   _ptr(out)))
+    return out.reshape(self.n_targets, 3)
+
+  def blob_blob_force_radii_device(self, radius_blobs, repulsion_strength, debye_length, out=None):
+    import torch
+    if not _is_torch_cuda(radius_blobs) or radius_blobs.numel() != self.n or not radius_blobs.is_contiguous():
+      raise ValueError("radius_blobs must be a contiguous CUDA float64 tensor with n entries")
+    if out is None:
+      out = torch.empty(3 * self.n_targets, dtype=torch.float64, device=radius_blobs.device)
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_blob_blob_force_radii_device(self._h, ctypes.c_void_p(radius_blobs.data_ptr()),
+                                                          float(repulsion_strength), float(debye_length),
+                                                          ctypes.c_void_p(out.data_ptr())))
+    return out
+
   def blob_blob_force_device(self, repulsion_strength, debye_length, blob_radius, out=None, device=None):
     import torch
     if out is None:

@@ -218,9 +218,10 @@ struct ForceArgs {
   double Lx, Ly, Lz, iLx, iLy, iLz;
   double eps_over_b, inv_b, two_a;
   ExpConsts ec;
+  const double* radii;   // per-blob radii (RADII variant: contact distance a_i + a_j, forces_numba.py:73-122) or nullptr
 };
 
-template <bool PERIODIC>
+template <bool PERIODIC, bool RADII = false>
 __global__ __launch_bounds__(kBlock) void force_sweep_kernel(const ForceArgs a) {
   __shared__ double4 tile[kTile];
   __shared__ double red[(kWaves - 1) * 3 * 64];
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(kBlock) void force_sweep_kernel(const ForceArgs a) 
   const long ti = a.tgt_begin + 64L * blockIdx.x + lane;
   const bool valid = ti < a.tgt_end;
   const double4 tp = a.pos[valid ? ti : a.tgt_end - 1];
+  double ra = 0.0;
+  if constexpr (RADII) ra = a.radii[valid ? ti : a.tgt_end - 1];
   const long c0 = (long)blockIdx.y * a.chunk_len;
   long c1 = c0 + a.chunk_len;
   if (c1 > a.n_src) c1 = a.n_src;
@@ -236,7 +239,11 @@ __global__ __launch_bounds__(kBlock) void force_sweep_kernel(const ForceArgs a) 
   for (long j0 = c0; j0 < c1; j0 += kTile) {
     const int n = (int)((c1 - j0 < kTile) ? (c1 - j0) : kTile);
     __syncthreads();
-    for (int t = threadIdx.x; t < n; t += kBlock) tile[t] = a.pos[j0 + t];
+    for (int t = threadIdx.x; t < n; t += kBlock) {
+      double4 p = a.pos[j0 + t];
+      if constexpr (RADII) p.w = a.radii[j0 + t];     // w is free here: forces use unclamped positions (b = 1)
+      tile[t] = p;
+    }
     __syncthreads();
     for (int s = wave; s < n; s += kWaves) {
       const double4 q = tile[s];
@@ -250,8 +257,9 @@ __global__ __launch_bounds__(kBlock) void force_sweep_kernel(const ForceArgs a) 
       const double ir = rsqrt_f64(r2);
       const double r = r2 * ir;
       // far: -(eps/b) exp(-(r-2a)/b)/r ; near (r <= 2a): -(eps/b)/max(r,1e-25) = -(eps/b) min(1/r, 1e25)
-      const bool far = r > a.two_a;
-      const double e = exp_nonpositive(a.ec, far ? (a.two_a - r) * a.inv_b : 0.0);
+      const double two_a = RADII ? ra + q.w : a.two_a;
+      const bool far = r > two_a;
+      const double e = exp_nonpositive(a.ec, far ? (two_a - r) * a.inv_b : 0.0);
       double f0 = -a.eps_over_b * (far ? e * ir : fmin(ir, 1e25));
       if (j0 + s == ti) f0 = 0.0;  // i == j (r2 = 0 -> ir = inf; select, do not multiply)
       if (j0 + s == ti) { dx = 0.0; dy = 0.0; dz = 0.0; }

@@ -375,7 +375,7 @@ rmb::ExpConsts exp_consts() {
   return e;
 }
 
-int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
+int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out, const double* radii = nullptr) {
   if (int rc = check_ready(c)) return rc;
   const long n_tgt = c->tgt_end - c->tgt_begin;
   if (n_tgt == 0) return 0;
@@ -384,7 +384,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   RMB_HIP(hipSetDevice(c->device));
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
+  if (!radii && c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
     // symmetric path: each unordered pair once (F_ji = -F_ij)
     const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
     const size_t acc_bytes = (size_t)3 * n_pad * sizeof(double);
@@ -420,9 +420,11 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     RMB_HIP(hipGetLastError());
     return 0;
   }
-  static int force_occ[2] = {0, 0};
-  const void* ffn = periodic ? (const void*)rmb::force_sweep_kernel<true> : (const void*)rmb::force_sweep_kernel<false>;
-  const long slots = 256L * resident_blocks(ffn, &force_occ[periodic ? 1 : 0]);
+  static int force_occ[2][2] = {{0, 0}, {0, 0}};
+  typedef void (*force_fn)(const rmb::ForceArgs);
+  const force_fn ffn = radii ? (periodic ? (force_fn)rmb::force_sweep_kernel<true, true> : (force_fn)rmb::force_sweep_kernel<false, true>)
+                             : (periodic ? (force_fn)rmb::force_sweep_kernel<true, false> : (force_fn)rmb::force_sweep_kernel<false, false>);
+  const long slots = 256L * resident_blocks((const void*)ffn, &force_occ[radii ? 1 : 0][periodic ? 1 : 0]);
   long n_chunks, chunk_len;
   choose_chunks(n_tgt, c->n, c->opt_chunks, slots, &n_chunks, &chunk_len);
   const long tiles = (n_tgt + 63) / 64;
@@ -444,6 +446,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   a.inv_b = 1.0 / b;
   a.two_a = 2.0 * blob_radius;
   a.ec = exp_consts();
+  a.radii = radii;
   if (n_chunks > 1) {
     if (int rc = c->partial.reserve((size_t)n_chunks * 3 * a.n_tgt_pad * sizeof(double))) return rc;
     a.partial = (double*)c->partial.p;
@@ -452,8 +455,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  if (periodic) hipLaunchKernelGGL((rmb::force_sweep_kernel<true>), grid, block, 0, c->stream, a);
-  else          hipLaunchKernelGGL((rmb::force_sweep_kernel<false>), grid, block, 0, c->stream, a);
+  hipLaunchKernelGGL(ffn, grid, block, 0, c->stream, a);
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
   if (n_chunks > 1) {
@@ -645,6 +647,27 @@ int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double
 
 int rmb_blob_blob_force_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
   return force_device_impl(c, eps, b, blob_radius, out);
+}
+
+int rmb_blob_blob_force_radii_device(rmb_ctx* c, const double* radii_dev, double eps, double b, double* out) {
+  if (!radii_dev) return fail(RMB_ERR_ARG, "null radii pointer");
+  return force_device_impl(c, eps, b, 0.0, out, radii_dev);
+}
+
+int rmb_blob_blob_force_radii(rmb_ctx* c, const double* radii, double eps, double b, double* out) {
+  if (int rc = check_ready(c)) return rc;
+  const long n_tgt = c->tgt_end - c->tgt_begin;
+  if (n_tgt == 0) return 0;
+  if (!out || !radii) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  const size_t ob = (size_t)3 * n_tgt * sizeof(double), rb = (size_t)c->n * sizeof(double);
+  if (int rc = c->out.reserve(ob)) return rc;
+  if (int rc = c->vec2.reserve(rb)) return rc;
+  RMB_HIP(hipMemcpyAsync(c->vec2.p, radii, rb, hipMemcpyHostToDevice, c->stream));
+  if (int rc = force_device_impl(c, eps, b, 0.0, (double*)c->out.p, (const double*)c->vec2.p)) return rc;
+  RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 int rmb_blob_blob_force(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {

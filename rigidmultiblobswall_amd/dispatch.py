@@ -58,6 +58,10 @@ def set_blob_blob_forces(implementation, accept_reference_gpu_names=False, *args
   table = {"None": _zero_forces, "hip": _forces.calc_blob_blob_forces_hip}
   if accept_reference_gpu_names:
     table["pycuda"] = table["hip"]
+  if implementation == "radii_hip":
+    # one radius per blob (multi_bodies_functions.py:270-277)
+    from functools import partial
+    return partial(_forces.calc_blob_blob_forces_radii_hip, radius_blobs=_radius_blobs(kwargs))
   if implementation not in table:
     raise ValueError("blob_blob_force_implementation %r is not served by the HIP engine" % (implementation,))
   return table[implementation]

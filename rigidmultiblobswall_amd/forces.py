@@ -32,3 +32,14 @@ def calc_blob_blob_forces_hip(r_vectors, *args, **kwargs):
   # wall=False: raw positions, no height clamp (the reference passes r_vectors untouched)
   ctx.set_positions(r_vectors, a, L, wall=False)
   return ctx.blob_blob_force(eps, b, a)
+
+
+def calc_blob_blob_forces_radii_hip(r_vectors, radius_blobs, *args, **kwargs):
+  """`radii_numba` twin (multi_bodies/forces_numba.py:125-137): every blob has its own radius and two blobs touch at
+  r = a_i + a_j.  Same keyword arguments as above (`blob_radius` is ignored, as in the reference kernel)."""
+  L = kwargs.get('periodic_length')
+  if L is None:
+    L = np.zeros(3)
+  ctx = _context()
+  ctx.set_positions(r_vectors, 1.0, L, wall=False)
+  return ctx.blob_blob_force_radii(radius_blobs, kwargs.get('repulsion_strength'), kwargs.get('debye_length'))

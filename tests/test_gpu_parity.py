@@ -69,11 +69,14 @@ def test_golden_vectors(mob, path):
 
 @pytest.mark.parametrize("path", golden_files("g5_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
 def test_golden_forces(path):
-  from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip
+  from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_hip, calc_blob_blob_forces_radii_hip
   g = load_golden(path)
-  F = calc_blob_blob_forces_hip(g["r_vectors"], periodic_length=g["periodic_length"],
-                                repulsion_strength=float(g["repulsion_strength"]),
-                                debye_length=float(g["debye_length"]), blob_radius=float(g["blob_radius"]))
+  kw = dict(periodic_length=g["periodic_length"], repulsion_strength=float(g["repulsion_strength"]),
+            debye_length=float(g["debye_length"]), blob_radius=float(g["blob_radius"]))
+  if "radius_blobs" in g:
+    F = calc_blob_blob_forces_radii_hip(g["r_vectors"], g["radius_blobs"], **kw)
+  else:
+    F = calc_blob_blob_forces_hip(g["r_vectors"], **kw)
   assert F.shape == g["force"].shape
   assert rel_err(F, g["force"]) < TOL_D2
 
@@ -515,6 +518,32 @@ def test_symmetric_force_kernel_matches_sweep_and_oracle(Ctx, oracle, L):
   ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=L, repulsion_strength=eps, debye_length=b, blob_radius=a)
   assert rel_err(F_det, ref) < TOL_D2 and rel_err(F_sym, ref) < TOL_D2
   assert np.abs(F_sym.sum(axis=0)).max() < 1e-10 * np.abs(F_sym).sum()
+  ctx.close()
+
+
+def test_radii_forces_vs_oracle_and_equal_radii_limit(Ctx, oracle):
+  """Per-blob radii (forces_numba.py:73-137): against the oracle on a cloud with chunked sources and a target
+  sub-range, and equal to the single-radius kernel when all radii are a."""
+  import torch
+  rng = np.random.RandomState(81)
+  N, a, b, eps = 3000, 0.13, 0.02, 3.92
+  r = rng.rand(N, 3) * (N ** (1.0 / 3.0)) * 2.2 * a
+  rad = a * (0.4 + 1.2 * rng.rand(N))
+  ctx = Ctx(0)
+  for L in (np.zeros(3), np.array([3.0, 3.5, 0.0])):
+    ctx.set_positions(r, 1.0, L, wall=False)
+    F = ctx.blob_blob_force_radii(rad, eps, b)
+    ref = oracle.calc_blob_blob_forces_radii_oracle(r, rad, periodic_length=L, repulsion_strength=eps, debye_length=b)
+    assert rel_err(F, ref) < TOL_D2
+    Fd = ctx.blob_blob_force_radii_device(torch.as_tensor(rad, device="cuda"), eps, b).cpu().numpy().reshape(-1, 3)
+    assert rel_err(Fd, ref) < TOL_D2
+    ctx.set_target_range(1000, 1777)
+    assert rel_err(ctx.blob_blob_force_radii(rad, eps, b), ref[1000:1777]) < TOL_D2
+    ctx.set_target_range(0, N)
+    same = ctx.blob_blob_force_radii(np.full(N, a), eps, b)
+    ctx.set_option("deterministic", 1)
+    assert rel_err(same, ctx.blob_blob_force(eps, b, a)) < 1e-14
+    ctx.set_option("deterministic", 0)
   ctx.close()
 
 

@@ -55,6 +55,8 @@ def test_dispatch_strings():
   assert fn.keywords["function"] is mobility.single_wall_mobility_trans_times_force_source_target_hip
   fn = dispatch.set_mobility_vector_prod("radii_hip_no_wall", radius_blobs=[0.5, 0.5])
   assert fn.keywords["function"] is mobility.no_wall_mobility_trans_times_force_source_target_hip
+  ff = dispatch.set_blob_blob_forces("radii_hip", radius_blobs=[0.1, 0.2])
+  assert ff.func is forces.calc_blob_blob_forces_radii_hip and np.array_equal(ff.keywords["radius_blobs"], [0.1, 0.2])
   fn = dispatch.set_mobility_vector_prod("radii_hip_free_surface", radius_blobs=[0.5])
   assert fn.keywords["function"] is mobility.free_surface_mobility_trans_times_force_source_target_hip
   with pytest.raises(ValueError):

@@ -33,10 +33,12 @@ def test_mobility_kernels_match_reference(oracle, path):
 @pytest.mark.parametrize("path", golden_files("g5_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
 def test_blob_blob_forces_match_reference(oracle, path):
   g = load_golden(path)
-  F = oracle.calc_blob_blob_forces_oracle(g["r_vectors"], periodic_length=g["periodic_length"],
-                                          repulsion_strength=float(g["repulsion_strength"]),
-                                          debye_length=float(g["debye_length"]),
-                                          blob_radius=float(g["blob_radius"]))
+  kw = dict(periodic_length=g["periodic_length"], repulsion_strength=float(g["repulsion_strength"]),
+            debye_length=float(g["debye_length"]), blob_radius=float(g["blob_radius"]))
+  if "radius_blobs" in g:       # forces_numba.py:125-137, one radius per blob
+    F = oracle.calc_blob_blob_forces_radii_oracle(g["r_vectors"], g["radius_blobs"], **kw)
+  else:
+    F = oracle.calc_blob_blob_forces_oracle(g["r_vectors"], **kw)
   assert F.shape == g["force"].shape
   assert rel_err(F, g["force"]) < TOL
 
