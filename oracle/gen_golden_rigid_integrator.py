@@ -202,6 +202,7 @@ def main():
       ("g9_rigid_stoch_EM", "stochastic_EM", mixed(1, 3), 2, dict(kT=kT, seed=7)),
       ("g9_rigid_stoch_traction_EM", "stochastic_traction_EM", mixed(1, 3), 2, dict(kT=kT, seed=8)),
       ("g9_rigid_stoch_traction_AB", "stochastic_traction_AB", mixed(1, 3), 3, dict(kT=kT, seed=9)),
+      ("g9_rigid_stoch_GDC_RFD", "stochastic_GDC_RFD", mixed(1, 3), 2, dict(kT=kT, seed=11)),
       ("g9_rigid_obstacle_det_euler", "deterministic_forward_euler", with_obstacle(3), 3, {}),
       ("g9_rigid_obstacle_slip_trapz", "stochastic_Slip_Trapz", with_obstacle(3), 2, dict(kT=kT, seed=10)),
       ("g9_rigid_stoch_slip_trapz_16shells", "stochastic_Slip_Trapz", mixed(0, 16), 2, dict(kT=kT, seed=6)),

@@ -9,7 +9,7 @@ to solver tolerance (tests/golden/g9_*, recorded from the reference's own multi_
   deterministic_forward_euler (:75)   deterministic_adams_bashforth (:142)   deterministic_midpoint (:188)
   stochastic_EM (:262)                stochastic_first_order_RFD (:326)      stochastic_adams_bashforth (:431)
   stochastic_traction_EM (:626)       stochastic_traction_AB (:803)
-  stochastic_Slip_Trapz (:925)        stochastic_Slip_Mid (:1214)
+  stochastic_Slip_Trapz (:925)        stochastic_GDC_RFD (:1048)             stochastic_Slip_Mid (:1214)
 
 Where things live: locations / quaternions are two tensors in HBM; a step is a sequence of
 `RigidSuspension.set_configuration` (batched rotation + K rebuild + position pack), saddle-point solves
@@ -18,7 +18,7 @@ Where things live: locations / quaternions are two tensors in HBM; a step is a s
 objects for every one of those (e.g. :86-91, :1003-1007).
 
 Not built: articulated bodies / constraints, prescribed kinematics (obstacles), the dense-algebra variants
-(`*_dense_algebra`, `Fixman`, `*_DLA`: O(N^3) teaching versions) and `stochastic_GDC_RFD`.
+(`*_dense_algebra`, `Fixman`, `*_DLA`: O(N^3) teaching versions).
 """
 import math
 
@@ -394,6 +394,52 @@ class RigidIntegrator(object):
 
   def stochastic_traction_AB(self, dt, *args, **kwargs):
     return self._traction_scheme(dt, True, kwargs.get("step"))
+
+  def _identity_unconstrained_velocity(self, slip):
+    """U = (K^T K)^+ K^T (-slip) per body: the unconstrained mobility problem with M = I and no force
+    (multi_bodies.py:693-711, `block_diagonal_preconditioner_identity`), at the bound configuration."""
+    out = torch.empty((self.Nbodies, 6), dtype=torch.float64, device=self.device)
+    for g in self.susp.groups:
+      KtK = torch.bmm(g.K.transpose(1, 2), g.K)
+      rhs = -torch.bmm(g.K.transpose(1, 2), self.susp._blobs_of(slip, g).unsqueeze(-1))
+      self.susp._put_bodies(out, g, torch.bmm(torch.linalg.pinv(KtK), rhs))
+    return out.reshape(-1)
+
+  def stochastic_GDC_RFD(self, dt, *args, **kwargs):
+    """Generalised drift-corrector scheme (:1048-1211): Brownian velocities of the unconstrained M = I problem at q^n
+    and at a randomly displaced configuration give div(U) by a random finite difference; the mid-point rigid solve
+    is then advanced with the step corrected by (1 + dt/2 div U).  1 rigid solve + 3 Lanczos per step."""
+    n3 = 3 * self.Nblobs
+    step = kwargs.get("step")
+    factor = math.sqrt(2 * self.kT / dt)
+    Lb = self.body_length.unsqueeze(1)
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      W = self._normal(n3)
+      self._move(*old)
+      self._refresh_preconditioner(step)
+      U_n = self._identity_unconstrained_velocity(-self._noise(W, factor))
+      WRFD = self._normal(6 * self.Nbodies).view(-1, 6)
+      self._move(old[0] + self.rf_delta * Lb * WRFD[:, 0:3],
+                 quaternion_multiply_torch(quaternion_from_rotation_torch(self.rf_delta * WRFD[:, 3:6]), old[1]))
+      self._refresh_preconditioner(step)
+      U_rfd = self._identity_unconstrained_velocity(-self._noise(W, factor))
+      dU = (U_rfd - U_n).view(-1, 6)
+      div = float(((dU[:, 0:3] * WRFD[:, 0:3]).sum(dim=1) / (self.rf_delta * self.body_length)).sum() +
+                  (dU[:, 3:6] * WRFD[:, 3:6]).sum() / self.rf_delta)
+      mid = self._advance(old[0], old[1], U_n, 0.5 * dt)
+      if not self._valid(*mid):
+        self._move(*old)
+        continue
+      self._move(*mid)
+      self._refresh_preconditioner(step)
+      U_mid = self._velocities(self.solve_mobility_problem(noise=self._noise(W, factor), guess=True))
+      new = self._advance(old[0], old[1], U_mid, dt * (1.0 + 0.5 * dt * div))
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
 
   def _slip_scheme(self, dt, trapezoidal, step):
     """Shared body of stochastic_Slip_Trapz (:925-1045) and stochastic_Slip_Mid (:1214-1343): predictor with the
