@@ -365,11 +365,12 @@ class RollersIntegrator(object):
   def deterministic_adams_bashforth(self, dt, *args, **kwargs):
     while True:
       det_velocity, _ = self._det()
-      if self.first_step is False:
+      if self.first_step is False and self.velocities_previous_step is not None:
         velocity = 1.5 * det_velocity - 0.5 * self.velocities_previous_step
       else:
         velocity = det_velocity
-        self.first_step = False     # as the reference: cleared even if the step is then rejected (:221)
+        self.first_step = False     # the reference clears it here even if the step is then rejected (:221) and would
+                                    # fail on the retry (None previous velocities); the retry is forward Euler again
       r_new = self.location + dt * velocity.view(-1, 3)
       if self._valid(r_new):
         self.velocities_previous_step = det_velocity
@@ -384,7 +385,7 @@ class RollersIntegrator(object):
         stoch_velocity = self.compute_stochastic_linear_velocity(dt)
       else:
         stoch_velocity = self.compute_stochastic_linear_velocity_uncorrelated(dt)
-      if self.first_step is False:
+      if self.first_step is False and self.velocities_previous_step is not None:
         velocity = 1.5 * det_velocity - 0.5 * self.velocities_previous_step + stoch_velocity
       else:
         velocity = det_velocity + stoch_velocity

@@ -1,0 +1,58 @@
+"""Physics checks of the Brownian integrators on the GPU: blobs above a wall in gravity + wall repulsion must keep the
+Gibbs-Boltzmann height distribution P(h) ~ exp(-U(h)/kT) whatever their hydrodynamic interactions.  That holds only if
+the noise has covariance 2 kT M / dt AND the stochastic drift kT div(M) is right -- dropping the drift term moves the mean
+height by -3 % within 200 steps (control below), the correct integrators stay within 1 %.
+(tools/exp_equilibrium.py is the stand-alone version; parameters of multi_bodies/examples/rollers/inputfile_rollers.dat.)"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_roller_schemes_keep_the_equilibrium_height_distribution():
+  import exp_equilibrium as E
+  ab = E.main(scheme="stochastic_adams_bashforth_rollers")
+  assert ab["rejected"] == 0
+  assert abs(ab["mean"] / ab["analytic_mean"] - 1.0) < 0.01, ab
+  assert abs(ab["var"] / ab["analytic_var"] - 1.0) < 0.08, ab
+  tr = E.main(scheme="stochastic_trapezoidal_rollers")
+  assert abs(tr["mean"] / tr["analytic_mean"] - 1.0) < 0.01, tr
+  control = E.main(drift=False)
+  assert control["mean"] / control["analytic_mean"] - 1.0 < -0.02, control      # the check has teeth
+
+
+def test_rigid_brownian_scheme_keeps_the_equilibrium_height_distribution():
+  """The rigid-multiblob machinery (preconditioned Lanczos, RFD on M and K^T, three GMRES solves per step) on bodies of
+  ONE blob each: same analytic distribution as the rollers."""
+  import exp_equilibrium as E
+  from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+  m1, var, h, cdf = E.analytic_moments()
+  N, steps, dt = 1024, 160, 0.016
+  rng = np.random.RandomState(5)
+  side = int(math.ceil(math.sqrt(N)))
+  ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:N].astype(float)
+  loc = np.empty((N, 3))
+  loc[:, :2] = ij * 5.0 * E.a
+  loc[:, 2] = np.interp(rng.rand(N), cdf, h)
+  quat = np.tile([1.0, 0.0, 0.0, 0.0], (N, 1))
+  integ = RigidIntegrator([np.zeros((1, 3))] * N, loc, quat, "stochastic_Slip_Trapz", E.a, E.eta, tolerance=1e-4,
+                          device="cuda:0", seed=7)
+  integ.kT, integ.g, integ.repulsion_strength_wall, integ.debye_length_wall = E.kT, E.mg, E.ew, E.bw
+  acc, count = 0.0, 0
+  for step in range(steps):
+    integ.advance_time_step(dt, step=step)
+    if step >= steps // 4:
+      acc += float(integ.location[:, 2].mean())
+      count += 1
+  assert integ.invalid_configuration_count == 0
+  assert abs(acc / count / m1 - 1.0) < 0.015, (acc / count, m1)
+  integ.close()
