@@ -85,6 +85,10 @@ class RigidIntegrator(object):
     self.update_PC = 1
     self.warm_start = False
     self.first_guess = None
+    # Tolerance of the rigid solve that only produces the random-finite-difference displacement W_RFD of the Slip schemes
+    # (None = solver tolerance, as the reference).  That solve sets the direction of a finite difference whose result is
+    # a kT-order correction, so a loose value (1e-2) cuts ~20 % of the pair sweeps of a step without visible bias.
+    self.rfd_solve_tolerance = None
     self.print_residual = False
     self.max_retries = 1000
     self._pc_built = False
@@ -178,7 +182,7 @@ class RigidIntegrator(object):
     return torch.zeros(3 * self.Nblobs, dtype=torch.float64, device=self.device)
 
   # ---- the rigid solve ------------------------------------------------------------------------------
-  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None, guess=False):
+  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None, guess=False, tolerance=None):
     """[M -K; -K^T 0][lambda; U] = [slip - noise; -(F + noise_FT)] at the bound configuration
     (quaternion_integrator_multi_bodies.py:1441-1547).  Returns the full solution tensor.
     guess=True marks the calls the reference makes with `x0 = self.first_guess, save_first_guess = True`.  There the
@@ -198,7 +202,8 @@ class RigidIntegrator(object):
     x0 = None
     if guess and self.warm_start and self.first_guess is not None:
       x0 = self.first_guess * float(torch.linalg.norm(RHS))
-    sol, info = self.susp.solve(RHS, tol=self.tolerance, restart=60, maxiter=1000, x0=x0)
+    sol, info = self.susp.solve(RHS, tol=self.tolerance if tolerance is None else tolerance, restart=60, maxiter=1000,
+                                x0=x0)
     self.det_iterations_count += info["iterations"]
     if guess and info.get("rhs_norm", 0.0) > 0:
       self.first_guess = sol / info["rhs_norm"]
@@ -463,7 +468,7 @@ class RigidIntegrator(object):
         noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))
       U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1, guess=True)).clone()
       rhs = torch.cat([-W_slip, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
-      W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs))
+      W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs, tolerance=self.rfd_solve_tolerance))
       self._move(*self._advance(old[0], old[1], W_RFD, self.rf_delta))
       M_rfdxW = self.susp.mobility_times_lambda(W_slip)
       KT_rfdxW = self.susp.KT_times_lambda(W_slip)

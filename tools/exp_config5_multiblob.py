@@ -22,6 +22,8 @@ integ.debye_length_wall = integ.debye_length = 0.0406
 torque = 8 * math.pi * eta * R ** 3 * 62.8
 FT = torch.zeros((nb, 6), dtype=torch.float64, device="cuda:0"); FT[:, 4] = torque
 integ.external_force_torque = lambda it: FT
+if len(sys.argv) > 4:
+  integ.rfd_solve_tolerance = float(sys.argv[4])
 torch.cuda.synchronize()
 print("setup %.2f s, blobs %d" % (time.perf_counter() - t0, integ.Nblobs), flush=True)
 for step in range(steps):
