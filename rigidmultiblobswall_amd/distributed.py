@@ -207,6 +207,15 @@ class ReplicatedContext(object):
     if ctx is not None:
       ctx.set_stream(stream_ptr)
 
+  def sync_scalars(self, t):
+    """Make rank 0's copy of a small control tensor (Hessenberg column, Lanczos coefficients) the one every rank acts
+    on.  The replicated Krylov loops branch on such scalars; identical hardware and identical inputs already give
+    identical values, this broadcast (a few bytes per iteration) turns that into a guarantee, so no rank can leave a
+    loop one iteration early and strand the others in a collective."""
+    if self.sm.world > 1:
+      dist.broadcast(t, src=dist.get_global_rank(self.sm.group, 0) if self.sm.group is not None else 0, group=self.sm.group)
+    return t
+
   def set_positions(self, r_vectors, a, periodic_length=None, wall=True):
     self.sm.set_replicated_positions(r_vectors, a, periodic_length, wall)
     self.n = self.sm.n

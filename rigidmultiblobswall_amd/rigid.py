@@ -344,7 +344,8 @@ class RigidSuspension(object):
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
     sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
-                                           restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm)
+                                           restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
+                                           sync=getattr(self.ctx, "sync_scalars", None))
     info["rhs_norm"] = nrm
     return sol * nrm, info
 
@@ -395,10 +396,10 @@ class RigidSuspension(object):
 
     return stochastic_forcing_lanczos(factor=factor, tolerance=tol, dim=3 * self.n_blobs, mobility_mult=mobility_pc,
                                       L_mult=lambda x: self._blockdiag(x, "Lchol"), z=z, print_residual=print_residual,
-                                      device=self.device)
+                                      device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
 
 
-def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None):
+def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None):
   """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
   Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after maxiter iterations in total.
   Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host.
@@ -406,12 +407,19 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
   quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
   dev = b.device
   n = b.numel()
-  bnorm = float(torch.linalg.norm(b))
+
+  def host_norm(v):
+    t = torch.linalg.vector_norm(v).reshape(1)
+    if sync is not None:
+      sync(t)
+    return float(t)
+
+  bnorm = host_norm(b)
   y = torch.zeros(n, dtype=torch.float64, device=dev)
   if x0 is not None:
     b = b - A(x0)
   r = b.clone()
-  beta = float(torch.linalg.norm(r))
+  beta = host_norm(r)
   its = 0
   res = beta / bnorm if bnorm > 0 else 0.0
   history = []
@@ -434,6 +442,8 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
       w = torch.addmv(w, Vj.t(), h2, alpha=-1.0)
       torch.add(h, h2, out=colbuf[:j + 1])
       torch.linalg.vector_norm(w, out=colbuf[j + 1])
+      if sync is not None:                                         # multi-rank: all ranks act on rank 0's numbers
+        sync(colbuf[:j + 2])
       col = colbuf[:j + 2].cpu().numpy()                          # the one host transfer of the iteration
       H[:j + 2, j] = col
       if col[-1] > 0:
@@ -458,7 +468,7 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
     y = y + V[:k_used].t() @ torch.as_tensor(coef, device=dev)
     if res > tol and its < maxiter:                                # restart: true residual
       r = b - A(Minv(y))
-      beta = float(torch.linalg.norm(r))
+      beta = host_norm(r)
       res = beta / bnorm
   x = Minv(y)
   if x0 is not None:

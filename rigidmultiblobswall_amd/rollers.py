@@ -169,7 +169,8 @@ class RollersIntegrator(object):
       if nrm > 0:
         rhs = rhs / nrm
       sol, info = gmres_right_preconditioned(lambda x: self._product("rr", x), lambda x: x, rhs, tol=self.tolerance,
-                                             restart=20, maxiter=1000, x0=self.deterministic_torque_previous_step)
+                                             restart=20, maxiter=1000, x0=self.deterministic_torque_previous_step,
+                                             sync=getattr(self.ctx, "sync_scalars", None))
       self.det_iterations_count += info["iterations"]
       self.deterministic_torque_previous_step = sol
       torque = sol * nrm if nrm > 0 else sol
@@ -223,7 +224,7 @@ class RollersIntegrator(object):
   def _lanczos(self, mult, dim, z, dt):
     noise, its = stochastic_forcing_lanczos(factor=math.sqrt(2 * self.kT / dt), tolerance=self.tolerance, dim=dim,
                                             mobility_mult=mult, z=z, print_residual=self.print_residual,
-                                            device=self.device)
+                                            device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
     self.stoch_iterations_count += its
     return noise
 
@@ -288,7 +289,7 @@ class RollersIntegrator(object):
       if nrm > 0:
         rhs = rhs / nrm
       sol, info = gmres_right_preconditioned(lambda x: self._product("rr", x), lambda x: x, rhs, tol=self.tolerance,
-                                             restart=20, maxiter=1000)
+                                             restart=20, maxiter=1000, sync=getattr(self.ctx, "sync_scalars", None))
       self.det_iterations_count += info["iterations"]
       torque = sol * nrm if nrm > 0 else sol
       v_stoch = self._product("tr", torque)

@@ -20,7 +20,7 @@ import torch
 
 
 def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=None, mobility=None,
-                               mobility_mult=None, L_mult=None, z=None, print_residual=False, device=None):
+                               mobility_mult=None, L_mult=None, z=None, print_residual=False, device=None, sync=None):
   """mobility_mult: callable(torch tensor (dim,)) -> torch tensor (dim,) on the same device
   (e.g. lambda v: ctx.matvec_device('tt', v, eta)); or `mobility` = dense torch/numpy matrix.
   z: numpy array or torch tensor; drawn from N(0,1) when None.  Returns (noise tensor, iterations)."""
@@ -55,7 +55,10 @@ def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=No
     hd = torch.dot(w, V[i])
     w = w - hd * V[i]
     hs = torch.linalg.norm(w)
-    hd_f, hs_f = (float(x) for x in torch.stack([hd, hs]).cpu())
+    pair = torch.stack([hd, hs])
+    if sync is not None:           # multi-rank replicated loop: every rank acts on rank 0's coefficients
+      sync(pair)
+    hd_f, hs_f = (float(x) for x in pair.cpu())
     h_diag.append(hd_f)
     h_sup.append(hs_f)
     if hs_f > 0:
