@@ -218,114 +218,129 @@ def main():
                                       % (len(times), N, cores, hw_threads)}
 
   if not args.no_sweep:
-    sweep = []
-    for nb, st, wu in ((100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
-      rs = run_config(torch, dist, sm, backend, nb, st, wu, world, rank, device)
-      pairs = float(nb) * nb / world
-      sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
-                    "kernel_ms_avg": round(rs["kern_ms"], 3),
-                    "valu_fp64_tflops": round(211.0 * pairs / (rs["kern_ms"] * 1e-3) / 1e12, 2),
-                    "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4),
-                    "launch": rs["launch"]})
-    line["sweep"] = sweep
+    try:
+      sweep = []
+      for nb, st, wu in ((100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
+        rs = run_config(torch, dist, sm, backend, nb, st, wu, world, rank, device)
+        pairs = float(nb) * nb / world
+        sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
+                      "kernel_ms_avg": round(rs["kern_ms"], 3),
+                      "valu_fp64_tflops": round(211.0 * pairs / (rs["kern_ms"] * 1e-3) / 1e12, 2),
+                      "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4),
+                      "launch": rs["launch"]})
+      line["sweep"] = sweep
+    except Exception as exc:      # an extra must never cost the headline line
+      line['sweep'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
   if world == 1 and not args.no_sweep:
-    # BASELINE.json configs[2]: 2048 rollers x 12-blob shells, full GMRES mobility solve on 1 GPU (reported
-    # beside the headline, not part of `value`)
-    from rigidmultiblobswall_amd import structures as st
-    from rigidmultiblobswall_amd.rigid import RigidSuspension
-    R, eta3 = 1.0155, 0.957e-3
-    shell = st.icosahedron_shell(0.792079207921 * R)
-    a3 = st.min_blob_separation(shell) / 2
-    nb = 2048
-    loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
-    FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
-    rs = RigidSuspension([shell] * nb, loc, quat, a3, eta3, device=device)
-    rs.solve_mobility_problem(force_torque=FT, tol=1e-8)        # warm-up (library initialisation)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
-    torch.cuda.synchronize(device)
-    line["config3_gmres"] = {"bodies": nb, "blobs": rs.n_blobs, "tolerance": 1e-8, "iterations": info["iterations"],
-                             "residual": float(info["residual"]), "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3)}
-    rs.close()
+    try:
+      # BASELINE.json configs[2]: 2048 rollers x 12-blob shells, full GMRES mobility solve on 1 GPU (reported
+      # beside the headline, not part of `value`)
+      from rigidmultiblobswall_amd import structures as st
+      from rigidmultiblobswall_amd.rigid import RigidSuspension
+      R, eta3 = 1.0155, 0.957e-3
+      shell = st.icosahedron_shell(0.792079207921 * R)
+      a3 = st.min_blob_separation(shell) / 2
+      nb = 2048
+      loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
+      FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
+      rs = RigidSuspension([shell] * nb, loc, quat, a3, eta3, device=device)
+      rs.solve_mobility_problem(force_torque=FT, tol=1e-8)        # warm-up (library initialisation)
+      torch.cuda.synchronize(device)
+      t0 = time.perf_counter()
+      U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
+      torch.cuda.synchronize(device)
+      line["config3_gmres"] = {"bodies": nb, "blobs": rs.n_blobs, "tolerance": 1e-8, "iterations": info["iterations"],
+                               "residual": float(info["residual"]), "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3)}
+      rs.close()
+    except Exception as exc:      # an extra must never cost the headline line
+      line['config3_gmres'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
   if not args.no_sweep:
-    # BASELINE.json configs[4] recipe: 2.6e5 single-blob rollers, Brownian Adams-Bashforth steps = forces kernel +
-    # M_tt F + M_tr T + Lanczos M^{1/2} z + 2 random-finite-difference products per step; physical parameters of
-    # multi_bodies/examples/rollers/inputfile_rollers.dat.  On N ranks the same replicated stepper runs on every
-    # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline.
-    from rigidmultiblobswall_amd import structures as st
-    from rigidmultiblobswall_amd.distributed import ReplicatedContext
-    from rigidmultiblobswall_amd.rollers import RollersIntegrator
-    n5, a5 = 262144, 0.656
-    loc5, _, _ = st.roller_monolayer(n5, radius=a5, seed=7)
-    integ = RollersIntegrator(loc5, "stochastic_adams_bashforth_rollers", a5, 1.0e-3, tolerance=1e-3, device=device,
-                              ctx=ReplicatedContext(sm), seed=11)
-    integ.kT, integ.g = 0.0041419464, 0.0024892
-    integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
-    integ.debye_length = integ.debye_length_wall = 0.0656
-    integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
-    integ.advance_time_step(0.016)      # warm-up (first step is forward Euler)
-    torch.cuda.synchronize(device)
-    if world > 1:
-      dist.barrier()
-    p0, l0, n5_steps = integ.mobility_products, integ.stoch_iterations_count, 2
-    t0 = time.perf_counter()
-    for _ in range(n5_steps):
-      integ.advance_time_step(0.016)
-    torch.cuda.synchronize(device)
-    if world > 1:
-      dist.barrier()
-    dt5 = time.perf_counter() - t0
-    if world > 1:
-      t = torch.tensor([dt5], dtype=torch.float64, device=device)
-      dist.all_reduce(t, op=dist.ReduceOp.MAX)
-      dt5 = float(t.item())
-    line["config5_rollers"] = {"rollers": n5, "scheme": integ.scheme, "lanczos_tolerance": 1e-3, "steps": n5_steps,
-                               "s_per_step": round(dt5 / n5_steps, 4),
-                               "mobility_products_per_step": (integ.mobility_products - p0) / n5_steps,
-                               "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
-                               "rejected_steps": integ.invalid_configuration_count}
+    try:
+      # BASELINE.json configs[4] recipe: 2.6e5 single-blob rollers, Brownian Adams-Bashforth steps = forces kernel +
+      # M_tt F + M_tr T + Lanczos M^{1/2} z + 2 random-finite-difference products per step; physical parameters of
+      # multi_bodies/examples/rollers/inputfile_rollers.dat.  On N ranks the same replicated stepper runs on every
+      # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline.
+      from rigidmultiblobswall_amd import structures as st
+      from rigidmultiblobswall_amd.distributed import ReplicatedContext
+      from rigidmultiblobswall_amd.rollers import RollersIntegrator
+      n5, a5 = 262144, 0.656
+      loc5, _, _ = st.roller_monolayer(n5, radius=a5, seed=7)
+      integ = RollersIntegrator(loc5, "stochastic_adams_bashforth_rollers", a5, 1.0e-3, tolerance=1e-3, device=device,
+                                ctx=ReplicatedContext(sm), seed=11)
+      integ.kT, integ.g = 0.0041419464, 0.0024892
+      integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
+      integ.debye_length = integ.debye_length_wall = 0.0656
+      integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
+      integ.advance_time_step(0.016)      # warm-up (first step is forward Euler)
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      p0, l0, n5_steps = integ.mobility_products, integ.stoch_iterations_count, 2
+      t0 = time.perf_counter()
+      for _ in range(n5_steps):
+        integ.advance_time_step(0.016)
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      dt5 = time.perf_counter() - t0
+      if world > 1:
+        t = torch.tensor([dt5], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt5 = float(t.item())
+      line["config5_rollers"] = {"rollers": n5, "scheme": integ.scheme, "lanczos_tolerance": 1e-3, "steps": n5_steps,
+                                 "s_per_step": round(dt5 / n5_steps, 4),
+                                 "mobility_products_per_step": (integ.mobility_products - p0) / n5_steps,
+                                 "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
+                                 "rejected_steps": integ.invalid_configuration_count}
+    except Exception as exc:      # an extra must never cost the headline line
+      line['config5_rollers'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
-    # The same config with rigid multiblobs instead of single-blob rollers: 21845 shells x 12 blobs = 262140 blobs,
-    # stochastic_Slip_Trapz (3 GMRES rigid solves + preconditioned Lanczos + forces kernel per step), parameters of
-    # multi_bodies/examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat (tolerance 1e-4, constant torque).
-    import math
-    from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
-    R5, eta5, nb5 = 1.0155, 0.957e-3, 21845
-    shell5 = st.icosahedron_shell(0.792079207921 * R5)
-    a5b = st.min_blob_separation(shell5) / 2
-    loc5, quat5, _ = st.roller_monolayer(nb5, radius=R5, seed=5)
-    ri = RigidIntegrator([shell5] * nb5, loc5, quat5, "stochastic_Slip_Trapz", a5b, eta5, tolerance=1e-4, device=device,
-                         ctx=ReplicatedContext(sm), seed=1)
-    ri.kT, ri.g = 0.0040749841, 0.0303 / 12
-    ri.repulsion_strength_wall = ri.repulsion_strength = 0.0326
-    ri.debye_length_wall = ri.debye_length = 0.0406
-    FT5 = torch.zeros((nb5, 6), dtype=torch.float64, device=device)
-    FT5[:, 4] = 8 * math.pi * eta5 * R5 ** 3 * 62.8
-    ri.external_force_torque = lambda it: FT5
-    ri.advance_time_step(0.01, step=0)          # warm-up
-    torch.cuda.synchronize(device)
-    if world > 1:
-      dist.barrier()
-    d0, l0, m0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count
-    t0 = time.perf_counter()
-    ri.advance_time_step(0.01, step=1)
-    torch.cuda.synchronize(device)
-    if world > 1:
-      dist.barrier()
-    dt5 = time.perf_counter() - t0
-    if world > 1:
-      t = torch.tensor([dt5], dtype=torch.float64, device=device)
-      dist.all_reduce(t, op=dist.ReduceOp.MAX)
-      dt5 = float(t.item())
-    line["config5_multiblob_brownian"] = {"bodies": nb5, "blobs": ri.Nblobs, "scheme": ri.scheme, "solver_tolerance": 1e-4,
-                                          "steps": 1, "s_per_step": round(dt5, 4),
-                                          "gmres_iterations_per_step": ri.det_iterations_count - d0,
-                                          "lanczos_iterations_per_step": ri.stoch_iterations_count - l0,
-                                          "pair_sweeps_per_step": ri.susp.matvec_count - m0,
-                                          "rejected_steps": ri.invalid_configuration_count}
+  if not args.no_sweep:
+    try:
+      # The same config with rigid multiblobs instead of single-blob rollers: 21845 shells x 12 blobs = 262140 blobs,
+      # stochastic_Slip_Trapz (3 GMRES rigid solves + preconditioned Lanczos + forces kernel per step), parameters of
+      # multi_bodies/examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat (tolerance 1e-4, constant torque).
+      import math
+      from rigidmultiblobswall_amd import structures as st
+      from rigidmultiblobswall_amd.distributed import ReplicatedContext
+      from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+      R5, eta5, nb5 = 1.0155, 0.957e-3, 21845
+      shell5 = st.icosahedron_shell(0.792079207921 * R5)
+      a5b = st.min_blob_separation(shell5) / 2
+      loc5, quat5, _ = st.roller_monolayer(nb5, radius=R5, seed=5)
+      ri = RigidIntegrator([shell5] * nb5, loc5, quat5, "stochastic_Slip_Trapz", a5b, eta5, tolerance=1e-4, device=device,
+                           ctx=ReplicatedContext(sm), seed=1)
+      ri.kT, ri.g = 0.0040749841, 0.0303 / 12
+      ri.repulsion_strength_wall = ri.repulsion_strength = 0.0326
+      ri.debye_length_wall = ri.debye_length = 0.0406
+      FT5 = torch.zeros((nb5, 6), dtype=torch.float64, device=device)
+      FT5[:, 4] = 8 * math.pi * eta5 * R5 ** 3 * 62.8
+      ri.external_force_torque = lambda it: FT5
+      ri.advance_time_step(0.01, step=0)          # warm-up
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      d0, l0, m0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count
+      t0 = time.perf_counter()
+      ri.advance_time_step(0.01, step=1)
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      dt5 = time.perf_counter() - t0
+      if world > 1:
+        t = torch.tensor([dt5], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt5 = float(t.item())
+      line["config5_multiblob_brownian"] = {"bodies": nb5, "blobs": ri.Nblobs, "scheme": ri.scheme, "solver_tolerance": 1e-4,
+                                            "steps": 1, "s_per_step": round(dt5, 4),
+                                            "gmres_iterations_per_step": ri.det_iterations_count - d0,
+                                            "lanczos_iterations_per_step": ri.stoch_iterations_count - l0,
+                                            "pair_sweeps_per_step": ri.susp.matvec_count - m0,
+                                            "rejected_steps": ri.invalid_configuration_count}
+    except Exception as exc:      # an extra must never cost the headline line
+      line['config5_multiblob_brownian'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
   if rank == 0:
     print(json.dumps(line), flush=True)
