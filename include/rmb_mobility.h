@@ -92,6 +92,15 @@ int rmb_matvec_device(rmb_ctx* ctx, int kind, int in_plane, const double* vec_de
  * caller all-reduces (or reduce-scatters) the outputs.  No reference counterpart (single device). */
 int rmb_matvec_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_dev, double eta, double* out_dev,
                                 long shard, long nshards);
+/* Two source vectors in ONE pass over the pairs (tt only): out_a = M vec_a, out_b = M vec_b.  The vector-independent
+ * part of every pair (geometry, both inverse square roots, RPY and wall coefficients) is evaluated once, so the call
+ * costs ~0.66 of two rmb_matvec_device calls.  Serves solvers that advance two right-hand sides in lockstep with the
+ * same mobility (the Brownian-slip and RFD solves of quaternion_integrator_multi_bodies.py:985-996).  Falls back to two
+ * single products where the symmetric kernel does not apply (n < 128, "deterministic", target sub-ranges). */
+int rmb_matvec2_device(rmb_ctx* ctx, int kind, const double* vec_a_dev, const double* vec_b_dev, double eta,
+                       double* out_a_dev, double* out_b_dev);
+int rmb_matvec2_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_a_dev, const double* vec_b_dev, double eta,
+                                 double* out_a_dev, double* out_b_dev, long shard, long nshards);
 
 /* Dense translation-translation mobility of each rigid body's own blobs (building block of the
  * block-diagonal preconditioner, multi_bodies/multi_bodies.py:516-531; replaces body/body.py:186-191 ->

@@ -31,6 +31,9 @@ SYMBOLS = {
     "rmb_set_target_range": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long]),
     "rmb_matvec": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
     "rmb_matvec_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_matvec2_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp, _vp]),
+    "rmb_matvec2_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp, _vp, ctypes.c_long,
+                                                    ctypes.c_long]),
     "rmb_matvec_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_long,
                                                    ctypes.c_long]),
     "rmb_body_mobility_dense_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_double, _vp]),

@@ -139,6 +139,28 @@ class MobilityContext(object):
                                                      ctypes.c_void_p(out.data_ptr()), int(shard), int(nshards)))
     return out
 
+  def matvec2_device(self, kind, vec_a, vec_b, eta, out_a=None, out_b=None, shard=0, nshards=1):
+    """Two tt products in one pass over the pairs: returns (M vec_a, M vec_b) (rmb_matvec2_device; with nshards > 1
+    the contribution of one pair shard, to be summed over shards).  out_a / out_b: optional contiguous 3n tensors."""
+    import torch
+    k = _lib.KINDS[kind] if isinstance(kind, str) else int(kind)
+    for v in (vec_a, vec_b):
+      if not _is_torch_cuda(v) or v.numel() != 3 * self.n or not v.is_contiguous():
+        raise ValueError("vectors must be contiguous CUDA float64 tensors with 3*n entries")
+    outs = []
+    for o in (out_a, out_b):
+      if o is None:
+        o = torch.empty(3 * self.n, dtype=torch.float64, device=vec_a.device)
+      elif not _is_torch_cuda(o) or o.numel() != 3 * self.n or not o.is_contiguous():
+        raise ValueError("outputs must be contiguous CUDA float64 tensors with 3*n entries")
+      outs.append(o)
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_matvec2_pairshard_device(self._h, k, ctypes.c_void_p(vec_a.data_ptr()),
+                                                      ctypes.c_void_p(vec_b.data_ptr()), float(eta),
+                                                      ctypes.c_void_p(outs[0].data_ptr()),
+                                                      ctypes.c_void_p(outs[1].data_ptr()), int(shard), int(nshards)))
+    return outs[0], outs[1]
+
   def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
     """Dense (3 n_b x 3 n_b) tt mobility of every listed body (int64 CUDA tensor of first-blob indices)."""
     import torch

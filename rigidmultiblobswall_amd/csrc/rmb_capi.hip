@@ -13,6 +13,7 @@
 
 #include "matvec_kernels.h"
 #include "sym_kernels.h"
+#include "sym2_kernels.h"
 #include "dense_kernels.h"
 #include "st_kernels.h"
 
@@ -206,6 +207,18 @@ template <int KIND, bool WALL, bool PER> SymEntry make_sym_entry() {
 SymEntry g_sym[4][2][2] = {RMB_SYM_ROW(rmb::KIND_TT), RMB_SYM_ROW(rmb::KIND_TR), RMB_SYM_ROW(rmb::KIND_RT), RMB_SYM_ROW(rmb::KIND_RR)};
 #undef RMB_SYM_ROW
 
+// Global SoA accumulators of the symmetric kernels: [2][3][n_pad] doubles (the two-vector kernel uses both halves),
+// zeroed once; every finalize kernel re-zeroes what its sweep touched.
+int sym_accumulators(rmb_ctx* c, long n_pad) {
+  const size_t acc_bytes = (size_t)6 * n_pad * sizeof(double);
+  if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
+    if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
+    RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));
+    c->symbuf_zeroed_for = n_pad;
+  }
+  return 0;
+}
+
 int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard = 0, long nshards = 1,
                bool accumulate = false) {
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
@@ -213,12 +226,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   const long n = c->n;
   const long tiles = (n + 63) / 64;
   const long n_pad = 64 * tiles;
-  const size_t acc_bytes = (size_t)3 * n_pad * sizeof(double);
-  if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
-    if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
-    RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));   // later calls: finalize re-zeroes
-    c->symbuf_zeroed_for = n_pad;
-  }
+  if (int rc = sym_accumulators(c, n_pad)) return rc;
   rmb::SymArgs a;
   a.pos = (const double4*)c->pos.p;
   a.vec = v;
@@ -288,6 +296,67 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   if (int rc = timing_end(c, slot)) return rc;
   const dim3 fgrid((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(se.fin, fgrid, dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+// Two source vectors, one pass over the unordered pairs (sym2_kernels.h).  Same schedule rules as sym_device.
+int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, double* out_a, double* out_b, long shard = 0,
+                long nshards = 1) {
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
+  if (int rc = sym_accumulators(c, n_pad)) return rc;
+  rmb::Sym2Args a;
+  a.pos = (const double4*)c->pos.p;
+  a.vec_a = va; a.vec_b = vb;
+  a.acc = (double*)c->symbuf.p;
+  a.out_a = out_a; a.out_b = out_b;
+  a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  {
+    const __int128 s_total = (__int128)a.n_units * 64;
+    a.step_begin = (long)(s_total * shard / nshards);
+    a.step_end = (long)(s_total * (shard + 1) / nshards);
+    const long block = (n + nshards - 1) / nshards;
+    a.self_begin = block * shard < n ? block * shard : n;
+    a.self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
+  }
+  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.k = make_pair_consts(c->a);
+  typedef void (*k2_fn)(const rmb::Sym2Args);
+  static int occ2[2][2] = {{0, 0}, {0, 0}};
+  const k2_fn fn = c->wall ? (periodic ? (k2_fn)rmb::sym2_kernel<true, true> : (k2_fn)rmb::sym2_kernel<true, false>)
+                           : (periodic ? (k2_fn)rmb::sym2_kernel<false, true> : (k2_fn)rmb::sym2_kernel<false, false>);
+  const int wps = resident_blocks((const void*)fn, &occ2[c->wall ? 1 : 0][periodic ? 1 : 0]);
+  const long round = 256L * wps;
+  long blocks = round * c->opt_sym_oversub;
+  const long total = a.step_end - a.step_begin;
+  const long per_wg = rmb::kSymWaves * c->opt_sym_min_steps;
+  const long need = (total + per_wg - 1) / per_wg > 0 ? (total + per_wg - 1) / per_wg : 1;
+  if (blocks > need) blocks = need;
+  if (blocks > round) blocks -= blocks % round;
+  if (blocks < round) {
+    long fine = (total + rmb::kSymWaves * 16L - 1) / (rmb::kSymWaves * 16L);
+    if (fine > round) fine = round;
+    if (fine > blocks) blocks = fine;
+  }
+  if (blocks < 1) blocks = 1;
+  {
+    const long waves = blocks * rmb::kSymWaves;
+    a.steps_per_wave = (total + waves - 1) / waves;
+  }
+  c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
+  const dim3 fgrid((unsigned)((n + 255) / 256));
+  if (c->wall) hipLaunchKernelGGL(rmb::sym2_finalize_kernel<true>, fgrid, dim3(256), 0, c->stream, a);
+  else         hipLaunchKernelGGL(rmb::sym2_finalize_kernel<false>, fgrid, dim3(256), 0, c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
 }
@@ -387,12 +456,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   if (!radii && c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
     // symmetric path: each unordered pair once (F_ji = -F_ij)
     const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
-    const size_t acc_bytes = (size_t)3 * n_pad * sizeof(double);
-    if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
-      if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
-      RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));
-      c->symbuf_zeroed_for = n_pad;
-    }
+    if (int rc = sym_accumulators(c, n_pad)) return rc;
     rmb::SymForceArgs a;
     a.pos = (const double4*)c->pos.p;
     a.acc = (double*)c->symbuf.p;
@@ -579,6 +643,32 @@ int rmb_set_target_range(rmb_ctx* c, long begin, long end) {
 
 int rmb_matvec_device(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out) {
   return matvec_device_impl(c, kind, in_plane, v, v2, eta, out);
+}
+
+int rmb_matvec2_pairshard_device(rmb_ctx* c, int kind, const double* vec_a, const double* vec_b, double eta,
+                                 double* out_a, double* out_b, long shard, long nshards) {
+  if (int rc = check_ready(c)) return rc;
+  if (kind != rmb::KIND_TT) return fail(RMB_ERR_ARG, "two-vector products exist for RMB_TT only");
+  if (!vec_a || !vec_b || !out_a || !out_b) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard");
+  RMB_HIP(hipSetDevice(c->device));
+  if (c->n < 128 || c->opt_deterministic || !c->opt_symmetric) {
+    if (nshards != 1) return fail(RMB_ERR_STATE, "pair shards need the symmetric path (n >= 128, not deterministic)");
+    if (int rc = matvec_device_impl(c, kind, 0, vec_a, nullptr, eta, out_a)) return rc;
+    return matvec_device_impl(c, kind, 0, vec_b, nullptr, eta, out_b);
+  }
+  return sym2_device(c, vec_a, vec_b, eta, out_a, out_b, shard, nshards);
+}
+
+int rmb_matvec2_device(rmb_ctx* c, int kind, const double* vec_a, const double* vec_b, double eta, double* out_a,
+                       double* out_b) {
+  if (int rc = check_ready(c)) return rc;
+  if (c->tgt_begin != 0 || c->tgt_end != c->n) {      // target shards: two one-sided sweeps
+    if (int rc = matvec_device_impl(c, kind, 0, vec_a, nullptr, eta, out_a)) return rc;
+    return matvec_device_impl(c, kind, 0, vec_b, nullptr, eta, out_b);
+  }
+  return rmb_matvec2_pairshard_device(c, kind, vec_a, vec_b, eta, out_a, out_b, 0, 1);
 }
 
 int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards) {

@@ -62,6 +62,9 @@ class HipBackend(object):
   def body_mobility_dense(self, first_blob, n_b, eta, out=None):
     return self.ctx.body_mobility_dense_device(first_blob, n_b, eta, out=out)
 
+  def matvec2_pairshard(self, kind, va, vb, eta, shard, nshards, out_a=None, out_b=None):
+    return self.ctx.matvec2_device(kind, va, vb, eta, out_a=out_a, out_b=out_b, shard=shard, nshards=nshards)
+
 
 class ShardedMobility(object):
   """M.v with targets sharded over the ranks of a process group."""
@@ -182,6 +185,18 @@ class ShardedMobility(object):
     self.backend.set_positions(r, a, L, wall)
     self.backend.set_target_range(self.begin, self.end)
 
+  def matvec2_replicated(self, kind, va_full, vb_full, eta):
+    """Two tt products with replicated vectors: one pass over this rank's pair shard with both vectors, then ONE
+    all-reduce of the stacked partials (2 x 24 N bytes).  Backends without the two-vector kernel run two products."""
+    va, vb = self._to_dev(va_full), self._to_dev(vb_full)
+    if hasattr(self.backend, "matvec2_pairshard") and self.backend.supports_pairshard(kind, bool(self._periodic)):
+      both = torch.empty((2, va.numel()), dtype=torch.float64, device=self.device)
+      self.backend.matvec2_pairshard(kind, va, vb, eta, self.rank, self.world, out_a=both[0], out_b=both[1])
+      if self.world > 1:
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
+      return both[0], both[1]
+    return self.matvec_replicated(kind, va, eta), self.matvec_replicated(kind, vb, eta)
+
   def blob_blob_force_replicated(self, eps, b, a):
     """Forces on ALL blobs on every rank: each rank sweeps its own target block, blocks are all-gathered."""
     f_local = self.backend.blob_blob_force(eps, b, a)
@@ -222,6 +237,14 @@ class ReplicatedContext(object):
 
   def matvec_device(self, kind, vec, eta, vec2=None, in_plane=False, out=None):
     return self.sm.matvec_replicated(kind, vec, eta, vec2_full=vec2, in_plane=in_plane, out=out)
+
+  def matvec2_device(self, kind, vec_a, vec_b, eta, out_a=None, out_b=None, shard=0, nshards=1):
+    a, b = self.sm.matvec2_replicated(kind, vec_a, vec_b, eta)
+    if out_a is not None:
+      out_a.copy_(a); a = out_a
+    if out_b is not None:
+      out_b.copy_(b); b = out_b
+    return a, b
 
   def blob_blob_force_device(self, repulsion_strength, debye_length, blob_radius, out=None, device=None):
     return self.sm.blob_blob_force_replicated(repulsion_strength, debye_length, blob_radius)

@@ -131,7 +131,8 @@ class RigidSuspension(object):
       g.rel = g.K = g.K_pc = g.Minv = g.Nbody = g.Lchol = g.Linv = g.A11 = g.A12 = g.A21 = g.A22 = None
       self.groups.append(g)
     self.size = 3 * self.n_blobs + 6 * self.n_bodies
-    self.matvec_count = 0
+    self.matvec_count = 0       # M.v products requested (a two-vector pass counts two)
+    self.matvec2_count = 0      # of which pairs served by one two-vector pass
     self.free = None            # (n_bodies, 1) 1.0 = free body, 0.0 = prescribed kinematics; None = all free
     self.prescribed_velocity = None
     if prescribed is not None and np.any(prescribed):
@@ -255,6 +256,27 @@ class RigidSuspension(object):
     bottom = -self.KT_times_lambda(lam).view(self.n_bodies, 6) + U * (1.0 - self.free)
     return torch.cat([top, bottom.reshape(-1)])
 
+  def apply_operator2(self, xa, xb):
+    """The operator applied to two vectors with ONE pass over the blob pairs (rmb_matvec2_device); the K products
+    stay per vector (they are O(N)).  Falls back to two applications when the fast path does not apply."""
+    if self.free is not None or len(self.groups) != 1 or not hasattr(self.ctx, "matvec2_device"):
+      return self.apply_operator(xa), self.apply_operator(xb)
+    n3 = 3 * self.n_blobs
+    g = self.groups[0]
+    res = torch.empty((2, self.size), dtype=torch.float64, device=self.device)
+    self.matvec_count += 2
+    self.matvec2_count += 1
+    ra, rb = self.ctx.matvec2_device("tt", xa[:n3].contiguous(), xb[:n3].contiguous(), self.eta,
+                                     out_a=res[0, :n3], out_b=res[1, :n3])
+    for row, r, x in ((res[0], ra, xa), (res[1], rb, xb)):
+      top = row[:n3]
+      if r.data_ptr() != top.data_ptr():
+        top.copy_(r)
+      top.view(self.n_bodies, 3 * g.n_b, 1).baddbmm_(g.K, x[n3:].reshape(self.n_bodies, 6, 1), alpha=-1.0)
+      bot = row[n3:].view(self.n_bodies, 6, 1)
+      torch.baddbmm(bot, g.K.transpose(1, 2), x[:n3].reshape(self.n_bodies, 3 * g.n_b, 1), beta=0.0, alpha=-1.0, out=bot)
+    return res[0], res[1]
+
   def prescribe(self, rhs):
     """RHS of a system whose bodies partly have prescribed kinematics (quaternion_integrator_multi_bodies.py:1478-1487):
     slip += K U_prescribed on their blobs, and their force rows are zero."""
@@ -349,6 +371,21 @@ class RigidSuspension(object):
     info["rhs_norm"] = nrm
     return sol * nrm, info
 
+  def solve_pair(self, rhs_a, rhs_b, tol=1e-8, restart=60, maxiter=1000):
+    """Two solves with the same operator and preconditioner advanced in lockstep (gmres_pair_right_preconditioned): each
+    sees exactly its own GMRES iterates, but while both run every iteration costs one two-vector pair sweep instead of
+    two sweeps.  Returns ((x_a, info_a), (x_b, info_b))."""
+    if self.groups[0].Lchol is None:
+      self.build_preconditioner()
+    na, nb_ = float(torch.linalg.norm(rhs_a)), float(torch.linalg.norm(rhs_b))
+    if na == 0.0 or nb_ == 0.0:
+      return self.solve(rhs_a, tol, restart, maxiter), self.solve(rhs_b, tol, restart, maxiter)
+    (xa, ia), (xb, ib) = gmres_pair_right_preconditioned(self.apply_operator, self.apply_operator2, self.apply_preconditioner,
+                                                         rhs_a / na, rhs_b / nb_, tol=tol, restart=restart, maxiter=maxiter,
+                                                         sync=getattr(self.ctx, "sync_scalars", None))
+    ia["rhs_norm"], ib["rhs_norm"] = na, nb_
+    return (xa * na, ia), (xb * nb_, ib)
+
   def solve_mobility_problem(self, slip=None, force_torque=None, tol=1e-8, restart=60, maxiter=1000, x0=None):
     """Returns (velocities (n_bodies, 6), lambda (n_blobs, 3), info).  RHS = [slip, -F]
     (quaternion_integrator_multi_bodies.py:1458-1475)."""
@@ -399,12 +436,10 @@ class RigidSuspension(object):
                                       device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
 
 
-def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None):
-  """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
-  Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after maxiter iterations in total.
-  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host.
-  x0: optional initial guess (the roller torque solve warm-starts from the previous step,
-  quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
+def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync):
+  """GMRES(restart) on A.Minv written as a coroutine: it YIELDS every vector it needs the operator applied to and
+  receives A(vector) back, so one driver can serve a single solve (gmres_right_preconditioned) or advance two solves
+  in lockstep and hand both requests to a two-vector operator (gmres_pair_right_preconditioned).  Returns (x, info)."""
   dev = b.device
   n = b.numel()
 
@@ -417,7 +452,7 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
   bnorm = host_norm(b)
   y = torch.zeros(n, dtype=torch.float64, device=dev)
   if x0 is not None:
-    b = b - A(x0)
+    b = b - (yield x0)
   r = b.clone()
   beta = host_norm(r)
   its = 0
@@ -434,7 +469,7 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
     g[0] = beta
     k_used = 0
     for j in range(m):
-      w = A(Minv(V[j]))
+      w = yield Minv(V[j])
       Vj = V[:j + 1]
       h = Vj @ w
       w = torch.addmv(w, Vj.t(), h, alpha=-1.0)
@@ -467,10 +502,53 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
     coef = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used]) if k_used > 0 else np.zeros(0)
     y = y + V[:k_used].t() @ torch.as_tensor(coef, device=dev)
     if res > tol and its < maxiter:                                # restart: true residual
-      r = b - A(Minv(y))
+      r = b - (yield Minv(y))
       beta = host_norm(r)
       res = beta / bnorm
   x = Minv(y)
   if x0 is not None:
     x = x + x0
   return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history)
+
+
+def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None):
+  """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
+  Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after maxiter iterations in total.
+  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host.
+  x0: optional initial guess (the roller torque solve warm-starts from the previous step,
+  quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
+  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync)
+  try:
+    request = next(steps)
+    while True:
+      request = steps.send(A(request))
+  except StopIteration as done:
+    return done.value
+
+
+def gmres_pair_right_preconditioned(A, A2, Minv, b_a, b_b, tol=1e-8, restart=60, maxiter=1000, sync=None):
+  """Two independent solves A x_a = b_a, A x_b = b_b advanced in lockstep: while both are running, each iteration
+  hands its two operator requests to A2(u, v) -> (A u, A v) -- one pass over the blob pairs with two vectors
+  (rmb_matvec2_device) instead of two.  Every solve sees exactly the iterates it would see alone.
+  Returns ((x_a, info_a), (x_b, info_b))."""
+  gens = [_gmres_steps(Minv, b, tol, restart, maxiter, None, sync) for b in (b_a, b_b)]
+  requests, results = [None, None], [None, None]
+  for k in (0, 1):
+    try:
+      requests[k] = next(gens[k])
+    except StopIteration as done:
+      results[k] = done.value
+  while results[0] is None or results[1] is None:
+    if results[0] is None and results[1] is None:
+      answers = A2(requests[0], requests[1])
+    else:
+      k = 0 if results[0] is None else 1
+      answers = [None, None]
+      answers[k] = A(requests[k])
+    for k in (0, 1):
+      if results[k] is None:
+        try:
+          requests[k] = gens[k].send(answers[k])
+        except StopIteration as done:
+          results[k] = done.value
+  return results[0], results[1]

@@ -89,6 +89,9 @@ class RigidIntegrator(object):
     # (None = solver tolerance, as the reference).  That solve sets the direction of a finite difference whose result is
     # a kT-order correction, so a loose value (1e-2) cuts ~20 % of the pair sweeps of a step without visible bias.
     self.rfd_solve_tolerance = None
+    # Slip schemes: advance the Brownian-slip solve and the RFD solve in lockstep (one two-vector sweep per iteration).
+    # Numerically neutral: each solve sees exactly its own GMRES iterates.
+    self.lockstep_solves = True
     self.print_residual = False
     self.max_retries = 1000
     self._pc_built = False
@@ -182,13 +185,7 @@ class RigidIntegrator(object):
     return torch.zeros(3 * self.Nblobs, dtype=torch.float64, device=self.device)
 
   # ---- the rigid solve ------------------------------------------------------------------------------
-  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None, guess=False, tolerance=None):
-    """[M -K; -K^T 0][lambda; U] = [slip - noise; -(F + noise_FT)] at the bound configuration
-    (quaternion_integrator_multi_bodies.py:1441-1547).  Returns the full solution tensor.
-    guess=True marks the calls the reference makes with `x0 = self.first_guess, save_first_guess = True`.  There the
-    guess is silently dropped (general_application_utils.gmres passes x0=None on the right-preconditioned path, :627), so
-    by default it is not used here either and the iteration counts equal the reference's; with `warm_start = True` the
-    previous (normalised) solution does seed GMRES, which pays in slowly varying deterministic runs."""
+  def _assemble_rhs(self, RHS=None, noise=None, noise_FT=None):
     n3 = 3 * self.Nblobs
     if RHS is None:
       FT = self.force_torque_calculator()
@@ -199,6 +196,16 @@ class RigidIntegrator(object):
       RHS = RHS.clone()
     if noise is not None:
       RHS[:n3] -= noise
+    return RHS
+
+  def solve_mobility_problem(self, RHS=None, noise=None, noise_FT=None, guess=False, tolerance=None):
+    """[M -K; -K^T 0][lambda; U] = [slip - noise; -(F + noise_FT)] at the bound configuration
+    (quaternion_integrator_multi_bodies.py:1441-1547).  Returns the full solution tensor.
+    guess=True marks the calls the reference makes with `x0 = self.first_guess, save_first_guess = True`.  There the
+    guess is silently dropped (general_application_utils.gmres passes x0=None on the right-preconditioned path, :627), so
+    by default it is not used here either and the iteration counts equal the reference's; with `warm_start = True` the
+    previous (normalised) solution does seed GMRES, which pays in slowly varying deterministic runs."""
+    RHS = self._assemble_rhs(RHS, noise, noise_FT)
     x0 = None
     if guess and self.warm_start and self.first_guess is not None:
       x0 = self.first_guess * float(torch.linalg.norm(RHS))
@@ -208,6 +215,19 @@ class RigidIntegrator(object):
     if guess and info.get("rhs_norm", 0.0) > 0:
       self.first_guess = sol / info["rhs_norm"]
     return self.susp.impose_prescribed_velocity(sol)
+
+  def solve_mobility_problem_pair(self, first, second):
+    """Two rigid solves at the same configuration advanced in lockstep (RigidSuspension.solve_pair); `first` / `second`
+    are the keyword arguments one would give solve_mobility_problem (RHS, noise, noise_FT, guess)."""
+    sols = []
+    rhs = [self._assemble_rhs(kw.get("RHS"), kw.get("noise"), kw.get("noise_FT")) for kw in (first, second)]
+    for kw, (sol, info) in zip((first, second), self.susp.solve_pair(rhs[0], rhs[1], tol=self.tolerance, restart=60,
+                                                                    maxiter=1000)):
+      self.det_iterations_count += info["iterations"]
+      if kw.get("guess") and info.get("rhs_norm", 0.0) > 0:
+        self.first_guess = sol / info["rhs_norm"]
+      sols.append(self.susp.impose_prescribed_velocity(sol))
+    return sols
 
   def _velocities(self, sol):
     return sol[3 * self.Nblobs:]
@@ -466,9 +486,15 @@ class RigidIntegrator(object):
       else:
         noise_W1 = self._noise(W1, math.sqrt(4 * self.kT / dt))
         noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))
-      U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1, guess=True)).clone()
       rhs = torch.cat([-W_slip, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
-      W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs, tolerance=self.rfd_solve_tolerance))
+      if self.lockstep_solves and self.rfd_solve_tolerance is None and not (self.warm_start and self.first_guess is not None):
+        # the Brownian-slip solve and the RFD solve share configuration, operator and preconditioner: their GMRES
+        # iterations advance together, one two-vector pair sweep per iteration instead of two sweeps
+        sol_1, sol_rfd = self.solve_mobility_problem_pair(dict(noise=noise_W1, guess=True), dict(RHS=rhs))
+        U_1, W_RFD = self._velocities(sol_1).clone(), self._velocities(sol_rfd)
+      else:
+        U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1, guess=True)).clone()
+        W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs, tolerance=self.rfd_solve_tolerance))
       self._move(*self._advance(old[0], old[1], W_RFD, self.rf_delta))
       M_rfdxW = self.susp.mobility_times_lambda(W_slip)
       KT_rfdxW = self.susp.KT_times_lambda(W_slip)

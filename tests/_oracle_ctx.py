@@ -30,6 +30,9 @@ class OracleContext(object):
       u = self._wrapped(kind, vec, eta, in_plane)
     return torch.from_numpy(u)
 
+  def matvec2_device(self, kind, vec_a, vec_b, eta, out_a=None, out_b=None, shard=0, nshards=1):
+    return self.matvec_device(kind, vec_a, eta), self.matvec_device(kind, vec_b, eta)
+
   def blob_blob_force_device(self, eps, b, a, out=None, device=None):
     F = self.o.calc_blob_blob_forces_oracle(self.r, periodic_length=self.L, repulsion_strength=eps, debye_length=b,
                                             blob_radius=a)

@@ -611,3 +611,31 @@ def test_source_target_equal_radii_reduces_to_tt(mob):
   u13 = mob.mobility_radii_trans_times_force(r, f, eta, a, ones, mob.single_wall_mobility_trans_times_force_source_target_hip)
   u1 = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
   assert rel_err(u13, u1) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# 8. two vectors in one pass (rmb_matvec2_device)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wall", [True, False])
+@pytest.mark.parametrize("L", [(0.0, 0.0, 0.0), (0.0, 7.5, 0.0), (9.0, 8.0, 0.0)])
+@pytest.mark.parametrize("N", [127, 128, 1000, 4100])
+def test_two_vector_product_equals_two_products(Ctx, oracle, wall, L, N):
+  import torch
+  r, f, eta, a = d1_cloud(N, seed=N) if N == 1000 else d2_cloud(N, seed=N)
+  g = np.random.RandomState(N + 1).randn(*f.shape)
+  ctx = Ctx(0)
+  ctx.set_positions(r, a, np.array(L), wall=wall)
+  fd, gd = torch.as_tensor(f.reshape(-1), device="cuda"), torch.as_tensor(g.reshape(-1), device="cuda")
+  both = torch.stack(ctx.matvec2_device("tt", fd, gd, eta)).cpu().numpy()
+  pre = "single_wall" if wall else "no_wall"
+  fn = getattr(oracle, pre + "_mobility_trans_times_force_oracle")
+  tol = TOL_D1 if N == 1000 else TOL_D2
+  assert rel_err(both[0], fn(r, f, eta, a, periodic_length=np.array(L))) < tol
+  assert rel_err(both[1], fn(r, g, eta, a, periodic_length=np.array(L))) < tol
+  # pair shards of the two-vector product sum to it
+  parts = sum(torch.stack(ctx.matvec2_device("tt", fd, gd, eta, shard=s, nshards=3)) for s in range(3)).cpu().numpy() \
+      if N >= 128 else both
+  assert rel_err(parts, both) < 1e-13
+  # a later single-vector product still sees clean accumulators
+  assert rel_err(ctx.matvec_device("tt", gd, eta).cpu().numpy(), both[1]) < 1e-13
+  ctx.close()

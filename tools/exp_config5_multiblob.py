@@ -22,15 +22,17 @@ integ.debye_length_wall = integ.debye_length = 0.0406
 torque = 8 * math.pi * eta * R ** 3 * 62.8
 FT = torch.zeros((nb, 6), dtype=torch.float64, device="cuda:0"); FT[:, 4] = torque
 integ.external_force_torque = lambda it: FT
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and sys.argv[4] != "-":
   integ.rfd_solve_tolerance = float(sys.argv[4])
+if len(sys.argv) > 5:
+  integ.lockstep_solves = bool(int(sys.argv[5]))
 torch.cuda.synchronize()
 print("setup %.2f s, blobs %d" % (time.perf_counter() - t0, integ.Nblobs), flush=True)
 for step in range(steps):
-  d0, s0, m0 = integ.det_iterations_count, integ.stoch_iterations_count, integ.susp.matvec_count
+  d0, s0, m0, p0 = integ.det_iterations_count, integ.stoch_iterations_count, integ.susp.matvec_count, integ.susp.matvec2_count
   t0 = time.perf_counter()
   integ.advance_time_step(0.01, step=step)
   torch.cuda.synchronize()
-  print("step %d: %.3f s, gmres its %d, lanczos its %d, pair sweeps %d, rejected %d" %
+  print("step %d: %.3f s, gmres its %d, lanczos its %d, M.v products %d (of which %d pairs in two-vector passes), rejected %d" %
         (step, time.perf_counter() - t0, integ.det_iterations_count - d0, integ.stoch_iterations_count - s0,
-         integ.susp.matvec_count - m0, integ.invalid_configuration_count), flush=True)
+         integ.susp.matvec_count - m0, integ.susp.matvec2_count - p0, integ.invalid_configuration_count), flush=True)
