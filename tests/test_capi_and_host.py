@@ -14,7 +14,7 @@ from conftest import ROOT
 def _declared_symbols():
   src = open(os.path.join(ROOT, "include", "rmb_mobility.h")).read()
   src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-  return sorted(set(re.findall(r"\b(rmb_[a-z_]+)\s*\(", src)))
+  return sorted(set(re.findall(r"\b(rmb_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
