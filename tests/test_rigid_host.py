@@ -143,3 +143,33 @@ def test_body_mobility_from_resistance_matches_pinv():
   N = _body_mobility_from_resistance(S)
   assert torch.allclose(N, torch.linalg.pinv(S), rtol=1e-9, atol=1e-10)
   assert float(N[0].abs().max()) < 1e3
+
+
+def test_lockstep_gmres_pair_equals_two_solves():
+  """gmres_pair_right_preconditioned: each of the two solves sees exactly the iterates it would see alone (same
+  solution, same iteration count), whatever the other one does -- including one finishing long before the other."""
+  from rigidmultiblobswall_amd.rigid import gmres_right_preconditioned, gmres_pair_right_preconditioned
+  rng = np.random.RandomState(21)
+  n = 240
+  A = torch.from_numpy(np.eye(n) * 3 + rng.randn(n, n) * 0.12)
+  P = torch.diag(1.0 / torch.diag(A))
+  b1 = torch.from_numpy(rng.randn(n))
+  b2 = A @ (P @ torch.from_numpy(np.eye(n)[3]))          # converges in one iteration
+  calls = {"single": 0, "pair": 0}
+
+  def op(x):
+    calls["single"] += 1
+    return A @ x
+
+  def op2(x, y):
+    calls["pair"] += 1
+    return A @ x, A @ y
+  for tol, restart in ((1e-10, 60), (1e-10, 7)):
+    calls["single"] = calls["pair"] = 0
+    (x1, i1), (x2, i2) = gmres_pair_right_preconditioned(op, op2, lambda v: P @ v, b1, b2, tol=tol, restart=restart)
+    s1, j1 = gmres_right_preconditioned(lambda v: A @ v, lambda v: P @ v, b1, tol=tol, restart=restart)
+    s2, j2 = gmres_right_preconditioned(lambda v: A @ v, lambda v: P @ v, b2, tol=tol, restart=restart)
+    assert torch.equal(x1, s1) and torch.equal(x2, s2)
+    assert i1["iterations"] == j1["iterations"] and i2["iterations"] == j2["iterations"] == 1
+    assert calls["pair"] == 1 and calls["single"] >= j1["iterations"] - 1
+    assert float(torch.linalg.norm(A @ x1 - b1) / torch.linalg.norm(b1)) < 1e-9
