@@ -183,6 +183,15 @@ def main():
                    kT=kT, seed=9, hydro_interactions=0, free_kinematics=fk)
     run_trajectory(lib, "g8_rollers_uncorrelated_GDC_free_%s" % fk, "stochastic_GDC_rollers", 16, 2, out_dir,
                    kT=kT, seed=10, hydro_interactions=0, free_kinematics=fk)
+  # Brownian steps in the other domains, pseudo-periodic noise, prescribed kinematics without hydrodynamics
+  run_trajectory(lib, "g8_rollers_stoch_ab_no_wall", "stochastic_adams_bashforth_rollers", 16, 2, out_dir, kT=kT, seed=13,
+                 domain="no_wall", repulsion_strength_wall=0.0)
+  run_trajectory(lib, "g8_rollers_stoch_first_order_in_plane", "stochastic_first_order_rollers", 16, 2, out_dir, kT=kT,
+                 seed=14, domain="in_plane")
+  run_trajectory(lib, "g8_rollers_stoch_mid_point_periodic", "stochastic_mid_point_rollers", 12, 2, out_dir, kT=kT, seed=15,
+                 periodic_length=(4.0, 4.0, 0.0))
+  run_trajectory(lib, "g8_rollers_uncorrelated_euler_free_False", "deterministic_forward_euler_rollers", 16, 2, out_dir,
+                 hydro_interactions=0, free_kinematics="False")
   # larger cases: on the GPU these take the symmetric pair kernels (N >= 128)
   run_trajectory(lib, "g8_rollers_stoch_ab_N160", "stochastic_adams_bashforth_rollers", 160, 2, out_dir, kT=kT, seed=12)
   run_trajectory(lib, "g8_rollers_det_ab_periodic_N144", "deterministic_adams_bashforth_rollers", 144, 2, out_dir,
