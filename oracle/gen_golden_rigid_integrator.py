@@ -207,6 +207,8 @@ def main():
       ("g9_rigid_obstacle_slip_trapz", "stochastic_Slip_Trapz", with_obstacle(3), 2, dict(kT=kT, seed=10)),
       ("g9_rigid_stoch_slip_trapz_16shells", "stochastic_Slip_Trapz", mixed(0, 16), 2, dict(kT=kT, seed=6)),
   ]
+  # a larger deterministic case (480 blobs: several tiles of the symmetric kernel, chunked sweeps), one step
+  cases.append(("g9_rigid_det_euler_40shells", "deterministic_forward_euler", mixed(0, 40), 1, {}))
   for name, scheme, bodies, n_steps, kw in cases:
     if args.only and args.only != name:
       continue
