@@ -209,6 +209,7 @@ def main():
   ]
   # a larger deterministic case (480 blobs: several tiles of the symmetric kernel, chunked sweeps), one step
   cases.append(("g9_rigid_det_euler_40shells", "deterministic_forward_euler", mixed(0, 40), 1, {}))
+  cases.append(("g9_rigid_stoch_slip_trapz_40shells", "stochastic_Slip_Trapz", mixed(0, 40), 1, dict(kT=kT, seed=12)))
   for name, scheme, bodies, n_steps, kw in cases:
     if args.only and args.only != name:
       continue

@@ -62,6 +62,18 @@ class OracleBackend(object):
     return torch.from_numpy(u.copy())
 
 
+def _matvec2_pairshard(self, kind, va, vb, eta, shard, nshards, out_a=None, out_b=None):
+  """Two-vector pair shard of the stand-in: both partials, written into the caller's (stacked) buffers."""
+  a = self.matvec_pairshard(kind, va, eta, shard, nshards)
+  b = self.matvec_pairshard(kind, vb, eta, shard, nshards)
+  out_a.copy_(a)
+  out_b.copy_(b)
+  return out_a, out_b
+
+
+OracleBackend.matvec2_pairshard = _matvec2_pairshard
+
+
 def rollers_replicated(rank, world, out_dir):
   """A replicated time stepper over sharded sweeps: RollersIntegrator on a ReplicatedContext must walk the
   reference trajectory (golden g8) on every rank, and all ranks must hold identical locations."""
