@@ -416,6 +416,21 @@ class RigidSuspension(object):
       self._put_blobs(out, g, torch.bmm(A, self._blobs_of(x, g).unsqueeze(-1)))
     return out
 
+  def _pc_mobility(self):
+    """w -> P^T M P w and the two-vector form (u, v) -> (P^T M P u, P^T M P v), P = blockdiag(L_b^-T)."""
+    def one(w):
+      return self._blockdiag(self.mobility_times_lambda(self._blockdiag(w, "Linv", transpose=True)), "Linv")
+
+    def two(u, v):
+      if not hasattr(self.ctx, "matvec2_device"):
+        return one(u), one(v)
+      self.matvec_count += 2
+      self.matvec2_count += 1
+      a, b = self.ctx.matvec2_device("tt", self._blockdiag(u, "Linv", transpose=True),
+                                     self._blockdiag(v, "Linv", transpose=True), self.eta)
+      return self._blockdiag(a, "Linv"), self._blockdiag(b, "Linv")
+    return one, two
+
   def stochastic_forcing(self, z, factor, tol=1e-8, print_residual=False):
     """factor * P^-1 (P^T M P)^{1/2} z with P = blockdiag(L_b^-T): the preconditioned Lanczos of
     quaternion_integrator_multi_bodies.py:966-973 / multi_bodies.py:590-614 (covariance factor^2 M; needs O(1)
@@ -425,16 +440,22 @@ class RigidSuspension(object):
     if self.groups[0].Lchol is None:
       self.build_preconditioner()
     self._stochastic_factors()
-
-    def mobility_pc(w):
-      v = self._blockdiag(w, "Linv", transpose=True)          # P w
-      v = self.mobility_times_lambda(v)
-      return self._blockdiag(v, "Linv")                        # P^T (M P w)
-
-    return stochastic_forcing_lanczos(factor=factor, tolerance=tol, dim=3 * self.n_blobs, mobility_mult=mobility_pc,
+    one, _ = self._pc_mobility()
+    return stochastic_forcing_lanczos(factor=factor, tolerance=tol, dim=3 * self.n_blobs, mobility_mult=one,
                                       L_mult=lambda x: self._blockdiag(x, "Lchol"), z=z, print_residual=print_residual,
                                       device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
 
+  def stochastic_forcing_pair(self, z_a, factor_a, z_b, factor_b, tol=1e-8, print_residual=False):
+    """Two forcings with the same mobility in lockstep (stochastic_forcing_lanczos_pair): one two-vector pair sweep per
+    iteration while both run.  Returns ((noise_a, its_a), (noise_b, its_b))."""
+    from .stochastic import stochastic_forcing_lanczos_pair
+    if self.groups[0].Lchol is None:
+      self.build_preconditioner()
+    self._stochastic_factors()
+    one, two = self._pc_mobility()
+    return stochastic_forcing_lanczos_pair((factor_a, factor_b), (z_a, z_b), one, two, tolerance=tol,
+                                           L_mult=lambda x: self._blockdiag(x, "Lchol"), print_residual=print_residual,
+                                           device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
 
 def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync):
   """GMRES(restart) on A.Minv written as a coroutine: it YIELDS every vector it needs the operator applied to and

@@ -483,6 +483,12 @@ class RigidIntegrator(object):
       self._refresh_preconditioner(step)
       if trapezoidal:
         noise_W1 = self._noise(W1, math.sqrt(2 * self.kT / dt))
+      elif self.lockstep_solves and self.kT > 0.0:
+        # both Brownian forcings of the mid-point scheme use the mobility of q^n: their Lanczos iterations advance together
+        (noise_W1, its_a), (noise_Wcor, its_b) = self.susp.stochastic_forcing_pair(
+            W1, math.sqrt(4 * self.kT / dt), Wcor, math.sqrt(self.kT / dt), tol=self.tolerance,
+            print_residual=self.print_residual)
+        self.stoch_iterations_count += its_a + its_b
       else:
         noise_W1 = self._noise(W1, math.sqrt(4 * self.kT / dt))
         noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))

@@ -19,27 +19,10 @@ import numpy as np
 import torch
 
 
-def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=None, mobility=None,
-                               mobility_mult=None, L_mult=None, z=None, print_residual=False, device=None, sync=None):
-  """mobility_mult: callable(torch tensor (dim,)) -> torch tensor (dim,) on the same device
-  (e.g. lambda v: ctx.matvec_device('tt', v, eta)); or `mobility` = dense torch/numpy matrix.
-  z: numpy array or torch tensor; drawn from N(0,1) when None.  Returns (noise tensor, iterations)."""
-  if z is not None and dim is None:
-    dim = int(z.numel() if isinstance(z, torch.Tensor) else np.size(z))
-  if isinstance(z, torch.Tensor) and device is None:
-    device = z.device
-  if device is None:
-    device = mobility.device if isinstance(mobility, torch.Tensor) else torch.device("cpu")
-  device = torch.device(device)
-  if factor == 0.0:
-    return torch.zeros(dim, dtype=torch.float64, device=device), 0
-  if z is None:
-    z = torch.randn(dim, dtype=torch.float64, device=device)
-  z = torch.as_tensor(z, dtype=torch.float64, device=device).reshape(-1).clone()
-  if mobility is not None:
-    Mt = torch.as_tensor(mobility, dtype=torch.float64, device=device)
-    mobility_mult = lambda v: Mt @ v  # noqa: E731
-
+def _lanczos_steps(factor, tolerance, max_iter, dim, z, print_residual, device, sync):
+  """The Lanczos iteration as a coroutine: YIELDS every vector it needs the mobility applied to and receives the
+  product back, so that one driver can run a single forcing or advance two of them in lockstep on a two-vector
+  product.  Returns (noise, iterations) before `L_mult`."""
   cap = min(max_iter + 2, 64)
   V = torch.empty((cap, dim), dtype=torch.float64, device=device)
   v_norm = float(torch.linalg.norm(z))
@@ -49,7 +32,7 @@ def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=No
   coef = None
   its = max_iter
   for i in range(max_iter + 1):
-    w = mobility_mult(V[i]).reshape(-1)
+    w = (yield V[i]).reshape(-1)
     if i > 0:
       w = w - h_sup[i - 1] * V[i - 1]
     hd = torch.dot(w, V[i])
@@ -95,9 +78,78 @@ def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=No
     coef_old = coef
   k = len(coef)
   noise = V[:k].t() @ torch.as_tensor(coef, dtype=torch.float64, device=device)
+  return noise, its
+
+
+def _prepare(z, dim, device, mobility):
+  if z is not None and dim is None:
+    dim = int(z.numel() if isinstance(z, torch.Tensor) else np.size(z))
+  if isinstance(z, torch.Tensor) and device is None:
+    device = z.device
+  if device is None:
+    device = mobility.device if isinstance(mobility, torch.Tensor) else torch.device("cpu")
+  device = torch.device(device)
+  if z is None:
+    z = torch.randn(dim, dtype=torch.float64, device=device)
+  z = torch.as_tensor(z, dtype=torch.float64, device=device).reshape(-1).clone()
+  return z, dim, device
+
+
+def stochastic_forcing_lanczos(factor=1.0, tolerance=1e-6, max_iter=1000, dim=None, mobility=None,
+                               mobility_mult=None, L_mult=None, z=None, print_residual=False, device=None, sync=None):
+  """mobility_mult: callable(torch tensor (dim,)) -> torch tensor (dim,) on the same device
+  (e.g. lambda v: ctx.matvec_device('tt', v, eta)); or `mobility` = dense torch/numpy matrix.
+  z: numpy array or torch tensor; drawn from N(0,1) when None.  Returns (noise tensor, iterations)."""
+  if z is not None and dim is None:
+    dim = int(z.numel() if isinstance(z, torch.Tensor) else np.size(z))
+  if factor == 0.0:
+    dev = z.device if isinstance(z, torch.Tensor) and device is None else (device if device is not None else
+                                                                            (mobility.device if isinstance(mobility, torch.Tensor) else "cpu"))
+    return torch.zeros(dim, dtype=torch.float64, device=torch.device(dev)), 0
+  z, dim, device = _prepare(z, dim, device, mobility)
+  if mobility is not None:
+    Mt = torch.as_tensor(mobility, dtype=torch.float64, device=device)
+    mobility_mult = lambda v: Mt @ v  # noqa: E731
+  steps = _lanczos_steps(factor, tolerance, max_iter, dim, z, print_residual, device, sync)
+  try:
+    request = next(steps)
+    while True:
+      request = steps.send(mobility_mult(request))
+  except StopIteration as done:
+    noise, its = done.value
   if L_mult is not None:
     noise = L_mult(noise).reshape(-1)
   return noise, its
+
+
+def stochastic_forcing_lanczos_pair(factors, zs, mobility_mult, mobility_mult2, tolerance=1e-6, max_iter=1000, L_mult=None,
+                                    print_residual=False, device=None, sync=None):
+  """Two forcings factor_k M^{1/2} z_k with the SAME mobility advanced in lockstep: while both run, each iteration hands
+  its two product requests to mobility_mult2(u, v) -> (M u, M v) (one pass over the pairs, rmb_matvec2_device).  Each
+  forcing sees exactly the iterates it would see alone.  Returns ((noise_a, its_a), (noise_b, its_b))."""
+  z0, dim, device = _prepare(zs[0], None, device, None)
+  z1, _, _ = _prepare(zs[1], None, device, None)
+  gens = [_lanczos_steps(f, tolerance, max_iter, dim, z, print_residual, device, sync) for f, z in zip(factors, (z0, z1))]
+  requests, results = [None, None], [None, None]
+  for k in (0, 1):
+    requests[k] = next(gens[k])
+  while results[0] is None or results[1] is None:
+    if results[0] is None and results[1] is None:
+      answers = mobility_mult2(requests[0], requests[1])
+    else:
+      k = 0 if results[0] is None else 1
+      answers = [None, None]
+      answers[k] = mobility_mult(requests[k])
+    for k in (0, 1):
+      if results[k] is None:
+        try:
+          requests[k] = gens[k].send(answers[k])
+        except StopIteration as done:
+          results[k] = done.value
+  out = []
+  for noise, its in results:
+    out.append((L_mult(noise).reshape(-1) if L_mult is not None else noise, its))
+  return out[0], out[1]
 
 
 # ---- dense forcings (stochastic_forcing/stochastic_forcing.py:7-109): O(n^3), for small systems and as checks --------

@@ -55,3 +55,25 @@ def test_dense_forcings(g6, oracle):
     G = np.array([fn(M, factor=1.0, z=eye[k]).numpy() for k in range(n)]).T       # G = the root itself
     assert np.abs(G @ G.T - M).max() < 1e-12 * np.abs(M).max()
   assert stochastic_forcing_eig(M).shape == (n,)
+
+
+def test_lockstep_lanczos_pair_equals_two_runs(g6, oracle):
+  from rigidmultiblobswall_amd.stochastic import stochastic_forcing_lanczos, stochastic_forcing_lanczos_pair
+  import torch
+  M = torch.from_numpy(oracle.dense("tt", 1, g6["r_vectors"], float(g6["eta"]), float(g6["a"])))
+  z2 = np.random.RandomState(3).randn(180)
+  calls = {"pair": 0, "single": 0}
+
+  def one(v):
+    calls["single"] += 1
+    return M @ v
+
+  def two(u, v):
+    calls["pair"] += 1
+    return M @ u, M @ v
+  (na, ia), (nb, ib) = stochastic_forcing_lanczos_pair((0.7, 1.3), (g6["z"], z2), one, two, tolerance=1e-10)
+  ra, ja = stochastic_forcing_lanczos(factor=0.7, tolerance=1e-10, mobility=M, z=g6["z"])
+  rb, jb = stochastic_forcing_lanczos(factor=1.3, tolerance=1e-10, mobility=M, z=z2)
+  assert torch.equal(na, ra) and torch.equal(nb, rb) and (ia, ib) == (ja, jb)
+  assert calls["pair"] == min(ja, jb) + 1 and calls["single"] == abs(ja - jb)
+  assert ia == int(g6["iterations_tol1e-10"])
