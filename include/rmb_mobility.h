@@ -63,9 +63,30 @@ int rmb_device_count(void);
  *  the reference re-uploads positions on every call.) */
 int rmb_ctx_create(int device, rmb_ctx** ctx);
 int rmb_ctx_destroy(rmb_ctx* ctx);
-/* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+/* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream.
+ * A context is SINGLE-STREAM at a time (its accumulators, workspaces and packed positions are re-used from call to
+ * call): when the handle changes, the new stream is made to wait (event) for everything already queued on the
+ * previous one.  Unchanged handle: no cost. */
 int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
-/* options: "chunks" (0 = auto source-chunk count), "timing" (1 = record HIP events per sweep) */
+/* Options (unknown key -> RMB_ERR_ARG).  Defaults in [].
+ *   "timing"          [0]  1 = bracket every pair-sweep launch with HIP events (rmb_timing_collect)
+ *   "symmetric"       [1]  1 = evaluate each unordered pair once and update both blobs (sym_kernels.h /
+ *                          symx_kernels.h) whenever the full target range is resident and n >= 128;
+ *                          0 = always the one-sided sweep (every ordered pair, atomic-free)
+ *   "deterministic"   [0]  1 = bit-reproducible results: forces the one-sided sweep (fixed summation order, no
+ *                          atomics); ~1.6x slower.  Pair shards (nshards > 1) ignore it.
+ *   "fused_symmetric" [1]  RMB_TT_TR: 1 = one symmetric pass sharing the pair geometry between both blocks,
+ *                          2 = two symmetric passes (tt, then tr accumulated), 0 = the one-sided fused sweep
+ *   "symx_single"     [0]  1 = run tt / tr / rt / rr (and the two-vector product) through the generic multi-block
+ *                          skeleton instead of the dedicated kernels (A/B measurements)
+ *   "chunks"          [0]  one-sided sweep: number of source chunks (blockIdx.y); 0 = chosen from the occupancy
+ *   "sym_oversub"     [8]  symmetric kernels: launch up to this many times the resident workgroup count
+ *   "sym_min_steps"   [64] symmetric kernels: floor on rotation steps per wave (one tile pair = 64 steps)
+ *   "sym_wps"         [0]  symmetric kernels: cap on resident workgroups per CU (0 = occupancy limit)
+ *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
+ *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics
+ *   "skip_pairs"      [0]  diagnostics, results are WRONG: bit 0 = no pair arithmetic, bit 1 = no flush of the
+ *                          per-wave LDS accumulators (tools/exp_prewarm.py prices the atomics with it)          */
 int rmb_ctx_set_option(rmb_ctx* ctx, const char* key, long value);
 
 /* Upload / pack positions: fuses shift_heights + damping_matrix_B (mobility.py:52-84).
@@ -96,11 +117,32 @@ int rmb_matvec_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_dev, d
  * part of every pair (geometry, both inverse square roots, RPY and wall coefficients) is evaluated once, so the call
  * costs ~0.66 of two rmb_matvec_device calls.  Serves solvers that advance two right-hand sides in lockstep with the
  * same mobility (the Brownian-slip and RFD solves of quaternion_integrator_multi_bodies.py:985-996).  Falls back to two
- * single products where the symmetric kernel does not apply (n < 128, "deterministic", target sub-ranges). */
+ * single products where the symmetric kernel does not apply (n < 128, "deterministic", target sub-ranges); a pair
+ * shard (nshards > 1) always runs the symmetric kernel, for any n. */
 int rmb_matvec2_device(rmb_ctx* ctx, int kind, const double* vec_a_dev, const double* vec_b_dev, double eta,
                        double* out_a_dev, double* out_b_dev);
 int rmb_matvec2_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_a_dev, const double* vec_b_dev, double eta,
                                  double* out_a_dev, double* out_b_dev, long shard, long nshards);
+
+/* Several blocks of the grand mobility from ONE pass over the unordered pairs: differences, both inverse square
+ * roots, the wall polynomials and the heights are evaluated once per pair and shared by all blocks.
+ *   RMB_OP_VELOCITY_FROM_FORCE_TORQUE  in: f, tau   out: u = M_tt f + M_tr tau          (= RMB_TT_TR;
+ *       mobility_pycuda.py:1266-1391 / :1394-1512)
+ *   RMB_OP_GRAND                       in: f, tau   out: u, w = [[M_tt, M_tr], [M_rt, M_rr]] [f; tau]
+ *       (quaternion_integrator/quaternion_integrator_rollers.py:1114-1121 applies the four blocks separately)
+ *   RMB_OP_FORCE_COLUMN                in: f        out: u = M_tt f, w = M_rt f   (the two random-finite-difference
+ *       products of one draw, quaternion_integrator_rollers.py:1138-1160)
+ *   RMB_OP_TT_MULTI                    in: k vectors (1..4)   out: M_tt applied to each (solves and Lanczos
+ *       recursions advanced in lockstep on the same configuration)
+ * in_dev / out_dev: arrays of n_in / n_out device pointers to 3n doubles (3*(end-begin) for outputs under a target
+ * range).  in_plane != 0 zeroes the z component of every input and output (mobility_numba.py:291, :690).
+ * Wall / no-wall / pseudo-periodic follow rmb_set_positions.  The *_pairshard variant evaluates pair shard `shard`
+ * of `nshards` into full-length partial outputs (sum over shards = product), as rmb_matvec_pairshard_device. */
+enum rmb_op { RMB_OP_VELOCITY_FROM_FORCE_TORQUE = 0, RMB_OP_GRAND = 1, RMB_OP_FORCE_COLUMN = 2, RMB_OP_TT_MULTI = 3 };
+int rmb_matvec_op_device(rmb_ctx* ctx, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
+                         double* const* out_dev, double eta);
+int rmb_matvec_op_pairshard_device(rmb_ctx* ctx, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
+                                   double* const* out_dev, double eta, long shard, long nshards);
 
 /* Dense translation-translation mobility of each rigid body's own blobs (building block of the
  * block-diagonal preconditioner, multi_bodies/multi_bodies.py:516-531; replaces body/body.py:186-191 ->

@@ -15,6 +15,10 @@ _vp = ctypes.c_void_p
 _lp = ctypes.POINTER(ctypes.c_long)
 
 KIND_TT, KIND_TR, KIND_RT, KIND_RR, KIND_TT_TR, KIND_TT_FREE = 0, 1, 2, 3, 4, 5
+OP_VELOCITY_FROM_FORCE_TORQUE, OP_GRAND, OP_FORCE_COLUMN, OP_TT_MULTI = 0, 1, 2, 3
+# name -> (rmb_op, inputs, outputs); "tt_multi" takes 1..4 vectors
+OPS = {"velocity_from_force_torque": (OP_VELOCITY_FROM_FORCE_TORQUE, 2, 1), "grand": (OP_GRAND, 2, 2),
+       "force_column": (OP_FORCE_COLUMN, 1, 2), "tt_multi": (OP_TT_MULTI, None, None)}
 KINDS = {"tt": KIND_TT, "tr": KIND_TR, "rt": KIND_RT, "rr": KIND_RR, "tt_tr": KIND_TT_TR, "tt_free": KIND_TT_FREE}
 
 # every symbol include/rmb_mobility.h declares: (restype, argtypes)
@@ -37,6 +41,10 @@ SYMBOLS = {
     "rmb_matvec_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_long,
                                                    ctypes.c_long]),
     "rmb_body_mobility_dense_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_double, _vp]),
+    "rmb_matvec_op_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,
+                                            ctypes.c_double]),
+    "rmb_matvec_op_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,
+                                                      ctypes.c_double, ctypes.c_long, ctypes.c_long]),
     "rmb_blob_blob_force": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_blob_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_blob_blob_force_radii": (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),

@@ -161,6 +161,41 @@ class MobilityContext(object):
                                                       ctypes.c_void_p(outs[1].data_ptr()), int(shard), int(nshards)))
     return outs[0], outs[1]
 
+  def matvec_op_device(self, op, vecs, eta, in_plane=False, outs=None, shard=0, nshards=1):
+    """Several blocks of the grand mobility from one pass over the pairs (rmb_matvec_op_device):
+      "velocity_from_force_torque"  (f, tau) -> (M_tt f + M_tr tau,)
+      "grand"                       (f, tau) -> (M_tt f + M_tr tau, M_rt f + M_rr tau)
+      "force_column"                (f,)     -> (M_tt f, M_rt f)
+      "tt_multi"                    k vectors -> M_tt applied to each (k = 1..4)
+    vecs / outs: sequences of contiguous CUDA float64 tensors with 3n (outs: 3*n_targets) entries; returns the tuple
+    of outputs.  With nshards > 1: the contribution of one pair shard to all n targets (to be summed over shards)."""
+    import torch
+    code, n_in, n_out = _lib.OPS[op]
+    if n_in is None:
+      n_in = n_out = len(vecs)
+    if len(vecs) != n_in:
+      raise ValueError("%s takes %d input vectors" % (op, n_in))
+    for v in vecs:
+      if not _is_torch_cuda(v) or v.numel() != 3 * self.n or not v.is_contiguous():
+        raise ValueError("vectors must be contiguous CUDA float64 tensors with 3*n entries")
+    n_res = 3 * (self.n if nshards > 1 else self.n_targets)
+    if outs is None:
+      outs = [torch.empty(n_res, dtype=torch.float64, device=vecs[0].device) for _ in range(n_out)]
+    outs = list(outs)
+    if len(outs) != n_out:
+      raise ValueError("%s produces %d output vectors" % (op, n_out))
+    for o in outs:
+      if not _is_torch_cuda(o) or o.numel() != n_res or not o.is_contiguous():
+        raise ValueError("outputs must be contiguous CUDA float64 tensors with %d entries" % n_res)
+    ins_p = (ctypes.c_void_p * n_in)(*[v.data_ptr() for v in vecs])
+    outs_p = (ctypes.c_void_p * n_out)(*[o.data_ptr() for o in outs])
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_matvec_op_pairshard_device(self._h, code, int(bool(in_plane)), n_in,
+                                                        ctypes.cast(ins_p, ctypes.c_void_p), n_out,
+                                                        ctypes.cast(outs_p, ctypes.c_void_p), float(eta), int(shard),
+                                                        int(nshards)))
+    return tuple(outs)
+
   def body_mobility_dense_device(self, first_blob, n_b, eta, out=None):
     """Dense (3 n_b x 3 n_b) tt mobility of every listed body (int64 CUDA tensor of first-blob indices)."""
     import torch

@@ -73,10 +73,10 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 // constants (v_mov_b64 + v_fmac) in the pair loop.
 struct WallTT { double iR, iR2, G1, G2, G3, G4, G5; };
 
-__device__ __forceinline__ WallTT wall_tt_factors(const PairConsts& k, double rho2, double Rz, double zj) {
+// iR = 1/|R| supplied by the caller (kernels that evaluate several blocks per pair share it)
+__device__ __forceinline__ WallTT wall_tt_from_iR(const PairConsts& k, double Rz, double iR, double zj) {
   WallTT W;
-  const double R2 = __builtin_fma(Rz, Rz, rho2);
-  W.iR = rsqrt_f64(R2);
+  W.iR = iR;
   W.iR2 = W.iR * W.iR;
   const double tau = k.a2 * W.iR2;
   const double ez = Rz * W.iR;
@@ -102,6 +102,10 @@ __device__ __forceinline__ WallTT wall_tt_factors(const PairConsts& k, double rh
   const double ut = uu * tau;
   W.G5 = -__builtin_fma(tau4, __builtin_fma(ut, -5.0, tau23) + uu, g2 * g2);
   return W;
+}
+
+__device__ __forceinline__ WallTT wall_tt_factors(const PairConsts& k, double rho2, double Rz, double zj) {
+  return wall_tt_from_iR(k, Rz, rsqrt_f64(__builtin_fma(Rz, Rz, rho2)), zj);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #include "matvec_kernels.h"
 #include "sym_kernels.h"
 #include "sym2_kernels.h"
+#include "symx_kernels.h"
 #include "dense_kernels.h"
 #include "st_kernels.h"
 
@@ -55,6 +56,10 @@ constexpr int kTimingRing = 8192;
 struct rmb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t stream_switch = nullptr;  // orders a newly set stream after the work queued on the previous one
+  // device properties (hipDeviceProp_t): a partitioned (CPX) device or another SKU changes both
+  long n_cu = 256;               // multiProcessorCount
+  size_t lds_per_cu = 160 * 1024;  // maxSharedMemoryPerMultiProcessor
   // resident configuration
   long n = 0;
   double a = 0.0;
@@ -65,7 +70,7 @@ struct rmb_ctx {
   // device memory
   DevBuf pos;      // double4[n]
   DevBuf r_stage;  // raw positions staging (host entry)
-  DevBuf vec, vec2, out, partial;
+  DevBuf vec, vec2, out, partial, tmp3n;
   DevBuf st[8];    // scratch of the source->target entry point
   DevBuf wave_clock;  // optional per-wave (start, end) wall-clock stamps of the symmetric kernel
   long wave_clock_n = 0;
@@ -77,7 +82,8 @@ struct rmb_ctx {
   long opt_chunks = 0;
   long opt_timing = 0;
   long opt_symmetric = 1;      // use the symmetric (each unordered pair once) kernel where applicable
-  long opt_fused_symmetric = 1;  // tt+tr: two symmetric passes instead of the fused one-sided sweep
+  long opt_fused_symmetric = 1;  // tt+tr: 1 = single symmetric pass (symx_kernels.h), 2 = two symmetric passes, 0 = one-sided fused sweep
+  long opt_symx_single = 0;      // route tt / tr / rt / rr through the generic skeleton (A/B against sym_kernel)
   long opt_deterministic = 0;  // force the atomic-free sweep kernel everywhere
   int last_path = 0;           // 0 = sweep, 1 = symmetric
   long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
@@ -207,16 +213,66 @@ template <int KIND, bool WALL, bool PER> SymEntry make_sym_entry() {
 SymEntry g_sym[4][2][2] = {RMB_SYM_ROW(rmb::KIND_TT), RMB_SYM_ROW(rmb::KIND_TR), RMB_SYM_ROW(rmb::KIND_RT), RMB_SYM_ROW(rmb::KIND_RR)};
 #undef RMB_SYM_ROW
 
-// Global SoA accumulators of the symmetric kernels: [2][3][n_pad] doubles (the two-vector kernel uses both halves),
+// Global SoA accumulators of the symmetric kernels: [4][3][n_pad] doubles (up to four output vectors per pass),
 // zeroed once; every finalize kernel re-zeroes what its sweep touched.
+constexpr int kSymMaxOut = 4;
 int sym_accumulators(rmb_ctx* c, long n_pad) {
-  const size_t acc_bytes = (size_t)6 * n_pad * sizeof(double);
+  const size_t acc_bytes = (size_t)3 * kSymMaxOut * n_pad * sizeof(double);
   if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
     if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
     RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));
     c->symbuf_zeroed_for = n_pad;
   }
   return 0;
+}
+
+// Launch plan of a symmetric sweep: `total` rotation steps over `blocks` workgroups of 4 waves.
+struct SymPlan { long blocks; long steps_per_wave; size_t dyn_lds; };
+
+// Static, exactly balanced schedule (sym_kernels.h): whole multiples of the resident workgroup count so that every
+// SIMD gets the same number of steps.  `pin` pads dynamic LDS so that exactly `wps` workgroups fit a CU (equal steps
+// per wave is then equal work per SIMD); CU count and LDS size come from hipDeviceProp_t (rmb_ctx_create).
+int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long total, bool pin, SymPlan* out) {
+  int wps = resident_blocks(fn, occ_cache);
+  if (c->opt_sym_wps > 0 && c->opt_sym_wps < wps) wps = (int)c->opt_sym_wps;
+  size_t pad = 0;
+  if (pin && c->opt_sym_pin) {
+    const size_t per_block = c->lds_per_cu / (size_t)wps;
+    if (per_block > static_lds + 1024) pad = per_block - static_lds - 512;
+    if (pad > 48 * 1024) RMB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+  }
+  const long round = c->n_cu * wps;
+  long blocks = round * c->opt_sym_oversub;
+  const long per_wg = rmb::kSymWaves * c->opt_sym_min_steps;
+  const long need = (total + per_wg - 1) / per_wg > 0 ? (total + per_wg - 1) / per_wg : 1;
+  if (blocks > need) blocks = need;
+  if (blocks > round) blocks -= blocks % round;   // whole rounds only: a partial last round is a tail
+  if (blocks < round) {
+    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): filling the round with
+    // shorter waves (down to 16 steps) beats leaving SIMDs with one or two waves and no latency hiding
+    // (1/4 shard of 1e4 blobs: 68.9 -> 60.3 us; tools/exp_pairshard.py)
+    const long per_wg_fine = rmb::kSymWaves * 16L;
+    long fine = (total + per_wg_fine - 1) / per_wg_fine;
+    if (fine > round) fine = round;
+    if (fine > blocks) blocks = fine;
+  }
+  if (blocks < 1) blocks = 1;
+  const long waves = blocks * rmb::kSymWaves;
+  out->blocks = blocks;
+  out->steps_per_wave = (total + waves - 1) / waves;
+  out->dyn_lds = pad;
+  return 0;
+}
+
+// step range and self-term ownership of pair shard `shard` of `nshards`
+void shard_ranges(long n, long n_units, long shard, long nshards, long* step_begin, long* step_end, long* self_begin,
+                  long* self_end) {
+  const __int128 s_total = (__int128)n_units * 64;
+  *step_begin = (long)(s_total * shard / nshards);
+  *step_end = (long)(s_total * (shard + 1) / nshards);
+  const long block = (n + nshards - 1) / nshards;       // same block partition as distributed.partition()
+  *self_begin = block * shard < n ? block * shard : n;
+  *self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
 }
 
 int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard = 0, long nshards = 1,
@@ -236,51 +292,19 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   a.n_pad = n_pad;
   a.n_tiles = (int)tiles;
   a.n_units = tiles * (tiles + 1) / 2;
-  {
-    const __int128 s_total = (__int128)a.n_units * 64;
-    a.step_begin = (long)(s_total * shard / nshards);
-    a.step_end = (long)(s_total * (shard + 1) / nshards);
-    const long block = (n + nshards - 1) / nshards;       // same block partition as distributed.partition()
-    a.self_begin = block * shard < n ? block * shard : n;
-    a.self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
-  }
+  shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
   a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
   a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
-  const void* fn = (const void*)se.sweep;
-  int wps = resident_blocks(fn, &se.occ);
-  if (c->opt_sym_wps > 0 && c->opt_sym_wps < wps) wps = (int)c->opt_sym_wps;
-  // dynamic LDS padding pins residency to exactly `wps` workgroups per CU, so that the static schedule
-  // (equal steps per wave) is also equal work per SIMD
-  size_t pad = 0;
-  if (c->opt_sym_pin) {
-    const size_t per_block = (size_t)(160 * 1024) / (size_t)wps;
-    const size_t stat = sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
-    if (per_block > stat + 1024) pad = per_block - stat - 512;
-    if (pad > 48 * 1024) RMB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-  }
-  long blocks = 256L * wps * c->opt_sym_oversub;
-  const long per_wg = rmb::kSymWaves * c->opt_sym_min_steps;
-  const long need = (a.step_end - a.step_begin + per_wg - 1) / per_wg > 0 ? (a.step_end - a.step_begin + per_wg - 1) / per_wg : 1;
-  if (blocks > need) blocks = need;
-  if (blocks > 256L * wps) blocks -= blocks % (256L * wps);   // whole rounds only: a partial last round is a tail
-  if (blocks < 256L * wps) {
-    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): filling the round with
-    // shorter waves (down to 16 steps) beats leaving SIMDs with one or two waves and no latency hiding
-    // (1/4 shard of 1e4 blobs: 68.9 -> 60.3 us; tools/exp_pairshard.py)
-    const long per_wg_fine = rmb::kSymWaves * 16L;
-    long fine = (a.step_end - a.step_begin + per_wg_fine - 1) / per_wg_fine;
-    if (fine > 256L * wps) fine = 256L * wps;
-    if (fine > blocks) blocks = fine;
-  }
+  SymPlan plan;
+  const size_t stat = sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
+  if (int rc = plan_sym(c, (const void*)se.sweep, &se.occ, stat, a.step_end - a.step_begin, true, &plan)) return rc;
+  const long blocks = plan.blocks;
+  a.steps_per_wave = plan.steps_per_wave;
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
-  {
-    const long waves = blocks * rmb::kSymWaves, total = a.step_end - a.step_begin;
-    a.steps_per_wave = (total + waves - 1) / waves;
-  }
   a.skip_pairs = (int)c->opt_skip_pairs;
   a.accumulate = accumulate ? 1 : 0;
   a.wave_clock = nullptr;
@@ -291,7 +315,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   }
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), pad, c->stream, a);
+  hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
   const dim3 fgrid((unsigned)((n + 255) / 256));
@@ -312,14 +336,7 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
   a.acc = (double*)c->symbuf.p;
   a.out_a = out_a; a.out_b = out_b;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
-  {
-    const __int128 s_total = (__int128)a.n_units * 64;
-    a.step_begin = (long)(s_total * shard / nshards);
-    a.step_end = (long)(s_total * (shard + 1) / nshards);
-    const long block = (n + nshards - 1) / nshards;
-    a.self_begin = block * shard < n ? block * shard : n;
-    a.self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
-  }
+  shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
   a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
@@ -330,24 +347,11 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
   static int occ2[2][2] = {{0, 0}, {0, 0}};
   const k2_fn fn = c->wall ? (periodic ? (k2_fn)rmb::sym2_kernel<true, true> : (k2_fn)rmb::sym2_kernel<true, false>)
                            : (periodic ? (k2_fn)rmb::sym2_kernel<false, true> : (k2_fn)rmb::sym2_kernel<false, false>);
-  const int wps = resident_blocks((const void*)fn, &occ2[c->wall ? 1 : 0][periodic ? 1 : 0]);
-  const long round = 256L * wps;
-  long blocks = round * c->opt_sym_oversub;
-  const long total = a.step_end - a.step_begin;
-  const long per_wg = rmb::kSymWaves * c->opt_sym_min_steps;
-  const long need = (total + per_wg - 1) / per_wg > 0 ? (total + per_wg - 1) / per_wg : 1;
-  if (blocks > need) blocks = need;
-  if (blocks > round) blocks -= blocks % round;
-  if (blocks < round) {
-    long fine = (total + rmb::kSymWaves * 16L - 1) / (rmb::kSymWaves * 16L);
-    if (fine > round) fine = round;
-    if (fine > blocks) blocks = fine;
-  }
-  if (blocks < 1) blocks = 1;
-  {
-    const long waves = blocks * rmb::kSymWaves;
-    a.steps_per_wave = (total + waves - 1) / waves;
-  }
+  SymPlan plan;
+  if (int rc = plan_sym(c, (const void*)fn, &occ2[c->wall ? 1 : 0][periodic ? 1 : 0], 0, a.step_end - a.step_begin, false, &plan))
+    return rc;
+  const long blocks = plan.blocks;
+  a.steps_per_wave = plan.steps_per_wave;
   c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
@@ -359,6 +363,67 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
   else         hipLaunchKernelGGL(rmb::sym2_finalize_kernel<false>, fgrid, dim3(256), 0, c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
+}
+
+// ---- generic symmetric operations (symx_kernels.h) ---------------------------------------------------------
+typedef void (*symx_fn)(const rmb::SymXArgs);
+struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n_in, n_out; };
+template <class OP, bool WALL, bool PER> SymXEntry make_symx_entry() {
+  return SymXEntry{rmb::symx_kernel<OP, WALL, PER>, rmb::symx_finalize_kernel<OP, WALL>, 0,
+                   sizeof(double2) * rmb::kSymWaves * 64 * rmb::SymXRec<OP::NIN>::d2 +
+                       sizeof(double) * rmb::kSymWaves * 3 * OP::NOUT * 64,
+                   OP::NIN, OP::NOUT};
+}
+enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_TT2, SX_TT3, SX_TT4, SX_FREE, SX_COUNT };
+// [op][wall][periodic]
+#define RMB_SX_ROW(OP) {{make_symx_entry<OP, false, false>(), make_symx_entry<OP, false, true>()}, {make_symx_entry<OP, true, false>(), make_symx_entry<OP, true, true>()}}
+SymXEntry g_symx[SX_COUNT][2][2] = {
+    RMB_SX_ROW(rmb::OpSingle<rmb::KIND_TT>), RMB_SX_ROW(rmb::OpSingle<rmb::KIND_TR>), RMB_SX_ROW(rmb::OpSingle<rmb::KIND_RT>),
+    RMB_SX_ROW(rmb::OpSingle<rmb::KIND_RR>), RMB_SX_ROW(rmb::OpFusedRow), RMB_SX_ROW(rmb::OpGrand), RMB_SX_ROW(rmb::OpColumnF),
+    RMB_SX_ROW(rmb::OpTTk<2>), RMB_SX_ROW(rmb::OpTTk<3>), RMB_SX_ROW(rmb::OpTTk<4>),
+    // the free-surface operation takes raw heights: only the wall = 0 column is ever launched
+    {{make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
+     {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}}};
+#undef RMB_SX_ROW
+
+int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane, long shard,
+                long nshards, int accumulate_mask = 0) {
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  SymXEntry& se = g_symx[op][c->wall ? 1 : 0][periodic ? 1 : 0];
+  const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
+  if (int rc = sym_accumulators(c, n_pad)) return rc;
+  rmb::SymXArgs a;
+  a.pos = (const double4*)c->pos.p;
+  for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
+  a.acc = (double*)c->symbuf.p;
+  a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
+  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.accumulate = accumulate_mask;
+  a.in_plane = in_plane ? 1 : 0;
+  a.skip_pairs = (int)c->opt_skip_pairs;
+  a.k = make_pair_consts(c->a);
+  SymPlan plan;
+  if (int rc = plan_sym(c, (const void*)se.sweep, &se.occ, se.static_lds, a.step_end - a.step_begin, true, &plan)) return rc;
+  a.steps_per_wave = plan.steps_per_wave;
+  c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  hipLaunchKernelGGL(se.sweep, dim3((unsigned)plan.blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
+  hipLaunchKernelGGL(se.fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+// whether the symmetric (each unordered pair once) path applies to the resident configuration
+bool sym_applies(const rmb_ctx* c) {
+  return c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128;
 }
 
 int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta,
@@ -376,21 +441,28 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
 
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (kind <= rmb::KIND_RR && !in_plane && c->opt_symmetric && !c->opt_deterministic &&
-      c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
+  if (sym_applies(c)) {
+    // every product of the surface is a symmetric operator: each unordered pair once, applied to both blobs
     c->last_path = 1;
-    return sym_device(c, kind, v, eta, out);
-  }
-  if (kind == rmb::KIND_TT_TR && !in_plane && c->opt_symmetric && !c->opt_deterministic && c->opt_fused_symmetric &&
-      c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
-    // M_tt f + M_tr tau as two symmetric passes into the same output: 2 x (N^2/2) pair evaluations beat one
-    // fused N^2 sweep (measured at 1e5 blobs, wall: 17.7 + 16.7 ms against 41.8 ms)
-    c->last_path = 1;
-    if (int rc = sym_device(c, rmb::KIND_TT, v, eta, out)) return rc;
-    return sym_device(c, rmb::KIND_TR, v2, eta, out, 0, 1, true);
+    const double* in[2] = {v, v2};
+    double* outs[1] = {out};
+    if (kind <= rmb::KIND_RR) {
+      if (in_plane || c->opt_symx_single) return symx_device(c, SX_TT + kind, in, outs, eta, in_plane, 0, 1);
+      return sym_device(c, kind, v, eta, out);
+    }
+    if (kind == rmb::KIND_TT_TR) {
+      if (c->opt_fused_symmetric == 2) {   // round-1 path, kept for A/B: two symmetric passes into one output
+        if (in_plane) return fail(RMB_ERR_ARG, "fused_symmetric = 2 has no in-plane variant");
+        if (int rc = sym_device(c, rmb::KIND_TT, v, eta, out)) return rc;
+        return sym_device(c, rmb::KIND_TR, v2, eta, out, 0, 1, true);
+      }
+      if (c->opt_fused_symmetric) return symx_device(c, SX_FUSED, in, outs, eta, in_plane, 0, 1);
+    }
+    if (kind == rmb::KIND_TT_FREE) return symx_device(c, SX_FREE, in, outs, eta, in_plane, 0, 1);
+    c->last_path = 0;
   }
   KernelEntry& ke = g_kernels[kind][c->wall ? 1 : 0][periodic ? 1 : 0];
-  const long slots = 256L * resident_blocks((const void*)ke.sweep, &ke.blocks_per_cu);
+  const long slots = c->n_cu * resident_blocks((const void*)ke.sweep, &ke.blocks_per_cu);
   long n_chunks, chunk_len;
   choose_chunks(n_tgt, c->n, c->opt_chunks, slots, &n_chunks, &chunk_len);
   const long tiles = (n_tgt + 63) / 64;
@@ -453,7 +525,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   RMB_HIP(hipSetDevice(c->device));
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (!radii && c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128) {
+  if (sym_applies(c)) {
     // symmetric path: each unordered pair once (F_ji = -F_ij)
     const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
     if (int rc = sym_accumulators(c, n_pad)) return rc;
@@ -468,16 +540,19 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
     a.eps_over_b = eps / b; a.inv_b = 1.0 / b; a.two_a = 2.0 * blob_radius;
     a.ec = exp_consts();
-    static int socc[2] = {0, 0};
-    const void* fn = periodic ? (const void*)rmb::sym_force_kernel<true> : (const void*)rmb::sym_force_kernel<false>;
-    long blocks = 256L * resident_blocks(fn, &socc[periodic ? 1 : 0]) * c->opt_sym_oversub;
+    a.radii = radii;
+    static int socc[2][2] = {{0, 0}, {0, 0}};
+    typedef void (*sforce_fn)(const rmb::SymForceArgs);
+    const sforce_fn sfn = radii ? (periodic ? (sforce_fn)rmb::sym_force_kernel<true, true> : (sforce_fn)rmb::sym_force_kernel<false, true>)
+                                : (periodic ? (sforce_fn)rmb::sym_force_kernel<true, false> : (sforce_fn)rmb::sym_force_kernel<false, false>);
+    const void* fn = (const void*)sfn;
+    long blocks = c->n_cu * resident_blocks(fn, &socc[radii ? 1 : 0][periodic ? 1 : 0]) * c->opt_sym_oversub;
     const long need = (a.n_units * 64 + 255) / 256;
     if (blocks > need) blocks = need;
     c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
     int slot;
     if (int rc = timing_begin(c, &slot)) return rc;
-    if (periodic) hipLaunchKernelGGL(rmb::sym_force_kernel<true>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
-    else          hipLaunchKernelGGL(rmb::sym_force_kernel<false>, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+    hipLaunchKernelGGL(sfn, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
     RMB_HIP(hipGetLastError());
     if (int rc = timing_end(c, slot)) return rc;
     hipLaunchKernelGGL(rmb::sym_force_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
@@ -488,7 +563,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   typedef void (*force_fn)(const rmb::ForceArgs);
   const force_fn ffn = radii ? (periodic ? (force_fn)rmb::force_sweep_kernel<true, true> : (force_fn)rmb::force_sweep_kernel<false, true>)
                              : (periodic ? (force_fn)rmb::force_sweep_kernel<true, false> : (force_fn)rmb::force_sweep_kernel<false, false>);
-  const long slots = 256L * resident_blocks((const void*)ffn, &force_occ[radii ? 1 : 0][periodic ? 1 : 0]);
+  const long slots = c->n_cu * resident_blocks((const void*)ffn, &force_occ[radii ? 1 : 0][periodic ? 1 : 0]);
   long n_chunks, chunk_len;
   choose_chunks(n_tgt, c->n, c->opt_chunks, slots, &n_chunks, &chunk_len);
   const long tiles = (n_tgt + 63) / 64;
@@ -546,6 +621,66 @@ int set_positions_impl(rmb_ctx* c, const double* r_dev, long n, double a, const 
   return 0;
 }
 
+__global__ void add_inplace_kernel(double* y, const double* x, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+
+// Multi-block operations (include/rmb_mobility.h, enum rmb_op).  One symmetric pass when that path applies (or for a
+// pair shard); otherwise composed from the one-sided sweeps (target sub-ranges, "deterministic", n < 128).
+int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* const* in, int n_out, double* const* out,
+                   double eta, long shard, long nshards) {
+  if (int rc = check_ready(c)) return rc;
+  if (!in || !out) return fail(RMB_ERR_ARG, "null vector / output list");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
+  int want_in = 0, want_out = 0, sx = -1;
+  switch (op) {
+    case RMB_OP_VELOCITY_FROM_FORCE_TORQUE: want_in = 2; want_out = 1; sx = SX_FUSED; break;
+    case RMB_OP_GRAND: want_in = 2; want_out = 2; sx = SX_GRAND; break;
+    case RMB_OP_FORCE_COLUMN: want_in = 1; want_out = 2; sx = SX_COLF; break;
+    case RMB_OP_TT_MULTI:
+      if (n_in < 1 || n_in > 4) return fail(RMB_ERR_ARG, "RMB_OP_TT_MULTI takes 1..4 vectors");
+      want_in = want_out = n_in;
+      sx = n_in == 1 ? SX_TT : SX_TT2 + (n_in - 2);
+      break;
+    default: return fail(RMB_ERR_ARG, "unknown rmb_op");
+  }
+  if (n_in != want_in || n_out != want_out) return fail(RMB_ERR_ARG, "wrong number of input / output vectors for this rmb_op");
+  for (int v = 0; v < n_in; ++v) if (!in[v]) return fail(RMB_ERR_ARG, "null input vector");
+  for (int v = 0; v < n_out; ++v) if (!out[v]) return fail(RMB_ERR_ARG, "null output vector");
+  if (c->n == 0) return 0;
+  RMB_HIP(hipSetDevice(c->device));
+  if (sym_applies(c) || nshards > 1) {
+    if (nshards > 1 && (c->tgt_begin != 0 || c->tgt_end != c->n))
+      return fail(RMB_ERR_STATE, "pair shards write all n targets: reset the target range to [0, n)");
+    return symx_device(c, sx, in, out, eta, in_plane, shard, nshards);
+  }
+  const long n_tgt = c->tgt_end - c->tgt_begin;
+  if (n_tgt == 0) return 0;
+  switch (op) {
+    case RMB_OP_VELOCITY_FROM_FORCE_TORQUE:
+      return matvec_device_impl(c, rmb::KIND_TT_TR, in_plane, in[0], in[1], eta, out[0]);
+    case RMB_OP_FORCE_COLUMN:
+      if (int rc = matvec_device_impl(c, rmb::KIND_TT, in_plane, in[0], nullptr, eta, out[0])) return rc;
+      return matvec_device_impl(c, rmb::KIND_RT, in_plane, in[0], nullptr, eta, out[1]);
+    case RMB_OP_GRAND: {
+      if (int rc = matvec_device_impl(c, rmb::KIND_TT_TR, in_plane, in[0], in[1], eta, out[0])) return rc;
+      if (int rc = matvec_device_impl(c, rmb::KIND_RT, in_plane, in[0], nullptr, eta, out[1])) return rc;
+      if (int rc = c->tmp3n.reserve((size_t)3 * n_tgt * sizeof(double))) return rc;
+      if (int rc = matvec_device_impl(c, rmb::KIND_RR, in_plane, in[1], nullptr, eta, (double*)c->tmp3n.p)) return rc;
+      hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((3 * n_tgt + 255) / 256)), dim3(256), 0, c->stream, out[1],
+                         (const double*)c->tmp3n.p, 3 * n_tgt);
+      RMB_HIP(hipGetLastError());
+      return 0;
+    }
+    default:
+      for (int v = 0; v < n_in; ++v)
+        if (int rc = matvec_device_impl(c, rmb::KIND_TT, in_plane, in[v], nullptr, eta, out[v])) return rc;
+      return 0;
+  }
+}
+
 std::mutex g_default_mu;
 rmb_ctx* g_default_ctx = nullptr;
 
@@ -570,8 +705,12 @@ int rmb_ctx_create(int device, rmb_ctx** out) {
     return fail(RMB_ERR_NO_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + ")");
   if (device < 0 || device >= n) return fail(RMB_ERR_ARG, "device index out of range");
   RMB_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  RMB_HIP(hipGetDeviceProperties(&prop, device));
   rmb_ctx* c = new rmb_ctx();
   c->device = device;
+  if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  if (prop.maxSharedMemoryPerMultiProcessor > 0) c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
   *out = c;
   return 0;
 }
@@ -580,7 +719,8 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->wave_clock.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release();
+  c->wave_clock.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release();
+  if (c->stream_switch) (void)hipEventDestroy(c->stream_switch);
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
   delete c;
@@ -589,7 +729,16 @@ int rmb_ctx_destroy(rmb_ctx* c) {
 
 int rmb_ctx_set_stream(rmb_ctx* c, void* s) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
-  c->stream = (hipStream_t)s;
+  const hipStream_t next = (hipStream_t)s;
+  if (next != c->stream) {
+    // A context is single-stream at a time: accumulators, workspaces and the packed positions are re-used from call
+    // to call, so the new stream must not start before what was queued on the previous one has finished.
+    RMB_HIP(hipSetDevice(c->device));
+    if (!c->stream_switch) RMB_HIP(hipEventCreateWithFlags(&c->stream_switch, hipEventDisableTiming));
+    RMB_HIP(hipEventRecord(c->stream_switch, c->stream));
+    RMB_HIP(hipStreamWaitEvent(next, c->stream_switch, 0));
+    c->stream = next;
+  }
   return 0;
 }
 
@@ -599,6 +748,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "timing")) { c->opt_timing = value; return 0; }
   if (!strcmp(key, "symmetric")) { c->opt_symmetric = value; return 0; }
   if (!strcmp(key, "fused_symmetric")) { c->opt_fused_symmetric = value; return 0; }
+  if (!strcmp(key, "symx_single")) { c->opt_symx_single = value; return 0; }
   if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
   if (!strcmp(key, "sym_wps")) { c->opt_sym_wps = value; return 0; }
   if (!strcmp(key, "wave_clock")) { c->opt_wave_clock = value; return 0; }
@@ -653,10 +803,16 @@ int rmb_matvec2_pairshard_device(rmb_ctx* c, int kind, const double* vec_a, cons
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard");
   RMB_HIP(hipSetDevice(c->device));
-  if (c->n < 128 || c->opt_deterministic || !c->opt_symmetric) {
-    if (nshards != 1) return fail(RMB_ERR_STATE, "pair shards need the symmetric path (n >= 128, not deterministic)");
+  if (!sym_applies(c) && nshards == 1) {
     if (int rc = matvec_device_impl(c, kind, 0, vec_a, nullptr, eta, out_a)) return rc;
     return matvec_device_impl(c, kind, 0, vec_b, nullptr, eta, out_b);
+  }
+  // a pair shard (nshards > 1) always runs the symmetric kernel, whatever n: it is the only kernel that can
+  // evaluate a slice of the unordered pairs (rmb_matvec_pairshard_device does the same)
+  if (c->opt_symx_single) {
+    const double* in[2] = {vec_a, vec_b};
+    double* outs[2] = {out_a, out_b};
+    return symx_device(c, SX_TT2, in, outs, eta, 0, shard, nshards);
   }
   return sym2_device(c, vec_a, vec_b, eta, out_a, out_b, shard, nshards);
 }
@@ -683,6 +839,16 @@ int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double et
   return sym_device(c, kind, v, eta, out, shard, nshards);
 }
 
+int rmb_matvec_op_device(rmb_ctx* c, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
+                         double* const* out_dev, double eta) {
+  return matvec_op_impl(c, op, in_plane, n_in, in_dev, n_out, out_dev, eta, 0, 1);
+}
+
+int rmb_matvec_op_pairshard_device(rmb_ctx* c, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
+                                   double* const* out_dev, double eta, long shard, long nshards) {
+  return matvec_op_impl(c, op, in_plane, n_in, in_dev, n_out, out_dev, eta, shard, nshards);
+}
+
 int rmb_body_mobility_dense_device(rmb_ctx* c, const long* first_blob_dev, long n_bodies, int n_b, double eta,
                                    double* out_dev) {
   if (int rc = check_ready(c)) return rc;
@@ -702,7 +868,7 @@ int rmb_body_mobility_dense_device(rmb_ctx* c, const long* first_blob_dev, long 
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
   // blockIdx.y splits the n_b^2 blob pairs of a body so that one big "body" (the dense builders) still fills the chip
-  long ysplit = ((long)n_b * n_b + 256L * 16 - 1) / (256L * 16);
+  long ysplit = ((long)n_b * n_b + 256L * 16 - 1) / (256L * 16);   // 256 threads x 16 blob pairs each
   if (ysplit < 1) ysplit = 1;
   if (ysplit > 4096) ysplit = 4096;
   const dim3 grid((unsigned)n_bodies, (unsigned)ysplit);
@@ -808,7 +974,7 @@ int rmb_mobility_source_target_device(rmb_ctx* c, long ns, const double* src_dev
   st_fn fn = wall == 2 ? (periodic ? (st_fn)rmb::st_sweep_kernel<2, true> : (st_fn)rmb::st_sweep_kernel<2, false>)
            : wall      ? (periodic ? (st_fn)rmb::st_sweep_kernel<1, true> : (st_fn)rmb::st_sweep_kernel<1, false>)
                        : (periodic ? (st_fn)rmb::st_sweep_kernel<0, true> : (st_fn)rmb::st_sweep_kernel<0, false>);
-  const long slots = 256L * resident_blocks((const void*)fn, &occ[wall == 2 ? 2 : (wall ? 1 : 0)][periodic ? 1 : 0]);
+  const long slots = c->n_cu * resident_blocks((const void*)fn, &occ[wall == 2 ? 2 : (wall ? 1 : 0)][periodic ? 1 : 0]);
   long n_chunks, chunk_len;
   choose_chunks(nt, ns, c->opt_chunks, slots, &n_chunks, &chunk_len);
   if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");

@@ -197,9 +197,9 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
         tt_pair_apply<WALL>(c, dx, dy, dz, vax, vay, vaz, q1.y, q2.x, q2.y, ua, tax, tay, taz);
         tt_pair_apply<WALL>(c, dx, dy, dz, vbx, vby, vbz, q3.x, q3.y, q4.x, ub, tbx, tby, tbz);
       } else {
-        if (px) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
-        if (py) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
-        if (pz) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+        if (px) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
+        if (py) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
+        if (pz) dz = wrap_nearest_pad_safe(dz, a.Lz, a.iLz);
         for (int bx = -px; bx <= px; ++bx)
           for (int by = -py; by <= py; ++by)
             for (int bz = -pz; bz <= pz; ++bz) {

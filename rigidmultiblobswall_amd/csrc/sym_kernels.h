@@ -252,6 +252,13 @@ __device__ __forceinline__ double wrap_nearest_sym(double r, double L, double in
   return __builtin_fma(-__builtin_trunc(q + h), L, r);
 }
 
+// Nearest image that leaves the padding sentinels (+-1e100) alone: wrapped, a sentinel can land exactly on a real
+// blob (fma(-trunc(1e100/L), L, 1e100) == 0 for power-of-two L) and 1/r = inf would reach the accumulators.
+__device__ __forceinline__ double wrap_nearest_pad_safe(double r, double L, double invL) {
+  const double w = wrap_nearest_sym(r, L, invL);
+  return (__builtin_fabs(r) < 1e50) ? w : r;
+}
+
 __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
   // row-major over the upper triangle: row I holds (T - I) units
   const double tt = 2.0 * T + 1.0;
@@ -346,9 +353,9 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
         if constexpr (!PERIODIC) {
           pair_sym<KIND, WALL>(a.k, dx, dy, dz, zi, q1.x, vix, viy, viz, q1.y, q2.x, q2.y, ui, tx, ty, tz);
         } else {
-          if (px) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
-          if (py) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
-          if (pz) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+          if (px) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
+          if (py) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
+          if (pz) dz = wrap_nearest_pad_safe(dz, a.Lz, a.iLz);
           tx = 0.0; ty = 0.0; tz = 0.0;
           for (int bx = -px; bx <= px; ++bx)
             for (int by = -py; by <= py; ++by)
@@ -383,9 +390,9 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
         if constexpr (!PERIODIC) {
           pair_apply<KIND, WALL>(a.k, dx, dy, dz, zi, q1.x, q1.y, q2.x, q2.y, 0.0, 0.0, 0.0, ui);
         } else {
-          if (px) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
-          if (py) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
-          if (pz) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+          if (px) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
+          if (py) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
+          if (pz) dz = wrap_nearest_pad_safe(dz, a.Lz, a.iLz);
           for (int bx = -px; bx <= px; ++bx)
             for (int by = -py; by <= py; ++by)
               for (int bz = -pz; bz <= pz; ++bz) {
@@ -450,29 +457,31 @@ struct SymForceArgs {
   double Lx, Ly, Lz, iLx, iLy, iLz;
   double eps_over_b, inv_b, two_a;
   ExpConsts ec;
+  const double* radii;  // RADII variant: one radius per blob, contact distance a_i + a_j (forces_numba.py:73-122)
 };
 
-// f0(r) dr for one pair; dr = r_j - r_i (minimal image).  Returns the force ON i; the force on j is minus it.
+// f0(r) dr for one pair; dr = r_j - r_i (minimal image), two_a = contact distance of the pair.
+// Returns the force ON i; the force on j is minus it.
 template <bool PERIODIC>
-__device__ __forceinline__ void pair_force(const SymForceArgs& a, double dx, double dy, double dz, double& fx, double& fy,
-                                           double& fz) {
+__device__ __forceinline__ void pair_force(const SymForceArgs& a, double two_a, double dx, double dy, double dz, double& fx,
+                                           double& fy, double& fz) {
   if constexpr (PERIODIC) {
-    if (a.Lx > 0) dx = wrap_nearest_sym(dx, a.Lx, a.iLx);
-    if (a.Ly > 0) dy = wrap_nearest_sym(dy, a.Ly, a.iLy);
-    if (a.Lz > 0) dz = wrap_nearest_sym(dz, a.Lz, a.iLz);
+    if (a.Lx > 0) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
+    if (a.Ly > 0) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
+    if (a.Lz > 0) dz = wrap_nearest_pad_safe(dz, a.Lz, a.iLz);
   }
   const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
   const double ir = rsqrt_f64(r2);
   const double r = r2 * ir;
   // far: -(eps/b) exp(-(r-2a)/b) / r ;  near (r <= 2a): -(eps/b) / max(r, 1e-25) = -(eps/b) min(1/r, 1e25)
-  const bool far = r > a.two_a;
-  const double x = far ? (a.two_a - r) * a.inv_b : 0.0;
+  const bool far = r > two_a;
+  const double x = far ? (two_a - r) * a.inv_b : 0.0;
   const double e = exp_nonpositive(a.ec, x);
   const double f0 = -a.eps_over_b * (far ? e * ir : fmin(ir, 1e25));
   fx = f0 * dx; fy = f0 * dy; fz = f0 * dz;
 }
 
-template <bool PERIODIC>
+template <bool PERIODIC, bool RADII = false>
 __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForceArgs a) {
   __shared__ double4 rec_all[kSymWaves][64];
   __shared__ double accj_all[kSymWaves][3 * 64];
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
   int I_cur = -1;
   long i = 0;
   bool vi_ok = false;
-  double xi = 0, yi = 0, zi = 0;
+  double xi = 0, yi = 0, zi = 0, ri = 0;
   double ax = 0, ay = 0, az = 0;
   while (s < s_end) {
     const int k0 = (int)(s & 63);
@@ -510,12 +519,14 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
       vi_ok = i < a.n;
       xi = 1e100; yi = 1e100; zi = 1e100;
       if (vi_ok) { const double4 p = a.pos[i]; xi = p.x; yi = p.y; zi = p.z; }
+      if constexpr (RADII) ri = vi_ok ? a.radii[i] : 0.0;
       ax = 0.0; ay = 0.0; az = 0.0;
     }
     {
       const long j = 64L * J + lane;
       double4 p = make_double4(-1e100, -1e100, -1e100, 0.0);
       if (j < a.n) p = a.pos[j];
+      if constexpr (RADII) p.w = (j < a.n) ? a.radii[j] : 0.0;   // w is free here: forces use unclamped positions (b = 1)
       rec[lane] = p;
       accj[lane] = 0.0; accj[64 + lane] = 0.0; accj[128 + lane] = 0.0;
     }
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
       const int jj = (lane + k) & 63;
       const double4 q = rec[jj];
       double fx, fy, fz;
-      pair_force<PERIODIC>(a, q.x - xi, q.y - yi, q.z - zi, fx, fy, fz);
+      pair_force<PERIODIC>(a, RADII ? ri + q.w : a.two_a, q.x - xi, q.y - yi, q.z - zi, fx, fy, fz);
       ax += fx; ay += fy; az += fz;
       if (!diag) {   // wave-uniform
         __hip_atomic_fetch_add(&accj[jj], -fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -1,0 +1,603 @@
+// symx_kernels.h -- generic symmetric pair sweep: several blocks of the grand mobility per pair (gfx950, fp64).
+//
+// sym_kernel (sym_kernels.h) evaluates ONE block (tt, tr, rt or rr) on ONE vector per pass.  The callers of the
+// path often need more from the same pair geometry:
+//   * u = M_tt f + M_tr tau in one loop -- the reference's K11/K12 (mobility/mobility_pycuda.py:1266-1391,
+//     :1394-1512 share the pair geometry between the UF and UT blocks);
+//   * the 6N grand-mobility product [u; w] = [[M_tt, M_tr], [M_rt, M_rr]] [f; tau] that the roller integrator
+//     applies once per Lanczos iteration as FOUR separate sweeps
+//     (quaternion_integrator/quaternion_integrator_rollers.py:1114-1121);
+//   * [u; w] = [M_tt; M_rt] f, the two random-finite-difference products of one draw (:1138-1160);
+//   * M_tt applied to k vectors at once (solves advanced in lockstep, quaternion_integrator_multi_bodies.py:985-996);
+//   * the in-plane products (mobility/mobility_numba.py:291, :690: a row/column mask of the symmetric matrix) and
+//     the free-surface product (:1770-1937: the image block P RPY(R) is reciprocal too).
+// All of them are symmetric operators on the stacked vector, so every unordered pair is still evaluated once and
+// applied to both blobs.  Differences, both inverse square roots, tau, e and the heights are computed once per pair
+// (Geom) and shared by all blocks: the grand product costs ~2.4x one tt pass instead of 4 passes.
+//
+// Skeleton = sym_kernel's: tile pairs (I <= J) of 64 blobs, one wave64 per unit, rotation j = (lane + k) & 63,
+// transposed contributions through ds_add_f64 into a per-wave LDS accumulator, static exactly balanced step
+// schedule, pair-shard step ranges, global SoA accumulators + finalize.  An operation is a policy class OP:
+//   OP::NIN / OP::NOUT   3-vectors per blob going in (LDS record) / coming out (accumulators)
+//   OP::pair<WALL>(k, dx,dy,dz, zi,zj, vi, vj, ui, t)   ui += (M_ij v_j) rows,  t = (M_ji v_i) rows
+//   OP::self<WALL>(k, zi, vi, ui)                        the i == j term, added once per target in finalize
+#pragma once
+#include "sym_kernels.h"
+
+namespace rmb {
+
+struct SymXArgs {
+  const double4* pos;
+  const double* in[4];    // [NIN] source vectors (AoS, 3n)
+  double* out[4];         // [NOUT] outputs (AoS, 3n)
+  double* acc;            // [NOUT][3][n_pad] global SoA accumulators; zero on entry, re-zeroed by finalize
+  long n, n_pad;
+  int n_tiles;
+  long n_units;
+  long step_begin, step_end, steps_per_wave;
+  long self_begin, self_end;
+  double Lx, Ly, Lz, iLx, iLy, iLz;
+  double prefactor;
+  int accumulate;         // bit c: finalize adds into out[c] instead of overwriting it
+  int in_plane;           // zero the z component of every input on load and of every output on store
+  int skip_pairs;         // diagnostics (timing only): 1 = no pair arithmetic, 2 = no flush of the LDS accumulators
+  PairConsts k;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Shared pair geometry and the per-block coefficient / contraction routines.
+// vi / vj / ui / t are pointers to 3 consecutive doubles (registers after inlining).
+// ACC = false: t is written; ACC = true: t is added to (second and later blocks of a fused operation).
+// ---------------------------------------------------------------------------------------------
+struct Geom {
+  double dx, dy, dz, rho2, r2, ir, ir2;
+  double Rz, iR, iR2;     // image separation R = (dx, dy, z_i + z_j); wall / free-surface operations only
+};
+
+template <bool IMAGE>
+__device__ __forceinline__ Geom make_geom(double dx, double dy, double dz, double zi, double zj) {
+  Geom g;
+  g.dx = dx; g.dy = dy; g.dz = dz;
+  g.rho2 = __builtin_fma(dy, dy, dx * dx);
+  g.r2 = __builtin_fma(dz, dz, g.rho2);
+  g.ir = rsqrt_f64(g.r2);
+  g.ir2 = g.ir * g.ir;
+  if constexpr (IMAGE) {
+    g.Rz = zi + zj;
+    g.iR = rsqrt_f64(__builtin_fma(g.Rz, g.Rz, g.rho2));
+    g.iR2 = g.iR * g.iR;
+  } else {
+    g.Rz = 0.0; g.iR = 0.0; g.iR2 = 0.0;
+  }
+  return g;
+}
+
+// RPY tt coefficients of separation r:  cF I + cD r r^T   (mobility_numba.py:209-239)
+__device__ __forceinline__ void rpy_tt_coeffs(const PairConsts& k, double r2, double ir, double ir2, double& cF, double& cD) {
+  cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
+  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
+  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
+    const double r = r2 * ir;
+    const bool near = r2 <= k.four_a2;
+    cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : cF;
+    cD = near ? k.tt_n2 * ir : cD;
+  }
+}
+
+struct TTc { double cF, cD, nG2, G3r, G4r, G5r; };
+
+template <bool WALL>
+__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zj) {
+  TTc c;
+  rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, c.cF, c.cD);
+  if constexpr (WALL) {
+    const WallTT W = wall_tt_from_iR(k, g.Rz, g.iR, zj);
+    const double iR3 = W.iR * W.iR2;
+    c.cF = __builtin_fma(-W.G1, W.iR, c.cF);
+    c.nG2 = -W.G2 * iR3;
+    c.G3r = W.G3 * W.iR2;
+    c.G4r = W.G4 * W.iR2;
+    c.G5r = W.G5 * W.iR;
+  } else {
+    c.nG2 = c.G3r = c.G4r = c.G5r = 0.0;
+  }
+  return c;
+}
+
+// ui += M_tt,ij vj ;  t (+)= M_tt,ji vi       (same algebra as pair_tt_sym)
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void tt_apply(const TTc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
+  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
+  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
+  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
+  const double t0 = ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0];
+  const double t1 = ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1];
+  if constexpr (!WALL) {
+    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    t[0] = __builtin_fma(cDi, g.dx, t0);
+    t[1] = __builtin_fma(cDi, g.dy, t1);
+    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
+  } else {
+    const double Rvj = __builtin_fma(g.Rz, vj[2], pj);
+    const double cRj = __builtin_fma(c.G3r, vj[2], c.nG2 * Rvj);
+    const double cbj = __builtin_fma(c.G5r, vj[2], c.G4r * Rvj);
+    const double cj = cDj + cRj;
+    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    ui[2] = __builtin_fma(cRj, g.Rz, ui[2]); ui[2] += cbj;
+    const double Rvi = __builtin_fma(g.Rz, vi[2], pi);
+    const double cRi = __builtin_fma(c.G4r, vi[2], c.nG2 * Rvi);
+    const double cbi = __builtin_fma(c.G5r, vi[2], c.G3r * Rvi);
+    const double ci = cDi + cRi;
+    t[0] = __builtin_fma(ci, g.dx, t0);
+    t[1] = __builtin_fma(ci, g.dy, t1);
+    t[2] = __builtin_fma(cRi, g.Rz, __builtin_fma(cDi, g.dz, __builtin_fma(c.cF, vi[2], ACC ? t[2] + cbi : cbi)));
+  }
+}
+
+// Coupling blocks tr / rt (same algebra as pair_coupling_sym).  p, s, f3 depend linearly on the anchoring
+// height; the _i set is anchored on z_i, the _j set on z_j.
+struct CPc { double c, f1, ex, ey, ez, p_i, s_i, f3_i, p_j, s_j, f3_j; };
+
+template <bool WALL>
+__device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
+  CPc C;
+  C.c = g.ir2 * g.ir;
+  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
+    const double r = g.r2 * g.ir;
+    C.c = (g.r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : C.c;
+  }
+  if constexpr (WALL) {
+    const double tau = k.a2 * g.iR2;
+    C.ez = g.Rz * g.iR; C.ex = g.dx * g.iR; C.ey = g.dy * g.iR;
+    const double uu = C.ez * C.ez;
+    const double eztau = C.ez * tau;
+    C.f1 = g.iR2;
+    const double p0 = g.iR2 * __builtin_fma(2.0, eztau, C.ez);
+    const double s0 = g.iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, 1.0);
+    const double f30 = 10.0 * g.iR2 * eztau;
+    const double gi = zi * g.iR, gj = zj * g.iR;
+    const double m2 = -2.0 * g.iR2, e12 = 12.0 * g.iR2 * C.ez, m6 = -6.0 * g.iR2;
+    C.p_i = __builtin_fma(m2, gi, p0); C.s_i = __builtin_fma(e12, gi, s0); C.f3_i = __builtin_fma(m6, gi, f30);
+    C.p_j = __builtin_fma(m2, gj, p0); C.s_j = __builtin_fma(e12, gj, s0); C.f3_j = __builtin_fma(m6, gj, f30);
+  } else {
+    C.f1 = C.ex = C.ey = C.ez = C.p_i = C.s_i = C.f3_i = C.p_j = C.s_j = C.f3_j = 0.0;
+  }
+  return C;
+}
+
+// tr: ui += M_tr,ij vj (torque of j -> velocity of i, wall part anchored on the TARGET height z_i);  t (+)= M_tr,ji vi
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void tr_apply(const CPc& C, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  double ax = __builtin_fma(vj[1], g.dz, -vj[2] * g.dy) * C.c, ay = __builtin_fma(vj[2], g.dx, -vj[0] * g.dz) * C.c,
+         az = __builtin_fma(vj[0], g.dy, -vj[1] * g.dx) * C.c;
+  double bx = __builtin_fma(vi[2], g.dy, -vi[1] * g.dz) * C.c, by = __builtin_fma(vi[0], g.dz, -vi[2] * g.dx) * C.c,
+         bz = __builtin_fma(vi[1], g.dx, -vi[0] * g.dy) * C.c;
+  if constexpr (WALL) {
+    const double c0 = __builtin_fma(C.ex, vj[1], -C.ey * vj[0]);
+    const double fc = C.f3_i * c0;
+    ax += __builtin_fma(C.f1 * C.ey, vj[2], __builtin_fma(C.p_i, vj[1], -fc * C.ex));
+    ay -= __builtin_fma(C.f1 * C.ex, vj[2], __builtin_fma(C.p_i, vj[0], fc * C.ey));
+    az += __builtin_fma(C.f3_i, C.ez, C.s_i) * c0;
+    const double c0i = __builtin_fma(C.ex, vi[1], -C.ey * vi[0]);
+    const double gc = C.f3_j * c0i;
+    bx += __builtin_fma(-C.f1 * C.ey, vi[2], __builtin_fma(C.p_j, vi[1], -gc * C.ex));
+    by += __builtin_fma(C.f1 * C.ex, vi[2], -__builtin_fma(C.p_j, vi[0], gc * C.ey));
+    bz -= __builtin_fma(C.f3_j, C.ez, C.s_j) * c0i;
+  }
+  ui[0] += ax; ui[1] += ay; ui[2] += az;
+  if constexpr (ACC) { t[0] += bx; t[1] += by; t[2] += bz; } else { t[0] = bx; t[1] = by; t[2] = bz; }
+}
+
+// rt: ui += M_rt,ij vj (force of j -> angular velocity of i, wall part anchored on the SOURCE height z_j);  t (+)= M_rt,ji vi
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void rt_apply(const CPc& C, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  double ax = __builtin_fma(vj[1], g.dz, -vj[2] * g.dy) * C.c, ay = __builtin_fma(vj[2], g.dx, -vj[0] * g.dz) * C.c,
+         az = __builtin_fma(vj[0], g.dy, -vj[1] * g.dx) * C.c;
+  double bx = __builtin_fma(vi[2], g.dy, -vi[1] * g.dz) * C.c, by = __builtin_fma(vi[0], g.dz, -vi[2] * g.dx) * C.c,
+         bz = __builtin_fma(vi[1], g.dx, -vi[0] * g.dy) * C.c;
+  if constexpr (WALL) {
+    const double E = __builtin_fma(C.ez, vj[2], __builtin_fma(C.ey, vj[1], C.ex * vj[0]));
+    const double kap = __builtin_fma(C.f3_j, E, C.s_j * vj[2]);
+    ax += __builtin_fma(kap, C.ey, -C.p_j * vj[1]);
+    ay += __builtin_fma(-kap, C.ex, C.p_j * vj[0]);
+    az += C.f1 * __builtin_fma(C.ex, vj[1], -C.ey * vj[0]);
+    const double Ei = __builtin_fma(C.ez, vi[2], -__builtin_fma(C.ey, vi[1], C.ex * vi[0]));
+    const double kapi = __builtin_fma(C.f3_i, Ei, C.s_i * vi[2]);
+    bx -= __builtin_fma(kapi, C.ey, C.p_i * vi[1]);
+    by += __builtin_fma(kapi, C.ex, C.p_i * vi[0]);
+    bz -= C.f1 * __builtin_fma(C.ex, vi[1], -C.ey * vi[0]);
+  }
+  ui[0] += ax; ui[1] += ay; ui[2] += az;
+  if constexpr (ACC) { t[0] += bx; t[1] += by; t[2] += bz; } else { t[0] = bx; t[1] = by; t[2] = bz; }
+}
+
+struct RRc { double cF, cD, cFxy, cFzj, cFzi, h5; };
+
+template <bool WALL>
+__device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
+  RRc c;
+  const double ir3 = g.ir2 * g.ir;
+  c.cF = -0.5 * ir3;
+  c.cD = 1.5 * ir3 * g.ir2;
+  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
+    const double r = g.r2 * g.ir;
+    const double r3 = g.r2 * r;
+    const bool near = g.r2 < k.four_a2;
+    c.cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : c.cF;
+    c.cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : c.cD;
+  }
+  if constexpr (WALL) {
+    const double iR3 = g.iR2 * g.iR;
+    const double uu = g.Rz * g.Rz * g.iR2;
+    c.cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, c.cF);
+    c.cFzj = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, c.cF);
+    c.cFzi = __builtin_fma(0.5, iR3, c.cF);
+    c.h5 = 1.5 * iR3 * g.iR2;
+  } else {
+    c.cFxy = c.cFzj = c.cFzi = c.h5 = 0.0;
+  }
+  return c;
+}
+
+// rr: ui += M_rr,ij vj ;  t (+)= M_rr,ji vi       (same algebra as pair_rr_sym)
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
+  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
+  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
+  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
+  if constexpr (!WALL) {
+    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    t[0] = __builtin_fma(cDi, g.dx, ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0]);
+    t[1] = __builtin_fma(cDi, g.dy, ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1]);
+    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
+  } else {
+    const double zvj = g.Rz * vj[2], zvi = g.Rz * vi[2];
+    const double Rvj = zvj + pj;
+    const double cj = __builtin_fma(-c.h5, __builtin_fma(2.0, pj, Rvj), cDj);
+    ui[0] = __builtin_fma(c.cFxy, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cFxy, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cFzj, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    ui[2] = __builtin_fma(c.h5 * Rvj, g.Rz, ui[2]);
+    const double Rvi = zvi + pi;
+    const double ci = __builtin_fma(-c.h5, __builtin_fma(3.0, pi, -zvi), cDi);
+    t[0] = __builtin_fma(ci, g.dx, ACC ? __builtin_fma(c.cFxy, vi[0], t[0]) : c.cFxy * vi[0]);
+    t[1] = __builtin_fma(ci, g.dy, ACC ? __builtin_fma(c.cFxy, vi[1], t[1]) : c.cFxy * vi[1]);
+    t[2] = __builtin_fma(-c.h5 * Rvi, g.Rz, __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cFzi, vi[2], t[2]) : c.cFzi * vi[2]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operations
+// ---------------------------------------------------------------------------------------------
+
+// One block on one vector through the verified pair_sym of sym_kernels.h (used for the in-plane products).
+template <int KIND>
+struct OpSingle {
+  static constexpr int NIN = 1, NOUT = 1;
+  static constexpr bool IMAGE_NO_WALL = false;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    Vec3 u = {ui[0], ui[1], ui[2]};
+    pair_sym<KIND, WALL>(k, dx, dy, dz, zi, zj, vi[0], vi[1], vi[2], vj[0], vj[1], vj[2], u, t[0], t[1], t[2]);
+    ui[0] = u.x; ui[1] = u.y; ui[2] = u.z;
+  }
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
+    Vec3 u = {ui[0], ui[1], ui[2]};
+    self_term<KIND, WALL>(k, zi, vi[0], vi[1], vi[2], 0.0, 0.0, 0.0, u);
+    ui[0] = u.x; ui[1] = u.y; ui[2] = u.z;
+  }
+};
+
+// u = M_tt f + M_tr tau    (in: f, tau; out: u)   -- K11 / K12
+struct OpFusedRow {
+  static constexpr int NIN = 2, NOUT = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+    tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
+  }
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
+    Vec3 u = {ui[0], ui[1], ui[2]};
+    self_term<KIND_TT_TR, WALL>(k, zi, vi[0], vi[1], vi[2], vi[3], vi[4], vi[5], u);
+    ui[0] = u.x; ui[1] = u.y; ui[2] = u.z;
+  }
+};
+
+// [u; w] = [[M_tt, M_tr], [M_rt, M_rr]] [f; tau]    (in: f, tau; out: u, w)
+struct OpGrand {
+  static constexpr int NIN = 2, NOUT = 2;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+    tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
+    rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+    const RRc b = rr_coeffs<WALL>(k, g);
+    rr_apply<WALL, true>(b, g, vi + 3, vj + 3, ui + 3, t + 3);
+  }
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
+    Vec3 u = {ui[0], ui[1], ui[2]}, w = {ui[3], ui[4], ui[5]};
+    self_term<KIND_TT_TR, WALL>(k, zi, vi[0], vi[1], vi[2], vi[3], vi[4], vi[5], u);
+    self_term<KIND_RT, WALL>(k, zi, vi[0], vi[1], vi[2], 0.0, 0.0, 0.0, w);
+    self_term<KIND_RR, WALL>(k, zi, vi[3], vi[4], vi[5], 0.0, 0.0, 0.0, w);
+    ui[0] = u.x; ui[1] = u.y; ui[2] = u.z; ui[3] = w.x; ui[4] = w.y; ui[5] = w.z;
+  }
+};
+
+// [u; w] = [M_tt; M_rt] f    (in: f; out: u, w)  -- both random-finite-difference products of one draw
+struct OpColumnF {
+  static constexpr int NIN = 1, NOUT = 2;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+    rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+  }
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
+    Vec3 u = {ui[0], ui[1], ui[2]}, w = {ui[3], ui[4], ui[5]};
+    self_term<KIND_TT, WALL>(k, zi, vi[0], vi[1], vi[2], 0.0, 0.0, 0.0, u);
+    self_term<KIND_RT, WALL>(k, zi, vi[0], vi[1], vi[2], 0.0, 0.0, 0.0, w);
+    ui[0] = u.x; ui[1] = u.y; ui[2] = u.z; ui[3] = w.x; ui[4] = w.y; ui[5] = w.z;
+  }
+};
+
+// M_tt applied to K vectors: coefficients once, contraction K times (K = 2 is sym2_kernel's operation).
+template <int K>
+struct OpTTk {
+  static constexpr int NIN = K, NOUT = K;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zj);
+#pragma unroll
+    for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+  }
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
+#pragma unroll
+    for (int v = 0; v < K; ++v) {
+      Vec3 u = {ui[3 * v], ui[3 * v + 1], ui[3 * v + 2]};
+      self_term<KIND_TT, WALL>(k, zi, vi[3 * v], vi[3 * v + 1], vi[3 * v + 2], 0.0, 0.0, 0.0, u);
+      ui[3 * v] = u.x; ui[3 * v + 1] = u.y; ui[3 * v + 2] = u.z;
+    }
+  }
+};
+
+// Free (stress-free) surface at z = 0: u_i = sum_j [RPY(d) + RPY(R) P] f_j, R = (d_x, d_y, z_i + z_j), P = diag(1,1,-1)
+// (mobility_numba.py:1846-1925).  The reversed pair sees R' = (-d_x, -d_y, R_z), so (RPY(R) P)_ji = P RPY(R)_ij:
+// reciprocal, both directions from one set of coefficients.  Raw heights (set_positions with wall = 0).
+struct OpFreeSurface {
+  static constexpr int NIN = 1, NOUT = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    const Geom g = make_geom<true>(dx, dy, dz, zi, zj);
+    TTc a;
+    rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, a.cF, a.cD);
+    a.nG2 = a.G3r = a.G4r = a.G5r = 0.0;
+    tt_apply<false, false>(a, g, vi, vj, ui, t);
+    double cF, cD;
+    rpy_tt_coeffs(k, __builtin_fma(g.Rz, g.Rz, g.rho2), g.iR, g.iR2, cF, cD);
+    // forward: cF P vj + cD (R . P vj) R ;  reversed: cF P vi + cD (R' . P vi) R'
+    const double sj = cD * __builtin_fma(-g.Rz, vj[2], __builtin_fma(dy, vj[1], dx * vj[0]));
+    const double si = cD * __builtin_fma(g.Rz, vi[2], __builtin_fma(dy, vi[1], dx * vi[0]));    // = -cD (R' . P vi)
+    ui[0] = __builtin_fma(cF, vj[0], ui[0]); ui[0] = __builtin_fma(sj, dx, ui[0]);
+    ui[1] = __builtin_fma(cF, vj[1], ui[1]); ui[1] = __builtin_fma(sj, dy, ui[1]);
+    ui[2] = __builtin_fma(-cF, vj[2], ui[2]); ui[2] = __builtin_fma(sj, g.Rz, ui[2]);
+    t[0] = __builtin_fma(si, dx, __builtin_fma(cF, vi[0], t[0]));
+    t[1] = __builtin_fma(si, dy, __builtin_fma(cF, vi[1], t[1]));
+    t[2] = __builtin_fma(-si, g.Rz, __builtin_fma(-cF, vi[2], t[2]));
+  }
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
+    Vec3 u = {ui[0], ui[1], ui[2]};
+    self_term<KIND_TT_FREE, false>(k, zi, vi[0], vi[1], vi[2], 0.0, 0.0, 0.0, u);
+    ui[0] = u.x; ui[1] = u.y; ui[2] = u.z;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Skeleton
+// ---------------------------------------------------------------------------------------------
+
+// LDS record of one blob: x, y, z, then NIN 3-vectors, in double2 units; an ODD number of double2 keeps the
+// per-lane ds_read_b128 of consecutive records conflict-free (48 / 80 / 112 / 144 bytes).
+template <int NIN> struct SymXRec { static constexpr int nd = 3 + 3 * NIN; static constexpr int d2 = ((nd + 1) / 2) | 1; };
+
+template <class OP, bool WALL, bool PERIODIC>
+__global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) {
+  constexpr int NI = OP::NIN, NO = OP::NOUT;
+  constexpr int RD2 = SymXRec<NI>::d2;
+  constexpr int RECB = RD2 * 16;
+  __shared__ double2 rec_all[kSymWaves][64 * RD2];
+  __shared__ double accj_all[kSymWaves][3 * NO * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double2* rec = rec_all[wave];
+  double* accj = accj_all[wave];
+  const char* rec_bytes = reinterpret_cast<const char*>(rec);
+
+  const long w = (long)blockIdx.x * kSymWaves + wave;
+  long s = a.step_begin + w * a.steps_per_wave;
+  long s_end = s + a.steps_per_wave;
+  if (s_end > a.step_end) s_end = a.step_end;
+  int I = 0, J = 0;
+  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+
+  int I_cur = -1;
+  long i = 0;
+  bool vi_ok = false;
+  double xi = 0, yi = 0, zi = 1.0;
+  double vi[3 * NI], ui[3 * NO];
+#pragma unroll
+  for (int c = 0; c < 3 * NI; ++c) vi[c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < 3 * NO; ++c) ui[c] = 0.0;
+
+  auto flush_row = [&]() {
+#pragma unroll
+    for (int c = 0; c < 3 * NO; ++c)
+      __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + i], ui[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  while (s < s_end) {
+    const int k0 = (int)(s & 63);
+    const long left = s_end - s;
+    const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    s += k1 - k0;
+
+    if (I != I_cur) {
+      if (I_cur >= 0 && vi_ok) flush_row();
+      I_cur = I;
+      i = 64L * I + lane;
+      vi_ok = i < a.n;
+      xi = 1e100; yi = 1e100; zi = 1.0;
+#pragma unroll
+      for (int c = 0; c < 3 * NI; ++c) vi[c] = 0.0;
+      if (vi_ok) {
+        const double4 p = a.pos[i];
+        xi = p.x; yi = p.y; zi = p.z;
+#pragma unroll
+        for (int v = 0; v < NI; ++v) {
+          vi[3 * v] = a.in[v][3 * i] * p.w; vi[3 * v + 1] = a.in[v][3 * i + 1] * p.w;
+          vi[3 * v + 2] = a.in_plane ? 0.0 : a.in[v][3 * i + 2] * p.w;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3 * NO; ++c) ui[c] = 0.0;
+    }
+    {   // tile J -> this wave's LDS slab (record l = blob 64 J + l), zero its accumulators
+      const long j = 64L * J + lane;
+      double rd[2 * RD2];
+#pragma unroll
+      for (int c = 0; c < 2 * RD2; ++c) rd[c] = 0.0;
+      rd[0] = -1e100; rd[1] = -1e100; rd[2] = 1.0;
+      if (j < a.n) {
+        const double4 p = a.pos[j];
+        rd[0] = p.x; rd[1] = p.y; rd[2] = p.z;
+#pragma unroll
+        for (int v = 0; v < NI; ++v) {
+          rd[3 + 3 * v] = a.in[v][3 * j] * p.w; rd[4 + 3 * v] = a.in[v][3 * j + 1] * p.w;
+          rd[5 + 3 * v] = a.in_plane ? 0.0 : a.in[v][3 * j + 2] * p.w;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < RD2; ++c) rec[lane * RD2 + c] = make_double2(rd[2 * c], rd[2 * c + 1]);
+#pragma unroll
+      for (int c = 0; c < 3 * NO; ++c) accj[c * 64 + lane] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int px = PERIODIC && a.Lx > 0, py = PERIODIC && a.Ly > 0, pz = PERIODIC && a.Lz > 0;
+    const bool diag = I == J;
+    // diagonal units visit every ordered pair of the tile once (forward direction only); step 0 is the blob
+    // itself: its central-box term is the self term (finalize), its periodic images use the pair formula
+    int kb = diag ? ((PERIODIC || k0 > 1) ? k0 : 1) : k0;
+    if (a.skip_pairs & 1) kb = k1;
+    for (int k = kb; k < k1; ++k) {
+      const int jj = (lane + k) & 63;
+      const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * RECB);
+      double rd[2 * RD2];
+#pragma unroll
+      for (int c = 0; c < RD2; ++c) { const double2 q = r[c]; rd[2 * c] = q.x; rd[2 * c + 1] = q.y; }
+      double dx = xi - rd[0], dy = yi - rd[1], dz = zi - rd[2];
+      double t[3 * NO];
+      if constexpr (!PERIODIC) {
+        OP::template pair<WALL>(a.k, dx, dy, dz, zi, rd[2], vi, rd + 3, ui, t);
+      } else {
+        if (px) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
+        if (py) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
+        if (pz) dz = wrap_nearest_pad_safe(dz, a.Lz, a.iLz);
+#pragma unroll
+        for (int c = 0; c < 3 * NO; ++c) t[c] = 0.0;
+        for (int bx = -px; bx <= px; ++bx)
+          for (int by = -py; by <= py; ++by)
+            for (int bz = -pz; bz <= pz; ++bz) {
+              if (diag && k == 0 && bx == 0 && by == 0 && bz == 0) continue;
+              double sx[3 * NO];
+              OP::template pair<WALL>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, rd[2], vi, rd + 3, ui, sx);
+#pragma unroll
+              for (int c = 0; c < 3 * NO; ++c) t[c] += sx[c];
+            }
+      }
+      if (!diag) {   // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 3 * NO; ++c)
+          __hip_atomic_fetch_add(&accj[c * 64 + jj], t[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    if (!diag) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long j = 64L * J + lane;
+      if (j < a.n && !(a.skip_pairs & 2)) {
+#pragma unroll
+        for (int c = 0; c < 3 * NO; ++c)
+          __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + j], accj[c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
+    if (k1 == 64) {
+      if (++J == a.n_tiles) { ++I; J = I; }
+    }
+  }
+  if (I_cur >= 0 && vi_ok) flush_row();
+}
+
+template <class OP, bool WALL>
+__global__ __launch_bounds__(256) void symx_finalize_kernel(const SymXArgs a) {
+  constexpr int NI = OP::NIN, NO = OP::NOUT;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const double4 p = a.pos[i];
+  const double b = p.w;
+  double vi[3 * NI], u[3 * NO];
+#pragma unroll
+  for (int v = 0; v < NI; ++v) {
+    vi[3 * v] = a.in[v][3 * i] * b; vi[3 * v + 1] = a.in[v][3 * i + 1] * b;
+    vi[3 * v + 2] = a.in_plane ? 0.0 : a.in[v][3 * i + 2] * b;
+  }
+#pragma unroll
+  for (int c = 0; c < 3 * NO; ++c) {
+    u[c] = a.acc[(long)c * a.n_pad + i];
+    a.acc[(long)c * a.n_pad + i] = 0.0;   // ready for the next product
+  }
+  if (i >= a.self_begin && i < a.self_end) OP::template self<WALL>(a.k, p.z, vi, u);
+  const double sc = a.prefactor * b;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    double* out = a.out[o];
+    const double x = u[3 * o] * sc, y = u[3 * o + 1] * sc, z = a.in_plane ? 0.0 : u[3 * o + 2] * sc;
+    if (a.accumulate & (1 << o)) { out[3 * i] += x; out[3 * i + 1] += y; out[3 * i + 2] += z; }
+    else { out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z; }
+  }
+}
+
+}  // namespace rmb

@@ -30,6 +30,16 @@ class OracleContext(object):
       u = self._wrapped(kind, vec, eta, in_plane)
     return torch.from_numpy(u)
 
+  def matvec_op_device(self, op, vecs, eta, in_plane=False, outs=None, shard=0, nshards=1):
+    if op == "velocity_from_force_torque":
+      return (self.matvec_device("tt_tr", vecs[0], eta, vec2=vecs[1], in_plane=in_plane),)
+    if op == "grand":
+      return (self.matvec_device("tt_tr", vecs[0], eta, vec2=vecs[1], in_plane=in_plane),
+              self.matvec_device("rt", vecs[0], eta, in_plane=in_plane) + self.matvec_device("rr", vecs[1], eta, in_plane=in_plane))
+    if op == "force_column":
+      return (self.matvec_device("tt", vecs[0], eta, in_plane=in_plane), self.matvec_device("rt", vecs[0], eta, in_plane=in_plane))
+    return tuple(self.matvec_device("tt", v, eta, in_plane=in_plane) for v in vecs)
+
   def matvec2_device(self, kind, vec_a, vec_b, eta, out_a=None, out_b=None, shard=0, nshards=1):
     return self.matvec_device(kind, vec_a, eta), self.matvec_device(kind, vec_b, eta)
 

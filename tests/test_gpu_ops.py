@@ -1,0 +1,279 @@
+"""GPU parity of the multi-block symmetric operations (csrc/symx_kernels.h, rmb_matvec_op_device) and of the products
+that moved onto the symmetric skeleton this round (in-plane, free surface, per-blob-radii forces), against the oracle.
+
+Reference semantics: the fused row is mobility/mobility_pycuda.py:1266-1391 (K11) / :1394-1512 (K12); the grand product
+is the four separate calls of quaternion_integrator/quaternion_integrator_rollers.py:1114-1121; in-plane
+mobility_numba.py:291, :690; free surface :1770-1937; radii forces multi_bodies/forces_numba.py:73-122.
+Tolerances as tests/test_gpu_parity.py (relative L2, 1e-12 D2 / 1e-10 D1).
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from test_gpu_parity import d1_cloud, d2_cloud, TOL_D1, TOL_D2, TOL_SHARD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+  import torch
+  return torch
+
+
+@pytest.fixture(scope="module")
+def Ctx():
+  from rigidmultiblobswall_amd import MobilityContext
+  return MobilityContext
+
+
+def _dev(torch, x):
+  return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64).reshape(-1), device="cuda")
+
+
+def _oracle_blocks(oracle, wall, r, f, t, eta, a, L=None, in_plane=False):
+  kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64), in_plane=in_plane)
+  W = lambda kind, v: oracle._wrapped(kind, int(wall), r, v, eta, a, **kw)
+  return dict(tt_f=W("tt", f), tr_t=W("tr", t), rt_f=W("rt", f), rr_t=W("rr", t))
+
+
+CASES = [
+    # (N, wall, L, cloud)
+    (130, True, None, "d2"), (1000, True, None, "d2"), (4097, True, None, "d2"), (1000, False, None, "d2"),
+    (3000, True, None, "d1"), (700, True, (14.0, 16.0, 0.0), "d2"), (700, False, (9.0, 0.0, 11.0), "d2"),
+]
+
+
+@pytest.mark.parametrize("N,wall,L,cloud", CASES)
+def test_ops_match_oracle_blocks(Ctx, oracle, torch_mod, N, wall, L, cloud):
+  torch = torch_mod
+  r, f, eta, a = (d2_cloud if cloud == "d2" else d1_cloud)(N, seed=N + 1)
+  t = np.random.RandomState(N + 2).randn(N, 3)
+  tol = TOL_D2 if cloud == "d2" else TOL_D1
+  ref = _oracle_blocks(oracle, wall, r, f, t, eta, a, L)
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+  fd, td = _dev(torch, f), _dev(torch, t)
+  (u,) = ctx.matvec_op_device("velocity_from_force_torque", (fd, td), eta)
+  assert ctx.last_launch()["chunks"] == 0            # symmetric path
+  assert rel_err(u.cpu().numpy(), ref["tt_f"] + ref["tr_t"]) < tol
+  u, w = ctx.matvec_op_device("grand", (fd, td), eta)
+  assert rel_err(u.cpu().numpy(), ref["tt_f"] + ref["tr_t"]) < tol
+  assert rel_err(w.cpu().numpy(), ref["rt_f"] + ref["rr_t"]) < tol
+  u, w = ctx.matvec_op_device("force_column", (fd,), eta)
+  assert rel_err(u.cpu().numpy(), ref["tt_f"]) < tol
+  assert rel_err(w.cpu().numpy(), ref["rt_f"]) < tol
+  # the same entry point as rmb_matvec_device(RMB_TT_TR) (single pass by default, two passes with option 2)
+  u1 = ctx.matvec_device("tt_tr", fd, eta, vec2=td).cpu().numpy()
+  ctx.set_option("fused_symmetric", 2)
+  u2 = ctx.matvec_device("tt_tr", fd, eta, vec2=td).cpu().numpy()
+  ctx.set_option("fused_symmetric", 0)
+  u0 = ctx.matvec_device("tt_tr", fd, eta, vec2=td).cpu().numpy()
+  for x in (u1, u2, u0):
+    assert rel_err(x, ref["tt_f"] + ref["tr_t"]) < tol
+  ctx.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,wall,L", [(1000, True, None), (257, False, None), (500, True, (12.0, 0.0, 0.0))])
+def test_tt_multi(Ctx, oracle, torch_mod, k, N, wall, L):
+  torch = torch_mod
+  r, _, eta, a = d2_cloud(N, seed=5 * N + k)
+  vs = [np.random.RandomState(100 * k + v).randn(N, 3) for v in range(k)]
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+  outs = ctx.matvec_op_device("tt_multi", [_dev(torch, v) for v in vs], eta)
+  assert len(outs) == k
+  kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64))
+  for v, o in zip(vs, outs):
+    assert rel_err(o.cpu().numpy(), oracle._wrapped("tt", int(wall), r, v, eta, a, **kw)) < TOL_D2
+  ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["tt", "tr", "rt", "rr"])
+@pytest.mark.parametrize("wall,L", [(True, None), (False, None), (True, (14.0, 16.0, 0.0))])
+def test_single_kinds_through_generic_skeleton(Ctx, oracle, torch_mod, kind, wall, L):
+  """OpSingle<KIND> in symx_kernel == sym_kernel<KIND> (option symx_single): same pair function, other skeleton."""
+  torch = torch_mod
+  r, v, eta, a = d2_cloud(900, seed=17)
+  ctx = Ctx(0)
+  ctx.set_option("symx_single", 1)
+  ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+  u = ctx.matvec_device(kind, _dev(torch, v), eta).cpu().numpy()
+  assert ctx.last_launch()["chunks"] == 0
+  kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64))
+  assert rel_err(u, oracle._wrapped(kind, int(wall), r, v, eta, a, **kw)) < TOL_D2
+  ctx.close()
+
+
+@pytest.mark.parametrize("N", [128, 1000, 2500])
+@pytest.mark.parametrize("L", [None, (13.0, 12.0, 0.0)])
+def test_in_plane_free_surface_on_symmetric_path(Ctx, oracle, torch_mod, N, L):
+  torch = torch_mod
+  r, v, eta, a = d2_cloud(N, seed=N + 40)
+  t = np.random.RandomState(N).randn(N, 3)
+  kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64))
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, L, wall=True)
+  for kind, ref_fn in (("tt", oracle.in_plane_mobility_trans_times_force_oracle),
+                       ("tr", oracle.in_plane_mobility_trans_times_torque_oracle)):
+    u = ctx.matvec_device(kind, _dev(torch, v), eta, in_plane=True).cpu().numpy()
+    assert ctx.last_launch()["chunks"] == 0, "in-plane %s fell back to the one-sided sweep" % kind
+    assert np.all(u.reshape(-1, 3)[:, 2] == 0.0)
+    assert rel_err(u, ref_fn(r, v, eta, a, **kw)) < TOL_D2
+  # fused in-plane row
+  (u,) = ctx.matvec_op_device("velocity_from_force_torque", (_dev(torch, v), _dev(torch, t)), eta, in_plane=True)
+  ref = (oracle.in_plane_mobility_trans_times_force_oracle(r, v, eta, a, **kw) +
+         oracle.in_plane_mobility_trans_times_torque_oracle(r, t, eta, a, **kw))
+  assert rel_err(u.cpu().numpy(), ref) < TOL_D2
+  # free surface: raw heights
+  ctx.set_positions(_dev(torch, r), a, L, wall=False)
+  u = ctx.matvec_device("tt_free", _dev(torch, v), eta).cpu().numpy()
+  assert ctx.last_launch()["chunks"] == 0, "free surface fell back to the one-sided sweep"
+  assert rel_err(u, oracle.free_surface_mobility_trans_times_force_oracle(r, v, eta, a, **kw)) < TOL_D2
+  ctx.set_option("deterministic", 1)
+  u_sweep = ctx.matvec_device("tt_free", _dev(torch, v), eta).cpu().numpy()
+  assert ctx.last_launch()["chunks"] >= 1
+  assert rel_err(u, u_sweep) < TOL_D2
+  ctx.close()
+
+
+def test_free_surface_overlapping_blobs(Ctx, oracle, torch_mod):
+  """Near-field branch of both the direct and the image RPY evaluation (blobs closer than 2a to each other and to
+  their own / each other's mirror image)."""
+  torch = torch_mod
+  rng = np.random.RandomState(3)
+  N, a, eta = 600, 0.4, 1.3
+  r = rng.rand(N, 3) * np.array([4.0, 4.0, 1.0])
+  r[:, 2] += 0.05
+  f = rng.randn(N, 3)
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, None, wall=False)
+  u = ctx.matvec_device("tt_free", _dev(torch, f), eta).cpu().numpy()
+  assert ctx.last_launch()["chunks"] == 0
+  assert rel_err(u, oracle.free_surface_mobility_trans_times_force_oracle(r, f, eta, a)) < TOL_D1
+  ctx.close()
+
+
+@pytest.mark.parametrize("N", [128, 777, 3000])
+@pytest.mark.parametrize("L", [None, (6.0, 7.0, 0.0), (8.0, 8.0, 8.0)])
+def test_radii_forces_on_symmetric_path(Ctx, oracle, torch_mod, N, L):
+  torch = torch_mod
+  rng = np.random.RandomState(N)
+  r = rng.rand(N, 3) * (N / 40.0) ** (1.0 / 3.0) * 2.0
+  radii = 0.1 + 0.4 * rng.rand(N)
+  eps, b = 0.7, 0.13
+  kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64), repulsion_strength=eps,
+            debye_length=b)
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), 0.25, L, wall=False)
+  F = ctx.blob_blob_force_radii_device(_dev(torch, radii), eps, b).cpu().numpy().reshape(N, 3)
+  assert ctx.last_launch()["chunks"] == 0, "radii forces fell back to the one-sided sweep"
+  assert rel_err(F, oracle.calc_blob_blob_forces_radii_oracle(r, radii, **kw)) < TOL_D2
+  ctx.close()
+
+
+@pytest.mark.parametrize("wall,z_special", [(True, 0.7), (False, 1.0)])
+@pytest.mark.parametrize("path", ["sym", "sym2", "symx"])
+def test_padding_sentinels_with_power_of_two_box(Ctx, oracle, torch_mod, wall, z_special, path):
+  """Padded lanes of the last tile (N % 64 != 0) carry +-1e100 coordinates; wrapped by a power-of-two box they
+  landed exactly on a real blob whose effective height is 1.0 (rsqrt(0) -> NaN).  a = 1: wall-clamped blobs
+  (z <= a) have z_eff = 1.0; without a wall some blobs sit at z = 1.0 exactly."""
+  torch = torch_mod
+  N, a, eta = 200, 1.0, 1.0
+  rng = np.random.RandomState(11)
+  r = rng.rand(N, 3) * np.array([8.0, 8.0, 6.0])
+  r[:, 2] += 1.2
+  r[::5, 2] = z_special
+  v = rng.randn(N, 3)
+  v2 = rng.randn(N, 3)
+  L = np.array([8.0, 8.0, 0.0])
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+  ref = oracle._wrapped("tt", int(wall), r, v, eta, a, periodic_length=L)
+  if path == "sym":
+    u = ctx.matvec_device("tt", _dev(torch, v), eta).cpu().numpy()
+  elif path == "sym2":
+    ua, ub = ctx.matvec2_device("tt", _dev(torch, v), _dev(torch, v2), eta)
+    u = ua.cpu().numpy()
+    assert np.all(np.isfinite(ub.cpu().numpy()))
+  else:
+    u, w = ctx.matvec_op_device("force_column", (_dev(torch, v),), eta)
+    assert np.all(np.isfinite(w.cpu().numpy()))
+    u = u.cpu().numpy()
+  assert ctx.last_launch()["chunks"] == 0
+  assert np.all(np.isfinite(u))
+  assert rel_err(u, ref) < TOL_D1
+  ctx.close()
+
+
+@pytest.mark.parametrize("op,n_in", [("velocity_from_force_torque", 2), ("grand", 2), ("force_column", 1), ("tt_multi", 3)])
+@pytest.mark.parametrize("N,L", [(1000, None), (90, None), (400, (11.0, 12.0, 0.0))])
+def test_op_pair_shards_sum_to_full_product(Ctx, torch_mod, op, n_in, N, L):
+  """What G ranks compute (pair shard g of G into a full-length partial) summed the way all_reduce will."""
+  torch = torch_mod
+  r, _, eta, a = d2_cloud(N, seed=N)
+  vs = [_dev(torch, np.random.RandomState(7 + v).randn(N, 3)) for v in range(n_in)]
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, L, wall=True)
+  full = ctx.matvec_op_device(op, vs, eta)
+  for G in (2, 3, 8):
+    parts = [ctx.matvec_op_device(op, vs, eta, shard=g, nshards=G) for g in range(G)]
+    for c in range(len(full)):
+      total = torch.stack([p[c] for p in parts]).sum(0)
+      assert rel_err(total.cpu().numpy(), full[c].cpu().numpy()) < TOL_SHARD
+  ctx.close()
+
+
+def test_ops_fall_back_below_the_symmetric_threshold_and_in_deterministic_mode(Ctx, oracle, torch_mod):
+  torch = torch_mod
+  for N, det in ((40, 0), (600, 1)):
+    r, f, eta, a = d2_cloud(N, seed=3)
+    t = np.random.RandomState(4).randn(N, 3)
+    ref = _oracle_blocks(oracle, True, r, f, t, eta, a)
+    ctx = Ctx(0)
+    ctx.set_option("deterministic", det)
+    ctx.set_positions(_dev(torch, r), a, None, wall=True)
+    u, w = ctx.matvec_op_device("grand", (_dev(torch, f), _dev(torch, t)), eta)
+    assert ctx.last_launch()["chunks"] >= 1           # one-sided sweeps
+    assert rel_err(u.cpu().numpy(), ref["tt_f"] + ref["tr_t"]) < TOL_D2
+    assert rel_err(w.cpu().numpy(), ref["rt_f"] + ref["rr_t"]) < TOL_D2
+    u, w = ctx.matvec_op_device("force_column", (_dev(torch, f),), eta)
+    assert rel_err(u.cpu().numpy(), ref["tt_f"]) < TOL_D2 and rel_err(w.cpu().numpy(), ref["rt_f"]) < TOL_D2
+    ctx.close()
+
+
+def test_two_vector_pair_shards_for_small_suspensions(Ctx, torch_mod):
+  """rmb_matvec2_pairshard_device refused nshards > 1 for n < 128 while the one-vector entry accepted it."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(24, seed=1)
+  g = np.random.RandomState(2).randn(24, 3)
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, None, wall=True)
+  fa, fb = _dev(torch, f), _dev(torch, g)
+  ua, ub = ctx.matvec2_device("tt", fa, fb, eta)
+  pa = [ctx.matvec2_device("tt", fa, fb, eta, shard=s, nshards=2) for s in range(2)]
+  assert rel_err((pa[0][0] + pa[1][0]).cpu().numpy(), ua.cpu().numpy()) < TOL_SHARD
+  assert rel_err((pa[0][1] + pa[1][1]).cpu().numpy(), ub.cpu().numpy()) < TOL_SHARD
+  ctx.close()
+
+
+def test_stream_switch_is_ordered(Ctx, oracle, torch_mod):
+  """A context follows torch's current stream; switching streams between calls must not let the new stream's sweep
+  overtake the finalize / memset still queued on the old one (rmb_ctx_set_stream waits on an event)."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(3000, seed=9)
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  ctx = Ctx(0)
+  rd, fd = _dev(torch, r), _dev(torch, f)
+  ctx.set_positions(rd, a, None, wall=True)
+  streams = [torch.cuda.Stream() for _ in range(3)]
+  torch.cuda.synchronize()
+  outs = []
+  for it in range(12):
+    with torch.cuda.stream(streams[it % 3]):
+      outs.append(ctx.matvec_device("tt", fd, eta))
+  torch.cuda.synchronize()
+  for o in outs:
+    assert rel_err(o.cpu().numpy(), ref) < TOL_D2
+  ctx.close()

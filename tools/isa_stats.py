@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Static instruction mix of the pair loop of a kernel, counted from the gfx950 ISA of THIS build.
+
+Why: bench.py prices the dominant kernel two ways that must not exceed 1 by construction --
+  executed fp64 flops / time / 78.6 TF   and   issued VALU wave-instructions / time / measured issue ceiling --
+and both need "what one rotation step of one wave executes".  That is a property of the compiled loop body, so it
+is read off the disassembly (hipcc -S --cuda-device-only of csrc/rmb_capi.hip) instead of being replayed from an
+old profile.  `SQ_INSTS_VALU` of the rocprofv3 --pmc passes under profiles/ cross-checks the count.
+
+The pair loop = the innermost loop (label ... backward branch) of the kernel with the most fp64 VALU instructions;
+blocks the compiler placed out of line behind the backward branch (the near-field r < 2a patch, taken only when
+some lane overlaps) are not part of the count.
+
+  python tools/isa_stats.py            -> writes rigidmultiblobswall_amd/librmb_mobility.isa.json
+"""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rigidmultiblobswall_amd", "csrc")
+OUT = os.path.join(ROOT, "rigidmultiblobswall_amd", "librmb_mobility.isa.json")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# name in the JSON -> mangled-name prefix of the kernel
+KERNELS = {
+    "sym_tt_wall": "_ZN3rmb10sym_kernelILi0ELb1ELb0EEE",
+    "sym_tt_nowall": "_ZN3rmb10sym_kernelILi0ELb0ELb0EEE",
+    "sym_tr_wall": "_ZN3rmb10sym_kernelILi1ELb1ELb0EEE",
+    "sym_rt_wall": "_ZN3rmb10sym_kernelILi2ELb1ELb0EEE",
+    "sym_rr_wall": "_ZN3rmb10sym_kernelILi3ELb1ELb0EEE",
+    "sweep_tt_wall": "_ZN3rmb12sweep_kernelILi0ELb1ELb0EEE",
+    "sym2_tt_wall": "_ZN3rmb11sym2_kernelILb1ELb0EEE",
+    "symx_single_tt_wall": "_ZN3rmb11symx_kernelINS_8OpSingleILi0EEELb1ELb0EEE",
+    "symx_fused_wall": "_ZN3rmb11symx_kernelINS_10OpFusedRowELb1ELb0EEE",
+    "symx_grand_wall": "_ZN3rmb11symx_kernelINS_7OpGrandELb1ELb0EEE",
+    "symx_column_wall": "_ZN3rmb11symx_kernelINS_9OpColumnFELb1ELb0EEE",
+    "symx_tt3_wall": "_ZN3rmb11symx_kernelINS_5OpTTkILi3EEELb1ELb0EEE",
+    "symx_free": "_ZN3rmb11symx_kernelINS_13OpFreeSurfaceELb0ELb0EEE",
+}
+
+
+def source_hash():
+  h = hashlib.sha1()
+  for f in sorted(os.listdir(CSRC)):
+    with open(os.path.join(CSRC, f), "rb") as fh:
+      h.update(f.encode()); h.update(fh.read())
+  return h.hexdigest()
+
+
+def device_asm():
+  out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S",
+                        "--cuda-device-only", "-o", "-", os.path.join(CSRC, "rmb_capi.hip")],
+                       check=True, capture_output=True, text=True)
+  return out.stdout
+
+
+def _classify(op):
+  """-> (is_valu, flops per lane, class)"""
+  if not op.startswith("v_"):
+    return False, 0, "other"
+  base = op
+  for suf in ("_e32", "_e64", "_dpp", "_sdwa"):
+    if base.endswith(suf):
+      base = base[:-len(suf)]
+  if base in ("v_fma_f64", "v_fmac_f64"):
+    return True, 2, "fma_f64"
+  if base in ("v_mul_f64", "v_add_f64", "v_min_f64", "v_max_f64"):
+    return True, 1, "mul_add_f64"
+  if base in ("v_rsq_f64", "v_rcp_f64", "v_sqrt_f64"):
+    return True, 1, "trans_f64"
+  if base.endswith("_f64") or "_f64_" in base:
+    return True, 0, "other_f64"          # compares, rounding, ldexp, conversions: issue slots, no flops
+  return True, 0, "int_or_move"
+
+
+def kernel_loop_stats(asm, mangled_prefix):
+  lines = asm.split("\n")
+  start = None
+  for i, l in enumerate(lines):
+    if l.startswith(mangled_prefix) and l.rstrip().split(":")[0].startswith(mangled_prefix) and ":" in l:
+      start = i
+      break
+  if start is None:
+    return None
+  end = start
+  while end < len(lines) and "s_endpgm" not in lines[end]:
+    end += 1
+  body = lines[start:end + 1]
+  labels = {}
+  for i, l in enumerate(body):
+    m = re.match(r"^(\.LBB\d+_\d+):", l)
+    if m:
+      labels[m.group(1)] = i
+  loops = []
+  for i, l in enumerate(body):
+    m = re.match(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.match(r"^\s+s_branch\s+(\.LBB\d+_\d+)", l)
+    if m and m.group(1) in labels and labels[m.group(1)] < i:
+      loops.append((labels[m.group(1)], i))
+  inner = [lp for lp in loops if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in loops)]
+  best = None
+  for lo, hi in inner:
+    counts = {}
+    valu = flops = lds = 0
+    for l in body[lo:hi + 1]:
+      m = re.match(r"^\s+([a-z_0-9]+)", l)
+      if not m:
+        continue
+      op = m.group(1)
+      is_valu, fl, cls = _classify(op)
+      if is_valu:
+        valu += 1
+        flops += fl
+        counts[cls] = counts.get(cls, 0) + 1
+      elif op.startswith("ds_"):
+        lds += 1
+    f64 = sum(v for k, v in counts.items() if k.endswith("f64"))
+    if best is None or f64 > best["f64_valu_per_step"]:
+      best = {"valu_per_step": valu, "f64_valu_per_step": f64, "flops_per_lane_step": flops, "lds_per_step": lds,
+              "classes": counts, "loop_lines": hi - lo + 1}
+  return best
+
+
+def generate(path=OUT):
+  asm = device_asm()
+  res = {"source_sha1": source_hash(), "compiler": subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.split("\n")[0],
+         "method": "static count over the innermost pair loop of the device ISA (tools/isa_stats.py); out-of-line near-field patch excluded",
+         "kernels": {}}
+  for name, pref in KERNELS.items():
+    st = kernel_loop_stats(asm, pref)
+    if st is not None:
+      res["kernels"][name] = st
+  with open(path, "w") as fh:
+    json.dump(res, fh, indent=1)
+  return res
+
+
+def load(regenerate=True):
+  """Stats of the current sources: the cached JSON if its hash matches, else regenerated (needs hipcc), else None."""
+  try:
+    with open(OUT) as fh:
+      res = json.load(fh)
+    if res.get("source_sha1") == source_hash():
+      return res
+  except (OSError, ValueError):
+    pass
+  if regenerate:
+    try:
+      return generate()
+    except (OSError, subprocess.CalledProcessError):
+      return None
+  return None
+
+
+if __name__ == "__main__":
+  r = generate()
+  for k, v in r["kernels"].items():
+    print("%-22s VALU/step %4d  (f64 %4d)  flops/lane-step %4d  LDS %2d  %s" % (k, v["valu_per_step"], v["f64_valu_per_step"],
+                                                                                 v["flops_per_lane_step"], v["lds_per_step"], v["classes"]))
