@@ -1,25 +1,41 @@
 #!/usr/bin/env python
-"""Headline benchmark: RPY-wall M.f matvecs/s on MI355X.
+"""Headline benchmark: RPY-wall M.f matvecs/s on MI355X (BASELINE.json).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one single_wall_mobility_trans_times_force product (BASELINE.json configs[1]: 1e4
-random blobs above a wall, fp64) with positions and the force vector already resident in HBM:
-all-gather of the force blocks (N > 1 only) + pair sweep + chunk reduction.  Targets are sharded
-over the ranks; total work is fixed => "strong" scaling.  Rank 0 prints ONE JSON line.
+N > 1 launched plainly (no torchrun environment): this process spawns the N ranks itself -- child processes with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, started BEFORE anything here touches the
+GPU (the parent never initialises HIP, never exec()s) -- waits for them and exits non-zero if any rank failed.
+Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one rank.
 
-Extra objects on that line:
-  roofline      dominant kernel (the pair sweep): algorithmic flops 211 N^2 per launch
-                / average launch duration from HIP events on the launch stream, against the fp64
-                vector peak.  The path is FP64-VALU bound, not HBM bound; the HBM view
-                (algorithmic 72 N bytes per launch, PMC traffic) is reported beside it.
-  cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N=1)
-  sweep         the same product at larger N_blobs (the metric is "... vs N_blobs")
+A "step" is one single_wall_mobility_trans_times_force product (configs[1]: 1e4 random blobs above a wall, fp64) with
+positions and the force vector already resident in HBM.  N > 1: the unordered blob pairs are sharded over the ranks
+and the partial velocities all-reduced over RCCL (fixed total work => "strong" scaling); the line also carries both
+decompositions (pair shard + all-reduce; target shard + all-gather of f, the one north_star describes) at 1e4 / 1e5 /
+1e6 blobs.  Rank 0 prints ONE JSON line.
+
+Before the W warm-up steps every rank primes the clocks with an untimed, DECLARED pre-warm (`prewarm` in the line):
+from idle the fp64 clock needs ~100 launches / 25 ms to settle (tools/exp_prewarm.py: 0.207 -> 0.230 -> 0.189 ms per
+launch), so `--warmup 5` alone would time the power-management ramp, not the kernel.
+
+Objects on the line
+  roofline      dominant kernel (the pair sweep).  The path is fp64-VALU bound, not HBM bound.
+                `achieved`/`frac` use SURVEY 8(d)'s ALGORITHMIC unit: 211 flops per ORDERED pair (the reference's
+                as-written arithmetic) x N^2 / kernel time -- the symmetric kernel evaluates each unordered pair once
+                with ~154 executed flops, so this fraction can exceed 1 and is a throughput figure, not a utilisation.
+                `executed` is the utilisation view, <= 1 by construction: fp64 flops the kernel really executes per
+                launch (FMA = 2, mul/add/rsq = 1, counted over the pair loop of THIS build's ISA by tools/isa_stats.py)
+                / kernel time / 78.6 TF.  `issue` = VALU wave-instructions per launch from the same ISA count / kernel
+                time against the fp64 issue ceiling measured live in this process (rmb_ubench_fp64_issue).
+                `traffic` (HBM bytes per launch) cannot be measured inside this process: it is the figure of the
+                committed rocprofv3 --pmc passes, tagged with its source, or null.
+  cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +43,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 FLOPS_PER_PAIR = {"tt_wall": 211.0}     # reference as-written op count, SURVEY.md 8(d)
 FP64_VECTOR_PEAK_TFLOPS = 78.6          # MI355X fp64 vector = 1/2 of the 157.3 TF fp32 vector peak (MI355X_MICROARCH.md)
@@ -43,26 +60,55 @@ def d2_cloud(N, seed=0):
   return r, rng.randn(N, 3), eta, a
 
 
-def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, device):
-  from rigidmultiblobswall_amd.distributed import partition
-  r, f, eta, a = d2_cloud(n_blobs, seed=0)
-  b, e, _ = partition(n_blobs, world, rank)
-  sm.set_local_positions(torch.as_tensor(r[b:e].reshape(-1), device=device), n_blobs, a, wall=True)
-  if world == 1:
-    f_local = torch.as_tensor(f[b:e].reshape(-1), device=device)
-    out = torch.empty(3 * (e - b), dtype=torch.float64, device=device)
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--blobs", type=int, default=10000, help="N_blobs of the headline workload (configs[1] = 1e4)")
+  ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                  help="untimed, declared clock pre-warm before the warm-up steps (0 disables)")
+  ap.add_argument("--no-sweep", action="store_true", help="skip the N_blobs sweep, decompositions and config extras")
+  ap.add_argument("--no-cpu", action="store_true")
+  return ap.parse_args()
 
-    def step():
-      sm.matvec_local("tt", f_local, eta, out=out)
-  else:
-    # replicated vectors: every rank holds f and receives u; unordered pairs are sharded over the
-    # ranks (each pair evaluated once, applied to both blobs) and u is all-reduced (RCCL)
-    f_full = torch.as_tensor(f.reshape(-1), device=device)
-    out = torch.empty(3 * n_blobs, dtype=torch.float64, device=device)
 
-    def step():
-      sm.matvec_replicated("tt", f_full, eta, out=out)
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks (the parent stays off the GPU)
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  procs = []
+  for rank in range(args.gpus):
+    env = dict(os.environ)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+  rc = 0
+  alive = set(range(len(procs)))
+  while alive:
+    for i in sorted(alive):
+      r = procs[i].poll()
+      if r is None:
+        continue
+      alive.discard(i)
+      if r != 0 and rc == 0:
+        rc = r if r > 0 else 1
+        sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (i, r))
+        for j in alive:
+          procs[j].terminate()          # exact PIDs we started
+    time.sleep(0.05)
+  return rc
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------
+def timed_region(torch, dist, world, device, backend, step, steps, warmup):
+  """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
   for _ in range(warmup):
     step()
   torch.cuda.synchronize(device)
@@ -78,49 +124,98 @@ def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, de
     dist.barrier()
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
   kern_ms = backend.ctx.timing_collect(steps)
   kern_ms_avg = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
   if world > 1:
-    t = torch.tensor([kern_ms_avg], dtype=torch.float64, device=device)
+    t = torch.tensor([dt, kern_ms_avg], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    kern_ms_avg = float(t.item())
-  return dict(dt=dt, kern_ms=kern_ms_avg, launch=backend.ctx.last_launch(), out=out, r=r, f=f, eta=eta, a=a,
-              n_local=e - b, begin=b, end=e)
+    dt, kern_ms_avg = float(t[0].item()), float(t[1].item())
+  return dt, kern_ms_avg
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=200)
-  ap.add_argument("--warmup", type=int, default=20)
-  ap.add_argument("--blobs", type=int, default=10000, help="N_blobs of the headline workload (configs[1] = 1e4)")
-  ap.add_argument("--no-sweep", action="store_true")
-  ap.add_argument("--no-cpu", action="store_true")
-  ap.add_argument("--traffic-bytes", type=float, default=None,
-                  help="HBM bytes per sweep launch from a separate rocprofv3 --pmc run (profiles/), if known")
-  args = ap.parse_args()
+def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, device, decomposition="pair", prewarm_ms=0.0):
+  """decomposition "pair": every rank holds f, evaluates its slice of the unordered pairs (each once, both blobs
+  updated) into a full-length partial, one all-reduce of u.  "target": rank g owns a block of targets, all-gather of
+  the f blocks, one-sided sweep of its targets against all sources, no reduction (north_star's layout)."""
+  from rigidmultiblobswall_amd.distributed import partition
+  r, f, eta, a = d2_cloud(n_blobs, seed=0)
+  b, e, _ = partition(n_blobs, world, rank)
+  sm.set_local_positions(torch.as_tensor(r[b:e].reshape(-1), device=device), n_blobs, a, wall=True)
+  if decomposition == "pair":
+    f_full = torch.as_tensor(f.reshape(-1), device=device)
+    out = torch.empty(3 * n_blobs, dtype=torch.float64, device=device)
+    if world == 1:
+      def step():
+        sm.matvec_local("tt", f_full, eta, out=out)
+    else:
+      def step():
+        sm.matvec_replicated("tt", f_full, eta, out=out)
+  else:
+    f_local = torch.as_tensor(f[b:e].reshape(-1), device=device)
+    out = torch.empty(3 * (e - b), dtype=torch.float64, device=device)
+    if world == 1:
+      backend.ctx.set_option("deterministic", 1)     # what one rank of a target shard runs: the one-sided sweep
 
+    def step():
+      sm.matvec_local("tt", f_local, eta, out=out)
+  prewarm = None
+  try:
+    if prewarm_ms > 0:
+      t0 = time.perf_counter()
+      n_pre = 0
+      while time.perf_counter() - t0 < prewarm_ms * 1e-3:
+        for _ in range(20):
+          step()
+        torch.cuda.synchronize(device)
+        n_pre += 20
+      prewarm = {"ms": round(1e3 * (time.perf_counter() - t0), 1), "steps": n_pre, "timed": False}
+    dt, kern_ms = timed_region(torch, dist, world, device, backend, step, steps, warmup)
+  finally:
+    backend.ctx.set_option("deterministic", 0)
+  return dict(dt=dt, kern_ms=kern_ms, launch=backend.ctx.last_launch(), out=out, r=r, f=f, eta=eta, a=a,
+              n_local=e - b, begin=b, end=e, prewarm=prewarm)
+
+
+def committed_traffic(N, sym):
+  """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), with their provenance."""
+  try:
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+      tj = json.load(fh)
+    key = ("sym_tt_wall_N%d" if sym else "sweep_tt_wall_N%d") % N
+    cand = [(k, v) for k, v in tj.items() if isinstance(v, dict) and k.endswith(key)]
+    if cand:
+      k, v = cand[-1]
+      return v["traffic_bytes"], {"measured_in_this_run": False, "source": "profiles/traffic.json[%s]" % k,
+                                  "files": v.get("files"), "commit": v.get("commit"),
+                                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, "
+                                            "gfx950 corrections of MI355X_MICROARCH.md"}
+  except (OSError, ValueError, KeyError):
+    pass
+  return None, {"measured_in_this_run": False, "source": None}
+
+
+def rank_main(args):
   import torch
   import torch.distributed as dist
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
   # rehearsal on a 1-GPU box: RMB_BENCH_BACKEND=gloo lets several ranks share cuda:0 (RCCL refuses that)
   backend_name = os.environ.get("RMB_BENCH_BACKEND", "nccl")
-  device = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))
+  n_dev = torch.cuda.device_count()
+  if backend_name == "nccl" and world > n_dev:
+    raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, n_dev))
+  device = torch.device("cuda:%d" % (local_rank % n_dev))
   torch.cuda.set_device(device)
   if world > 1:
     if backend_name == "nccl":
       dist.init_process_group("nccl", device_id=device)
     else:
       dist.init_process_group(backend_name)
-  assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
   from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
   backend = HipBackend(device)
@@ -128,51 +223,68 @@ def main():
   sm = ShardedMobility(backend, device=device)
 
   N = args.blobs
-  res = run_config(torch, dist, sm, backend, N, args.steps, args.warmup, world, rank, device)
+  res = run_config(torch, dist, sm, backend, N, args.steps, args.warmup, world, rank, device, "pair", args.prewarm_ms)
   ms_per_step = 1e3 * res["dt"] / args.steps
   value = args.steps / res["dt"]
-
-  # roofline of the dominant kernel: one rank's launch covers 1/world of the N x N ordered pairs
-  pairs_per_launch = float(N) * N / world
-  flops = FLOPS_PER_PAIR["tt_wall"] * pairs_per_launch
-  achieved_tf = flops / (res["kern_ms"] * 1e-3) / 1e12
-  alg_bytes = 48.0 * N + 24.0 * res["n_local"]       # read r,f of all sources; write u of own targets
-  traffic = args.traffic_bytes
-  valu_instr = issue_ceiling = None
-  if traffic is None:
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    try:
-      with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-        tj = json.load(fh)
-      key = "sym_tt_wall_N%d" % N if res["launch"]["chunks"] == 0 else "sweep_tt_wall_N%d" % N
-      cand = [v for k, v in tj.items() if k.endswith(key)]
-      if cand and world == 1:
-        traffic = cand[-1]["traffic_bytes"]
-        valu_instr = cand[-1].get("SQ_INSTS_VALU_per_launch")
-        issue_ceiling = tj.get("_fp64_issue_ceiling_G_wave_instr_per_s")
-    except (OSError, ValueError, KeyError):
-      traffic = None
   sym = res["launch"]["chunks"] == 0
+  issue_peak = backend.ctx.ubench_fp64_issue(40)      # same process, clocks still primed by the timed loop
+  if world > 1:
+    t = torch.tensor([issue_peak], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    issue_peak = float(t.item())
+
+  # ---- roofline of the dominant kernel: one rank's launch covers 1/world of the pairs -------------------------
+  kern_s = res["kern_ms"] * 1e-3
+  pairs_ordered = float(N) * N / world
+  alg_tf = FLOPS_PER_PAIR["tt_wall"] * pairs_ordered / kern_s / 1e12
+  alg_bytes = 48.0 * N + 24.0 * (res["n_local"] if world == 1 else N)
+  traffic, traffic_src = committed_traffic(N, sym) if world == 1 else (None, {"measured_in_this_run": False, "source": None})
+  executed = issue = None
+  try:
+    import isa_stats
+    isa = isa_stats.load()
+    st = isa["kernels"]["sym_tt_wall" if sym else "sweep_tt_wall"] if isa else None
+  except Exception:
+    isa = st = None
+  if st is not None:
+    if sym:
+      tiles = (N + 63) // 64
+      wave_steps = (tiles * (tiles + 1) // 2 * 64 - tiles) / world       # rotation steps (diagonal units skip k = 0)
+      pair_evals = float(N) * (N - 1) / 2 / world                         # real (unpadded) unordered pairs
+    else:
+      wave_steps = float(-(-res["n_local"] // 64)) * N
+      pair_evals = float(res["n_local"]) * N
+    ex_flops = st["flops_per_lane_step"] * pair_evals
+    ex_tf = ex_flops / kern_s / 1e12
+    executed = {"flops_per_pair_evaluation": st["flops_per_lane_step"], "pair_evaluations_per_launch": pair_evals,
+                "achieved": round(ex_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ex_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+                "source": "FMA = 2, mul/add/rsq = 1 flop, counted over the pair loop of this build's ISA "
+                          "(tools/isa_stats.py, csrc sha1 %s); padded lanes not counted" % isa["source_sha1"][:12],
+                "instruction_mix_per_step": st["classes"]}
+    valu = st["valu_per_step"] * wave_steps
+    issue = {"valu_wave_instr_per_launch": valu, "achieved": round(valu / kern_s / 1e9, 1), "peak": round(issue_peak, 1),
+             "unit": "G wave-instr/s", "frac": round(valu / kern_s / 1e9 / issue_peak, 4),
+             "peak_source": "rmb_ubench_fp64_issue: independent v_fma_f64, 4 waves per SIMD on every CU, 40 launches, "
+                            "measured in this process right after the timed loop",
+             "note": "two of the %d VALU instructions per step are v_rsq_f64, which issue at ~0.3x the FMA rate "
+                     "(profiles/r1_ubench_fp64_issue_rates.txt)" % st["valu_per_step"]}
   roofline = {
       "bound": "valu_fp64",
-      "kernel": "rmb::sym_kernel<TT,wall> (each unordered pair once)" if sym else "rmb::sweep_kernel<TT,wall>",
-      "note": "achieved = ALGORITHMIC flops (211 per ordered pair, the reference's as-written count, SURVEY 8d) / measured "
-              "kernel time; the kernel executes ~55 (symmetric) or ~93 (sweep) fp64 VALU instructions per ordered pair, so "
-              "frac can exceed 1; measured fp64 issue ceiling of the chip: 479 G wave-instr/s (profiles/r1_ubench_*)",
-      "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-      "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-      "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_per_launch,
+      "kernel": "rmb::sym_kernel<TT,wall> (each unordered pair once, both blobs updated)" if sym else "rmb::sweep_kernel<TT,wall>",
+      "achieved": round(alg_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+      "frac": round(alg_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+      "unit_of_work": "ALGORITHMIC: 211 flops per ordered pair (the reference's as-written count, SURVEY 8d) x N^2 per "
+                      "matvec; the kernel needs fewer (see `executed`), so this fraction may exceed 1 -- it is a "
+                      "throughput in the reference's unit, not a utilisation",
+      "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_ordered,
       "kernel_ms_avg": round(res["kern_ms"], 5), "launch": res["launch"],
-      "traffic": traffic,
-      # executed-instruction view (what the kernel actually issues vs what the chip can issue): SQ_INSTS_VALU per
-      # launch from the committed rocprofv3 --pmc pass of this command / live kernel time, against the fp64 VALU
-      # issue ceiling measured by tools/ubench.hip on the same chip family
-      "issue": None if not valu_instr else {
-          "valu_wave_instr_per_launch": valu_instr, "achieved": round(valu_instr / (res["kern_ms"] * 1e-3) / 1e9, 1),
-          "peak": issue_ceiling, "unit": "G wave-instr/s", "frac": round(valu_instr / (res["kern_ms"] * 1e-3) / 1e9 / issue_ceiling, 4)},
+      "executed": executed, "frac_executed": executed["frac"] if executed else None,
+      "issue": issue,
+      "traffic": traffic, "traffic_provenance": traffic_src,
       "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
-              "achieved": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": round(alg_bytes / (res["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+              "achieved": round(alg_bytes / kern_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, 6)},
   }
 
   line = {
@@ -186,6 +298,9 @@ def main():
                  "parallelism": ("single GPU" if world == 1 else
                                  "unordered blob pairs sharded over %d ranks (each pair once, both blobs updated), "
                                  "f replicated, one RCCL all-reduce of u per matvec" % world)},
+      "world_size": world,
+      "collective_backend": None if world == 1 else ("nccl (RCCL)" if backend_name == "nccl" else backend_name),
+      "prewarm": res["prewarm"],
       "roofline": roofline,
   }
 
@@ -218,19 +333,26 @@ def main():
                                       % (len(times), N, cores, hw_threads)}
 
   if not args.no_sweep:
+    # both decompositions at 1e4 / 1e5 / 1e6 blobs (the metric is "... vs N_blobs at 1/2/4/8 MI355X")
     try:
-      sweep = []
-      for nb, st, wu in ((100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
-        rs = run_config(torch, dist, sm, backend, nb, st, wu, world, rank, device)
-        pairs = float(nb) * nb / world
-        sweep.append({"n_blobs": nb, "matvecs_per_s": round(st / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st, 3),
-                      "kernel_ms_avg": round(rs["kern_ms"], 3),
-                      "valu_fp64_tflops": round(211.0 * pairs / (rs["kern_ms"] * 1e-3) / 1e12, 2),
-                      "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4),
-                      "launch": rs["launch"]})
-      line["sweep"] = sweep
+      dec = {"pair_shard_allreduce": [], "target_shard_allgather": []}
+      for nb, st_, wu in ((10000, 50, 5), (100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
+        rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "pair", 100.0 if nb == 10000 else 0.0)
+        dec["pair_shard_allreduce"].append({
+            "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
+            "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
+            "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
+            "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]})
+      for nb, st_, wu in ((10000, 50, 5), (100000, 3, 1), (1000000, 1, 1)):
+        rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "target", 100.0 if nb == 10000 else 0.0)
+        dec["target_shard_allgather"].append({
+            "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
+            "kernel_ms_avg": round(rs["kern_ms"], 4), "allgather_bytes": 0 if world == 1 else 24 * nb,
+            "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
+            "launch": rs["launch"]})
+      line["decompositions"] = dec
     except Exception as exc:      # an extra must never cost the headline line
-      line['sweep'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+      line["decompositions"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
   if world == 1 and not args.no_sweep:
     try:
@@ -261,7 +383,8 @@ def main():
       # BASELINE.json configs[4] recipe: 2.6e5 single-blob rollers, Brownian Adams-Bashforth steps = forces kernel +
       # M_tt F + M_tr T + Lanczos M^{1/2} z + 2 random-finite-difference products per step; physical parameters of
       # multi_bodies/examples/rollers/inputfile_rollers.dat.  On N ranks the same replicated stepper runs on every
-      # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline.
+      # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline; the full
+      # 100-step run is tools/run_config5.py (profiles/).
       from rigidmultiblobswall_amd import structures as st
       from rigidmultiblobswall_amd.distributed import ReplicatedContext
       from rigidmultiblobswall_amd.rollers import RollersIntegrator
@@ -346,6 +469,13 @@ def main():
     print(json.dumps(line), flush=True)
   if world > 1:
     dist.destroy_process_group()
+
+
+def main():
+  args = parse_args()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(spawn_ranks(args))
+  rank_main(args)
 
 
 if __name__ == "__main__":

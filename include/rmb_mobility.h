@@ -170,6 +170,10 @@ int rmb_blob_blob_force_radii_device(rmb_ctx* ctx, const double* radii_dev, doub
  * "timing" option is on.  Copies up to max_n most recent durations (ms) into ms[], returns count. */
 int rmb_timing_collect(rmb_ctx* ctx, double* ms, int max_n);
 int rmb_timing_reset(rmb_ctx* ctx);
+/* Measurement aid: chip-wide issue rate of independent v_fma_f64 (G wave-instructions per second, 4 waves per SIMD on
+ * every CU, no memory traffic) over `launches` back-to-back launches on the context's stream -- the ceiling bench.py
+ * prices the VALU-bound pair sweeps against, measured in the same process and clock state.  Synchronous. */
+int rmb_ubench_fp64_issue(rmb_ctx* ctx, int launches, double* g_wave_instr_per_s);
 /* Schedule diagnostics: with option "wave_clock" = 1 the symmetric kernel stamps every wave's start and end
  * (100 MHz wall clock); copies (start, end) pairs of the last launch into stamps[2*max_waves], returns count. */
 int rmb_wave_clock_collect(rmb_ctx* ctx, long long* stamps, long max_waves);

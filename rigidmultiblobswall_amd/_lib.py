@@ -51,6 +51,7 @@ SYMBOLS = {
     "rmb_blob_blob_force_radii_device": (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_timing_collect": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
     "rmb_timing_reset": (ctypes.c_int, [_vp]),
+    "rmb_ubench_fp64_issue": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
     "rmb_wave_clock_collect": (ctypes.c_int, [_vp, _vp, ctypes.c_long]),
     "rmb_last_launch": (ctypes.c_int, [_vp, _lp, _lp, _lp]),
     "rmb_ctx_synchronize": (ctypes.c_int, [_vp]),

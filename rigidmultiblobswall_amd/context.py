@@ -261,6 +261,13 @@ class MobilityContext(object):
       _lib.check(n)
     return buf[:n]
 
+  def ubench_fp64_issue(self, launches=40):
+    """G wave-instructions/s of independent v_fma_f64 on this chip right now (rmb_ubench_fp64_issue)."""
+    out = ctypes.c_double()
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_ubench_fp64_issue(self._h, int(launches), ctypes.byref(out)))
+    return float(out.value)
+
   def timing_reset(self):
     _lib.check(self._lib.rmb_timing_reset(self._h))
 

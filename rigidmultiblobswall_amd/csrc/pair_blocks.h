@@ -1,0 +1,275 @@
+// pair_blocks.h -- the four blocks of the pair mobility on a SHARED pair geometry, both directions (gfx950, fp64).
+//
+// Kernels that evaluate each unordered pair once (sym_kernels.h, symx_kernels.h) need, per pair, M_ij v_j for blob i
+// and M_ji v_i for blob j, possibly for several blocks (tt, tr, rt, rr) at once.  Everything that does not depend on
+// the vectors -- differences, both inverse square roots, tau, the wall polynomials -- is computed once (Geom and the
+// *_coeffs routines); the *_apply routines are the cheap contractions.  Reference formulas:
+//   tt  mobility/mobility_numba.py:199-281    tr  :609-684    rt  :998-1071    rr  :1250-1326
+#pragma once
+#include "pair_ops.h"
+
+namespace rmb {
+
+// ---------------------------------------------------------------------------------------------
+// Shared pair geometry and the per-block coefficient / contraction routines.
+// vi / vj / ui / t are pointers to 3 consecutive doubles (registers after inlining).
+// ACC = false: t is written; ACC = true: t is added to (second and later blocks of a fused operation).
+// ---------------------------------------------------------------------------------------------
+struct Geom {
+  double dx, dy, dz, rho2, r2, ir, ir2;
+  double Rz, iR, iR2;     // image separation R = (dx, dy, z_i + z_j); wall / free-surface operations only
+};
+
+template <bool IMAGE>
+__device__ __forceinline__ Geom make_geom(double dx, double dy, double dz, double zi, double zj) {
+  Geom g;
+  g.dx = dx; g.dy = dy; g.dz = dz;
+  g.rho2 = __builtin_fma(dy, dy, dx * dx);
+  g.r2 = __builtin_fma(dz, dz, g.rho2);
+  g.ir = rsqrt_f64(g.r2);
+  g.ir2 = g.ir * g.ir;
+  if constexpr (IMAGE) {
+    g.Rz = zi + zj;
+    g.iR = rsqrt_f64(__builtin_fma(g.Rz, g.Rz, g.rho2));
+    g.iR2 = g.iR * g.iR;
+  } else {
+    g.Rz = 0.0; g.iR = 0.0; g.iR2 = 0.0;
+  }
+  return g;
+}
+
+// RPY tt coefficients of separation r:  cF I + cD r r^T   (mobility_numba.py:209-239)
+__device__ __forceinline__ void rpy_tt_coeffs(const PairConsts& k, double r2, double ir, double ir2, double& cF, double& cD) {
+  cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
+  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
+  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
+    const double r = r2 * ir;
+    const bool near = r2 <= k.four_a2;
+    cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : cF;
+    cD = near ? k.tt_n2 * ir : cD;
+  }
+}
+
+struct TTc { double cF, cD, nG2, G3r, G4r, G5r; };
+
+template <bool WALL>
+__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zj) {
+  TTc c;
+  rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, c.cF, c.cD);
+  if constexpr (WALL) {
+    const WallTT W = wall_tt_from_iR(k, g.Rz, g.iR, zj);
+    const double iR3 = W.iR * W.iR2;
+    c.cF = __builtin_fma(-W.G1, W.iR, c.cF);
+    c.nG2 = -W.G2 * iR3;
+    c.G3r = W.G3 * W.iR2;
+    c.G4r = W.G4 * W.iR2;
+    c.G5r = W.G5 * W.iR;
+  } else {
+    c.nG2 = c.G3r = c.G4r = c.G5r = 0.0;
+  }
+  return c;
+}
+
+// ui += M_tt,ij vj ;  t (+)= M_tt,ji vi       (same algebra as pair_tt_sym)
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void tt_apply(const TTc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
+  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
+  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
+  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
+  const double t0 = ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0];
+  const double t1 = ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1];
+  if constexpr (!WALL) {
+    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    t[0] = __builtin_fma(cDi, g.dx, t0);
+    t[1] = __builtin_fma(cDi, g.dy, t1);
+    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
+  } else {
+    const double Rvj = __builtin_fma(g.Rz, vj[2], pj);
+    const double cRj = __builtin_fma(c.G3r, vj[2], c.nG2 * Rvj);
+    const double cbj = __builtin_fma(c.G5r, vj[2], c.G4r * Rvj);
+    const double cj = cDj + cRj;
+    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    ui[2] = __builtin_fma(cRj, g.Rz, ui[2]); ui[2] += cbj;
+    const double Rvi = __builtin_fma(g.Rz, vi[2], pi);
+    const double cRi = __builtin_fma(c.G4r, vi[2], c.nG2 * Rvi);
+    const double cbi = __builtin_fma(c.G5r, vi[2], c.G3r * Rvi);
+    const double ci = cDi + cRi;
+    t[0] = __builtin_fma(ci, g.dx, t0);
+    t[1] = __builtin_fma(ci, g.dy, t1);
+    t[2] = __builtin_fma(cRi, g.Rz, __builtin_fma(cDi, g.dz, __builtin_fma(c.cF, vi[2], ACC ? t[2] + cbi : cbi)));
+  }
+}
+
+// Coupling blocks tr / rt.  With e = R/|R|, the reference's wall correction of M_tr tau (anchored on the target
+// height, mobility_numba.py:646-679) is
+//   ( f1 e_y t_z + p t_y - f3 c0 e_x,  -f1 e_x t_z - p t_x - f3 c0 e_y,  (f3 e_z + s) c0 ),   c0 = e_x t_y - e_y t_x
+// and the RPY part is c (t x d).  Written on the UNNORMALISED separation (e_x = d_x/|R|, c0 = C0/|R| with
+// C0 = d_x t_y - d_y t_x) the two parts share their terms:
+//   u_x =  A d_y t_z + B t_y - D C0 d_x      A = 1/|R|^3 - c            (f1 = 1/R^2)
+//   u_y = -A d_x t_z - B t_x - D C0 d_y      B = c d_z + p             D = f3 / R^2
+//   u_z =  E C0                              E = D R_z + S,  S = s/|R| - c
+// 11 instructions per direction instead of 25.  M_rt f (anchored on the source height, :1035-1066) is the transpose:
+//   w_x = -(p - c d_z) f_y + K d_y,  w_y = (p - c d_z) f_x - K d_x,  w_z = A (d_x f_y - d_y f_x),  K = D (R.f) + S f_z.
+// p, s, f3 depend linearly on the anchoring height g = z/|R|; `_i` is anchored on z_i, `_j` on z_j.  The reversed
+// pair sees d' = -d, R' = (-d_x, -d_y, R_z).
+struct CPc {
+  double c;                    // RPY coupling coefficient: 1/r^3, or 1/(2a^3) - 3r/(16a^4) for overlapping blobs
+  double A, B_i, Bjp;          // B_i = c d_z + p_i (forward, anchored on i);  Bjp = p_j - c d_z (reversed pair, anchored on j)
+  double D_i, D_j, S_i, S_j, E_i, E_j;
+};
+
+template <bool WALL>
+__device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
+  CPc C;
+  C.c = g.ir2 * g.ir;
+  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
+    const double r = g.r2 * g.ir;
+    C.c = (g.r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : C.c;
+  }
+  if constexpr (WALL) {
+    const double tau = k.a2 * g.iR2;
+    const double ez = g.Rz * g.iR;
+    const double uu = ez * ez;
+    const double eztau = ez * tau;
+    const double p0 = g.iR2 * __builtin_fma(2.0, eztau, ez);                            // p = p0 - 2 iR2 g
+    const double s0 = g.iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, 1.0);  // s = s0 + 12 iR2 ez g
+    const double f30 = 10.0 * g.iR2 * eztau;                                            // f3 = f30 - 6 iR2 g
+    const double gi = zi * g.iR, gj = zj * g.iR;
+    const double m2 = -2.0 * g.iR2, e12 = 12.0 * g.iR2 * ez, m6 = -6.0 * g.iR2;
+    const double p_i = __builtin_fma(m2, gi, p0), s_i = __builtin_fma(e12, gi, s0), f3_i = __builtin_fma(m6, gi, f30);
+    const double p_j = __builtin_fma(m2, gj, p0), s_j = __builtin_fma(e12, gj, s0), f3_j = __builtin_fma(m6, gj, f30);
+    C.A = __builtin_fma(g.iR2, g.iR, -C.c);
+    const double cdz = C.c * g.dz;
+    C.B_i = cdz + p_i;
+    C.Bjp = p_j - cdz;
+    C.D_i = f3_i * g.iR2; C.D_j = f3_j * g.iR2;
+    C.S_i = __builtin_fma(s_i, g.iR, -C.c); C.S_j = __builtin_fma(s_j, g.iR, -C.c);
+    C.E_i = __builtin_fma(C.D_i, g.Rz, C.S_i); C.E_j = __builtin_fma(C.D_j, g.Rz, C.S_j);
+  } else {
+    C.A = C.B_i = C.Bjp = C.D_i = C.D_j = C.S_i = C.S_j = C.E_i = C.E_j = 0.0;
+  }
+  return C;
+}
+
+// RPY part alone (no wall): ui += c (vj x d),  t (+)= -c (vi x d)
+template <bool ACC>
+__device__ __forceinline__ void coupling_rpy_apply(double c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  ui[0] = __builtin_fma(__builtin_fma(vj[1], g.dz, -vj[2] * g.dy), c, ui[0]);
+  ui[1] = __builtin_fma(__builtin_fma(vj[2], g.dx, -vj[0] * g.dz), c, ui[1]);
+  ui[2] = __builtin_fma(__builtin_fma(vj[0], g.dy, -vj[1] * g.dx), c, ui[2]);
+  const double bx = __builtin_fma(vi[2], g.dy, -vi[1] * g.dz), by = __builtin_fma(vi[0], g.dz, -vi[2] * g.dx),
+               bz = __builtin_fma(vi[1], g.dx, -vi[0] * g.dy);
+  if constexpr (ACC) { t[0] = __builtin_fma(bx, c, t[0]); t[1] = __builtin_fma(by, c, t[1]); t[2] = __builtin_fma(bz, c, t[2]); }
+  else { t[0] = bx * c; t[1] = by * c; t[2] = bz * c; }
+}
+
+// tr: ui += M_tr,ij vj (torque of j -> velocity of i, wall part anchored on the TARGET height z_i);  t (+)= M_tr,ji vi
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void tr_apply(const CPc& C, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  if constexpr (!WALL) {
+    coupling_rpy_apply<ACC>(C.c, g, vi, vj, ui, t);
+  } else {
+    const double C0 = __builtin_fma(g.dx, vj[1], -g.dy * vj[0]);
+    const double Az = C.A * vj[2];
+    const double DC = C.D_i * C0;
+    ui[0] = __builtin_fma(Az, g.dy, ui[0]); ui[0] = __builtin_fma(C.B_i, vj[1], ui[0]); ui[0] = __builtin_fma(-DC, g.dx, ui[0]);
+    ui[1] = __builtin_fma(-Az, g.dx, ui[1]); ui[1] = __builtin_fma(-C.B_i, vj[0], ui[1]); ui[1] = __builtin_fma(-DC, g.dy, ui[1]);
+    ui[2] = __builtin_fma(C.E_i, C0, ui[2]);
+    // reversed pair (d' = -d, anchored on z_j): (-A d_y t_z + B' t_y - D C0i d_x,  A d_x t_z - B' t_x - D C0i d_y,  -E C0i)
+    const double C0i = __builtin_fma(g.dx, vi[1], -g.dy * vi[0]);
+    const double Azi = C.A * vi[2];
+    const double DCi = C.D_j * C0i;
+    const double b0 = ACC ? __builtin_fma(-Azi, g.dy, t[0]) : -Azi * g.dy;
+    const double b1 = ACC ? __builtin_fma(Azi, g.dx, t[1]) : Azi * g.dx;
+    t[0] = __builtin_fma(-DCi, g.dx, __builtin_fma(C.Bjp, vi[1], b0));
+    t[1] = __builtin_fma(-DCi, g.dy, __builtin_fma(-C.Bjp, vi[0], b1));
+    t[2] = ACC ? __builtin_fma(-C.E_j, C0i, t[2]) : -C.E_j * C0i;
+  }
+}
+
+// rt: ui += M_rt,ij vj (force of j -> angular velocity of i, wall part anchored on the SOURCE height z_j);  t (+)= M_rt,ji vi
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void rt_apply(const CPc& C, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  if constexpr (!WALL) {
+    coupling_rpy_apply<ACC>(C.c, g, vi, vj, ui, t);
+  } else {
+    const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
+    const double K = __builtin_fma(C.D_j, __builtin_fma(g.Rz, vj[2], pj), C.S_j * vj[2]);
+    const double C0 = __builtin_fma(g.dx, vj[1], -g.dy * vj[0]);
+    ui[0] = __builtin_fma(-C.Bjp, vj[1], ui[0]); ui[0] = __builtin_fma(K, g.dy, ui[0]);
+    ui[1] = __builtin_fma(C.Bjp, vj[0], ui[1]); ui[1] = __builtin_fma(-K, g.dx, ui[1]);
+    ui[2] = __builtin_fma(C.A, C0, ui[2]);
+    // reversed pair (R' = (-d_x, -d_y, R_z), anchored on z_i)
+    const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
+    const double Ki = __builtin_fma(C.D_i, __builtin_fma(g.Rz, vi[2], -pi), C.S_i * vi[2]);
+    const double C0i = __builtin_fma(g.dx, vi[1], -g.dy * vi[0]);
+    t[0] = __builtin_fma(-Ki, g.dy, ACC ? __builtin_fma(-C.B_i, vi[1], t[0]) : -C.B_i * vi[1]);
+    t[1] = __builtin_fma(Ki, g.dx, ACC ? __builtin_fma(C.B_i, vi[0], t[1]) : C.B_i * vi[0]);
+    t[2] = ACC ? __builtin_fma(-C.A, C0i, t[2]) : -C.A * C0i;
+  }
+}
+
+struct RRc { double cF, cD, cFxy, cFzj, cFzi, h5; };
+
+template <bool WALL>
+__device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
+  RRc c;
+  const double ir3 = g.ir2 * g.ir;
+  c.cF = -0.5 * ir3;
+  c.cD = 1.5 * ir3 * g.ir2;
+  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
+    const double r = g.r2 * g.ir;
+    const double r3 = g.r2 * r;
+    const bool near = g.r2 < k.four_a2;
+    c.cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : c.cF;
+    c.cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : c.cD;
+  }
+  if constexpr (WALL) {
+    const double iR3 = g.iR2 * g.iR;
+    const double uu = g.Rz * g.Rz * g.iR2;
+    c.cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, c.cF);
+    c.cFzj = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, c.cF);
+    c.cFzi = __builtin_fma(0.5, iR3, c.cF);
+    c.h5 = 1.5 * iR3 * g.iR2;
+  } else {
+    c.cFxy = c.cFzj = c.cFzi = c.h5 = 0.0;
+  }
+  return c;
+}
+
+// rr: ui += M_rr,ij vj ;  t (+)= M_rr,ji vi       (same algebra as pair_rr_sym)
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
+  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
+  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
+  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
+  if constexpr (!WALL) {
+    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    t[0] = __builtin_fma(cDi, g.dx, ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0]);
+    t[1] = __builtin_fma(cDi, g.dy, ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1]);
+    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
+  } else {
+    const double zvj = g.Rz * vj[2], zvi = g.Rz * vi[2];
+    const double Rvj = zvj + pj;
+    const double cj = __builtin_fma(-c.h5, __builtin_fma(2.0, pj, Rvj), cDj);
+    ui[0] = __builtin_fma(c.cFxy, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.cFxy, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.cFzj, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    ui[2] = __builtin_fma(c.h5 * Rvj, g.Rz, ui[2]);
+    const double Rvi = zvi + pi;
+    const double ci = __builtin_fma(-c.h5, __builtin_fma(3.0, pi, -zvi), cDi);
+    t[0] = __builtin_fma(ci, g.dx, ACC ? __builtin_fma(c.cFxy, vi[0], t[0]) : c.cFxy * vi[0]);
+    t[1] = __builtin_fma(ci, g.dy, ACC ? __builtin_fma(c.cFxy, vi[1], t[1]) : c.cFxy * vi[1]);
+    t[2] = __builtin_fma(-c.h5 * Rvi, g.Rz, __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cFzi, vi[2], t[2]) : c.cFzi * vi[2]));
+  }
+}
+
+}  // namespace rmb

@@ -17,6 +17,7 @@
 #include "symx_kernels.h"
 #include "dense_kernels.h"
 #include "st_kernels.h"
+#include "diag_kernels.h"
 
 namespace {
 
@@ -1056,6 +1057,28 @@ int rmb_wave_clock_collect(rmb_ctx* c, long long* stamps, long max_waves) {
   if (n > 0 && c->wave_clock.p) RMB_HIP(hipMemcpy(stamps, c->wave_clock.p, (size_t)2 * n * sizeof(long long), hipMemcpyDeviceToHost));
   else n = 0;
   return (int)n;
+}
+
+int rmb_ubench_fp64_issue(rmb_ctx* c, int launches, double* g_wave_instr_per_s) {
+  if (!c || !g_wave_instr_per_s || launches < 1) return fail(RMB_ERR_ARG, "bad ubench arguments");
+  RMB_HIP(hipSetDevice(c->device));
+  const long blocks = c->n_cu * 4;                    // 4 workgroups of 4 waves per CU = 4 waves per SIMD
+  if (int rc = c->tmp3n.reserve((size_t)blocks * 256 * sizeof(double))) return rc;
+  hipEvent_t e0, e1;
+  RMB_HIP(hipEventCreate(&e0));
+  RMB_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(rmb::ubench_fma64_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (double*)c->tmp3n.p, 1.0000001, 1e-9);
+  RMB_HIP(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < launches; ++i)
+    hipLaunchKernelGGL(rmb::ubench_fma64_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (double*)c->tmp3n.p, 1.0000001, 1e-9);
+  RMB_HIP(hipEventRecord(e1, c->stream));
+  RMB_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RMB_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  const double instr = (double)launches * blocks * 4 * rmb::kUbenchIters * rmb::kUbenchFmaPerIter;
+  *g_wave_instr_per_s = instr / (ms * 1e-3) / 1e9;
+  return 0;
 }
 
 int rmb_timing_reset(rmb_ctx* c) {

@@ -26,7 +26,7 @@
 // fixed: results agree with the deterministic sweep_kernel to rounding (~1e-15 relative) but are not
 // bit-reproducible; the "deterministic" context option selects sweep_kernel instead.
 #pragma once
-#include "pair_ops.h"
+#include "pair_blocks.h"
 
 namespace rmb {
 
@@ -174,65 +174,19 @@ __device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, doub
 // Coupling blocks, both directions.  KIND_TR: u = M_tr tau, wall part anchored on the TARGET height of each
 // direction (z_i forward, z_j transposed); KIND_RT: w = M_rt f, anchored on the SOURCE height (z_j forward,
 // z_i transposed).  The two directions share both rsqrt, tau, e and differ only in g = z iR, which enters
-// p, s, f3 linearly.  The reversed pair sees e' = (-e_x, -e_y, e_z) and d' = -d.
+// p, s, f3 linearly (pair_blocks.h: cpl_coeffs / tr_apply / rt_apply on the unnormalised separation).
 template <bool TR, bool WALL>
 __device__ __forceinline__ void pair_coupling_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                                   double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                                   Vec3& ui, double& tx, double& ty, double& tz) {
-  const double rho2 = __builtin_fma(dy, dy, dx * dx);
-  const double r2 = __builtin_fma(dz, dz, rho2);
-  const double c = coupling_coeff(k, r2);
-  // c (v_j x d)  and  -c (v_i x d)
-  double ax = __builtin_fma(vjy, dz, -vjz * dy) * c, ay = __builtin_fma(vjz, dx, -vjx * dz) * c, az = __builtin_fma(vjx, dy, -vjy * dx) * c;
-  double bx = __builtin_fma(viz, dy, -viy * dz) * c, by = __builtin_fma(vix, dz, -viz * dx) * c, bz = __builtin_fma(viy, dx, -vix * dy) * c;
-  if constexpr (WALL) {
-    const double Rz = zi + zj;
-    const double R2 = __builtin_fma(Rz, Rz, rho2);
-    const double iR = rsqrt_f64(R2);
-    const double iR2 = iR * iR;
-    const double tau = k.a2 * iR2;
-    const double ez = Rz * iR, ex = dx * iR, ey = dy * iR;
-    const double uu = ez * ez;
-    const double eztau = ez * tau;
-    const double f1 = iR2;
-    const double p0 = iR2 * __builtin_fma(2.0, eztau, ez);                      // p = p0 - 2 iR2 g
-    const double s0 = iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, 1.0);   // s = s0 + 12 iR2 ez g
-    const double f30 = 10.0 * iR2 * eztau;                                      // f3 = f30 - 6 iR2 g
-    const double gF = (TR ? zi : zj) * iR;       // forward anchor
-    const double gT = (TR ? zj : zi) * iR;       // transposed anchor
-    const double m2 = -2.0 * iR2, e12 = 12.0 * iR2 * ez, m6 = -6.0 * iR2;
-    const double pF = __builtin_fma(m2, gF, p0), sF = __builtin_fma(e12, gF, s0), f3F = __builtin_fma(m6, gF, f30);
-    const double pT = __builtin_fma(m2, gT, p0), sT = __builtin_fma(e12, gT, s0), f3T = __builtin_fma(m6, gT, f30);
-    if constexpr (TR) {
-      // forward (pair_tr):  (-f3 ex c0 + p vy + f1 ey vz, -f3 ey c0 - p vx - f1 ex vz, (s + f3 ez) c0)
-      const double c0 = __builtin_fma(ex, vjy, -ey * vjx);
-      const double fc = f3F * c0;
-      ax += __builtin_fma(f1 * ey, vjz, __builtin_fma(pF, vjy, -fc * ex));
-      ay -= __builtin_fma(f1 * ex, vjz, __builtin_fma(pF, vjx, fc * ey));
-      az += __builtin_fma(f3F, ez, sF) * c0;
-      // reversed pair: (-f3 ex c0i + p viy - f1 ey viz, -f3 ey c0i - p vix + f1 ex viz, -(s + f3 ez) c0i)
-      const double c0i = __builtin_fma(ex, viy, -ey * vix);
-      const double gc = f3T * c0i;
-      bx += __builtin_fma(-f1 * ey, viz, __builtin_fma(pT, viy, -gc * ex));
-      by += __builtin_fma(f1 * ex, viz, -__builtin_fma(pT, vix, gc * ey));
-      bz -= __builtin_fma(f3T, ez, sT) * c0i;
-    } else {
-      // forward (pair_rt): (kap ey - p vy, -kap ex + p vx, f1 (ex vy - ey vx)), kap = f3 E + s vz
-      const double E = __builtin_fma(ez, vjz, __builtin_fma(ey, vjy, ex * vjx));
-      const double kap = __builtin_fma(f3F, E, sF * vjz);
-      ax += __builtin_fma(kap, ey, -pF * vjy);
-      ay += __builtin_fma(-kap, ex, pF * vjx);
-      az += f1 * __builtin_fma(ex, vjy, -ey * vjx);
-      // reversed pair: E' = -ex vix - ey viy + ez viz; (-kap' ey - p viy, kap' ex + p vix, -f1 (ex viy - ey vix))
-      const double Ei = __builtin_fma(ez, viz, -__builtin_fma(ey, viy, ex * vix));
-      const double kapi = __builtin_fma(f3T, Ei, sT * viz);
-      bx -= __builtin_fma(kapi, ey, pT * viy);
-      by += __builtin_fma(kapi, ex, pT * vix);
-      bz -= f1 * __builtin_fma(ex, viy, -ey * vix);
-    }
-  }
-  ui.x += ax; ui.y += ay; ui.z += az;
-  tx = bx; ty = by; tz = bz;
+  const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+  const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+  const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
+  double u[3] = {ui.x, ui.y, ui.z}, t[3];
+  if constexpr (TR) tr_apply<WALL, false>(C, g, vi, vj, u, t);
+  else              rt_apply<WALL, false>(C, g, vi, vj, u, t);
+  ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
+  tx = t[0]; ty = t[1]; tz = t[2];
 }
 
 // dispatcher

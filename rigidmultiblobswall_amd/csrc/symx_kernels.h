@@ -45,236 +45,6 @@ struct SymXArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Shared pair geometry and the per-block coefficient / contraction routines.
-// vi / vj / ui / t are pointers to 3 consecutive doubles (registers after inlining).
-// ACC = false: t is written; ACC = true: t is added to (second and later blocks of a fused operation).
-// ---------------------------------------------------------------------------------------------
-struct Geom {
-  double dx, dy, dz, rho2, r2, ir, ir2;
-  double Rz, iR, iR2;     // image separation R = (dx, dy, z_i + z_j); wall / free-surface operations only
-};
-
-template <bool IMAGE>
-__device__ __forceinline__ Geom make_geom(double dx, double dy, double dz, double zi, double zj) {
-  Geom g;
-  g.dx = dx; g.dy = dy; g.dz = dz;
-  g.rho2 = __builtin_fma(dy, dy, dx * dx);
-  g.r2 = __builtin_fma(dz, dz, g.rho2);
-  g.ir = rsqrt_f64(g.r2);
-  g.ir2 = g.ir * g.ir;
-  if constexpr (IMAGE) {
-    g.Rz = zi + zj;
-    g.iR = rsqrt_f64(__builtin_fma(g.Rz, g.Rz, g.rho2));
-    g.iR2 = g.iR * g.iR;
-  } else {
-    g.Rz = 0.0; g.iR = 0.0; g.iR2 = 0.0;
-  }
-  return g;
-}
-
-// RPY tt coefficients of separation r:  cF I + cD r r^T   (mobility_numba.py:209-239)
-__device__ __forceinline__ void rpy_tt_coeffs(const PairConsts& k, double r2, double ir, double ir2, double& cF, double& cD) {
-  cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
-  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
-  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
-    const double r = r2 * ir;
-    const bool near = r2 <= k.four_a2;
-    cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : cF;
-    cD = near ? k.tt_n2 * ir : cD;
-  }
-}
-
-struct TTc { double cF, cD, nG2, G3r, G4r, G5r; };
-
-template <bool WALL>
-__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zj) {
-  TTc c;
-  rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, c.cF, c.cD);
-  if constexpr (WALL) {
-    const WallTT W = wall_tt_from_iR(k, g.Rz, g.iR, zj);
-    const double iR3 = W.iR * W.iR2;
-    c.cF = __builtin_fma(-W.G1, W.iR, c.cF);
-    c.nG2 = -W.G2 * iR3;
-    c.G3r = W.G3 * W.iR2;
-    c.G4r = W.G4 * W.iR2;
-    c.G5r = W.G5 * W.iR;
-  } else {
-    c.nG2 = c.G3r = c.G4r = c.G5r = 0.0;
-  }
-  return c;
-}
-
-// ui += M_tt,ij vj ;  t (+)= M_tt,ji vi       (same algebra as pair_tt_sym)
-template <bool WALL, bool ACC>
-__device__ __forceinline__ void tt_apply(const TTc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
-  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
-  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
-  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
-  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
-  const double t0 = ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0];
-  const double t1 = ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1];
-  if constexpr (!WALL) {
-    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    t[0] = __builtin_fma(cDi, g.dx, t0);
-    t[1] = __builtin_fma(cDi, g.dy, t1);
-    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
-  } else {
-    const double Rvj = __builtin_fma(g.Rz, vj[2], pj);
-    const double cRj = __builtin_fma(c.G3r, vj[2], c.nG2 * Rvj);
-    const double cbj = __builtin_fma(c.G5r, vj[2], c.G4r * Rvj);
-    const double cj = cDj + cRj;
-    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    ui[2] = __builtin_fma(cRj, g.Rz, ui[2]); ui[2] += cbj;
-    const double Rvi = __builtin_fma(g.Rz, vi[2], pi);
-    const double cRi = __builtin_fma(c.G4r, vi[2], c.nG2 * Rvi);
-    const double cbi = __builtin_fma(c.G5r, vi[2], c.G3r * Rvi);
-    const double ci = cDi + cRi;
-    t[0] = __builtin_fma(ci, g.dx, t0);
-    t[1] = __builtin_fma(ci, g.dy, t1);
-    t[2] = __builtin_fma(cRi, g.Rz, __builtin_fma(cDi, g.dz, __builtin_fma(c.cF, vi[2], ACC ? t[2] + cbi : cbi)));
-  }
-}
-
-// Coupling blocks tr / rt (same algebra as pair_coupling_sym).  p, s, f3 depend linearly on the anchoring
-// height; the _i set is anchored on z_i, the _j set on z_j.
-struct CPc { double c, f1, ex, ey, ez, p_i, s_i, f3_i, p_j, s_j, f3_j; };
-
-template <bool WALL>
-__device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
-  CPc C;
-  C.c = g.ir2 * g.ir;
-  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
-    const double r = g.r2 * g.ir;
-    C.c = (g.r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : C.c;
-  }
-  if constexpr (WALL) {
-    const double tau = k.a2 * g.iR2;
-    C.ez = g.Rz * g.iR; C.ex = g.dx * g.iR; C.ey = g.dy * g.iR;
-    const double uu = C.ez * C.ez;
-    const double eztau = C.ez * tau;
-    C.f1 = g.iR2;
-    const double p0 = g.iR2 * __builtin_fma(2.0, eztau, C.ez);
-    const double s0 = g.iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, 1.0);
-    const double f30 = 10.0 * g.iR2 * eztau;
-    const double gi = zi * g.iR, gj = zj * g.iR;
-    const double m2 = -2.0 * g.iR2, e12 = 12.0 * g.iR2 * C.ez, m6 = -6.0 * g.iR2;
-    C.p_i = __builtin_fma(m2, gi, p0); C.s_i = __builtin_fma(e12, gi, s0); C.f3_i = __builtin_fma(m6, gi, f30);
-    C.p_j = __builtin_fma(m2, gj, p0); C.s_j = __builtin_fma(e12, gj, s0); C.f3_j = __builtin_fma(m6, gj, f30);
-  } else {
-    C.f1 = C.ex = C.ey = C.ez = C.p_i = C.s_i = C.f3_i = C.p_j = C.s_j = C.f3_j = 0.0;
-  }
-  return C;
-}
-
-// tr: ui += M_tr,ij vj (torque of j -> velocity of i, wall part anchored on the TARGET height z_i);  t (+)= M_tr,ji vi
-template <bool WALL, bool ACC>
-__device__ __forceinline__ void tr_apply(const CPc& C, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
-  double ax = __builtin_fma(vj[1], g.dz, -vj[2] * g.dy) * C.c, ay = __builtin_fma(vj[2], g.dx, -vj[0] * g.dz) * C.c,
-         az = __builtin_fma(vj[0], g.dy, -vj[1] * g.dx) * C.c;
-  double bx = __builtin_fma(vi[2], g.dy, -vi[1] * g.dz) * C.c, by = __builtin_fma(vi[0], g.dz, -vi[2] * g.dx) * C.c,
-         bz = __builtin_fma(vi[1], g.dx, -vi[0] * g.dy) * C.c;
-  if constexpr (WALL) {
-    const double c0 = __builtin_fma(C.ex, vj[1], -C.ey * vj[0]);
-    const double fc = C.f3_i * c0;
-    ax += __builtin_fma(C.f1 * C.ey, vj[2], __builtin_fma(C.p_i, vj[1], -fc * C.ex));
-    ay -= __builtin_fma(C.f1 * C.ex, vj[2], __builtin_fma(C.p_i, vj[0], fc * C.ey));
-    az += __builtin_fma(C.f3_i, C.ez, C.s_i) * c0;
-    const double c0i = __builtin_fma(C.ex, vi[1], -C.ey * vi[0]);
-    const double gc = C.f3_j * c0i;
-    bx += __builtin_fma(-C.f1 * C.ey, vi[2], __builtin_fma(C.p_j, vi[1], -gc * C.ex));
-    by += __builtin_fma(C.f1 * C.ex, vi[2], -__builtin_fma(C.p_j, vi[0], gc * C.ey));
-    bz -= __builtin_fma(C.f3_j, C.ez, C.s_j) * c0i;
-  }
-  ui[0] += ax; ui[1] += ay; ui[2] += az;
-  if constexpr (ACC) { t[0] += bx; t[1] += by; t[2] += bz; } else { t[0] = bx; t[1] = by; t[2] = bz; }
-}
-
-// rt: ui += M_rt,ij vj (force of j -> angular velocity of i, wall part anchored on the SOURCE height z_j);  t (+)= M_rt,ji vi
-template <bool WALL, bool ACC>
-__device__ __forceinline__ void rt_apply(const CPc& C, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
-  double ax = __builtin_fma(vj[1], g.dz, -vj[2] * g.dy) * C.c, ay = __builtin_fma(vj[2], g.dx, -vj[0] * g.dz) * C.c,
-         az = __builtin_fma(vj[0], g.dy, -vj[1] * g.dx) * C.c;
-  double bx = __builtin_fma(vi[2], g.dy, -vi[1] * g.dz) * C.c, by = __builtin_fma(vi[0], g.dz, -vi[2] * g.dx) * C.c,
-         bz = __builtin_fma(vi[1], g.dx, -vi[0] * g.dy) * C.c;
-  if constexpr (WALL) {
-    const double E = __builtin_fma(C.ez, vj[2], __builtin_fma(C.ey, vj[1], C.ex * vj[0]));
-    const double kap = __builtin_fma(C.f3_j, E, C.s_j * vj[2]);
-    ax += __builtin_fma(kap, C.ey, -C.p_j * vj[1]);
-    ay += __builtin_fma(-kap, C.ex, C.p_j * vj[0]);
-    az += C.f1 * __builtin_fma(C.ex, vj[1], -C.ey * vj[0]);
-    const double Ei = __builtin_fma(C.ez, vi[2], -__builtin_fma(C.ey, vi[1], C.ex * vi[0]));
-    const double kapi = __builtin_fma(C.f3_i, Ei, C.s_i * vi[2]);
-    bx -= __builtin_fma(kapi, C.ey, C.p_i * vi[1]);
-    by += __builtin_fma(kapi, C.ex, C.p_i * vi[0]);
-    bz -= C.f1 * __builtin_fma(C.ex, vi[1], -C.ey * vi[0]);
-  }
-  ui[0] += ax; ui[1] += ay; ui[2] += az;
-  if constexpr (ACC) { t[0] += bx; t[1] += by; t[2] += bz; } else { t[0] = bx; t[1] = by; t[2] = bz; }
-}
-
-struct RRc { double cF, cD, cFxy, cFzj, cFzi, h5; };
-
-template <bool WALL>
-__device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
-  RRc c;
-  const double ir3 = g.ir2 * g.ir;
-  c.cF = -0.5 * ir3;
-  c.cD = 1.5 * ir3 * g.ir2;
-  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
-    const double r = g.r2 * g.ir;
-    const double r3 = g.r2 * r;
-    const bool near = g.r2 < k.four_a2;
-    c.cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : c.cF;
-    c.cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : c.cD;
-  }
-  if constexpr (WALL) {
-    const double iR3 = g.iR2 * g.iR;
-    const double uu = g.Rz * g.Rz * g.iR2;
-    c.cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, c.cF);
-    c.cFzj = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, c.cF);
-    c.cFzi = __builtin_fma(0.5, iR3, c.cF);
-    c.h5 = 1.5 * iR3 * g.iR2;
-  } else {
-    c.cFxy = c.cFzj = c.cFzi = c.h5 = 0.0;
-  }
-  return c;
-}
-
-// rr: ui += M_rr,ij vj ;  t (+)= M_rr,ji vi       (same algebra as pair_rr_sym)
-template <bool WALL, bool ACC>
-__device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
-  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
-  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
-  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
-  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
-  if constexpr (!WALL) {
-    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    t[0] = __builtin_fma(cDi, g.dx, ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0]);
-    t[1] = __builtin_fma(cDi, g.dy, ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1]);
-    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
-  } else {
-    const double zvj = g.Rz * vj[2], zvi = g.Rz * vi[2];
-    const double Rvj = zvj + pj;
-    const double cj = __builtin_fma(-c.h5, __builtin_fma(2.0, pj, Rvj), cDj);
-    ui[0] = __builtin_fma(c.cFxy, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cFxy, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cFzj, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    ui[2] = __builtin_fma(c.h5 * Rvj, g.Rz, ui[2]);
-    const double Rvi = zvi + pi;
-    const double ci = __builtin_fma(-c.h5, __builtin_fma(3.0, pi, -zvi), cDi);
-    t[0] = __builtin_fma(ci, g.dx, ACC ? __builtin_fma(c.cFxy, vi[0], t[0]) : c.cFxy * vi[0]);
-    t[1] = __builtin_fma(ci, g.dy, ACC ? __builtin_fma(c.cFxy, vi[1], t[1]) : c.cFxy * vi[1]);
-    t[2] = __builtin_fma(-c.h5 * Rvi, g.Rz, __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cFzi, vi[2], t[2]) : c.cFzi * vi[2]));
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Operations
 // ---------------------------------------------------------------------------------------------
 

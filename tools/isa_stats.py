@@ -78,10 +78,14 @@ def _classify(op):
 
 
 def kernel_loop_stats(asm, mangled_prefix):
+  """Instruction mix of the pair loop: LLVM annotates every block with the loop it belongs to
+  (`; =>This Inner Loop Header` / `; in Loop: Header=BBf_n`); the pair loop is the innermost loop with the most fp64
+  VALU instructions.  Member blocks that are the near-field patch (a handful of instructions around v_cndmask, entered
+  only when some lane has r < 2a, leaving through s_branch) are left out of the per-step count."""
   lines = asm.split("\n")
   start = None
   for i, l in enumerate(lines):
-    if l.startswith(mangled_prefix) and l.rstrip().split(":")[0].startswith(mangled_prefix) and ":" in l:
+    if l.startswith(mangled_prefix) and ":" in l:
       start = i
       break
   if start is None:
@@ -90,37 +94,48 @@ def kernel_loop_stats(asm, mangled_prefix):
   while end < len(lines) and "s_endpgm" not in lines[end]:
     end += 1
   body = lines[start:end + 1]
-  labels = {}
-  for i, l in enumerate(body):
-    m = re.match(r"^(\.LBB\d+_\d+):", l)
+  blocks = []   # (label, annotation, [instruction mnemonics])
+  cur = None
+  for l in body:
+    m = re.match(r"^\.(LBB\d+_\d+):(.*)$", l)
     if m:
-      labels[m.group(1)] = i
-  loops = []
-  for i, l in enumerate(body):
-    m = re.match(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.match(r"^\s+s_branch\s+(\.LBB\d+_\d+)", l)
-    if m and m.group(1) in labels and labels[m.group(1)] < i:
-      loops.append((labels[m.group(1)], i))
-  inner = [lp for lp in loops if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in loops)]
+      cur = [m.group(1), m.group(2), []]
+      blocks.append(cur)
+      continue
+    if cur is None:
+      continue
+    if re.match(r"^\s+;", l):
+      cur[1] += " " + l.strip()
+      continue
+    m = re.match(r"^\s+([a-z_0-9]+)", l)
+    if m:
+      cur[2].append(m.group(1))
   best = None
-  for lo, hi in inner:
+  for label, ann, _ in blocks:
+    if "Inner Loop Header" not in ann:
+      continue
+    hdr = label[1:]           # LBB75_32 -> BB75_32
+    members = [b for b in blocks if b[0] == label or re.search(r"in Loop: Header=%s\b" % hdr, b[1])]
     counts = {}
-    valu = flops = lds = 0
-    for l in body[lo:hi + 1]:
-      m = re.match(r"^\s+([a-z_0-9]+)", l)
-      if not m:
+    valu = flops = lds = patch = 0
+    for lb, an, ops in members:
+      is_patch = (lb != label and len(ops) <= 16 and any(o.startswith("v_cndmask") for o in ops) and ops and
+                  ops[-1] == "s_branch")
+      if is_patch:
+        patch += len(ops)
         continue
-      op = m.group(1)
-      is_valu, fl, cls = _classify(op)
-      if is_valu:
-        valu += 1
-        flops += fl
-        counts[cls] = counts.get(cls, 0) + 1
-      elif op.startswith("ds_"):
-        lds += 1
+      for op in ops:
+        is_valu, fl, cls = _classify(op)
+        if is_valu:
+          valu += 1
+          flops += fl
+          counts[cls] = counts.get(cls, 0) + 1
+        elif op.startswith("ds_"):
+          lds += 1
     f64 = sum(v for k, v in counts.items() if k.endswith("f64"))
     if best is None or f64 > best["f64_valu_per_step"]:
       best = {"valu_per_step": valu, "f64_valu_per_step": f64, "flops_per_lane_step": flops, "lds_per_step": lds,
-              "classes": counts, "loop_lines": hi - lo + 1}
+              "classes": counts, "near_field_patch_instructions_excluded": patch, "loop_header": label}
   return best
 
 
