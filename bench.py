@@ -185,10 +185,15 @@ def committed_traffic(N, sym):
     cand = [(k, v) for k, v in tj.items() if isinstance(v, dict) and k.endswith(key)]
     if cand:
       k, v = cand[-1]
-      return v["traffic_bytes"], {"measured_in_this_run": False, "source": "profiles/traffic.json[%s]" % k,
-                                  "files": v.get("files"), "commit": v.get("commit"),
-                                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, "
-                                            "gfx950 corrections of MI355X_MICROARCH.md"}
+      prov = {"measured_in_this_run": False, "source": "profiles/traffic.json[%s]" % k,
+              "files": v.get("files"), "commit": v.get("commit"), "command": v.get("command"),
+              "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, "
+                        "gfx950 corrections of MI355X_MICROARCH.md"}
+      if "valu_active_per_busy_cycle" in v:
+        # VALU utilisation from the same PMC passes: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, ceiling 8
+        prov["valu_active_per_busy_cycle"] = {"kernel": v["valu_active_per_busy_cycle"], "ceiling": 8.0,
+                                              "pure_v_fma_f64_ubench": v.get("ubench_valu_active_per_busy_cycle")}
+      return v["traffic_bytes"], prov
   except (OSError, ValueError, KeyError):
     pass
   return None, {"measured_in_this_run": False, "source": None}

@@ -104,17 +104,19 @@ class ReadInput(object):
 
   def random_generator(self, save=True):
     """numpy RandomState of the run as multi_bodies.py:1150-1162 sets it up: restored from the pickled state named by
-    `random_state`, else seeded with `seed`, else None (callers then use a device generator); the state at the start of the
-    run is pickled to `<output_name>.random_state` so that a run can be repeated or resumed."""
+    `random_state`, else seeded with `seed`, else seeded from OS entropy (the reference leaves numpy's global generator
+    entropy-seeded: repeated launches of an unseeded deck form an ensemble); the state at the start of the run is ALWAYS
+    pickled to `<output_name>.random_state` so that any run can be repeated or resumed."""
     import pickle
-    rng = None
     if self.random_state is not None:
       rng = np.random.RandomState()
       with open(self.resolve(self.random_state), "rb") as fh:
         rng.set_state(pickle.load(fh))
     elif self.seed is not None:
       rng = np.random.RandomState(int(self.seed))
-    if rng is not None and save:
+    else:
+      rng = np.random.RandomState()
+    if save:
       with open(self.output_name + ".random_state", "wb") as fh:
         pickle.dump(rng.get_state(), fh)
     return rng

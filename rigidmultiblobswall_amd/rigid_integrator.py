@@ -29,6 +29,32 @@ from .rigid import (RigidSuspension, quaternion_from_rotation_torch, quaternion_
                     quaternion_rotation_matrix_torch)
 
 
+def seeded_generator(device, seed, ctx=None):
+  """Device generator for a stepper that was not handed a numpy stream.  `seed=None` means what it means in the
+  reference (numpy left entropy-seeded, multi_bodies.py:1154-1161): a fresh seed from the OS, so that repeated launches
+  form an ensemble; an explicit `seed=` is reproducible.  On several ranks the seed of rank 0 is the one every rank
+  uses (replicated steppers must draw identical numbers).  Returns (generator, seed used)."""
+  gen = torch.Generator(device=device)
+  if seed is None:
+    seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
+    sync = getattr(ctx, "sync_scalars", None)
+    if sync is not None:
+      t = torch.tensor([seed], dtype=torch.int64, device=device)
+      seed = int(sync(t).item())
+  gen.manual_seed(int(seed))
+  return gen, int(seed)
+
+
+def replicate_rng(rng, read, ctx, device):
+  """A deck without `seed` / `random_state` gives every process its own entropy-seeded numpy stream; replicated
+  steppers (ReplicatedContext) need ONE stream: re-seed from a number rank 0 draws."""
+  sync = getattr(ctx, "sync_scalars", None)
+  if rng is None or sync is None or read.seed is not None or read.random_state is not None:
+    return rng
+  t = torch.tensor([int(rng.randint(0, 2 ** 31 - 1))], dtype=torch.int64, device=device)
+  return np.random.RandomState(int(sync(t).item()))
+
+
 def lab_frame_slip(susp, slip_body_frame):
   """Active slip given per blob in the body frame (.slip files), rotated to the bodies' current orientation:
   slip_lab = R(q) slip_body (multi_bodies_functions.py:123-140).  (Nblobs, 3) tensor -> (3 Nblobs,)."""
@@ -112,8 +138,7 @@ class RigidIntegrator(object):
     self.rng = rng
     self._gen = None
     if rng is None:
-      self._gen = torch.Generator(device=self.device)
-      self._gen.manual_seed(0 if seed is None else int(seed))
+      self._gen, self.seed = seeded_generator(self.device, seed, ctx)
 
   def close(self):
     self.susp.close()
@@ -538,6 +563,7 @@ def bodies_from_input(read):
   """Bodies of a deck as multi_bodies/multi_bodies.py:1160-1212 creates them: every `structure` line = vertex file +
   clones file (+ optional .slip file with one body-frame slip per blob).  Returns a dict with one reference
   configuration and one body-frame slip array per body, stacked locations / quaternions, and bodies per structure."""
+  from . import deck_modes
   from . import structures as st
   refs, locs, quats, slips, body_types = [], [], [], [], []
   any_slip = False
@@ -545,7 +571,7 @@ def bodies_from_input(read):
     raise ValueError("articulated bodies are not supported")
   prescribed = []
   for sid, structure in enumerate(read.structures):
-    ref = st.read_vertex_file(read.resolve(structure[0]))[:, :3]
+    ref = deck_modes.uniform_vertices(st.read_vertex_file(read.resolve(structure[0])), read.blob_radius, structure[0])
     n, loc, quat = st.read_clones_file(read.resolve(structure[1]))
     slip = None
     for extra in structure[2:]:
@@ -568,10 +594,13 @@ def bodies_from_input(read):
 
 def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
   """Integrator wired from a ReadInput deck as multi_bodies/multi_bodies.py:1319-1393 wires QuaternionIntegrator."""
+  from . import deck_modes
+  deck_modes.validate(read, uses_dense_blocks=True)     # ValueError for modes this engine does not run
   b = bodies_from_input(read)
   refs, body_types, any_slip = b["refs"], b["body_types"], b["slips"] is not None
   if rng is None:
     rng = read.random_generator(save=False)
+  rng = replicate_rng(rng, read, ctx, device)
   integ = RigidIntegrator(refs, b["locations"], b["quaternions"], read.scheme, read.blob_radius, read.eta,
                           tolerance=read.solver_tolerance, domain=read.domain, periodic_length=read.periodic_length,
                           device=device, ctx=ctx, rng=rng, prescribed=b["prescribed"])

@@ -79,8 +79,8 @@ class RollersIntegrator(object):
     self.rng = rng
     self._gen = None
     if rng is None:
-      self._gen = torch.Generator(device=self.device)
-      self._gen.manual_seed(0 if seed is None else int(seed))
+      from .rigid_integrator import seeded_generator
+      self._gen, self.seed = seeded_generator(self.device, seed, ctx)   # seed=None: fresh OS entropy, as the reference
     self.ctx = ctx if ctx is not None else MobilityContext(self.device.index or 0)
     self._own_ctx = ctx is None
     self.mobility_products = 0
@@ -501,11 +501,13 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
   :1379-1390 wire QuaternionIntegratorRollers.  Every `structure` must be a one-blob vertex file (the
   reference's Structures/blob.vertex); its .clones file lists the rollers.  With `seed` in the deck the
   random numbers are numpy's stream for that seed (the reference calls np.random.seed, :1157-1158)."""
+  from . import deck_modes
   from . import structures as st
+  deck_modes.validate(read, uses_dense_blocks=False)    # ValueError for modes this engine does not run
   locations = []
   body_types = []
   for vertex_file, clones_file in [s[:2] for s in read.structures]:
-    ref = st.read_vertex_file(read.resolve(vertex_file))
+    ref = deck_modes.uniform_vertices(st.read_vertex_file(read.resolve(vertex_file)), read.blob_radius, vertex_file)
     if len(ref) != 1:
       raise ValueError("%s has %d blobs: the roller schemes are for single-blob bodies (use RigidSuspension)" %
                        (vertex_file, len(ref)))
@@ -516,6 +518,8 @@ def integrator_from_input(read, device="cuda:0", ctx=None, rng=None):
     raise ValueError("input deck lists no structure")
   if rng is None:
     rng = read.random_generator(save=False)
+  from .rigid_integrator import replicate_rng
+  rng = replicate_rng(rng, read, ctx, device)
   integ = RollersIntegrator(np.concatenate(locations), read.scheme, read.blob_radius, read.eta,
                             tolerance=read.solver_tolerance, domain=read.domain, device=device, ctx=ctx, rng=rng)
   integ.kT = read.kT
