@@ -652,11 +652,8 @@ int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* con
   for (int v = 0; v < n_out; ++v) if (!out[v]) return fail(RMB_ERR_ARG, "null output vector");
   if (c->n == 0) return 0;
   RMB_HIP(hipSetDevice(c->device));
-  if (sym_applies(c) || nshards > 1) {
-    if (nshards > 1 && (c->tgt_begin != 0 || c->tgt_end != c->n))
-      return fail(RMB_ERR_STATE, "pair shards write all n targets: reset the target range to [0, n)");
-    return symx_device(c, sx, in, out, eta, in_plane, shard, nshards);
-  }
+  // a pair shard always writes all n targets, whatever target range is set (as rmb_matvec_pairshard_device)
+  if (sym_applies(c) || nshards > 1) return symx_device(c, sx, in, out, eta, in_plane, shard, nshards);
   const long n_tgt = c->tgt_end - c->tgt_begin;
   if (n_tgt == 0) return 0;
   switch (op) {

@@ -62,6 +62,9 @@ class HipBackend(object):
   def body_mobility_dense(self, first_blob, n_b, eta, out=None):
     return self.ctx.body_mobility_dense_device(first_blob, n_b, eta, out=out)
 
+  def matvec_op_pairshard(self, op, vecs, eta, shard, nshards, in_plane=False, outs=None):
+    return self.ctx.matvec_op_device(op, vecs, eta, in_plane=in_plane, outs=outs, shard=shard, nshards=nshards)
+
   def matvec2_pairshard(self, kind, va, vb, eta, shard, nshards, out_a=None, out_b=None):
     return self.ctx.matvec2_device(kind, va, vb, eta, out_a=out_a, out_b=out_b, shard=shard, nshards=nshards)
 
@@ -159,6 +162,14 @@ class ShardedMobility(object):
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
     v2 = self._to_dev(vec2_full) if vec2_full is not None else None
+    if kind == "tt_tr" and v2 is not None and hasattr(self.backend, "matvec_op_pairshard"):
+      # fused M_tt f + M_tr tau: one pass over this rank's pair shard for both blocks, one all-reduce
+      part = out if out is not None else torch.empty(3 * self.n, dtype=torch.float64, device=self.device)
+      self.backend.matvec_op_pairshard("velocity_from_force_torque", (v, v2), eta, self.rank, self.world, in_plane=in_plane,
+                                       outs=[part])
+      if self.world > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+      return part
     if (kind == "tt_tr" and v2 is not None and not in_plane and self.world > 1
         and hasattr(self.backend, "supports_pairshard") and self.backend.supports_pairshard("tt", periodic)
         and self.backend.supports_pairshard("tr", periodic)):
@@ -196,6 +207,31 @@ class ShardedMobility(object):
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
       return both[0], both[1]
     return self.matvec_replicated(kind, va, eta), self.matvec_replicated(kind, vb, eta)
+
+  def matvec_op_replicated(self, op, vecs, eta, in_plane=False):
+    """Multi-block operation (context.matvec_op_device: "velocity_from_force_torque", "grand", "force_column",
+    "tt_multi") with replicated vectors: one pass over this rank's pair shard for all blocks, then ONE all-reduce of the
+    stacked partial outputs.  Backends without the multi-block kernel compose it from single products."""
+    vecs = [self._to_dev(v) for v in vecs]
+    if hasattr(self.backend, "matvec_op_pairshard"):
+      from ._lib import OPS
+      n_out = OPS[op][2] if OPS[op][2] is not None else len(vecs)
+      stacked = torch.empty((n_out, 3 * self.n), dtype=torch.float64, device=self.device)
+      self.backend.matvec_op_pairshard(op, vecs, eta, self.rank, self.world, in_plane=in_plane,
+                                       outs=[stacked[c] for c in range(n_out)])
+      if self.world > 1:
+        dist.all_reduce(stacked, op=dist.ReduceOp.SUM, group=self.group)
+      return tuple(stacked[c] for c in range(n_out))
+    mv = lambda kind, v, v2=None: self.matvec_replicated(kind, v, eta, vec2_full=v2, in_plane=in_plane)
+    if op == "velocity_from_force_torque":
+      return (mv("tt_tr", vecs[0], vecs[1]),)
+    if op == "grand":
+      return (mv("tt_tr", vecs[0], vecs[1]), mv("rt", vecs[0]) + mv("rr", vecs[1]))
+    if op == "force_column":
+      return (mv("tt", vecs[0]), mv("rt", vecs[0]))
+    if op == "tt_multi":
+      return tuple(mv("tt", v) for v in vecs)
+    raise ValueError("unknown operation %r" % (op,))
 
   def blob_blob_force_replicated(self, eps, b, a):
     """Forces on ALL blobs on every rank: each rank sweeps its own target block, blocks are all-gathered."""
@@ -237,6 +273,14 @@ class ReplicatedContext(object):
 
   def matvec_device(self, kind, vec, eta, vec2=None, in_plane=False, out=None):
     return self.sm.matvec_replicated(kind, vec, eta, vec2_full=vec2, in_plane=in_plane, out=out)
+
+  def matvec_op_device(self, op, vecs, eta, in_plane=False, outs=None, shard=0, nshards=1):
+    res = self.sm.matvec_op_replicated(op, vecs, eta, in_plane=in_plane)
+    if outs is not None:
+      for o, r in zip(outs, res):
+        o.copy_(r)
+      return tuple(outs)
+    return res
 
   def matvec2_device(self, kind, vec_a, vec_b, eta, out_a=None, out_b=None, shard=0, nshards=1):
     a, b = self.sm.matvec2_replicated(kind, vec_a, vec_b, eta)

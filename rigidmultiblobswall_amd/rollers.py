@@ -106,12 +106,19 @@ class RollersIntegrator(object):
     in_plane = self.domain == "in_plane"
     if in_plane and kind in ("rt", "rr"):
       raise ValueError("domain in_plane has no rot products (quaternion_integrator_rollers.py:85-91)")
-    if vec2 is not None:
-      if in_plane:   # no fused in-plane kernel in the reference either: two sweeps
-        return (self.ctx.matvec_device("tt", vec.contiguous(), self.eta, in_plane=True) +
-                self.ctx.matvec_device("tr", vec2.contiguous(), self.eta, in_plane=True))
-      return self.ctx.matvec_device("tt_tr", vec.contiguous(), self.eta, vec2=vec2.contiguous())
+    if vec2 is not None:    # M_tt F + M_tr T in one pass over the pairs (in-plane too)
+      return self.ctx.matvec_op_device("velocity_from_force_torque", (vec.contiguous(), vec2.contiguous()), self.eta,
+                                       in_plane=in_plane)[0]
     return self.ctx.matvec_device(kind, vec.contiguous(), self.eta, in_plane=in_plane)
+
+  def _products_of_one_vector(self, kinds, vec):
+    """Several blocks applied to the same vector on the bound configuration.  ("rt", "tt") -- the pair the random
+    finite difference of the 6N drift needs (:1138-1160) -- is one pass with the shared pair geometry."""
+    if tuple(kinds) == ("rt", "tt") and self.domain != "in_plane":
+      self.mobility_products += 1
+      u, w = self.ctx.matvec_op_device("force_column", (vec.contiguous(),), self.eta)
+      return [w, u]
+    return [self._product(k, vec) for k in kinds]
 
   def mobility_trans_times_force(self, r, force):
     self._bind(r)
@@ -234,9 +241,9 @@ class RollersIntegrator(object):
     dx = self._randn(3 * self.Nblobs)
     half = dx.view(-1, 3) * (self.rf_delta * self.a * 0.5)
     self._bind(r + half)
-    plus = [self._product(k, dx) for k in kinds]
+    plus = self._products_of_one_vector(kinds, dx)
     self._bind(r - half)
-    return [p - self._product(k, dx) for k, p in zip(kinds, plus)]
+    return [p - m for p, m in zip(plus, self._products_of_one_vector(kinds, dx))]
 
   def compute_stochastic_linear_velocity(self, dt):
     """sqrt(2kT/dt) M_tt^{1/2} W + kT div(M_tt) by Lanczos + random finite difference (:1203-1260)."""
@@ -262,13 +269,15 @@ class RollersIntegrator(object):
     return torch.zeros(3 * self.Nblobs, dtype=torch.float64, device=self.device)
 
   def grand_mobility(self, force_torque):
-    """[v; w] = [[M_tt, M_tr], [M_rt, M_rr]] [F; T] on the bound configuration (:1114-1121): the top row is
-    one fused sweep."""
+    """[v; w] = [[M_tt, M_tr], [M_rt, M_rr]] [F; T] on the bound configuration.  The reference applies the four
+    blocks as four products per Lanczos iteration (:1114-1121); here all four come from ONE pass over the pairs
+    (rmb_matvec_op_device, RMB_OP_GRAND: shared differences, inverse square roots and wall factors)."""
     n3 = 3 * self.Nblobs
-    F, T = force_torque[:n3], force_torque[n3:]
-    v = self._product("tt", F, vec2=T)
-    w = self._product("rt", F) + self._product("rr", T)
-    return torch.cat([v, w])
+    F, T = force_torque[:n3].contiguous(), force_torque[n3:].contiguous()
+    self.mobility_products += 1
+    out = torch.empty(2 * n3, dtype=torch.float64, device=force_torque.device)
+    self.ctx.matvec_op_device("grand", (F, T), self.eta, outs=(out[:n3], out[n3:]))
+    return out
 
   def compute_stochastic_velocity(self, dt):
     """Noise from the 6N grand mobility, stochastic torque solve for prescribed kinematics (:1082-1200)."""

@@ -31,14 +31,20 @@ class OracleContext(object):
     return torch.from_numpy(u)
 
   def matvec_op_device(self, op, vecs, eta, in_plane=False, outs=None, shard=0, nshards=1):
+    mv = lambda kind, v, v2=None: self.matvec_device(kind, v, eta, vec2=v2, in_plane=in_plane)
     if op == "velocity_from_force_torque":
-      return (self.matvec_device("tt_tr", vecs[0], eta, vec2=vecs[1], in_plane=in_plane),)
-    if op == "grand":
-      return (self.matvec_device("tt_tr", vecs[0], eta, vec2=vecs[1], in_plane=in_plane),
-              self.matvec_device("rt", vecs[0], eta, in_plane=in_plane) + self.matvec_device("rr", vecs[1], eta, in_plane=in_plane))
-    if op == "force_column":
-      return (self.matvec_device("tt", vecs[0], eta, in_plane=in_plane), self.matvec_device("rt", vecs[0], eta, in_plane=in_plane))
-    return tuple(self.matvec_device("tt", v, eta, in_plane=in_plane) for v in vecs)
+      res = (mv("tt_tr", vecs[0], vecs[1]),)
+    elif op == "grand":
+      res = (mv("tt_tr", vecs[0], vecs[1]), mv("rt", vecs[0]) + mv("rr", vecs[1]))
+    elif op == "force_column":
+      res = (mv("tt", vecs[0]), mv("rt", vecs[0]))
+    else:
+      res = tuple(mv("tt", v) for v in vecs)
+    if outs is not None:
+      for o, r in zip(outs, res):
+        o.copy_(r)
+      return tuple(outs)
+    return res
 
   def matvec2_device(self, kind, vec_a, vec_b, eta, out_a=None, out_b=None, shard=0, nshards=1):
     return self.matvec_device(kind, vec_a, eta), self.matvec_device(kind, vec_b, eta)

@@ -64,7 +64,9 @@ def test_golden_vectors(mob, path):
       continue
     u = getattr(mob, stem + "_hip")(r, v, eta, a, periodic_length=L)
     assert u.shape == (3 * len(r),)
-    assert rel_err(u, g[key]) < TOL_D1, (key, rel_err(u, g[key]))
+    # 1e-12 for the well-separated D2-style cloud, 1e-10 for the dense / contact test_blobs clouds
+    tol = TOL_D2 if "wall_cloud" in path else TOL_D1
+    assert rel_err(u, g[key]) < tol, (key, rel_err(u, g[key]))
 
 
 @pytest.mark.parametrize("path", golden_files("g5_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
@@ -450,7 +452,7 @@ def test_large_linearity_symmetry_and_spot_check(Ctx, oracle, N):
   ctx.close()
 
 
-@pytest.mark.parametrize("N", [262144, 1000000])
+@pytest.mark.parametrize("N", [262144, 300007, 1000000])    # 300007: N % 64 = 39, a partial last tile
 def test_baseline_full_sizes_spot_check_and_symmetry(Ctx, oracle, N):
   """BASELINE.json configs[4] / configs[3] sizes on one GPU: oracle on a sample of targets (all N sources each),
   reciprocity g.Mf = f.Mg, and the symmetric path against the one-sided sweep on the same sample."""
@@ -466,7 +468,11 @@ def test_baseline_full_sizes_spot_check_and_symmetry(Ctx, oracle, N):
   Mg = ctx.matvec_device("tt", gd, eta)
   gMf, fMg = float(torch.dot(gd, Mf)), float(torch.dot(fd, Mg))
   assert abs(gMf - fMg) < 1e-11 * float(torch.linalg.norm(gd) * torch.linalg.norm(Mf))
-  tg = np.random.RandomState(33).choice(N, 32, replace=False)
+  # 24 random targets plus deterministic picks on the tile structure of the symmetric kernel: first / last blob of
+  # the first tile, first blob of the second, the tile-row boundary in the middle, and the last (partial) tile
+  last_tile = 64 * ((N - 1) // 64)
+  picks = [0, 63, 64, 64 * (N // 128) - 1, 64 * (N // 128), last_tile - 1, last_tile, N - 1]
+  tg = np.unique(np.concatenate([np.random.RandomState(33).choice(N, 24, replace=False), np.array(picks)]))
   r_eff, b, _ = oracle.wall_regularisation(r, a)
   ref = oracle.raw_matvec_targets("tt", 1, r_eff, f, eta, a, tg)
   got = Mf.cpu().numpy().reshape(-1, 3)[tg].reshape(-1)
