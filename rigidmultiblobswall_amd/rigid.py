@@ -133,6 +133,8 @@ class RigidSuspension(object):
     self.size = 3 * self.n_blobs + 6 * self.n_bodies
     self.matvec_count = 0       # M.v products requested (a two-vector pass counts two)
     self.matvec2_count = 0      # of which pairs served by one two-vector pass
+    self.sweep_count = 0        # passes over the blob pairs actually launched (a k-vector pass counts once)
+    self.lockstep_width = 4     # vectors per pass in lockstep products (1 = one pass per vector)
     self.free = None            # (n_bodies, 1) 1.0 = free body, 0.0 = prescribed kinematics; None = all free
     self.prescribed_velocity = None
     if prescribed is not None and np.any(prescribed):
@@ -212,7 +214,28 @@ class RigidSuspension(object):
   # ---- pieces of the operator -------------------------------------------------------------------
   def mobility_times_lambda(self, lam):
     self.matvec_count += 1
+    self.sweep_count += 1
     return self.ctx.matvec_device("tt", lam.contiguous(), self.eta)
+
+  def mobility_times_lambdas(self, lams):
+    """M applied to several blob vectors with as few passes over the pairs as possible: up to `lockstep_width` vectors
+    share one pass (rmb_matvec_op_device, RMB_OP_TT_MULTI: the vector-independent part of every pair -- differences,
+    both inverse square roots, RPY and wall coefficients -- is evaluated once)."""
+    lams = [l.contiguous() for l in lams]
+    out = []
+    width = max(1, int(self.lockstep_width))
+    for lo in range(0, len(lams), width):
+      chunk = lams[lo:lo + width]
+      self.matvec_count += len(chunk)
+      self.sweep_count += 1
+      if len(chunk) == 1 or not hasattr(self.ctx, "matvec_op_device"):
+        self.sweep_count += len(chunk) - 1
+        out.extend(self.ctx.matvec_device("tt", v, self.eta) for v in chunk)
+      else:
+        if len(chunk) == 2:
+          self.matvec2_count += 1
+        out.extend(self.ctx.matvec_op_device("tt_multi", chunk, self.eta))
+    return out
 
   def K_times_U(self, U):
     """U (6 n_bodies,) -> (3 n_blobs,)   (multi_bodies.py:327-349)."""
@@ -240,6 +263,7 @@ class RigidSuspension(object):
       res = torch.empty_like(x)
       top = res[:n3]
       self.matvec_count += 1
+      self.sweep_count += 1
       r = self.ctx.matvec_device("tt", lam.contiguous(), self.eta, out=top)
       if r.data_ptr() != top.data_ptr():       # contexts that do not write in place (test stand-ins)
         top.copy_(r)
@@ -266,6 +290,7 @@ class RigidSuspension(object):
     res = torch.empty((2, self.size), dtype=torch.float64, device=self.device)
     self.matvec_count += 2
     self.matvec2_count += 1
+    self.sweep_count += 1
     ra, rb = self.ctx.matvec2_device("tt", xa[:n3].contiguous(), xb[:n3].contiguous(), self.eta,
                                      out_a=res[0, :n3], out_b=res[1, :n3])
     for row, r, x in ((res[0], ra, xa), (res[1], rb, xb)):
@@ -386,6 +411,84 @@ class RigidSuspension(object):
     ia["rhs_norm"], ib["rhs_norm"] = na, nb_
     return (xa * na, ia), (xb * nb_, ib)
 
+  # ---- lockstep tasks: coroutines that yield blob vectors and receive M . vector ----------------------
+  def operator_from_product(self, x, Mlam):
+    """[M lambda - K U; -K^T lambda] given the blob product M lambda (the O(N) rest of apply_operator)."""
+    n3 = 3 * self.n_blobs
+    lam, U = x[:n3], x[n3:]
+    if self.free is None:
+      return torch.cat([Mlam - self.K_times_U(U), -self.KT_times_lambda(lam)])
+    U = U.view(self.n_bodies, 6)
+    top = Mlam - self.K_times_U((U * self.free).reshape(-1))
+    bottom = -self.KT_times_lambda(lam).view(self.n_bodies, 6) + U * (1.0 - self.free)
+    return torch.cat([top, bottom.reshape(-1)])
+
+  def solve_task(self, rhs, tol=1e-8, restart=60, maxiter=1000, x0=None):
+    """`solve` as a lockstep task (run_lockstep): yields the blob part of every vector GMRES needs the operator applied
+    to, receives M . that vector, returns (x, info)."""
+    if self.groups[0].Lchol is None:
+      self.build_preconditioner()
+    nrm = float(torch.linalg.norm(rhs))
+    if nrm == 0.0:
+      return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[], rhs_norm=0.0)
+    n3 = 3 * self.n_blobs
+    steps = _gmres_steps(self.apply_preconditioner, rhs / nrm, tol, restart, maxiter, None if x0 is None else x0 / nrm,
+                         getattr(self.ctx, "sync_scalars", None))
+    try:
+      y = next(steps)
+      while True:
+        Mlam = yield y[:n3]
+        y = steps.send(self.operator_from_product(y, Mlam))
+    except StopIteration as done:
+      sol, info = done.value
+    info["rhs_norm"] = nrm
+    return sol * nrm, info
+
+  def forcing_task(self, z, factor, tol=1e-8, print_residual=False):
+    """`stochastic_forcing` (preconditioned Lanczos, P = blockdiag(L_b^-T)) as a lockstep task: returns (noise, its)."""
+    from .stochastic import _lanczos_steps, _prepare
+    if self.groups[0].Lchol is None:
+      self.build_preconditioner()
+    self._stochastic_factors()
+    z, dim, _ = _prepare(z, None, self.device, None)
+    steps = _lanczos_steps(factor, tol, 1000, dim, z, print_residual, self.device, getattr(self.ctx, "sync_scalars", None))
+    try:
+      w = next(steps)
+      while True:
+        Mx = yield self._blockdiag(w, "Linv", transpose=True)
+        w = steps.send(self._blockdiag(Mx, "Linv"))
+    except StopIteration as done:
+      noise, its = done.value
+    return self._blockdiag(noise, "Lchol").reshape(-1), its
+
+  @staticmethod
+  def product_task(v):
+    """One product M . v as a lockstep task."""
+    res = yield v
+    return res
+
+  def run_lockstep(self, tasks):
+    """Advance independent tasks that all need products with the mobility of the BOUND configuration (GMRES solves,
+    Lanczos recursions, single products): every round collects one request per running task and serves them with one
+    k-vector pass over the pairs (mobility_times_lambdas).  Each task sees exactly the iterates it would see alone.
+    Returns the tasks' return values, in order."""
+    n = len(tasks)
+    requests, results, running = [None] * n, [None] * n, [True] * n
+    for k, t in enumerate(tasks):
+      try:
+        requests[k] = next(t)
+      except StopIteration as done:
+        results[k], running[k] = done.value, False
+    while any(running):
+      act = [k for k in range(n) if running[k]]
+      answers = self.mobility_times_lambdas([requests[k] for k in act])
+      for k, ans in zip(act, answers):
+        try:
+          requests[k] = tasks[k].send(ans)
+        except StopIteration as done:
+          results[k], running[k] = done.value, False
+    return results
+
   def solve_mobility_problem(self, slip=None, force_torque=None, tol=1e-8, restart=60, maxiter=1000, x0=None):
     """Returns (velocities (n_bodies, 6), lambda (n_blobs, 3), info).  RHS = [slip, -F]
     (quaternion_integrator_multi_bodies.py:1458-1475)."""
@@ -426,6 +529,7 @@ class RigidSuspension(object):
         return one(u), one(v)
       self.matvec_count += 2
       self.matvec2_count += 1
+      self.sweep_count += 1
       a, b = self.ctx.matvec2_device("tt", self._blockdiag(u, "Linv", transpose=True),
                                      self._blockdiag(v, "Linv", transpose=True), self.eta)
       return self._blockdiag(a, "Linv"), self._blockdiag(b, "Linv")
@@ -534,7 +638,10 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync):
 
 def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None):
   """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
-  Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after maxiter iterations in total.
+  Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after `maxiter` INNER iterations in total -- not restart
+  cycles: scipy (and the reference's call, maxiter=1000 with restart=60) counts cycles, i.e. up to 60 000 inner
+  iterations; the solves here converge in tens of iterations, so the cap only differs in how soon a diverging solve
+  gives up.
   Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host.
   x0: optional initial guess (the roller torque solve warm-starts from the previous step,
   quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""

@@ -115,7 +115,8 @@ class RigidIntegrator(object):
     # (None = solver tolerance, as the reference).  That solve sets the direction of a finite difference whose result is
     # a kT-order correction, so a loose value (1e-2) cuts ~20 % of the pair sweeps of a step without visible bias.
     self.rfd_solve_tolerance = None
-    # Slip schemes: advance the Brownian-slip solve and the RFD solve in lockstep (one two-vector sweep per iteration).
+    # Slip schemes: advance everything that shares the mobility of time level n (M W_slip, the Lanczos forcing(s), the RFD
+    # solve) in lockstep, one k-vector pass over the blob pairs per round.
     # Numerically neutral: each solve sees exactly its own GMRES iterates.
     self.lockstep_solves = True
     self.print_residual = False
@@ -503,27 +504,36 @@ class RigidIntegrator(object):
       W_slip = self._normal(n3)
       Wcor = None if trapezoidal else W1 + self._normal(n3)
       self._move(*old)
-      MxW = self.susp.mobility_times_lambda(W_slip)
       KTxW = self.susp.KT_times_lambda(W_slip)
       self._refresh_preconditioner(step)
-      if trapezoidal:
-        noise_W1 = self._noise(W1, math.sqrt(2 * self.kT / dt))
-      elif self.lockstep_solves and self.kT > 0.0:
-        # both Brownian forcings of the mid-point scheme use the mobility of q^n: their Lanczos iterations advance together
-        (noise_W1, its_a), (noise_Wcor, its_b) = self.susp.stochastic_forcing_pair(
-            W1, math.sqrt(4 * self.kT / dt), Wcor, math.sqrt(self.kT / dt), tol=self.tolerance,
-            print_residual=self.print_residual)
-        self.stoch_iterations_count += its_a + its_b
-      else:
-        noise_W1 = self._noise(W1, math.sqrt(4 * self.kT / dt))
-        noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))
       rhs = torch.cat([-W_slip, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
-      if self.lockstep_solves and self.rfd_solve_tolerance is None and not (self.warm_start and self.first_guess is not None):
-        # the Brownian-slip solve and the RFD solve share configuration, operator and preconditioner: their GMRES
-        # iterations advance together, one two-vector pair sweep per iteration instead of two sweeps
-        sol_1, sol_rfd = self.solve_mobility_problem_pair(dict(noise=noise_W1, guess=True), dict(RHS=rhs))
-        U_1, W_RFD = self._velocities(sol_1).clone(), self._velocities(sol_rfd)
+      f1 = math.sqrt(2 * self.kT / dt) if trapezoidal else math.sqrt(4 * self.kT / dt)
+      rfd_tol = self.tolerance if self.rfd_solve_tolerance is None else self.rfd_solve_tolerance
+      if self.lockstep_solves:
+        # Everything at time level n that needs the mobility M(q^n) and does not depend on another result: the product
+        # M W_slip, the Brownian forcing(s) (Lanczos) and the RFD solve advance together, one k-vector pass over the
+        # pairs per round.  The Brownian-slip solve needs the forcing and follows; the corrector solve and the second
+        # RFD product use other configurations (other mobilities) and cannot join.
+        tasks = [self.susp.product_task(W_slip), self.susp.solve_task(rhs, tol=rfd_tol)]
+        if self.kT > 0.0:
+          tasks.append(self.susp.forcing_task(W1, f1, tol=self.tolerance, print_residual=self.print_residual))
+          if not trapezoidal:
+            tasks.append(self.susp.forcing_task(Wcor, math.sqrt(self.kT / dt), tol=self.tolerance,
+                                                print_residual=self.print_residual))
+        res = self.susp.run_lockstep(tasks)
+        MxW, (sol_rfd, info_rfd) = res[0], res[1]
+        self.det_iterations_count += info_rfd["iterations"]
+        W_RFD = self._velocities(self.susp.impose_prescribed_velocity(sol_rfd))
+        zero = torch.zeros(n3, dtype=torch.float64, device=self.device)
+        noise_W1 = res[2][0] if self.kT > 0.0 else zero
+        noise_Wcor = (res[3][0] if self.kT > 0.0 else zero) if not trapezoidal else None
+        self.stoch_iterations_count += sum(r[1] for r in res[2:])
+        U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1, guess=True)).clone()
       else:
+        MxW = self.susp.mobility_times_lambda(W_slip)
+        noise_W1 = self._noise(W1, f1)
+        if not trapezoidal:
+          noise_Wcor = self._noise(Wcor, math.sqrt(self.kT / dt))
         U_1 = self._velocities(self.solve_mobility_problem(noise=noise_W1, guess=True)).clone()
         W_RFD = self._velocities(self.solve_mobility_problem(RHS=rhs, tolerance=self.rfd_solve_tolerance))
       self._move(*self._advance(old[0], old[1], W_RFD, self.rf_delta))

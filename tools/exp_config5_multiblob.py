@@ -1,4 +1,5 @@
-"""configs[4] recipe with rigid multiblobs: 21845 shells x 12 blobs = 262140 blobs, stochastic_Slip_Trapz steps
+"""usage: exp_config5_multiblob.py [bodies] [steps] [tol] [rfd_tol|-] [lockstep 0/1] [warm_start 0/1] [lockstep_width]
+configs[4] recipe with rigid multiblobs: 21845 shells x 12 blobs = 262140 blobs, stochastic_Slip_Trapz steps
 (physical parameters of examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat).  Prints per-step timing."""
 import math, os, sys, time
 import numpy as np
@@ -26,13 +27,17 @@ if len(sys.argv) > 4 and sys.argv[4] != "-":
   integ.rfd_solve_tolerance = float(sys.argv[4])
 if len(sys.argv) > 5:
   integ.lockstep_solves = bool(int(sys.argv[5]))
+if len(sys.argv) > 6:
+  integ.warm_start = bool(int(sys.argv[6]))
+if len(sys.argv) > 7:
+  integ.susp.lockstep_width = int(sys.argv[7])
 torch.cuda.synchronize()
 print("setup %.2f s, blobs %d" % (time.perf_counter() - t0, integ.Nblobs), flush=True)
 for step in range(steps):
-  d0, s0, m0, p0 = integ.det_iterations_count, integ.stoch_iterations_count, integ.susp.matvec_count, integ.susp.matvec2_count
+  d0, s0, m0, p0 = integ.det_iterations_count, integ.stoch_iterations_count, integ.susp.matvec_count, integ.susp.sweep_count
   t0 = time.perf_counter()
   integ.advance_time_step(0.01, step=step)
   torch.cuda.synchronize()
-  print("step %d: %.3f s, gmres its %d, lanczos its %d, M.v products %d (of which %d pairs in two-vector passes), rejected %d" %
+  print("step %d: %.3f s, gmres its %d, lanczos its %d, M.v products %d in %d passes over the pairs, rejected %d" %
         (step, time.perf_counter() - t0, integ.det_iterations_count - d0, integ.stoch_iterations_count - s0,
-         integ.susp.matvec_count - m0, integ.susp.matvec2_count - p0, integ.invalid_configuration_count), flush=True)
+         integ.susp.matvec_count - m0, integ.susp.sweep_count - p0, integ.invalid_configuration_count), flush=True)
