@@ -132,13 +132,14 @@ int rmb_matvec2_pairshard_device(rmb_ctx* ctx, int kind, const double* vec_a_dev
  *       (quaternion_integrator/quaternion_integrator_rollers.py:1114-1121 applies the four blocks separately)
  *   RMB_OP_FORCE_COLUMN                in: f        out: u = M_tt f, w = M_rt f   (the two random-finite-difference
  *       products of one draw, quaternion_integrator_rollers.py:1138-1160)
- *   RMB_OP_TT_MULTI                    in: k vectors (1..4)   out: M_tt applied to each (solves and Lanczos
- *       recursions advanced in lockstep on the same configuration)
+ *   RMB_OP_TT_MULTI (TR_ / RT_ / RR_)  in: k vectors (1..4)   out: the block applied to each (solves and Lanczos
+ *       recursions advanced in lockstep on the same configuration: geometry and coefficients once per pair)
  * in_dev / out_dev: arrays of n_in / n_out device pointers to 3n doubles (3*(end-begin) for outputs under a target
  * range).  in_plane != 0 zeroes the z component of every input and output (mobility_numba.py:291, :690).
  * Wall / no-wall / pseudo-periodic follow rmb_set_positions.  The *_pairshard variant evaluates pair shard `shard`
  * of `nshards` into full-length partial outputs (sum over shards = product), as rmb_matvec_pairshard_device. */
-enum rmb_op { RMB_OP_VELOCITY_FROM_FORCE_TORQUE = 0, RMB_OP_GRAND = 1, RMB_OP_FORCE_COLUMN = 2, RMB_OP_TT_MULTI = 3 };
+enum rmb_op { RMB_OP_VELOCITY_FROM_FORCE_TORQUE = 0, RMB_OP_GRAND = 1, RMB_OP_FORCE_COLUMN = 2, RMB_OP_TT_MULTI = 3,
+              RMB_OP_TR_MULTI = 4, RMB_OP_RT_MULTI = 5, RMB_OP_RR_MULTI = 6 };
 int rmb_matvec_op_device(rmb_ctx* ctx, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
                          double* const* out_dev, double eta);
 int rmb_matvec_op_pairshard_device(rmb_ctx* ctx, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,

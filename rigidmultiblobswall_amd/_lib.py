@@ -15,10 +15,11 @@ _vp = ctypes.c_void_p
 _lp = ctypes.POINTER(ctypes.c_long)
 
 KIND_TT, KIND_TR, KIND_RT, KIND_RR, KIND_TT_TR, KIND_TT_FREE = 0, 1, 2, 3, 4, 5
-OP_VELOCITY_FROM_FORCE_TORQUE, OP_GRAND, OP_FORCE_COLUMN, OP_TT_MULTI = 0, 1, 2, 3
-# name -> (rmb_op, inputs, outputs); "tt_multi" takes 1..4 vectors
+OP_VELOCITY_FROM_FORCE_TORQUE, OP_GRAND, OP_FORCE_COLUMN, OP_TT_MULTI, OP_TR_MULTI, OP_RT_MULTI, OP_RR_MULTI = range(7)
+# name -> (rmb_op, inputs, outputs); the "*_multi" operations take 1..4 vectors
 OPS = {"velocity_from_force_torque": (OP_VELOCITY_FROM_FORCE_TORQUE, 2, 1), "grand": (OP_GRAND, 2, 2),
-       "force_column": (OP_FORCE_COLUMN, 1, 2), "tt_multi": (OP_TT_MULTI, None, None)}
+       "force_column": (OP_FORCE_COLUMN, 1, 2), "tt_multi": (OP_TT_MULTI, None, None), "tr_multi": (OP_TR_MULTI, None, None),
+       "rt_multi": (OP_RT_MULTI, None, None), "rr_multi": (OP_RR_MULTI, None, None)}
 KINDS = {"tt": KIND_TT, "tr": KIND_TR, "rt": KIND_RT, "rr": KIND_RR, "tt_tr": KIND_TT_TR, "tt_free": KIND_TT_FREE}
 
 # every symbol include/rmb_mobility.h declares: (restype, argtypes)

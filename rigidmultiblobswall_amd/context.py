@@ -166,7 +166,7 @@ class MobilityContext(object):
       "velocity_from_force_torque"  (f, tau) -> (M_tt f + M_tr tau,)
       "grand"                       (f, tau) -> (M_tt f + M_tr tau, M_rt f + M_rr tau)
       "force_column"                (f,)     -> (M_tt f, M_rt f)
-      "tt_multi"                    k vectors -> M_tt applied to each (k = 1..4)
+      "tt_multi" (tr_ / rt_ / rr_)  k vectors -> the block applied to each (k = 1..4)
     vecs / outs: sequences of contiguous CUDA float64 tensors with 3n (outs: 3*n_targets) entries; returns the tuple
     of outputs.  With nshards > 1: the contribution of one pair shard to all n targets (to be summed over shards)."""
     import torch

@@ -375,16 +375,21 @@ template <class OP, bool WALL, bool PER> SymXEntry make_symx_entry() {
                        sizeof(double) * rmb::kSymWaves * 3 * OP::NOUT * 64,
                    OP::NIN, OP::NOUT};
 }
-enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_TT2, SX_TT3, SX_TT4, SX_FREE, SX_COUNT };
+// SX_K2 + 4 (k - 2) + kind: one block on k = 2..4 vectors
+enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_K2, SX_COUNT = SX_K2 + 12 };
 // [op][wall][periodic]
 #define RMB_SX_ROW(OP) {{make_symx_entry<OP, false, false>(), make_symx_entry<OP, false, true>()}, {make_symx_entry<OP, true, false>(), make_symx_entry<OP, true, true>()}}
 SymXEntry g_symx[SX_COUNT][2][2] = {
     RMB_SX_ROW(rmb::OpSingle<rmb::KIND_TT>), RMB_SX_ROW(rmb::OpSingle<rmb::KIND_TR>), RMB_SX_ROW(rmb::OpSingle<rmb::KIND_RT>),
     RMB_SX_ROW(rmb::OpSingle<rmb::KIND_RR>), RMB_SX_ROW(rmb::OpFusedRow), RMB_SX_ROW(rmb::OpGrand), RMB_SX_ROW(rmb::OpColumnF),
-    RMB_SX_ROW(rmb::OpTTk<2>), RMB_SX_ROW(rmb::OpTTk<3>), RMB_SX_ROW(rmb::OpTTk<4>),
     // the free-surface operation takes raw heights: only the wall = 0 column is ever launched
     {{make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
-     {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}}};
+     {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
+#define RMB_SX_K(K) RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_TT, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_TR, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_RT, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_RR, K))
+#define RMB_SX_KIND(KIND, K) rmb::OpKindK<KIND, K>
+    RMB_SX_K(2), RMB_SX_K(3), RMB_SX_K(4)};
+#undef RMB_SX_K
+#undef RMB_SX_KIND
 #undef RMB_SX_ROW
 
 int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane, long shard,
@@ -635,16 +640,18 @@ int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* con
   if (!in || !out) return fail(RMB_ERR_ARG, "null vector / output list");
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
-  int want_in = 0, want_out = 0, sx = -1;
+  int want_in = 0, want_out = 0, sx = -1, multi_kind = rmb::KIND_TT;
   switch (op) {
     case RMB_OP_VELOCITY_FROM_FORCE_TORQUE: want_in = 2; want_out = 1; sx = SX_FUSED; break;
     case RMB_OP_GRAND: want_in = 2; want_out = 2; sx = SX_GRAND; break;
     case RMB_OP_FORCE_COLUMN: want_in = 1; want_out = 2; sx = SX_COLF; break;
-    case RMB_OP_TT_MULTI:
-      if (n_in < 1 || n_in > 4) return fail(RMB_ERR_ARG, "RMB_OP_TT_MULTI takes 1..4 vectors");
+    case RMB_OP_TT_MULTI: case RMB_OP_TR_MULTI: case RMB_OP_RT_MULTI: case RMB_OP_RR_MULTI: {
+      if (n_in < 1 || n_in > 4) return fail(RMB_ERR_ARG, "RMB_OP_*_MULTI takes 1..4 vectors");
       want_in = want_out = n_in;
-      sx = n_in == 1 ? SX_TT : SX_TT2 + (n_in - 2);
+      multi_kind = op - RMB_OP_TT_MULTI;      // rmb_kind of the block
+      sx = n_in == 1 ? SX_TT + multi_kind : SX_K2 + 4 * (n_in - 2) + multi_kind;
       break;
+    }
     default: return fail(RMB_ERR_ARG, "unknown rmb_op");
   }
   if (n_in != want_in || n_out != want_out) return fail(RMB_ERR_ARG, "wrong number of input / output vectors for this rmb_op");
@@ -674,7 +681,7 @@ int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* con
     }
     default:
       for (int v = 0; v < n_in; ++v)
-        if (int rc = matvec_device_impl(c, rmb::KIND_TT, in_plane, in[v], nullptr, eta, out[v])) return rc;
+        if (int rc = matvec_device_impl(c, multi_kind, in_plane, in[v], nullptr, eta, out[v])) return rc;
       return 0;
   }
 }
@@ -810,7 +817,7 @@ int rmb_matvec2_pairshard_device(rmb_ctx* c, int kind, const double* vec_a, cons
   if (c->opt_symx_single) {
     const double* in[2] = {vec_a, vec_b};
     double* outs[2] = {out_a, out_b};
-    return symx_device(c, SX_TT2, in, outs, eta, 0, shard, nshards);
+    return symx_device(c, SX_K2, in, outs, eta, 0, shard, nshards);
   }
   return sym2_device(c, vec_a, vec_b, eta, out_a, out_b, shard, nshards);
 }

@@ -8,7 +8,8 @@
 //     applies once per Lanczos iteration as FOUR separate sweeps
 //     (quaternion_integrator/quaternion_integrator_rollers.py:1114-1121);
 //   * [u; w] = [M_tt; M_rt] f, the two random-finite-difference products of one draw (:1138-1160);
-//   * M_tt applied to k vectors at once (solves advanced in lockstep, quaternion_integrator_multi_bodies.py:985-996);
+//   * one block (M_tt above all) applied to k vectors at once (solves and Lanczos recursions advanced in lockstep,
+//     quaternion_integrator_multi_bodies.py:966-996);
 //   * the in-plane products (mobility/mobility_numba.py:291, :690: a row/column mask of the symmetric matrix) and
 //     the free-surface product (:1770-1937: the image block P RPY(R) is reciprocal too).
 // All of them are symmetric operators on the stacked vector, so every unordered pair is still evaluated once and
@@ -134,28 +135,43 @@ struct OpColumnF {
   }
 };
 
-// M_tt applied to K vectors: coefficients once, contraction K times (K = 2 is sym2_kernel's operation).
-template <int K>
-struct OpTTk {
+// One block (tt, tr, rt or rr) applied to K vectors: geometry and coefficients once, contraction K times
+// (KIND_TT, K = 2 is sym2_kernel's operation).
+template <int KIND, int K>
+struct OpKindK {
   static constexpr int NIN = K, NOUT = K;
   template <bool WALL>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    if constexpr (KIND == KIND_TT) {
+      const TTc a = tt_coeffs<WALL>(k, g, zj);
 #pragma unroll
-    for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+    } else if constexpr (KIND == KIND_RR) {
+      const RRc b = rr_coeffs<WALL>(k, g);
+#pragma unroll
+      for (int v = 0; v < K; ++v) rr_apply<WALL, false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+    } else {
+      const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+#pragma unroll
+      for (int v = 0; v < K; ++v) {
+        if constexpr (KIND == KIND_TR) tr_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+        else                           rt_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      }
+    }
   }
   template <bool WALL>
   static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
 #pragma unroll
     for (int v = 0; v < K; ++v) {
       Vec3 u = {ui[3 * v], ui[3 * v + 1], ui[3 * v + 2]};
-      self_term<KIND_TT, WALL>(k, zi, vi[3 * v], vi[3 * v + 1], vi[3 * v + 2], 0.0, 0.0, 0.0, u);
+      self_term<KIND, WALL>(k, zi, vi[3 * v], vi[3 * v + 1], vi[3 * v + 2], 0.0, 0.0, 0.0, u);
       ui[3 * v] = u.x; ui[3 * v + 1] = u.y; ui[3 * v + 2] = u.z;
     }
   }
 };
+template <int K> using OpTTk = OpKindK<KIND_TT, K>;
 
 // Free (stress-free) surface at z = 0: u_i = sum_j [RPY(d) + RPY(R) P] f_j, R = (d_x, d_y, z_i + z_j), P = diag(1,1,-1)
 // (mobility_numba.py:1846-1925).  The reversed pair sees R' = (-d_x, -d_y, R_z), so (RPY(R) P)_ji = P RPY(R)_ij:
@@ -198,6 +214,9 @@ struct OpFreeSurface {
 // per-lane ds_read_b128 of consecutive records conflict-free (48 / 80 / 112 / 144 bytes).
 template <int NIN> struct SymXRec { static constexpr int nd = 3 + 3 * NIN; static constexpr int d2 = ((nd + 1) / 2) | 1; };
 
+// (Measured and dropped: storing every record / accumulator slot twice so that the rotation index lane + k needs no
+//  `& 63` wrap removes 2 of the 4 integer instructions per step -- 106 -> 104 -- and changes nothing in time,
+//  0.1853 vs 0.1849 ms at 1e4 blobs, 17.17 vs 17.27 ms at 1e5: the integer work already hides under fp64 issue.)
 template <class OP, bool WALL, bool PERIODIC>
 __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) {
   constexpr int NI = OP::NIN, NO = OP::NOUT;

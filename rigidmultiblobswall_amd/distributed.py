@@ -210,7 +210,7 @@ class ShardedMobility(object):
 
   def matvec_op_replicated(self, op, vecs, eta, in_plane=False):
     """Multi-block operation (context.matvec_op_device: "velocity_from_force_torque", "grand", "force_column",
-    "tt_multi") with replicated vectors: one pass over this rank's pair shard for all blocks, then ONE all-reduce of the
+    "tt_multi" / "tr_multi" / "rt_multi" / "rr_multi") with replicated vectors: one pass over this rank's pair shard for all blocks, then ONE all-reduce of the
     stacked partial outputs.  Backends without the multi-block kernel compose it from single products."""
     vecs = [self._to_dev(v) for v in vecs]
     if hasattr(self.backend, "matvec_op_pairshard"):
@@ -229,8 +229,8 @@ class ShardedMobility(object):
       return (mv("tt_tr", vecs[0], vecs[1]), mv("rt", vecs[0]) + mv("rr", vecs[1]))
     if op == "force_column":
       return (mv("tt", vecs[0]), mv("rt", vecs[0]))
-    if op == "tt_multi":
-      return tuple(mv("tt", v) for v in vecs)
+    if op.endswith("_multi") and op[:2] in ("tt", "tr", "rt", "rr"):
+      return tuple(mv(op[:2], v) for v in vecs)
     raise ValueError("unknown operation %r" % (op,))
 
   def blob_blob_force_replicated(self, eps, b, a):

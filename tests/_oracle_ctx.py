@@ -39,7 +39,7 @@ class OracleContext(object):
     elif op == "force_column":
       res = (mv("tt", vecs[0]), mv("rt", vecs[0]))
     else:
-      res = tuple(mv("tt", v) for v in vecs)
+      res = tuple(mv(op[:2], v) for v in vecs)      # "tt_multi", "tr_multi", "rt_multi", "rr_multi"
     if outs is not None:
       for o, r in zip(outs, res):
         o.copy_(r)

@@ -90,6 +90,27 @@ def test_tt_multi(Ctx, oracle, torch_mod, k, N, wall, L):
   ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["tr", "rt", "rr"])
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+@pytest.mark.parametrize("wall,L", [(True, None), (False, None), (True, (0.0, 13.0, 0.0))])
+def test_kind_multi(Ctx, oracle, torch_mod, kind, k, wall, L):
+  """tr / rt / rr applied to k vectors in one pass (RMB_OP_TR_MULTI / RT / RR), incl. two pair shards."""
+  torch = torch_mod
+  N = 700
+  r, _, eta, a = d2_cloud(N, seed=3 * k + 1)
+  vs = [np.random.RandomState(10 * k + v).randn(N, 3) for v in range(k)]
+  ctx = Ctx(0)
+  ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+  dv = [_dev(torch, v) for v in vs]
+  outs = ctx.matvec_op_device(kind + "_multi", dv, eta)
+  parts = [ctx.matvec_op_device(kind + "_multi", dv, eta, shard=s, nshards=2) for s in range(2)]
+  kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64))
+  for c, (v, o) in enumerate(zip(vs, outs)):
+    assert rel_err(o.cpu().numpy(), oracle._wrapped(kind, int(wall), r, v, eta, a, **kw)) < TOL_D2
+    assert rel_err((parts[0][c] + parts[1][c]).cpu().numpy(), o.cpu().numpy()) < TOL_SHARD
+  ctx.close()
+
+
 @pytest.mark.parametrize("kind", ["tt", "tr", "rt", "rr"])
 @pytest.mark.parametrize("wall,L", [(True, None), (False, None), (True, (14.0, 16.0, 0.0))])
 def test_single_kinds_through_generic_skeleton(Ctx, oracle, torch_mod, kind, wall, L):

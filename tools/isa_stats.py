@@ -38,7 +38,10 @@ KERNELS = {
     "symx_fused_wall": "_ZN3rmb11symx_kernelINS_10OpFusedRowELb1ELb0EEE",
     "symx_grand_wall": "_ZN3rmb11symx_kernelINS_7OpGrandELb1ELb0EEE",
     "symx_column_wall": "_ZN3rmb11symx_kernelINS_9OpColumnFELb1ELb0EEE",
-    "symx_tt3_wall": "_ZN3rmb11symx_kernelINS_5OpTTkILi3EEELb1ELb0EEE",
+    "symx_tt2_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi2EEELb1ELb0EEE",
+    "symx_tt3_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi3EEELb1ELb0EEE",
+    "symx_tt4_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi4EEELb1ELb0EEE",
+    "symx_rr2_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi3ELi2EEELb1ELb0EEE",
     "symx_free": "_ZN3rmb11symx_kernelINS_13OpFreeSurfaceELb0ELb0EEE",
 }
 
