@@ -48,6 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 FLOPS_PER_PAIR = {"tt_wall": 211.0}     # reference as-written op count, SURVEY.md 8(d)
 FP64_VECTOR_PEAK_TFLOPS = 78.6          # MI355X fp64 vector = 1/2 of the 157.3 TF fp32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+TIMING_STRIDE = 4                       # HIP events bracket every 4th sweep launch of the timed region
 
 
 def d2_cloud(N, seed=0):
@@ -115,7 +116,7 @@ def timed_region(torch, dist, world, device, backend, step, steps, warmup):
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize(device)
-  backend.ctx.timing_reset()
+  backend.ctx.timing_reset()      # the first timed launch is sampled, then every TIMING_STRIDE-th
   t0 = time.perf_counter()
   for _ in range(steps):
     step()
@@ -124,7 +125,7 @@ def timed_region(torch, dist, world, device, backend, step, steps, warmup):
     dist.barrier()
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
-  kern_ms = backend.ctx.timing_collect(steps)
+  kern_ms = backend.ctx.timing_collect(steps)     # the sampled launches of the timed region
   kern_ms_avg = float(np.mean(kern_ms)) if len(kern_ms) else float("nan")
   if world > 1:
     t = torch.tensor([dt, kern_ms_avg], dtype=torch.float64, device=device)
@@ -224,7 +225,9 @@ def rank_main(args):
 
   from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
   backend = HipBackend(device)
-  backend.ctx.set_option("timing", 1)
+  # HIP events around every 4th sweep of the timed region: an event pair serialises 4-8 us around a 190 us launch
+  # (tools/exp_graph.py), so bracketing every launch would lower `value` by ~4 %; the sample gives kernel_ms_avg
+  backend.ctx.set_option("timing", TIMING_STRIDE)
   sm = ShardedMobility(backend, device=device)
 
   N = args.blobs
@@ -283,7 +286,10 @@ def rank_main(args):
                       "matvec; the kernel needs fewer (see `executed`), so this fraction may exceed 1 -- it is a "
                       "throughput in the reference's unit, not a utilisation",
       "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_ordered,
-      "kernel_ms_avg": round(res["kern_ms"], 5), "launch": res["launch"],
+      "kernel_ms_avg": round(res["kern_ms"], 5),
+      "kernel_ms_avg_source": "HIP events on the launch stream around every %d-th sweep launch of the timed region "
+                              "(%d launches sampled)" % (TIMING_STRIDE, -(-args.steps // TIMING_STRIDE)),
+      "launch": res["launch"],
       "executed": executed, "frac_executed": executed["frac"] if executed else None,
       "issue": issue,
       "traffic": traffic, "traffic_provenance": traffic_src,

@@ -69,7 +69,8 @@ int rmb_ctx_destroy(rmb_ctx* ctx);
  * previous one.  Unchanged handle: no cost. */
 int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
 /* Options (unknown key -> RMB_ERR_ARG).  Defaults in [].
- *   "timing"          [0]  1 = bracket every pair-sweep launch with HIP events (rmb_timing_collect)
+ *   "timing"          [0]  n >= 1 = bracket every n-th pair-sweep launch with HIP events (rmb_timing_collect); an
+ *                          event pair serialises ~4-8 us around the launch, so throughput runs sample (n = 4)
  *   "symmetric"       [1]  1 = evaluate each unordered pair once and update both blobs (sym_kernels.h /
  *                          symx_kernels.h) whenever the full target range is resident and n >= 128;
  *                          0 = always the one-sided sweep (every ordered pair, atomic-free)

@@ -95,6 +95,7 @@ struct rmb_ctx {
   // timing ring (events around the sweep kernel)
   std::vector<hipEvent_t> ev0, ev1;
   int ev_count = 0;  // events recorded since last reset (capped at ring size)
+  long timing_launches = 0;  // sweeps seen since the last reset (sampling stride of the "timing" option)
   // last launch
   long last_tiles = 0, last_chunks = 0, last_wgs = 0;
 };
@@ -178,6 +179,9 @@ int resident_blocks(const void* fn, int* cache) {
 int timing_begin(rmb_ctx* c, int* slot) {
   *slot = -1;
   if (!c->opt_timing) return 0;
+  // "timing" = n > 1: bracket every n-th sweep only.  An event pair costs ~4-8 us of serialisation around a launch
+  // (tools/exp_graph.py: 188 us per 1e4-blob step without events, 199 us with), so a throughput measurement samples.
+  if (c->opt_timing > 1 && (c->timing_launches++ % c->opt_timing) != 0) return 0;
   if (c->ev0.empty()) {
     c->ev0.resize(kTimingRing);
     c->ev1.resize(kTimingRing);
@@ -1088,6 +1092,7 @@ int rmb_ubench_fp64_issue(rmb_ctx* c, int launches, double* g_wave_instr_per_s) 
 int rmb_timing_reset(rmb_ctx* c) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
   c->ev_count = 0;
+  c->timing_launches = 0;
   return 0;
 }
 
