@@ -8,7 +8,7 @@
 // matrix-free pair operator of pair_ops.h to the three unit vectors.  Same regularisation as the
 // products: M_body = B M(z_eff) B.
 #pragma once
-#include "pair_ops.h"
+#include "pair_blocks.h"
 
 namespace rmb {
 

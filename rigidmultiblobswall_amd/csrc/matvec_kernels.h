@@ -15,7 +15,7 @@
 // The pair loop has no self test: pairs with i == j contribute through `self_term` in the
 // epilogue and are skipped only in the one tile that overlaps the workgroup's own targets.
 #pragma once
-#include "pair_ops.h"
+#include "pair_blocks.h"
 
 namespace rmb {
 

@@ -272,4 +272,43 @@ __device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const doub
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One ORDERED pair of kind KIND (one-sided kernels: sweep_kernel, dense builders, diagonal tile units).
+// (vx,vy,vz) is the source vector; (wx,wy,wz) the source torque for the fused tt+tr kind
+// (mobility/mobility_pycuda.py:1351-1375 evaluates both blocks in one pass).  The coupling kinds use the
+// unnormalised-separation algebra above with the reversed direction left to dead-code elimination.
+// ---------------------------------------------------------------------------------------------
+template <bool TR, bool WALL>
+__device__ __forceinline__ void pair_coupling_forward(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                                      double vx, double vy, double vz, Vec3& u) {
+  const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+  const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+  const double vi[3] = {0.0, 0.0, 0.0}, vj[3] = {vx, vy, vz};
+  double u3[3] = {u.x, u.y, u.z}, t[3];
+  if constexpr (TR) tr_apply<WALL, false>(C, g, vi, vj, u3, t);
+  else              rt_apply<WALL, false>(C, g, vi, vj, u3, t);
+  u.x = u3[0]; u.y = u3[1]; u.z = u3[2];
+}
+
+template <int KIND, bool WALL>
+__device__ __forceinline__ void pair_apply(const PairConsts& k, double dx, double dy, double dz, double zi,
+                                           double zj, double vx, double vy, double vz, double wx, double wy,
+                                           double wz, Vec3& u) {
+  const double Rz = zi + zj;
+  if constexpr (KIND == KIND_TT) pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+  if constexpr (KIND == KIND_TR) pair_coupling_forward<true, WALL>(k, dx, dy, dz, zi, zj, vx, vy, vz, u);
+  if constexpr (KIND == KIND_RT) pair_coupling_forward<false, WALL>(k, dx, dy, dz, zi, zj, vx, vy, vz, u);
+  if constexpr (KIND == KIND_RR) pair_rr<WALL>(k, dx, dy, dz, Rz, vx, vy, vz, u);
+  if constexpr (KIND == KIND_TT_TR) {
+    pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+    pair_coupling_forward<true, WALL>(k, dx, dy, dz, zi, zj, wx, wy, wz, u);
+  }
+  if constexpr (KIND == KIND_TT_FREE) {
+    // free (stress-free) surface at z = 0: RPY(d) f + RPY(R) (f_x, f_y, -f_z), R = (d_x, d_y, z_i + z_j)
+    // (mobility/mobility_numba.py:1846-1925; image block added with the z column negated, :1915-1923)
+    pair_tt<false>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+    pair_tt<false>(k, dx, dy, Rz, Rz, zj, vx, vy, -vz, u);
+  }
+}
+
 }  // namespace rmb

@@ -19,8 +19,8 @@
 // 30-instruction IEEE sqrt+divide sequence.  The near-field (r < 2a, overlapping blobs) RPY
 // branch is taken per wave only when some lane needs it.
 //
-// A wall-tt pair costs ~93 fp64 VALU instructions here (sweep) and ~55 per ordered pair in the symmetric
-// kernel of sym_kernels.h; the reference's as-written count is 211 flops.
+// A wall-tt pair costs 95 VALU instructions in the one-sided sweep and 106 per UNORDERED pair (53 per ordered pair)
+// in the symmetric kernel of sym_kernels.h (tools/isa_stats.py); the reference's as-written count is 211 flops.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -150,82 +150,8 @@ __device__ __forceinline__ void pair_tt(const PairConsts& k, double dx, double d
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// RPY coupling (tr and rt share it): c(r) (v x d),  c = 1/r^3 (far) or 1/(2a^3) - 3r/(16a^4)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double coupling_coeff(const PairConsts& k, double r2) {
-  const double ir = rsqrt_f64(r2);
-  double c = ir * ir * ir;
-  if (__builtin_expect(__any(r2 < k.four_a2), 0)) {
-    const double r = r2 * ir;
-    c = (r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : c;
-  }
-  return c;
-}
-
-// Wall factors shared by tr and rt; `zh` is the anchoring height (source for rt, target for tr).
-struct CouplingWall { double iR, f1, p, s, f3, ez; };
-
-__device__ __forceinline__ CouplingWall coupling_wall(const PairConsts& k, double rho2, double Rz, double zh) {
-  CouplingWall c;
-  const double R2 = __builtin_fma(Rz, Rz, rho2);
-  c.iR = rsqrt_f64(R2);
-  const double iR2 = c.iR * c.iR;
-  const double tau = k.a2 * iR2;
-  c.ez = Rz * c.iR;
-  const double g = zh * c.iR;
-  const double uu = c.ez * c.ez;
-  const double eztau = c.ez * tau;
-  c.f1 = iR2;
-  c.p = iR2 * (__builtin_fma(2.0, eztau - g, c.ez));                                    // ez - 2g + 2 ez tau
-  c.s = iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, __builtin_fma(12.0 * g, c.ez, 1.0));
-  c.f3 = -2.0 * iR2 * __builtin_fma(-5.0, eztau, 3.0 * g);
-  return c;
-}
-
-// rt:  w += [RPY_c(d) + W_rt] f      (wall anchored on SOURCE height z_j)
-template <bool WALL>
-__device__ __forceinline__ void pair_rt(const PairConsts& k, double dx, double dy, double dz, double Rz,
-                                        double zj, double vx, double vy, double vz, Vec3& u) {
-  const double rho2 = __builtin_fma(dy, dy, dx * dx);
-  const double r2 = __builtin_fma(dz, dz, rho2);
-  const double c = coupling_coeff(k, r2);
-  double ax = __builtin_fma(vy, dz, -vz * dy) * c;
-  double ay = __builtin_fma(vz, dx, -vx * dz) * c;
-  double az = __builtin_fma(vx, dy, -vy * dx) * c;
-  if constexpr (WALL) {
-    const CouplingWall W = coupling_wall(k, rho2, Rz, zj);
-    const double ex = dx * W.iR, ey = dy * W.iR;
-    const double E = __builtin_fma(W.ez, vz, __builtin_fma(ey, vy, ex * vx));
-    const double kap = __builtin_fma(W.f3, E, W.s * vz);
-    ax += __builtin_fma(kap, ey, -W.p * vy);
-    ay += __builtin_fma(-kap, ex, W.p * vx);
-    az += W.f1 * __builtin_fma(ex, vy, -ey * vx);
-  }
-  u.x += ax; u.y += ay; u.z += az;
-}
-
-// tr:  u += [RPY_c(d) + W_tr] tau     (wall anchored on TARGET height z_i; reference negates rx, ry)
-template <bool WALL>
-__device__ __forceinline__ void pair_tr(const PairConsts& k, double dx, double dy, double dz, double Rz,
-                                        double zi, double vx, double vy, double vz, Vec3& u) {
-  const double rho2 = __builtin_fma(dy, dy, dx * dx);
-  const double r2 = __builtin_fma(dz, dz, rho2);
-  const double c = coupling_coeff(k, r2);
-  double ax = __builtin_fma(vy, dz, -vz * dy) * c;
-  double ay = __builtin_fma(vz, dx, -vx * dz) * c;
-  double az = __builtin_fma(vx, dy, -vy * dx) * c;
-  if constexpr (WALL) {
-    const CouplingWall W = coupling_wall(k, rho2, Rz, zi);
-    const double ex = dx * W.iR, ey = dy * W.iR;
-    const double c0 = __builtin_fma(ex, vy, -ey * vx);
-    const double f3c0 = W.f3 * c0;
-    ax += __builtin_fma(W.f1 * ey, vz, __builtin_fma(W.p, vy, -f3c0 * ex));
-    ay -= __builtin_fma(W.f1 * ex, vz, __builtin_fma(W.p, vx, f3c0 * ey));
-    az += __builtin_fma(W.f3, W.ez, W.s) * c0;
-  }
-  u.x += ax; u.y += ay; u.z += az;
-}
+// (tr / rt: the coupling blocks live in pair_blocks.h -- cpl_coeffs / tr_apply / rt_apply on the unnormalised
+//  separation, shared by the one-sided and the symmetric kernels.)
 
 // rr:  w += [RPY_rr(d) + W_rr] tau
 template <bool WALL>
@@ -321,29 +247,6 @@ __device__ __forceinline__ void self_term(const PairConsts& k, double zi, double
     const double iz = 1.0 / zi, iz2 = iz * iz;
     const double c = 0.125 * k.a2 * iz2 * iz2;
     u.x = __builtin_fma(-c, vy, u.x); u.y = __builtin_fma(c, vx, u.y);
-  }
-}
-
-// One pair of kind KIND.  (vx,vy,vz) is the source vector; (wx,wy,wz) the source torque for the
-// fused tt+tr kind (mobility/mobility_pycuda.py:1351-1375 evaluates both blocks in one pass).
-template <int KIND, bool WALL>
-__device__ __forceinline__ void pair_apply(const PairConsts& k, double dx, double dy, double dz, double zi,
-                                           double zj, double vx, double vy, double vz, double wx, double wy,
-                                           double wz, Vec3& u) {
-  const double Rz = zi + zj;
-  if constexpr (KIND == KIND_TT) pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
-  if constexpr (KIND == KIND_TR) pair_tr<WALL>(k, dx, dy, dz, Rz, zi, vx, vy, vz, u);
-  if constexpr (KIND == KIND_RT) pair_rt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
-  if constexpr (KIND == KIND_RR) pair_rr<WALL>(k, dx, dy, dz, Rz, vx, vy, vz, u);
-  if constexpr (KIND == KIND_TT_TR) {
-    pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
-    pair_tr<WALL>(k, dx, dy, dz, Rz, zi, wx, wy, wz, u);
-  }
-  if constexpr (KIND == KIND_TT_FREE) {
-    // free (stress-free) surface at z = 0: RPY(d) f + RPY(R) (f_x, f_y, -f_z), R = (d_x, d_y, z_i + z_j)
-    // (mobility/mobility_numba.py:1846-1925; image block added with the z column negated, :1915-1923)
-    pair_tt<false>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
-    pair_tt<false>(k, dx, dy, Rz, Rz, zj, vx, vy, -vz, u);
   }
 }
 
