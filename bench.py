@@ -456,7 +456,7 @@ def rank_main(args):
       torch.cuda.synchronize(device)
       if world > 1:
         dist.barrier()
-      d0, l0, m0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count
+      d0, l0, m0, p0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count, ri.susp.sweep_count
       t0 = time.perf_counter()
       ri.advance_time_step(0.01, step=1)
       torch.cuda.synchronize(device)
@@ -471,7 +471,8 @@ def rank_main(args):
                                             "steps": 1, "s_per_step": round(dt5, 4),
                                             "gmres_iterations_per_step": ri.det_iterations_count - d0,
                                             "lanczos_iterations_per_step": ri.stoch_iterations_count - l0,
-                                            "pair_sweeps_per_step": ri.susp.matvec_count - m0,
+                                            "mobility_products_per_step": ri.susp.matvec_count - m0,
+                                            "passes_over_the_pairs_per_step": ri.susp.sweep_count - p0,
                                             "rejected_steps": ri.invalid_configuration_count}
     except Exception as exc:      # an extra must never cost the headline line
       line['config5_multiblob_brownian'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
