@@ -99,7 +99,7 @@ for N in SIZES:
     ctx.set_option("deterministic", 1)
     sw = timed(ctx, lambda: ctx.matvec_device(kind, fd, eta, in_plane=True), reps, 1)
     ctx.set_option("deterministic", 0)
-    row(N, "in-plane " + kind, "one-sided sweep (round 1)", sw)
+    row(N, "in-plane " + kind, "one-sided sweep", sw)
     row(N, "in-plane " + kind, "symmetric (symx OpSingle, in_plane)", timed(ctx, lambda: ctx.matvec_device(kind, fd, eta, in_plane=True), reps, 1), sw)
 
   # no wall: free surface, radii forces, forces
@@ -107,13 +107,13 @@ for N in SIZES:
   ctx.set_option("deterministic", 1)
   sw = timed(ctx, lambda: ctx.matvec_device("tt_free", fd, eta), reps, 1)
   ctx.set_option("deterministic", 0)
-  row(N, "free surface tt", "one-sided sweep (round 1)", sw)
+  row(N, "free surface tt", "one-sided sweep", sw)
   row(N, "free surface tt", "symmetric (symx OpFreeSurface)", timed(ctx, lambda: ctx.matvec_device("tt_free", fd, eta), reps, 1), sw)
   rad = dev(a * (0.5 + rng.rand(N)))
   ctx.set_option("deterministic", 1)
   sw = timed(ctx, lambda: ctx.blob_blob_force_radii_device(rad, 3.92, 0.1 * a), reps, 1)
   ctx.set_option("deterministic", 0)
-  row(N, "forces, per-blob radii", "one-sided sweep (round 1)", sw)
+  row(N, "forces, per-blob radii", "one-sided sweep", sw)
   row(N, "forces, per-blob radii", "symmetric (sym_force_kernel<RADII>)", timed(ctx, lambda: ctx.blob_blob_force_radii_device(rad, 3.92, 0.1 * a), reps, 1), sw)
   row(N, "forces", "symmetric", timed(ctx, lambda: ctx.blob_blob_force_device(3.92, 0.1 * a, a), reps, 1))
   for kind in ("tt", "tr", "rt", "rr"):
