@@ -72,6 +72,8 @@ struct rmb_ctx {
   DevBuf pos;      // double4[n]
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial, tmp3n;
+  DevBuf det_ws;                 // per-unit partials of the deterministic symmetric pass
+  long opt_det_workspace_mb = 1024;
   DevBuf st[8];    // scratch of the source->target entry point
   DevBuf wave_clock;  // optional per-wave (start, end) wall-clock stamps of the symmetric kernel
   long wave_clock_n = 0;
@@ -372,12 +374,12 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
 
 // ---- generic symmetric operations (symx_kernels.h) ---------------------------------------------------------
 typedef void (*symx_fn)(const rmb::SymXArgs);
-struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n_in, n_out; };
+struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n_in, n_out; symx_fn det_sweep; symx_fn det_reduce; int det_occ; };
 template <class OP, bool WALL, bool PER> SymXEntry make_symx_entry() {
-  return SymXEntry{rmb::symx_kernel<OP, WALL, PER>, rmb::symx_finalize_kernel<OP, WALL>, 0,
+  return SymXEntry{rmb::symx_kernel<OP, WALL, PER, false>, rmb::symx_finalize_kernel<OP, WALL>, 0,
                    sizeof(double2) * rmb::kSymWaves * 64 * rmb::SymXRec<OP::NIN>::d2 +
                        sizeof(double) * rmb::kSymWaves * 3 * OP::NOUT * 64,
-                   OP::NIN, OP::NOUT};
+                   OP::NIN, OP::NOUT, rmb::symx_kernel<OP, WALL, PER, true>, rmb::symx_det_reduce_kernel<OP::NOUT>, 0};
 }
 // SX_K2 + 4 (k - 2) + kind: one block on k = 2..4 vectors
 enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_K2, SX_COUNT = SX_K2 + 12 };
@@ -431,9 +433,68 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   return 0;
 }
 
+// Deterministic symmetric pass ("deterministic" = 2): same pair arithmetic as symx_device, but whole units per wave and
+// per-unit partial results in a bounded workspace instead of atomics, summed in a fixed order by
+// symx_det_reduce_kernel; the unit list is processed in chunks that fit the workspace ("det_workspace_mb").
+int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane) {
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  SymXEntry& se = g_symx[op][c->wall ? 1 : 0][periodic ? 1 : 0];
+  const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
+  if (int rc = sym_accumulators(c, n_pad)) return rc;
+  rmb::SymXArgs a;
+  a.pos = (const double4*)c->pos.p;
+  for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
+  a.acc = (double*)c->symbuf.p;
+  a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  a.self_begin = 0; a.self_end = n;
+  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
+  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
+  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
+  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.accumulate = 0;
+  a.in_plane = in_plane ? 1 : 0;
+  a.skip_pairs = 0;
+  a.k = make_pair_consts(c->a);
+  // whole units per wave: enough waves for `sym_oversub` resident rounds, never less than one unit each
+  const int wps = resident_blocks((const void*)se.det_sweep, &se.det_occ);
+  const long max_waves = c->n_cu * wps * rmb::kSymWaves * c->opt_sym_oversub;
+  const long upw = (a.n_units + max_waves - 1) / max_waves;
+  const size_t slot = (size_t)3 * se.n_out * 64 * sizeof(double);
+  long chunk_units = (long)(((size_t)c->opt_det_workspace_mb << 20) / (2 * slot));
+  chunk_units -= chunk_units % upw;
+  if (chunk_units < upw) chunk_units = upw;
+  if (chunk_units > a.n_units) chunk_units = ((a.n_units + upw - 1) / upw) * upw;
+  if (int rc = c->det_ws.reserve((size_t)2 * chunk_units * slot)) return rc;
+  a.part_I = (double*)c->det_ws.p;
+  a.part_J = a.part_I + chunk_units * (3L * se.n_out * 64);
+  a.units_per_wave = upw;
+  a.steps_per_wave = 64 * upw;
+  c->last_path = 2; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = 0;
+  for (long ub = 0; ub < a.n_units; ub += chunk_units) {
+    const long ue = ub + chunk_units < a.n_units ? ub + chunk_units : a.n_units;
+    a.unit_begin = ub; a.unit_end = ue;
+    a.step_begin = 64 * ub; a.step_end = 64 * ue;
+    a.first_chunk = ub == 0 ? 1 : 0;
+    const long waves = (ue - ub + upw - 1) / upw;
+    const long blocks = (waves + rmb::kSymWaves - 1) / rmb::kSymWaves;
+    c->last_wgs += blocks;
+    int slot_t;
+    if (int rc = timing_begin(c, &slot_t)) return rc;
+    hipLaunchKernelGGL(se.det_sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(se.det_reduce, dim3((unsigned)tiles), dim3(256), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+    if (int rc = timing_end(c, slot_t)) return rc;
+  }
+  hipLaunchKernelGGL(se.fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
 // whether the symmetric (each unordered pair once) path applies to the resident configuration
 bool sym_applies(const rmb_ctx* c) {
-  return c->opt_symmetric && !c->opt_deterministic && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128;
+  return c->opt_symmetric && c->opt_deterministic != 1 && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128;
 }
 
 int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta,
@@ -456,6 +517,10 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
     c->last_path = 1;
     const double* in[2] = {v, v2};
     double* outs[1] = {out};
+    if (c->opt_deterministic == 2) {   // bit-reproducible AND symmetric: ordered reduction instead of atomics
+      const int sx = kind <= rmb::KIND_RR ? SX_TT + kind : (kind == rmb::KIND_TT_TR ? SX_FUSED : SX_FREE);
+      return symx_det_device(c, sx, in, outs, eta, in_plane);
+    }
     if (kind <= rmb::KIND_RR) {
       if (in_plane || c->opt_symx_single) return symx_device(c, SX_TT + kind, in, outs, eta, in_plane, 0, 1);
       return sym_device(c, kind, v, eta, out);
@@ -535,8 +600,9 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
   RMB_HIP(hipSetDevice(c->device));
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (sym_applies(c)) {
-    // symmetric path: each unordered pair once (F_ji = -F_ij)
+  if (sym_applies(c) && c->opt_deterministic == 0) {
+    // symmetric path: each unordered pair once (F_ji = -F_ij); its flushes are atomics, so both deterministic modes
+    // take the one-sided sweep below
     const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
     if (int rc = sym_accumulators(c, n_pad)) return rc;
     rmb::SymForceArgs a;
@@ -664,6 +730,7 @@ int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* con
   if (c->n == 0) return 0;
   RMB_HIP(hipSetDevice(c->device));
   // a pair shard always writes all n targets, whatever target range is set (as rmb_matvec_pairshard_device)
+  if (nshards == 1 && sym_applies(c) && c->opt_deterministic == 2) return symx_det_device(c, sx, in, out, eta, in_plane);
   if (sym_applies(c) || nshards > 1) return symx_device(c, sx, in, out, eta, in_plane, shard, nshards);
   const long n_tgt = c->tgt_end - c->tgt_begin;
   if (n_tgt == 0) return 0;
@@ -728,7 +795,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->wave_clock.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release();
+  c->wave_clock.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release();
   if (c->stream_switch) (void)hipEventDestroy(c->stream_switch);
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
@@ -759,6 +826,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "fused_symmetric")) { c->opt_fused_symmetric = value; return 0; }
   if (!strcmp(key, "symx_single")) { c->opt_symx_single = value; return 0; }
   if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
+  if (!strcmp(key, "det_workspace_mb")) { c->opt_det_workspace_mb = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_wps")) { c->opt_sym_wps = value; return 0; }
   if (!strcmp(key, "wave_clock")) { c->opt_wave_clock = value; return 0; }
   if (!strcmp(key, "skip_pairs")) { c->opt_skip_pairs = value; return 0; }
@@ -818,9 +886,10 @@ int rmb_matvec2_pairshard_device(rmb_ctx* c, int kind, const double* vec_a, cons
   }
   // a pair shard (nshards > 1) always runs the symmetric kernel, whatever n: it is the only kernel that can
   // evaluate a slice of the unordered pairs (rmb_matvec_pairshard_device does the same)
-  if (c->opt_symx_single) {
+  if (c->opt_symx_single || (c->opt_deterministic == 2 && nshards == 1)) {
     const double* in[2] = {vec_a, vec_b};
     double* outs[2] = {out_a, out_b};
+    if (c->opt_deterministic == 2 && nshards == 1) return symx_det_device(c, SX_K2, in, outs, eta, 0);
     return symx_device(c, SX_K2, in, outs, eta, 0, shard, nshards);
   }
   return sym2_device(c, vec_a, vec_b, eta, out_a, out_b, shard, nshards);

@@ -42,6 +42,12 @@ struct SymXArgs {
   int accumulate;         // bit c: finalize adds into out[c] instead of overwriting it
   int in_plane;           // zero the z component of every input on load and of every output on store
   int skip_pairs;         // diagnostics (timing only): 1 = no pair arithmetic, 2 = no flush of the LDS accumulators
+  // deterministic variant (DET): whole units per wave; instead of atomics every unit stores its two partial results
+  // (64 lanes x 3 NOUT doubles each) into a workspace that symx_det_reduce_kernel sums in a fixed order
+  double* part_I;         // [unit - unit_begin][3 NOUT][64]  row-side partial, valid only on the last unit of a row run
+  double* part_J;         // [unit - unit_begin][3 NOUT][64]  column-side partial of every off-diagonal unit
+  long unit_begin, unit_end, units_per_wave;
+  int first_chunk;        // reduce: start from zero instead of the running accumulators
   PairConsts k;
 };
 
@@ -217,7 +223,7 @@ template <int NIN> struct SymXRec { static constexpr int nd = 3 + 3 * NIN; stati
 // (Measured and dropped: storing every record / accumulator slot twice so that the rotation index lane + k needs no
 //  `& 63` wrap removes 2 of the 4 integer instructions per step -- 106 -> 104 -- and changes nothing in time,
 //  0.1853 vs 0.1849 ms at 1e4 blobs, 17.17 vs 17.27 ms at 1e5: the integer work already hides under fp64 issue.)
-template <class OP, bool WALL, bool PERIODIC>
+template <class OP, bool WALL, bool PERIODIC, bool DET = false>
 __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) {
   constexpr int NI = OP::NIN, NO = OP::NOUT;
   constexpr int RD2 = SymXRec<NI>::d2;
@@ -247,20 +253,29 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
 #pragma unroll
   for (int c = 0; c < 3 * NO; ++c) ui[c] = 0.0;
 
-  auto flush_row = [&]() {
+  // `u_last` = the unit the row run ends with (DET: its workspace slot receives the row partial)
+  auto flush_row = [&](long u_last) {
+    if constexpr (DET) {
+      double* p = a.part_I + (u_last - a.unit_begin) * (3 * NO * 64) + lane;
 #pragma unroll
-    for (int c = 0; c < 3 * NO; ++c)
-      __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + i], ui[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int c = 0; c < 3 * NO; ++c) p[c * 64] = ui[c];
+    } else {
+      if (!vi_ok) return;
+#pragma unroll
+      for (int c = 0; c < 3 * NO; ++c)
+        __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + i], ui[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   };
 
   while (s < s_end) {
     const int k0 = (int)(s & 63);
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    const long unit = s >> 6;
     s += k1 - k0;
 
     if (I != I_cur) {
-      if (I_cur >= 0 && vi_ok) flush_row();
+      if (I_cur >= 0) flush_row(unit - 1);
       I_cur = I;
       i = 64L * I + lane;
       vi_ok = i < a.n;
@@ -346,7 +361,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const long j = 64L * J + lane;
-      if (j < a.n && !(a.skip_pairs & 2)) {
+      if constexpr (DET) {
+        double* p = a.part_J + (unit - a.unit_begin) * (3 * NO * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < 3 * NO; ++c) p[c * 64] = accj[c * 64 + lane];
+      } else if (j < a.n && !(a.skip_pairs & 2)) {
 #pragma unroll
         for (int c = 0; c < 3 * NO; ++c)
           __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + j], accj[c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -357,7 +376,42 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
       if (++J == a.n_tiles) { ++I; J = I; }
     }
   }
-  if (I_cur >= 0 && vi_ok) flush_row();
+  if (I_cur >= 0) flush_row(((s_end - 1) >> 6));
+}
+
+// Deterministic reduction of the per-unit partials of one chunk [unit_begin, unit_end) into the running accumulators
+// acc[3 NOUT][n_pad]: one workgroup per tile T, one thread per (component, lane); every thread adds, in a fixed order,
+// first the row partials of row T (units (T, J), J ascending, only the slots that end a row run), then the column
+// partials of column T (units (I, T), I ascending).  Chunks are processed in order, so the summation order of every
+// output depends only on N and the launch geometry -- bit-reproducible, unlike the atomic flushes.
+template <int NO>
+__global__ __launch_bounds__(256) void symx_det_reduce_kernel(const SymXArgs a) {
+  const long T = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int nt = a.n_tiles;
+  const long ub = a.unit_begin, ue = a.unit_end, upw = a.units_per_wave;
+  auto rowstart = [nt](long I) { return I * nt - I * (I - 1) / 2; };
+  // rows that own units of this chunk
+  int I_lo, I_hi, dummy;
+  unit_to_tiles(ub, nt, I_lo, dummy);
+  unit_to_tiles(ue - 1, nt, I_hi, dummy);
+  for (int c = threadIdx.x >> 6; c < 3 * NO; c += (int)(blockDim.x >> 6)) {
+    double acc = a.first_chunk ? 0.0 : a.acc[(long)c * a.n_pad + 64 * T + lane];
+    // row partials: units (T, J), J = T .. nt-1
+    const long r0 = rowstart(T), r1 = r0 + (nt - T);
+    const long lo = r0 > ub ? r0 : ub, hi = r1 < ue ? r1 : ue;
+    for (long u = lo; u < hi; ++u) {
+      const bool ends_run = (u == r1 - 1) || (u == ue - 1) || ((u - ub + 1) % upw == 0);
+      if (ends_run) acc += a.part_I[(u - ub) * (3 * NO * 64) + c * 64 + lane];
+    }
+    // column partials: units (I, T), I < T
+    const long Ia = I_lo, Ib = (I_hi < T - 1) ? I_hi : T - 1;
+    for (long I = Ia; I <= Ib; ++I) {
+      const long u = rowstart(I) + (T - I);
+      if (u >= ub && u < ue) acc += a.part_J[(u - ub) * (3 * NO * 64) + c * 64 + lane];
+    }
+    a.acc[(long)c * a.n_pad + 64 * T + lane] = acc;
+  }
 }
 
 template <class OP, bool WALL>

@@ -298,3 +298,52 @@ def test_stream_switch_is_ordered(Ctx, oracle, torch_mod):
   for o in outs:
     assert rel_err(o.cpu().numpy(), ref) < TOL_D2
   ctx.close()
+
+
+@pytest.mark.parametrize("N,wall,L", [(130, True, None), (1000, True, None), (4097, True, None), (1500, False, None),
+                                       (700, True, (14.0, 16.0, 0.0))])
+def test_deterministic_symmetric_mode_is_bit_reproducible_and_correct(Ctx, oracle, torch_mod, N, wall, L):
+  """`deterministic = 2`: the symmetric pass with per-unit partials reduced in a fixed order.  Bit-identical across
+  repeated launches and across fresh contexts (the default atomic path agrees only to rounding), equal to the oracle,
+  for single kinds, the fused row, the grand product and the two-vector product; also with a workspace so small that
+  the unit list is processed in many chunks."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(N, seed=N + 7)
+  t = np.random.RandomState(N + 8).randn(N, 3)
+  ref = _oracle_blocks(oracle, wall, r, f, t, eta, a, L)
+  fd, td = _dev(torch, f), _dev(torch, t)
+
+  def run(workspace_mb=None):
+    ctx = Ctx(0)
+    ctx.set_option("deterministic", 2)
+    if workspace_mb is not None:
+      ctx.set_option("det_workspace_mb", workspace_mb)
+    ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+    res = {}
+    for kind in ("tt", "tr", "rt", "rr"):
+      res[kind] = ctx.matvec_device(kind, fd, eta).cpu().numpy()
+      assert ctx.last_launch()["chunks"] == 0                  # still the symmetric path
+    res["fused"] = ctx.matvec_device("tt_tr", fd, eta, vec2=td).cpu().numpy()
+    u, w = ctx.matvec_op_device("grand", (fd, td), eta)
+    res["grand_u"], res["grand_w"] = u.cpu().numpy(), w.cpu().numpy()
+    ua, ub = ctx.matvec2_device("tt", fd, td, eta)
+    res["two_a"], res["two_b"] = ua.cpu().numpy(), ub.cpu().numpy()
+    res["tt_again"] = ctx.matvec_device("tt", fd, eta).cpu().numpy()
+    ctx.close()
+    return res
+
+  a1, a2 = run(), run()
+  for k in a1:
+    assert np.array_equal(a1[k], a2[k]), k                      # bit-identical across contexts
+  assert np.array_equal(a1["tt"], a1["tt_again"])               # and across launches
+  tol = TOL_D2
+  assert rel_err(a1["tt"], ref["tt_f"]) < tol and rel_err(a1["tr"], oracle._wrapped("tr", int(wall), r, f, eta, a,
+      periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64))) < tol
+  assert rel_err(a1["fused"], ref["tt_f"] + ref["tr_t"]) < tol
+  assert rel_err(a1["grand_u"], ref["tt_f"] + ref["tr_t"]) < tol and rel_err(a1["grand_w"], ref["rt_f"] + ref["rr_t"]) < tol
+  assert rel_err(a1["two_a"], ref["tt_f"]) < tol
+  # many chunks (1 MB workspace): same mathematics, still correct and reproducible
+  b1, b2 = run(workspace_mb=1), run(workspace_mb=1)
+  for k in b1:
+    assert np.array_equal(b1[k], b2[k]), k
+    assert rel_err(b1[k], a1[k]) < 1e-13, k

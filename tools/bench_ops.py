@@ -27,6 +27,8 @@ def timed(ctx, fn, reps, launches_per_product):
   for _ in range(reps):
     fn()
   torch.cuda.synchronize()
+  if launches_per_product is None:          # however many bracketed launches a product takes (chunked passes)
+    return float(np.sum(ctx.timing_collect(8192))) / reps
   ms = ctx.timing_collect(reps * launches_per_product)
   assert len(ms) == reps * launches_per_product, (len(ms), reps, launches_per_product)
   return float(np.sum(ms)) / reps
@@ -68,6 +70,10 @@ for N in SIZES:
   ctx.set_option("deterministic", 1)
   t["tt_sweep"] = timed(ctx, lambda: ctx.matvec_device("tt", fd, eta), reps, 1)
   row(N, "wall tt", "one-sided sweep (deterministic)", t["tt_sweep"])
+  ctx.set_option("deterministic", 2)
+  # the per-product time of mode 2 = sweep + ordered reduction (bracketed together), times the number of chunks
+  det2 = timed(ctx, lambda: ctx.matvec_device("tt", fd, eta), reps, None)
+  row(N, "wall tt", "deterministic symmetric (ordered reduction of per-unit partials)", det2, t["tt_sweep"])
   ctx.set_option("deterministic", 0)
 
   # fused row
