@@ -77,9 +77,9 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *   "deterministic"   [0]  bit-reproducible results (for a given N and device).  1 = the one-sided sweep (every
  *                          ordered pair, fixed summation order, no workspace; ~1.5x the default time);
  *                          2 = the symmetric pass with per-unit partials summed in a fixed order instead of
- *                          atomics (~1.05x; workspace bounded by "det_workspace_mb").  Pair shards (nshards > 1)
- *                          ignore it.  Forces: 1 and 2 both take the one-sided sweep.
- *   "det_workspace_mb" [1024]  workspace of mode 2; the unit list is processed in chunks that fit
+ *                          atomics (1.06-1.18x; workspace min(0.19 N^2 B, "det_workspace_mb")).  Pair shards
+ *                          (nshards > 1) ignore it.  Forces: 1 and 2 both take the one-sided sweep.
+ *   "det_workspace_mb" [8192]  workspace of mode 2; the unit list is processed in chunks that fit
  *   "fused_symmetric" [1]  RMB_TT_TR: 1 = one symmetric pass sharing the pair geometry between both blocks,
  *                          2 = two symmetric passes (tt, then tr accumulated), 0 = the one-sided fused sweep
  *   "symx_single"     [0]  1 = run tt / tr / rt / rr (and the two-vector product) through the generic multi-block

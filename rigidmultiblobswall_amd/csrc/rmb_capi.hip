@@ -73,7 +73,7 @@ struct rmb_ctx {
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial, tmp3n;
   DevBuf det_ws;                 // per-unit partials of the deterministic symmetric pass
-  long opt_det_workspace_mb = 1024;
+  long opt_det_workspace_mb = 8192;   // 8 GiB of the 288: at most a handful of chunks up to 1e6 blobs... see symx_det_device
   DevBuf st[8];    // scratch of the source->target entry point
   DevBuf wave_clock;  // optional per-wave (start, end) wall-clock stamps of the symmetric kernel
   long wave_clock_n = 0;
@@ -374,12 +374,15 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
 
 // ---- generic symmetric operations (symx_kernels.h) ---------------------------------------------------------
 typedef void (*symx_fn)(const rmb::SymXArgs);
-struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n_in, n_out; symx_fn det_sweep; symx_fn det_reduce; int det_occ; };
+typedef void (*symx_combine_fn)(const rmb::SymXArgs, int);
+struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n_in, n_out; symx_fn det_sweep; symx_fn det_reduce;
+                   symx_combine_fn det_combine; int det_occ; };
 template <class OP, bool WALL, bool PER> SymXEntry make_symx_entry() {
   return SymXEntry{rmb::symx_kernel<OP, WALL, PER, false>, rmb::symx_finalize_kernel<OP, WALL>, 0,
                    sizeof(double2) * rmb::kSymWaves * 64 * rmb::SymXRec<OP::NIN>::d2 +
                        sizeof(double) * rmb::kSymWaves * 3 * OP::NOUT * 64,
-                   OP::NIN, OP::NOUT, rmb::symx_kernel<OP, WALL, PER, true>, rmb::symx_det_reduce_kernel<OP::NOUT>, 0};
+                   OP::NIN, OP::NOUT, rmb::symx_kernel<OP, WALL, PER, true>, rmb::symx_det_reduce_kernel<OP::NOUT>,
+                   rmb::symx_det_combine_kernel<OP::NOUT>, 0};
 }
 // SX_K2 + 4 (k - 2) + kind: one block on k = 2..4 vectors
 enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_K2, SX_COUNT = SX_K2 + 12 };
@@ -456,18 +459,24 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
   a.in_plane = in_plane ? 1 : 0;
   a.skip_pairs = 0;
   a.k = make_pair_consts(c->a);
-  // whole units per wave: enough waves for `sym_oversub` resident rounds, never less than one unit each
+  // Chunk = as many units as the workspace holds; whole units per wave, as many waves PER CHUNK LAUNCH as `sym_oversub`
+  // resident rounds (so that every chunk fills the chip), never less than one unit each.
   const int wps = resident_blocks((const void*)se.det_sweep, &se.det_occ);
   const long max_waves = c->n_cu * wps * rmb::kSymWaves * c->opt_sym_oversub;
-  const long upw = (a.n_units + max_waves - 1) / max_waves;
   const size_t slot = (size_t)3 * se.n_out * 64 * sizeof(double);
   long chunk_units = (long)(((size_t)c->opt_det_workspace_mb << 20) / (2 * slot));
-  chunk_units -= chunk_units % upw;
-  if (chunk_units < upw) chunk_units = upw;
-  if (chunk_units > a.n_units) chunk_units = ((a.n_units + upw - 1) / upw) * upw;
-  if (int rc = c->det_ws.reserve((size_t)2 * chunk_units * slot)) return rc;
+  if (chunk_units > a.n_units) chunk_units = a.n_units;
+  if (chunk_units < 1) chunk_units = 1;
+  const long upw = (chunk_units + max_waves - 1) / max_waves;
+  chunk_units = ((chunk_units + upw - 1) / upw) * upw;
+  // slices per tile in the ordered reduction: enough workgroups to fill the chip when there are few tiles
+  long segs = (4 * c->n_cu + tiles - 1) / tiles;
+  if (segs > 32) segs = 32;
+  if (segs < 1) segs = 1;
+  if (int rc = c->det_ws.reserve((size_t)2 * chunk_units * slot + (size_t)tiles * segs * slot)) return rc;
   a.part_I = (double*)c->det_ws.p;
   a.part_J = a.part_I + chunk_units * (3L * se.n_out * 64);
+  a.det_seg = a.part_J + chunk_units * (3L * se.n_out * 64);
   a.units_per_wave = upw;
   a.steps_per_wave = 64 * upw;
   c->last_path = 2; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = 0;
@@ -483,7 +492,8 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
     if (int rc = timing_begin(c, &slot_t)) return rc;
     hipLaunchKernelGGL(se.det_sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
     RMB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(se.det_reduce, dim3((unsigned)tiles), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(se.det_reduce, dim3((unsigned)tiles, (unsigned)segs), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(se.det_combine, dim3((unsigned)tiles), dim3(256), 0, c->stream, a, (int)segs);
     RMB_HIP(hipGetLastError());
     if (int rc = timing_end(c, slot_t)) return rc;
   }

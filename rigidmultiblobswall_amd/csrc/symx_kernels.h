@@ -46,6 +46,7 @@ struct SymXArgs {
   // (64 lanes x 3 NOUT doubles each) into a workspace that symx_det_reduce_kernel sums in a fixed order
   double* part_I;         // [unit - unit_begin][3 NOUT][64]  row-side partial, valid only on the last unit of a row run
   double* part_J;         // [unit - unit_begin][3 NOUT][64]  column-side partial of every off-diagonal unit
+  double* det_seg;        // [n_tiles][det_segments][3 NOUT][64]  slice sums of the ordered reduction
   long unit_begin, unit_end, units_per_wave;
   int first_chunk;        // reduce: start from zero instead of the running accumulators
   PairConsts k;
@@ -380,36 +381,61 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
 }
 
 // Deterministic reduction of the per-unit partials of one chunk [unit_begin, unit_end) into the running accumulators
-// acc[3 NOUT][n_pad]: one workgroup per tile T, one thread per (component, lane); every thread adds, in a fixed order,
-// first the row partials of row T (units (T, J), J ascending, only the slots that end a row run), then the column
-// partials of column T (units (I, T), I ascending).  Chunks are processed in order, so the summation order of every
-// output depends only on N and the launch geometry -- bit-reproducible, unlike the atomic flushes.
+// acc[3 NOUT][n_pad].  For tile T the contributions are, in this fixed order: the row partials of row T (units (T, J),
+// J ascending, only the slots that end a row run), then the column partials of column T (units (I, T), I ascending).
+// Stage 1 (grid n_tiles x det_segments): workgroup (T, s) adds the s-th contiguous slice of that list sequentially,
+// one thread per (component, lane), four independent loads in flight; stage 2 adds the slice sums in order.  Chunks
+// are processed in order, so the summation order of every output depends only on N and the launch geometry --
+// bit-reproducible, unlike the atomic flushes.
 template <int NO>
 __global__ __launch_bounds__(256) void symx_det_reduce_kernel(const SymXArgs a) {
   const long T = blockIdx.x;
+  const int seg = blockIdx.y, S = gridDim.y;
   const int lane = threadIdx.x & 63;
   const int nt = a.n_tiles;
   const long ub = a.unit_begin, ue = a.unit_end, upw = a.units_per_wave;
   auto rowstart = [nt](long I) { return I * nt - I * (I - 1) / 2; };
-  // rows that own units of this chunk
   int I_lo, I_hi, dummy;
-  unit_to_tiles(ub, nt, I_lo, dummy);
+  unit_to_tiles(ub, nt, I_lo, dummy);       // rows that own units of this chunk
   unit_to_tiles(ue - 1, nt, I_hi, dummy);
+  const long r0 = rowstart(T), r1 = r0 + (nt - T);
+  const long lo = r0 > ub ? r0 : ub, hi = r1 < ue ? r1 : ue;
+  const long n_row = hi > lo ? hi - lo : 0;
+  const long Ia = I_lo, Ib = (I_hi < T - 1) ? I_hi : T - 1;
+  const long n_col = Ib >= Ia ? Ib - Ia + 1 : 0;
+  const long len = n_row + n_col;
+  const long t0 = len * seg / S, t1 = len * (seg + 1) / S;
+  constexpr long SLOT = 3 * NO * 64;
+  // value of list entry t for component c (0 when the slot is not a contribution)
+  auto entry = [&](long t, int c) -> double {
+    if (t < n_row) {
+      const long u = lo + t;
+      const bool ends_run = (u == r1 - 1) || (u == ue - 1) || ((u - ub + 1) % upw == 0);
+      return ends_run ? a.part_I[(u - ub) * SLOT + c * 64 + lane] : 0.0;
+    }
+    const long I = Ia + (t - n_row);
+    const long u = rowstart(I) + (T - I);
+    return (u >= ub && u < ue) ? a.part_J[(u - ub) * SLOT + c * 64 + lane] : 0.0;
+  };
+  for (int c = threadIdx.x >> 6; c < 3 * NO; c += (int)(blockDim.x >> 6)) {
+    double acc = 0.0;
+    long t = t0;
+    for (; t + 4 <= t1; t += 4) {
+      const double v0 = entry(t, c), v1 = entry(t + 1, c), v2 = entry(t + 2, c), v3 = entry(t + 3, c);
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; t < t1; ++t) acc += entry(t, c);
+    a.det_seg[((T * S + seg) * 3 * NO + c) * 64 + lane] = acc;
+  }
+}
+
+template <int NO>
+__global__ __launch_bounds__(256) void symx_det_combine_kernel(const SymXArgs a, int S) {
+  const long T = blockIdx.x;
+  const int lane = threadIdx.x & 63;
   for (int c = threadIdx.x >> 6; c < 3 * NO; c += (int)(blockDim.x >> 6)) {
     double acc = a.first_chunk ? 0.0 : a.acc[(long)c * a.n_pad + 64 * T + lane];
-    // row partials: units (T, J), J = T .. nt-1
-    const long r0 = rowstart(T), r1 = r0 + (nt - T);
-    const long lo = r0 > ub ? r0 : ub, hi = r1 < ue ? r1 : ue;
-    for (long u = lo; u < hi; ++u) {
-      const bool ends_run = (u == r1 - 1) || (u == ue - 1) || ((u - ub + 1) % upw == 0);
-      if (ends_run) acc += a.part_I[(u - ub) * (3 * NO * 64) + c * 64 + lane];
-    }
-    // column partials: units (I, T), I < T
-    const long Ia = I_lo, Ib = (I_hi < T - 1) ? I_hi : T - 1;
-    for (long I = Ia; I <= Ib; ++I) {
-      const long u = rowstart(I) + (T - I);
-      if (u >= ub && u < ue) acc += a.part_J[(u - ub) * (3 * NO * 64) + c * 64 + lane];
-    }
+    for (int s = 0; s < S; ++s) acc += a.det_seg[((T * S + s) * 3 * NO + c) * 64 + lane];
     a.acc[(long)c * a.n_pad + 64 * T + lane] = acc;
   }
 }
