@@ -73,7 +73,7 @@ struct rmb_ctx {
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial, tmp3n;
   DevBuf det_ws;                 // per-unit partials of the deterministic symmetric pass
-  long opt_det_workspace_mb = 8192;   // 8 GiB of the 288: at most a handful of chunks up to 1e6 blobs... see symx_det_device
+  long opt_det_workspace_mb = 8192;   // cap on the partial-result workspace of deterministic = 2 (symx_det_device)
   DevBuf st[8];    // scratch of the source->target entry point
   DevBuf wave_clock;  // optional per-wave (start, end) wall-clock stamps of the symmetric kernel
   long wave_clock_n = 0;
