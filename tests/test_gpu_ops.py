@@ -229,7 +229,7 @@ def test_padding_sentinels_with_power_of_two_box(Ctx, oracle, torch_mod, wall, z
 
 
 @pytest.mark.parametrize("op,n_in", [("velocity_from_force_torque", 2), ("grand", 2), ("force_column", 1), ("tt_multi", 3)])
-@pytest.mark.parametrize("N,L", [(1000, None), (90, None), (400, (11.0, 12.0, 0.0))])
+@pytest.mark.parametrize("N,L", [(1000, None), (90, None), (24, None), (400, (11.0, 12.0, 0.0))])
 def test_op_pair_shards_sum_to_full_product(Ctx, torch_mod, op, n_in, N, L):
   """What G ranks compute (pair shard g of G into a full-length partial) summed the way all_reduce will."""
   torch = torch_mod
