@@ -379,13 +379,13 @@ struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n
                    symx_combine_fn det_combine; int det_occ; };
 template <class OP, bool WALL, bool PER> SymXEntry make_symx_entry() {
   return SymXEntry{rmb::symx_kernel<OP, WALL, PER, false>, rmb::symx_finalize_kernel<OP, WALL>, 0,
-                   sizeof(double2) * rmb::kSymWaves * 64 * rmb::SymXRec<OP::NIN>::d2 +
+                   sizeof(double2) * rmb::kSymWaves * 64 * rmb::SymXRec<OP::NIN, rmb::SymXExtra<OP>::value>::d2 +
                        sizeof(double) * rmb::kSymWaves * 3 * OP::NOUT * 64,
                    OP::NIN, OP::NOUT, rmb::symx_kernel<OP, WALL, PER, true>, rmb::symx_det_reduce_kernel<OP::NOUT>,
                    rmb::symx_det_combine_kernel<OP::NOUT>, 0};
 }
 // SX_K2 + 4 (k - 2) + kind: one block on k = 2..4 vectors
-enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_K2, SX_COUNT = SX_K2 + 12 };
+enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_RADII, SX_K2, SX_COUNT = SX_K2 + 12 };
 // [op][wall][periodic]
 #define RMB_SX_ROW(OP) {{make_symx_entry<OP, false, false>(), make_symx_entry<OP, false, true>()}, {make_symx_entry<OP, true, false>(), make_symx_entry<OP, true, true>()}}
 SymXEntry g_symx[SX_COUNT][2][2] = {
@@ -394,6 +394,7 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
     // the free-surface operation takes raw heights: only the wall = 0 column is ever launched
     {{make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
      {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
+    RMB_SX_ROW(rmb::OpRadiiTT),
 #define RMB_SX_K(K) RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_TT, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_TR, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_RT, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_RR, K))
 #define RMB_SX_KIND(KIND, K) rmb::OpKindK<KIND, K>
     RMB_SX_K(2), RMB_SX_K(3), RMB_SX_K(4)};
@@ -401,27 +402,35 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
 #undef RMB_SX_KIND
 #undef RMB_SX_ROW
 
+// Configuration a symmetric pass runs on: the context's resident one, or a caller-packed one (per-blob radii)
+struct SymConf { const double4* pos; long n; double L[3]; int wall; const double* extra; };
+SymConf conf_of(const rmb_ctx* c) {
+  return SymConf{(const double4*)c->pos.p, c->n, {c->L[0], c->L[1], c->L[2]}, c->wall, nullptr};
+}
+
 int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane, long shard,
-                long nshards, int accumulate_mask = 0) {
-  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
-  SymXEntry& se = g_symx[op][c->wall ? 1 : 0][periodic ? 1 : 0];
-  const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
+                long nshards, int accumulate_mask = 0, const SymConf* conf_in = nullptr) {
+  const SymConf cf = conf_in ? *conf_in : conf_of(c);
+  const bool periodic = cf.L[0] > 0 || cf.L[1] > 0 || cf.L[2] > 0;
+  SymXEntry& se = g_symx[op][cf.wall ? 1 : 0][periodic ? 1 : 0];
+  const long n = cf.n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
   if (int rc = sym_accumulators(c, n_pad)) return rc;
   rmb::SymXArgs a;
-  a.pos = (const double4*)c->pos.p;
+  a.pos = cf.pos;
+  a.extra = cf.extra;
   for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
   a.acc = (double*)c->symbuf.p;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
   shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
-  a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
-  a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
-  a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
-  a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
+  a.Lx = cf.L[0]; a.Ly = cf.L[1]; a.Lz = cf.L[2];
+  a.iLx = cf.L[0] > 0 ? 1.0 / cf.L[0] : 0.0;
+  a.iLy = cf.L[1] > 0 ? 1.0 / cf.L[1] : 0.0;
+  a.iLz = cf.L[2] > 0 ? 1.0 / cf.L[2] : 0.0;
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.accumulate = accumulate_mask;
   a.in_plane = in_plane ? 1 : 0;
   a.skip_pairs = (int)c->opt_skip_pairs;
-  a.k = make_pair_consts(c->a);
+  a.k = make_pair_consts(c->a > 0.0 ? c->a : 1.0);   // unused by the per-blob-radii operation
   SymPlan plan;
   if (int rc = plan_sym(c, (const void*)se.sweep, &se.occ, se.static_lds, a.step_end - a.step_begin, true, &plan)) return rc;
   a.steps_per_wave = plan.steps_per_wave;
@@ -446,6 +455,7 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
   if (int rc = sym_accumulators(c, n_pad)) return rc;
   rmb::SymXArgs a;
   a.pos = (const double4*)c->pos.p;
+  a.extra = nullptr;
   for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
   a.acc = (double*)c->symbuf.p;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
@@ -1039,6 +1049,19 @@ int rmb_mobility_source_target_device(rmb_ctx* c, long ns, const double* src_dev
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   RMB_HIP(hipSetDevice(c->device));
   if (ns == 0) { RMB_HIP(hipMemsetAsync(out_dev, 0, (size_t)3 * nt * sizeof(double), c->stream)); return 0; }
+  if (src_dev == tgt_dev && rad_s_dev == rad_t_dev && ns == nt && ns >= 128 && (wall == 0 || wall == 1) &&
+      c->opt_symmetric && c->opt_deterministic == 0) {
+    // Sources == targets (the reference's `radii_*` mobility modes, mobility/mobility.py:1369-1374): the operator is
+    // symmetric, each unordered pair once on the generic symmetric skeleton (symx_kernels.h, OpRadiiTT)
+    if (int rc = c->st[0].reserve((size_t)ns * sizeof(double4))) return rc;
+    hipLaunchKernelGGL(rmb::pack_positions_radii_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, src_dev,
+                       rad_s_dev, ns, wall, (double4*)c->st[0].p);
+    RMB_HIP(hipGetLastError());
+    SymConf cf{(const double4*)c->st[0].p, ns, {L ? L[0] : 0.0, L ? L[1] : 0.0, L ? L[2] : 0.0}, wall, rad_s_dev};
+    const double* in[1] = {force_dev};
+    double* outs[1] = {out_dev};
+    return symx_device(c, SX_RADII, in, outs, eta, 0, 0, 1, 0, &cf);
+  }
   if (int rc = c->st[0].reserve((size_t)ns * sizeof(double4))) return rc;
   if (int rc = c->st[1].reserve((size_t)nt * sizeof(double4))) return rc;
   hipLaunchKernelGGL(rmb::pack_positions_radii_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, src_dev,
@@ -1111,8 +1134,13 @@ int rmb_mobility_source_target(long ns, const double* src, const double* rad_s, 
   }
   RMB_HIP(hipMemcpyAsync(c->st[4].p, tgt, bt3, hipMemcpyHostToDevice, c->stream));
   RMB_HIP(hipMemcpyAsync(c->st[5].p, rad_t, bt1, hipMemcpyHostToDevice, c->stream));
-  if (int rc = rmb_mobility_source_target_device(c, ns, (const double*)c->st[2].p, (const double*)c->st[3].p, nt,
-                                                 (const double*)c->st[4].p, (const double*)c->st[5].p,
+  // sources == targets (same arrays, or equal contents): hand the device entry the SAME pointers, which selects its
+  // symmetric path
+  const bool same = ns == nt && ns > 0 && (src == tgt || !memcmp(src, tgt, (size_t)3 * ns * sizeof(double))) &&
+                    (rad_s == rad_t || !memcmp(rad_s, rad_t, (size_t)ns * sizeof(double)));
+  const double* tgt_d = same ? (const double*)c->st[2].p : (const double*)c->st[4].p;
+  const double* radt_d = same ? (const double*)c->st[3].p : (const double*)c->st[5].p;
+  if (int rc = rmb_mobility_source_target_device(c, ns, (const double*)c->st[2].p, (const double*)c->st[3].p, nt, tgt_d, radt_d,
                                                  (const double*)c->st[6].p, eta, L, wall, (double*)c->st[7].p))
     return rc;
   RMB_HIP(hipMemcpyAsync(out, c->st[7].p, bt3, hipMemcpyDeviceToHost, c->stream));

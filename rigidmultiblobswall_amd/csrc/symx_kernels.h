@@ -30,6 +30,7 @@ namespace rmb {
 struct SymXArgs {
   const double4* pos;
   const double* in[4];    // [NIN] source vectors (AoS, 3n)
+  const double* extra;    // [n] one extra scalar per blob for operations with OP::NEXTRA = 1 (per-blob radius), else unused
   double* out[4];         // [NOUT] outputs (AoS, 3n)
   double* acc;            // [NOUT][3][n_pad] global SoA accumulators; zero on entry, re-zeroed by finalize
   long n, n_pad;
@@ -213,21 +214,124 @@ struct OpFreeSurface {
   }
 };
 
+// Translation mobility of blobs with DIFFERENT radii, sources == targets (the reference's `radii_*` modes call the
+// source->target kernel with the same array on both sides, mobility/mobility.py:1369-1374; pair formulas
+// mobility_numba.py:1480-1658, restated one-sided in st_kernels.h).  The unbounded part (Zuk et al., three regimes)
+// is symmetric in the two radii; of the five wall scalars alpha, beta, eps are symmetric under the exchange of the
+// two blobs and gamma <-> delta swap, so the reversed pair costs one more contraction.  vi[3] / vj[3] = radius.
+struct STc { double C1, C2, alpha, beta, gamma, delta, eps, rz; };
+
+template <bool WALL>
+__device__ __forceinline__ STc st_coeffs(double dx, double dy, double dz, double x3, double y3, double at, double as) {
+  STc c;
+  const double rho2 = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, rho2);
+  const double a2 = at * at, b2 = as * as, s = a2 + b2;
+  const double ir = rsqrt_f64(r2);
+  const double ir2 = ir * ir;
+  c.C1 = __builtin_fma(s * (1.0 / 3.0), ir2, 1.0) * ir;
+  c.C2 = __builtin_fma(-s, ir2, 1.0) * ir2 * ir;
+  const double sum = at + as;
+  if (__builtin_expect(__any(!(r2 > sum * sum)), 0)) {
+    // overlapping blobs (rare): Zuk et al. regimes 2 and 3, evaluated with true divisions
+    const double r = (r2 > 0.0) ? sqrt(r2) : 0.0;
+    const double dm = (as - at) * (as - at);
+    const double r3 = r2 * r;
+    const double t = dm + 3.0 * r2, q = dm - r2;
+    const double pre = (4.0 / 3.0) / (as * at);
+    const double C1m = ((16.0 * sum * r3 - t * t) / (32.0 * r3)) * pre;
+    const double C2m = ((3.0 * q * q / (32.0 * r3)) / r2) * pre;
+    const bool far = r > sum;
+    const bool mid = r > fabs(as - at);
+    c.C1 = far ? c.C1 : (mid ? C1m : (4.0 / 3.0) / fmax(at, as));
+    c.C2 = far ? c.C2 : (mid ? C2m : 0.0);
+  }
+  c.rz = x3 + y3;
+  if constexpr (WALL) {
+    const double rz = c.rz;
+    const double R2 = __builtin_fma(rz, rz, rho2);
+    const double i1 = rsqrt_f64(R2);
+    const double i2 = i1 * i1, i3 = i1 * i2, i5 = i3 * i2, i7 = i5 * i2, i9 = i7 * i2;
+    const double ab = a2 * b2, xy = x3 * y3;
+    const double m = rz * __builtin_fma(a2, y3, b2 * x3);
+    const double ab23 = ab * (2.0 / 3.0);
+    const double rz2 = rz * rz;
+    c.alpha = __builtin_fma(ab23, __builtin_fma(5.0 * rz2, i7, -i5),
+                            __builtin_fma(-2.0 * m, i5, __builtin_fma(__builtin_fma(2.0, xy, s * (1.0 / 3.0)), i3, i1)));
+    c.beta = __builtin_fma(ab23, __builtin_fma(-35.0 * rz2, i9, 5.0 * i7),
+                           __builtin_fma(10.0 * m, i7, __builtin_fma(-__builtin_fma(6.0, xy, s), i5, i3)));
+    const double abz = ab * (20.0 / 3.0) * rz * i7;
+    const double dab = 2.0 * (a2 - b2) * i5;
+    c.gamma = __builtin_fma(x3, __builtin_fma(-2.0, i3, dab), abz);
+    c.delta = __builtin_fma(y3, -__builtin_fma(2.0, i3, dab), abz);
+    c.eps = -__builtin_fma(ab * (4.0 / 3.0), i5, __builtin_fma(s * (2.0 / 3.0), i3, i1 + i1));
+  } else {
+    c.alpha = c.beta = c.gamma = c.delta = c.eps = 0.0;
+  }
+  return c;
+}
+
+// u += M(target <- source) f with the wall scalars (gam, del) of that direction and the image separation
+// R = (sx dx, sx dy, rz), sx = +1 forward / -1 reversed (g = (-f_x, -f_y, f_z))
+template <bool WALL>
+__device__ __forceinline__ void st_apply(const STc& c, double dx, double dy, double dz, double sx, double gam, double del,
+                                         const double* f, double* u) {
+  const double pxy = __builtin_fma(dy, f[1], dx * f[0]);
+  const double cD = c.C2 * __builtin_fma(dz, f[2], pxy);
+  if constexpr (!WALL) {
+    u[0] = __builtin_fma(c.C1, f[0], u[0]); u[0] = __builtin_fma(cD, dx, u[0]);
+    u[1] = __builtin_fma(c.C1, f[1], u[1]); u[1] = __builtin_fma(cD, dy, u[1]);
+    u[2] = __builtin_fma(c.C1, f[2], u[2]); u[2] = __builtin_fma(cD, dz, u[2]);
+  } else {
+    const double Rg = __builtin_fma(c.rz, f[2], -sx * pxy);      // R . g
+    const double cR = __builtin_fma(c.beta, Rg, gam * f[2]);
+    const double cz = __builtin_fma(del, Rg, c.eps * f[2]);
+    const double cFxy = c.C1 - c.alpha, cFz = c.C1 + c.alpha;
+    const double cDR = __builtin_fma(sx, cR, cD);                // coefficient of (d_x, d_y)
+    u[0] = __builtin_fma(cFxy, f[0], u[0]); u[0] = __builtin_fma(cDR, dx, u[0]);
+    u[1] = __builtin_fma(cFxy, f[1], u[1]); u[1] = __builtin_fma(cDR, dy, u[1]);
+    u[2] = __builtin_fma(cFz, f[2], u[2]); u[2] = __builtin_fma(cD, dz, u[2]);
+    u[2] = __builtin_fma(cR, c.rz, u[2]); u[2] += cz;
+  }
+}
+
+struct OpRadiiTT {
+  static constexpr int NIN = 1, NOUT = 1, NEXTRA = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const PairConsts&, double dx, double dy, double dz, double zi, double zj,
+                                              const double* vi, const double* vj, double* ui, double* t) {
+    const STc c = st_coeffs<WALL>(dx, dy, dz, zi, zj, vi[3], vj[3]);
+    st_apply<WALL>(c, dx, dy, dz, 1.0, c.gamma, c.delta, vj, ui);
+    t[0] = 0.0; t[1] = 0.0; t[2] = 0.0;
+    st_apply<WALL>(c, dx, dy, dz, -1.0, c.delta, c.gamma, vi, t);   // reversed pair: gamma <-> delta, R' = (-d_x, -d_y, r_z)
+  }
+  // i == j is an ordinary pair of the formulas (r = 0 is the third Zuk regime; the blob's own wall image)
+  template <bool WALL>
+  static __device__ __forceinline__ void self(const PairConsts&, double zi, const double* vi, double* ui) {
+    const STc c = st_coeffs<WALL>(0.0, 0.0, 0.0, zi, zi, vi[3], vi[3]);
+    st_apply<WALL>(c, 0.0, 0.0, 0.0, 1.0, c.gamma, c.delta, vi, ui);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Skeleton
 // ---------------------------------------------------------------------------------------------
 
 // LDS record of one blob: x, y, z, then NIN 3-vectors, in double2 units; an ODD number of double2 keeps the
 // per-lane ds_read_b128 of consecutive records conflict-free (48 / 80 / 112 / 144 bytes).
-template <int NIN> struct SymXRec { static constexpr int nd = 3 + 3 * NIN; static constexpr int d2 = ((nd + 1) / 2) | 1; };
+template <int NIN, int NEXTRA = 0> struct SymXRec { static constexpr int nd = 3 + 3 * NIN + NEXTRA; static constexpr int d2 = ((nd + 1) / 2) | 1; };
+// OP::NEXTRA (optional, default 0): per-blob scalars that travel with the vectors (vi / vj carry them after the 3 NIN
+// vector components)
+template <class OP, class = void> struct SymXExtra { static constexpr int value = 0; };
+template <class OP> struct SymXExtra<OP, decltype((void)OP::NEXTRA)> { static constexpr int value = OP::NEXTRA; };
 
 // (Measured and dropped: storing every record / accumulator slot twice so that the rotation index lane + k needs no
 //  `& 63` wrap removes 2 of the 4 integer instructions per step -- 106 -> 104 -- and changes nothing in time,
 //  0.1853 vs 0.1849 ms at 1e4 blobs, 17.17 vs 17.27 ms at 1e5: the integer work already hides under fp64 issue.)
 template <class OP, bool WALL, bool PERIODIC, bool DET = false>
 __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) {
-  constexpr int NI = OP::NIN, NO = OP::NOUT;
-  constexpr int RD2 = SymXRec<NI>::d2;
+  constexpr int NI = OP::NIN, NO = OP::NOUT, NX = SymXExtra<OP>::value;
+  constexpr int RD2 = SymXRec<NI, NX>::d2;
   constexpr int RECB = RD2 * 16;
   __shared__ double2 rec_all[kSymWaves][64 * RD2];
   __shared__ double accj_all[kSymWaves][3 * NO * 64];
@@ -248,9 +352,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
   long i = 0;
   bool vi_ok = false;
   double xi = 0, yi = 0, zi = 1.0;
-  double vi[3 * NI], ui[3 * NO];
+  double vi[3 * NI + NX], ui[3 * NO];
 #pragma unroll
-  for (int c = 0; c < 3 * NI; ++c) vi[c] = 0.0;
+  for (int c = 0; c < 3 * NI + NX; ++c) vi[c] = 0.0;
 #pragma unroll
   for (int c = 0; c < 3 * NO; ++c) ui[c] = 0.0;
 
@@ -282,10 +386,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
       vi_ok = i < a.n;
       xi = 1e100; yi = 1e100; zi = 1.0;
 #pragma unroll
-      for (int c = 0; c < 3 * NI; ++c) vi[c] = 0.0;
+      for (int c = 0; c < 3 * NI + NX; ++c) vi[c] = 0.0;
       if (vi_ok) {
         const double4 p = a.pos[i];
         xi = p.x; yi = p.y; zi = p.z;
+        if constexpr (NX > 0) vi[3 * NI] = a.extra[i];
 #pragma unroll
         for (int v = 0; v < NI; ++v) {
           vi[3 * v] = a.in[v][3 * i] * p.w; vi[3 * v + 1] = a.in[v][3 * i + 1] * p.w;
@@ -309,6 +414,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
           rd[3 + 3 * v] = a.in[v][3 * j] * p.w; rd[4 + 3 * v] = a.in[v][3 * j + 1] * p.w;
           rd[5 + 3 * v] = a.in_plane ? 0.0 : a.in[v][3 * j + 2] * p.w;
         }
+        if constexpr (NX > 0) rd[3 + 3 * NI] = a.extra[j];
       }
 #pragma unroll
       for (int c = 0; c < RD2; ++c) rec[lane * RD2 + c] = make_double2(rd[2 * c], rd[2 * c + 1]);
@@ -442,12 +548,13 @@ __global__ __launch_bounds__(256) void symx_det_combine_kernel(const SymXArgs a,
 
 template <class OP, bool WALL>
 __global__ __launch_bounds__(256) void symx_finalize_kernel(const SymXArgs a) {
-  constexpr int NI = OP::NIN, NO = OP::NOUT;
+  constexpr int NI = OP::NIN, NO = OP::NOUT, NX = SymXExtra<OP>::value;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const double4 p = a.pos[i];
   const double b = p.w;
-  double vi[3 * NI], u[3 * NO];
+  double vi[3 * NI + NX], u[3 * NO];
+  if constexpr (NX > 0) vi[3 * NI] = a.extra[i];
 #pragma unroll
   for (int v = 0; v < NI; ++v) {
     vi[3 * v] = a.in[v][3 * i] * b; vi[3 * v + 1] = a.in[v][3 * i + 1] * b;

@@ -347,3 +347,48 @@ def test_deterministic_symmetric_mode_is_bit_reproducible_and_correct(Ctx, oracl
   for k in b1:
     assert np.array_equal(b1[k], b2[k]), k
     assert rel_err(b1[k], a1[k]) < 1e-13, k
+
+
+@pytest.mark.parametrize("N", [128, 700, 3000])
+@pytest.mark.parametrize("wall", [1, 0])
+@pytest.mark.parametrize("L", [None, (9.0, 10.0, 0.0)])
+def test_radii_mobility_sources_equal_targets_is_symmetric_pass(Ctx, oracle, torch_mod, N, wall, L):
+  """`radii_*` mobility modes call the source->target product with the same blobs on both sides
+  (mobility/mobility.py:1369-1374); that operator is symmetric and runs on the symmetric skeleton (OpRadiiTT):
+  overlapping blobs of very different radii (all three Zuk regimes), blobs below their own radius (per-blob clamp +
+  B), pseudo-periodic images; against the oracle and against the one-sided source->target sweep."""
+  import ctypes
+  from rigidmultiblobswall_amd import _lib, mobility as mob
+  torch = torch_mod
+  rng = np.random.RandomState(N + wall)
+  box = (N ** (1.0 / 3.0)) * 0.9
+  r = rng.rand(N, 3) * box
+  rad = 0.05 + 0.6 * rng.rand(N) ** 2
+  f = rng.randn(N, 3)
+  eta = 0.8
+  Lv = np.zeros(3) if L is None else np.asarray(L, dtype=np.float64)
+  pre = "single_wall" if wall else "no_wall"
+  ref = getattr(oracle, pre + "_mobility_trans_times_force_source_target_oracle")(r, r, f, rad, rad, eta, periodic_length=Lv)
+  # host surface: same arrays on both sides
+  fn = getattr(mob, pre + "_mobility_trans_times_force_source_target_hip")
+  u = mob.mobility_radii_trans_times_force(r, f, eta, 0.3, rad, fn, periodic_length=Lv)
+  assert rel_err(u, ref) < TOL_D1, rel_err(u, ref)
+  # equal contents in different arrays take the same path
+  u_b = fn(r.copy(), r, f, rad.copy(), rad, eta, periodic_length=Lv)
+  assert rel_err(u_b, u) < 1e-13
+  # device entry: symmetric path (chunks == 0) when the pointers coincide, one-sided sweep otherwise; same numbers
+  ctx = Ctx(0)
+  lib = _lib.load()
+  rd, radd, fd = _dev(torch, r), _dev(torch, rad), _dev(torch, f)
+  rd2, radd2 = rd.clone(), radd.clone()
+  out = torch.empty(3 * N, dtype=torch.float64, device="cuda")
+  out2 = torch.empty_like(out)
+  vp = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+  Lp = ctypes.c_void_p(Lv.ctypes.data)
+  _lib.check(lib.rmb_mobility_source_target_device(ctx._h, N, vp(rd), vp(radd), N, vp(rd), vp(radd), vp(fd), eta, Lp, wall, vp(out)))
+  assert ctx.last_launch()["chunks"] == 0
+  _lib.check(lib.rmb_mobility_source_target_device(ctx._h, N, vp(rd), vp(radd), N, vp(rd2), vp(radd2), vp(fd), eta, Lp, wall, vp(out2)))
+  assert ctx.last_launch()["chunks"] >= 1
+  assert rel_err(out.cpu().numpy(), ref) < TOL_D1
+  assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < 1e-12
+  ctx.close()
