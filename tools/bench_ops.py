@@ -122,6 +122,18 @@ for N in SIZES:
   row(N, "forces, per-blob radii", "one-sided sweep", sw)
   row(N, "forces, per-blob radii", "symmetric (sym_force_kernel<RADII>)", timed(ctx, lambda: ctx.blob_blob_force_radii_device(rad, 3.92, 0.1 * a), reps, 1), sw)
   row(N, "forces", "symmetric", timed(ctx, lambda: ctx.blob_blob_force_device(3.92, 0.1 * a, a), reps, 1))
+  # per-blob-radii mobility, sources == targets (the reference's radii_* modes), wall
+  import ctypes
+  from rigidmultiblobswall_amd import _lib
+  lib = _lib.load()
+  vp = lambda t: ctypes.c_void_p(t.data_ptr())
+  rd2, rad2, outr = rd.clone(), rad.clone(), torch.empty_like(fd)
+  L0 = np.zeros(3)
+  Lp = ctypes.c_void_p(L0.ctypes.data)
+  st = lambda tgt, radt: _lib.check(lib.rmb_mobility_source_target_device(ctx._h, N, vp(rd), vp(rad), N, vp(tgt), vp(radt), vp(fd), eta, Lp, 1, vp(outr)))
+  sw = timed(ctx, lambda: st(rd2, rad2), reps, 1)
+  row(N, "radii mobility, wall (sources == targets)", "one-sided source->target sweep", sw)
+  row(N, "radii mobility, wall (sources == targets)", "symmetric (symx OpRadiiTT)", timed(ctx, lambda: st(rd, rad), reps, 1), sw)
   for kind in ("tt", "tr", "rt", "rr"):
     row(N, "no-wall " + kind, "sym_kernel", timed(ctx, lambda: ctx.matvec_device(kind, fd, eta), reps, 1))
   row(N, "no-wall grand", "single symmetric pass (symx OpGrand)", timed(ctx, lambda: ctx.matvec_op_device("grand", (fd, td), eta), reps, 1))
