@@ -349,8 +349,13 @@ def rank_main(args):
       dec = {"pair_shard_allreduce": [], "target_shard_allgather": []}
       for nb, st_, wu in ((10000, 50, 5), (100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
         rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "pair", 100.0 if nb == 10000 else 0.0)
+        tb, prov = committed_traffic(nb, True) if world == 1 else (None, {})
         dec["pair_shard_allreduce"].append({
             "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
+            # HBM-side traffic of one launch from the committed rocprofv3 --pmc passes (not measured in this run) over
+            # this run's kernel time: what the metric's "HBM GB/s vs N_blobs" is for a VALU-bound kernel
+            "hbm_traffic_gbps": None if tb is None else round(tb / (rs["kern_ms"] * 1e-3) / 1e9, 1),
+            "hbm_traffic_source": prov.get("source"),
             "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
             "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
             "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]})
