@@ -50,58 +50,73 @@ __device__ __forceinline__ void rpy_tt_coeffs(const PairConsts& k, double r2, do
   }
 }
 
-struct TTc { double cF, cD, nG2, G3r, G4r, G5r; };
+// A pair block of the form (d = (d_x, d_y, d_z), R = (d_x, d_y, R_z); tt and rr with and without wall all have it)
+//        | F + P dx dx    P dx dy     Q3 dx |
+//   M =  |   P dx dy    F + P dy dy   Q3 dy |          M^T = the same with Q3 <-> Q4
+//        |   Q4 dx        Q4 dy       Szz   |
+// applied as  p = d_x v_x + d_y v_y,  s = P p + Q3 v_z,  (M v)_xy = F v_xy + s d_xy,  (M v)_z = Q4 p + Szz v_z :
+// ten instructions per direction and vector, whatever the block costs to build.
+struct BlockM { double F, P, Q3, Q4, Szz; };
+
+// ui += M vj ;  t (+)= M^T vi
+template <bool ACC>
+__device__ __forceinline__ void block_apply(const BlockM& m, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
+  const double sj = __builtin_fma(m.P, pj, m.Q3 * vj[2]);
+  ui[0] = __builtin_fma(m.F, vj[0], ui[0]); ui[0] = __builtin_fma(sj, g.dx, ui[0]);
+  ui[1] = __builtin_fma(m.F, vj[1], ui[1]); ui[1] = __builtin_fma(sj, g.dy, ui[1]);
+  ui[2] = __builtin_fma(m.Q4, pj, ui[2]); ui[2] = __builtin_fma(m.Szz, vj[2], ui[2]);
+  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
+  const double si = __builtin_fma(m.P, pi, m.Q4 * vi[2]);
+  t[0] = __builtin_fma(si, g.dx, ACC ? __builtin_fma(m.F, vi[0], t[0]) : m.F * vi[0]);
+  t[1] = __builtin_fma(si, g.dy, ACC ? __builtin_fma(m.F, vi[1], t[1]) : m.F * vi[1]);
+  t[2] = __builtin_fma(m.Szz, vi[2], ACC ? __builtin_fma(m.Q3, pi, t[2]) : m.Q3 * pi);
+}
+
+// tt:  M = cF I + cD d d^T  (+ wall: -G1 iR I + nG2 R R^T + G3r R z^T + G4r z R^T + G5r z z^T, see wall_tt_from_iR)
+typedef BlockM TTc;
 
 template <bool WALL>
 __device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zj) {
-  TTc c;
-  rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, c.cF, c.cD);
+  TTc m;
+  double cF, cD;
+  rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, cF, cD);
   if constexpr (WALL) {
+    const double cDdz = cD * g.dz;
     const WallTT W = wall_tt_from_iR(k, g.Rz, g.iR, zj);
     const double iR3 = W.iR * W.iR2;
-    c.cF = __builtin_fma(-W.G1, W.iR, c.cF);
-    c.nG2 = -W.G2 * iR3;
-    c.G3r = W.G3 * W.iR2;
-    c.G4r = W.G4 * W.iR2;
-    c.G5r = W.G5 * W.iR;
+    const double nG2 = -W.G2 * iR3, G3r = W.G3 * W.iR2, G4r = W.G4 * W.iR2;
+    cF = __builtin_fma(-W.G1, W.iR, cF);
+    const double t1 = nG2 * g.Rz;
+    const double tz = cDdz + t1;                       // cD d_z + nG2 R_z
+    m.F = cF;
+    m.P = cD + nG2;
+    m.Q3 = tz + G3r;
+    m.Q4 = tz + G4r;
+    // Szz = cF + cD dz^2 + nG2 Rz^2 + (G3r + G4r) Rz + G5 iR
+    m.Szz = __builtin_fma(t1 + (G3r + G4r), g.Rz, __builtin_fma(cDdz, g.dz, __builtin_fma(W.G5, W.iR, cF)));
   } else {
-    c.nG2 = c.G3r = c.G4r = c.G5r = 0.0;
+    m.F = cF; m.P = cD;          // tt_apply<false> contracts these two directly
+    m.Q3 = m.Q4 = m.Szz = 0.0;
   }
-  return c;
+  return m;
 }
 
-// ui += M_tt,ij vj ;  t (+)= M_tt,ji vi       (same algebra as pair_tt_sym)
+// ui += M_tt,ij vj ;  t (+)= M_tt,ji vi
 template <bool WALL, bool ACC>
 __device__ __forceinline__ void tt_apply(const TTc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
-  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
-  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
-  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
-  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
-  const double t0 = ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0];
-  const double t1 = ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1];
-  if constexpr (!WALL) {
-    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    t[0] = __builtin_fma(cDi, g.dx, t0);
-    t[1] = __builtin_fma(cDi, g.dy, t1);
-    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
+  if constexpr (WALL) {
+    block_apply<ACC>(c, g, vi, vj, ui, t);
   } else {
-    const double Rvj = __builtin_fma(g.Rz, vj[2], pj);
-    const double cRj = __builtin_fma(c.G3r, vj[2], c.nG2 * Rvj);
-    const double cbj = __builtin_fma(c.G5r, vj[2], c.G4r * Rvj);
-    const double cj = cDj + cRj;
-    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    ui[2] = __builtin_fma(cRj, g.Rz, ui[2]); ui[2] += cbj;
-    const double Rvi = __builtin_fma(g.Rz, vi[2], pi);
-    const double cRi = __builtin_fma(c.G4r, vi[2], c.nG2 * Rvi);
-    const double cbi = __builtin_fma(c.G5r, vi[2], c.G3r * Rvi);
-    const double ci = cDi + cRi;
-    t[0] = __builtin_fma(ci, g.dx, t0);
-    t[1] = __builtin_fma(ci, g.dy, t1);
-    t[2] = __builtin_fma(cRi, g.Rz, __builtin_fma(cDi, g.dz, __builtin_fma(c.cF, vi[2], ACC ? t[2] + cbi : cbi)));
+    // no wall: F v + cD (d.v) d needs nothing built (tt_coeffs<false> leaves Q3, Q4, Szz unset)
+    const double cDj = c.P * __builtin_fma(g.dz, vj[2], __builtin_fma(g.dy, vj[1], g.dx * vj[0]));
+    const double cDi = c.P * __builtin_fma(g.dz, vi[2], __builtin_fma(g.dy, vi[1], g.dx * vi[0]));
+    ui[0] = __builtin_fma(c.F, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
+    ui[1] = __builtin_fma(c.F, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
+    ui[2] = __builtin_fma(c.F, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
+    t[0] = __builtin_fma(cDi, g.dx, ACC ? __builtin_fma(c.F, vi[0], t[0]) : c.F * vi[0]);
+    t[1] = __builtin_fma(cDi, g.dy, ACC ? __builtin_fma(c.F, vi[1], t[1]) : c.F * vi[1]);
+    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.F, vi[2], t[2]) : c.F * vi[2]);
   }
 }
 
@@ -270,6 +285,27 @@ __device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const doub
     t[1] = __builtin_fma(ci, g.dy, ACC ? __builtin_fma(c.cFxy, vi[1], t[1]) : c.cFxy * vi[1]);
     t[2] = __builtin_fma(-c.h5 * Rvi, g.Rz, __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cFzi, vi[2], t[2]) : c.cFzi * vi[2]));
   }
+}
+
+// The same rr block in the form of BlockM (k-vector passes: built once, ten instructions per direction and vector
+// instead of sixteen): F = cF + (3.5 - 6u) iR3, P = cD - 3 h5, Q3 = cD d_z - h5 R_z, Q4 = cD d_z + h5 R_z,
+// Szz = cF + 0.5 iR3 + cD d_z^2 - h5 R_z^2.
+template <bool WALL>
+__device__ __forceinline__ BlockM rr_block(const RRc& c, const Geom& g) {
+  BlockM m;
+  const double cDdz = c.cD * g.dz;
+  if constexpr (WALL) {
+    const double hz = c.h5 * g.Rz;
+    m.F = c.cFxy;
+    m.P = __builtin_fma(-3.0, c.h5, c.cD);
+    m.Q3 = cDdz - hz;
+    m.Q4 = cDdz + hz;
+    m.Szz = __builtin_fma(-hz, g.Rz, __builtin_fma(cDdz, g.dz, c.cFzi));
+  } else {
+    m.F = c.cF; m.P = c.cD; m.Q3 = cDdz; m.Q4 = cDdz;
+    m.Szz = __builtin_fma(cDdz, g.dz, c.cF);
+  }
+  return m;
 }
 
 // ---------------------------------------------------------------------------------------------

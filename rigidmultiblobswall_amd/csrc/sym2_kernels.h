@@ -34,76 +34,27 @@ struct Sym2Args {
 
 constexpr int kSym2RecBytes = 80;
 
-// Vector-independent part of one tt pair.
-struct TTPair {
-  double cF, cD;                     // RPY: cF v + cD (d.v) d   (cF already includes -G1 iR with wall)
-  double nG2, G3r, G4r, G5r, Rz;     // wall: see pair_tt_sym
-};
+// Vector-independent part of one tt pair: the block of pair_blocks.h (built once, contracted per vector).
+struct TTPair { Geom g; TTc c; };
 
 template <bool WALL>
-__device__ __forceinline__ TTPair tt_pair_coefficients(const PairConsts& k, double dx, double dy, double dz, double Rz,
+__device__ __forceinline__ TTPair tt_pair_coefficients(const PairConsts& k, double dx, double dy, double dz, double zi,
                                                        double zj) {
-  TTPair c;
-  const double rho2 = __builtin_fma(dy, dy, dx * dx);
-  const double r2 = __builtin_fma(dz, dz, rho2);
-  const double ir = rsqrt_f64(r2);
-  const double ir2 = ir * ir;
-  c.cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
-  c.cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
-  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
-    const double r = r2 * ir;
-    const bool near = r2 <= k.four_a2;
-    c.cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : c.cF;
-    c.cD = near ? k.tt_n2 * ir : c.cD;
-  }
-  c.Rz = Rz;
-  if constexpr (WALL) {
-    const WallTT W = wall_tt_factors(k, rho2, Rz, zj);
-    const double iR3 = W.iR * W.iR2;
-    c.cF = __builtin_fma(-W.G1, W.iR, c.cF);
-    c.nG2 = -W.G2 * iR3;
-    c.G3r = W.G3 * W.iR2;
-    c.G4r = W.G4 * W.iR2;
-    c.G5r = W.G5 * W.iR;
-  } else {
-    c.nG2 = c.G3r = c.G4r = c.G5r = 0.0;
-  }
-  return c;
+  TTPair p;
+  p.g = make_geom<WALL>(dx, dy, dz, zi, zj);
+  p.c = tt_coeffs<WALL>(k, p.g, zj);
+  return p;
 }
 
 // Both directions for one vector pair: ui += M_ij v_j,  (tx,ty,tz) = M_ij^T v_i.
 template <bool WALL>
-__device__ __forceinline__ void tt_pair_apply(const TTPair& c, double dx, double dy, double dz, double vix, double viy,
-                                              double viz, double vjx, double vjy, double vjz, Vec3& ui, double& tx,
-                                              double& ty, double& tz) {
-  const double pj = __builtin_fma(dy, vjy, dx * vjx);
-  const double pi = __builtin_fma(dy, viy, dx * vix);
-  const double cDj = c.cD * __builtin_fma(dz, vjz, pj);
-  const double cDi = c.cD * __builtin_fma(dz, viz, pi);
-  if constexpr (!WALL) {
-    ui.x = __builtin_fma(c.cF, vjx, ui.x); ui.x = __builtin_fma(cDj, dx, ui.x);
-    ui.y = __builtin_fma(c.cF, vjy, ui.y); ui.y = __builtin_fma(cDj, dy, ui.y);
-    ui.z = __builtin_fma(c.cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
-    tx = __builtin_fma(cDi, dx, c.cF * vix);
-    ty = __builtin_fma(cDi, dy, c.cF * viy);
-    tz = __builtin_fma(cDi, dz, c.cF * viz);
-  } else {
-    const double Rvj = __builtin_fma(c.Rz, vjz, pj);
-    const double cRj = __builtin_fma(c.G3r, vjz, c.nG2 * Rvj);
-    const double cbj = __builtin_fma(c.G5r, vjz, c.G4r * Rvj);
-    const double cj = cDj + cRj;
-    ui.x = __builtin_fma(c.cF, vjx, ui.x); ui.x = __builtin_fma(cj, dx, ui.x);
-    ui.y = __builtin_fma(c.cF, vjy, ui.y); ui.y = __builtin_fma(cj, dy, ui.y);
-    ui.z = __builtin_fma(c.cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
-    ui.z = __builtin_fma(cRj, c.Rz, ui.z); ui.z += cbj;
-    const double Rvi = __builtin_fma(c.Rz, viz, pi);
-    const double cRi = __builtin_fma(c.G4r, viz, c.nG2 * Rvi);
-    const double cbi = __builtin_fma(c.G5r, viz, c.G3r * Rvi);
-    const double ci = cDi + cRi;
-    tx = __builtin_fma(ci, dx, c.cF * vix);
-    ty = __builtin_fma(ci, dy, c.cF * viy);
-    tz = __builtin_fma(cRi, c.Rz, __builtin_fma(cDi, dz, __builtin_fma(c.cF, viz, cbi)));
-  }
+__device__ __forceinline__ void tt_pair_apply(const TTPair& p, double vix, double viy, double viz, double vjx, double vjy,
+                                              double vjz, Vec3& ui, double& tx, double& ty, double& tz) {
+  const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
+  double u[3] = {ui.x, ui.y, ui.z}, t[3];
+  tt_apply<WALL, false>(p.c, p.g, vi, vj, u, t);
+  ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
+  tx = t[0]; ty = t[1]; tz = t[2];
 }
 
 template <bool WALL, bool PERIODIC>
@@ -193,9 +144,9 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
       double dx = xi - q0.x, dy = yi - q0.y, dz = zi - q1.x;
       double tax = 0, tay = 0, taz = 0, tbx = 0, tby = 0, tbz = 0;
       if constexpr (!PERIODIC) {
-        const TTPair c = tt_pair_coefficients<WALL>(a.k, dx, dy, dz, zi + q1.x, q1.x);
-        tt_pair_apply<WALL>(c, dx, dy, dz, vax, vay, vaz, q1.y, q2.x, q2.y, ua, tax, tay, taz);
-        tt_pair_apply<WALL>(c, dx, dy, dz, vbx, vby, vbz, q3.x, q3.y, q4.x, ub, tbx, tby, tbz);
+        const TTPair c = tt_pair_coefficients<WALL>(a.k, dx, dy, dz, zi, q1.x);
+        tt_pair_apply<WALL>(c, vax, vay, vaz, q1.y, q2.x, q2.y, ua, tax, tay, taz);
+        tt_pair_apply<WALL>(c, vbx, vby, vbz, q3.x, q3.y, q4.x, ub, tbx, tby, tbz);
       } else {
         if (px) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
         if (py) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
@@ -205,11 +156,11 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
             for (int bz = -pz; bz <= pz; ++bz) {
               if (diag && k == 0 && bx == 0 && by == 0 && bz == 0) continue;   // the blob itself: self term (finalize)
               const double ex = dx + bx * a.Lx, ey = dy + by * a.Ly, ez = dz + bz * a.Lz;
-              const TTPair c = tt_pair_coefficients<WALL>(a.k, ex, ey, ez, zi + q1.x, q1.x);
+              const TTPair c = tt_pair_coefficients<WALL>(a.k, ex, ey, ez, zi, q1.x);
               double sx, sy, sz;
-              tt_pair_apply<WALL>(c, ex, ey, ez, vax, vay, vaz, q1.y, q2.x, q2.y, ua, sx, sy, sz);
+              tt_pair_apply<WALL>(c, vax, vay, vaz, q1.y, q2.x, q2.y, ua, sx, sy, sz);
               tax += sx; tay += sy; taz += sz;
-              tt_pair_apply<WALL>(c, ex, ey, ez, vbx, vby, vbz, q3.x, q3.y, q4.x, ub, sx, sy, sz);
+              tt_pair_apply<WALL>(c, vbx, vby, vbz, q3.x, q3.y, q4.x, ub, sx, sy, sz);
               tbx += sx; tby += sy; tbz += sz;
             }
       }

@@ -54,62 +54,20 @@ constexpr int kSymWaves = 4;
 constexpr int kSymRecBytes = 48;
 
 // Both directions of one pair.  (vix..) = target's own vector, (vjx..) = source vector.
-// Adds M_ij v_j to ui and returns M_ij^T v_i in (tx,ty,tz).
+// Adds M_ij v_j to ui and returns M_ij^T v_i in (tx,ty,tz).  The block is built once in the form of pair_blocks.h
+// (BlockM: F, P, Q3, Q4, Szz) and contracted with ten instructions per direction.
 template <bool WALL>
-__device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, double dy, double dz, double Rz, double zj,
+__device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                             double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                             Vec3& ui, double& tx, double& ty, double& tz) {
-  const double rho2 = __builtin_fma(dy, dy, dx * dx);
-  const double r2 = __builtin_fma(dz, dz, rho2);
-  const double ir = rsqrt_f64(r2);
-  const double ir2 = ir * ir;
-  double cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
-  double cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
-  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
-    const double r = r2 * ir;
-    const bool near = r2 <= k.four_a2;
-    cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : cF;
-    cD = near ? k.tt_n2 * ir : cD;
-  }
-  const double pj = __builtin_fma(dy, vjy, dx * vjx);   // in-plane parts of d.v_j and R.v_j
-  const double pi = __builtin_fma(dy, viy, dx * vix);
-  const double cDj = cD * __builtin_fma(dz, vjz, pj);
-  const double cDi = cD * __builtin_fma(dz, viz, pi);
-  if constexpr (!WALL) {
-    ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cDj, dx, ui.x);
-    ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cDj, dy, ui.y);
-    ui.z = __builtin_fma(cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
-    tx = __builtin_fma(cDi, dx, cF * vix);
-    ty = __builtin_fma(cDi, dy, cF * viy);
-    tz = __builtin_fma(cDi, dz, cF * viz);
-  } else {
-    const WallTT W = wall_tt_factors(k, rho2, Rz, zj);
-    const double iR3 = W.iR * W.iR2;
-    cF = __builtin_fma(-W.G1, W.iR, cF);
-    const double nG2 = -W.G2 * iR3;      // coefficient of (R.v) R
-    const double G3r = W.G3 * W.iR2;     // G3 iR^2 : v_z R (forward)  /  (R.v) z (transposed)
-    const double G4r = W.G4 * W.iR2;     // G4 iR^2 : (R.v) z (forward) /  v_z R (transposed)
-    const double G5r = W.G5 * W.iR;      // G5 iR   : v_z z
-    // forward: W v_j
-    const double Rvj = __builtin_fma(Rz, vjz, pj);
-    const double cRj = __builtin_fma(G3r, vjz, nG2 * Rvj);
-    const double cbj = __builtin_fma(G5r, vjz, G4r * Rvj);
-    const double cj = cDj + cRj;
-    ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cj, dx, ui.x);
-    ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cj, dy, ui.y);
-    ui.z = __builtin_fma(cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
-    ui.z = __builtin_fma(cRj, Rz, ui.z); ui.z += cbj;
-    // transposed: W^T v_i  (f3 <-> f4)
-    const double Rvi = __builtin_fma(Rz, viz, pi);
-    const double cRi = __builtin_fma(G4r, viz, nG2 * Rvi);
-    const double cbi = __builtin_fma(G5r, viz, G3r * Rvi);
-    const double ci = cDi + cRi;
-    tx = __builtin_fma(ci, dx, cF * vix);
-    ty = __builtin_fma(ci, dy, cF * viy);
-    tz = __builtin_fma(cRi, Rz, __builtin_fma(cDi, dz, __builtin_fma(cF, viz, cbi)));
-  }
+  const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+  const TTc c = tt_coeffs<WALL>(k, g, zj);
+  const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
+  double u[3] = {ui.x, ui.y, ui.z}, t[3];
+  tt_apply<WALL, false>(c, g, vi, vj, u, t);
+  ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
+  tx = t[0]; ty = t[1]; tz = t[2];
 }
-
 
 // rr, both directions.  W_rr = f1 I + f2 e e^T + f3 z e^T + f4 Q (Q = xy block, symmetric), so W^T moves f3 to
 // e z^T:  (W v)_xy = iR3{(3.5-6u) v - (1.5E + 3E_par) e},        (W v)_z = iR3{(0.5-3u) v_z + 1.5 E e_z}
@@ -194,7 +152,7 @@ template <int KIND, bool WALL>
 __device__ __forceinline__ void pair_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                          double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                          Vec3& ui, double& tx, double& ty, double& tz) {
-  if constexpr (KIND == KIND_TT) pair_tt_sym<WALL>(k, dx, dy, dz, zi + zj, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_TT) pair_tt_sym<WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
   if constexpr (KIND == KIND_RR) pair_rr_sym<WALL>(k, dx, dy, dz, zi + zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
   if constexpr (KIND == KIND_TR) pair_coupling_sym<true, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
   if constexpr (KIND == KIND_RT) pair_coupling_sym<false, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);

@@ -157,9 +157,9 @@ struct OpKindK {
 #pragma unroll
       for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else if constexpr (KIND == KIND_RR) {
-      const RRc b = rr_coeffs<WALL>(k, g);
+      const BlockM b = rr_block<WALL>(rr_coeffs<WALL>(k, g), g);
 #pragma unroll
-      for (int v = 0; v < K; ++v) rr_apply<WALL, false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      for (int v = 0; v < K; ++v) block_apply<false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else {
       const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
 #pragma unroll
@@ -190,9 +190,7 @@ struct OpFreeSurface {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<true>(dx, dy, dz, zi, zj);
-    TTc a;
-    rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, a.cF, a.cD);
-    a.nG2 = a.G3r = a.G4r = a.G5r = 0.0;
+    const TTc a = tt_coeffs<false>(k, g, zj);
     tt_apply<false, false>(a, g, vi, vj, ui, t);
     double cF, cD;
     rpy_tt_coeffs(k, __builtin_fma(g.Rz, g.Rz, g.rho2), g.iR, g.iR2, cF, cD);
