@@ -73,28 +73,49 @@ __device__ __forceinline__ void block_apply(const BlockM& m, const Geom& g, cons
   t[2] = __builtin_fma(m.Szz, vi[2], ACC ? __builtin_fma(m.Q3, pi, t[2]) : m.Q3 * pi);
 }
 
-// tt:  M = cF I + cD d d^T  (+ wall: -G1 iR I + nG2 R R^T + G3r R z^T + G4r z R^T + G5r z z^T, see wall_tt_from_iR)
+// tt:  M = cF I + cD d d^T  (+ wall: -G1 iR I - G2 iR^3 R R^T + G3 iR^2 R z^T + G4 iR^2 z R^T + G5 iR z z^T with the
+// polynomials of wall_tt_from_iR).  Substituting e_z = R_z/|R|, g = z_j/|R|, w = z_i z_j/R^2 into the block entries
+// the z_j-dependent parts collapse (the 12 R_z w terms of Q3 cancel):  with s = 1/|R|, q = s^2, T = a^2 q,
+// U = R_z^2 q = 1 - rho^2 q, W = z_i z_j q and
+//   H  = 1 - 6W + T [ (10U - 2) + T (10 - 70U/3) ]                 (= G2 + 20 T^2/3)
+//   F   = cF - s { 1 + 2W + T [ (2/3 - 2U) + T (10U/3 - 2/3) ] }
+//   P   = cD - s q ( H - 20 T^2/3 )
+//   Q3  = cD d_z + s q [ 2 z_j + R_z (H - 2) ]
+//   Q4  = cD d_z + s q [ 2 z_j - R_z H ]
+//   Szz = F + cD d_z^2 + s { 4W - U (1 + 6W) + T [ U (10U - 6) + T (70 U (1 - U)/3 - 8/3) ] }
+// 41 instructions instead of 50 for polynomials + block (checked against the G-form to rounding, and by every parity
+// test).
 typedef BlockM TTc;
 
 template <bool WALL>
-__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zj) {
+__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
   TTc m;
   double cF, cD;
   rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, cF, cD);
   if constexpr (WALL) {
+    // every fma below has at most one non-inline constant (gfx9 VOP3 reads one SGPR / literal): no v_mov in the loop
+    const double s = g.iR, q = g.iR2;
+    const double q3 = s * q;
+    const double T = k.a2 * q;
+    const double U = __builtin_fma(-g.rho2, q, 1.0);
+    const double W = (zi * zj) * q;
+    const double p5 = __builtin_fma(U, 5.0, -1.0);            // 5U - 1
+    const double V = 1.0 - U;
+    const double Ta = (T * T) * (2.0 / 3.0);                  // (2/3) T^2
+    // H = 1 - 6W + T (10U - 2) + T^2 (10 - 70U/3),   T^2 (10 - 70U/3) = Ta (15 V - 20 U)
+    const double H = __builtin_fma(Ta, __builtin_fma(U, -20.0, V * 15.0),
+                                   __builtin_fma(T, p5 + p5, __builtin_fma(W, -6.0, 1.0)));
+    const double zj2 = zj + zj;
     const double cDdz = cD * g.dz;
-    const WallTT W = wall_tt_from_iR(k, g.Rz, g.iR, zj);
-    const double iR3 = W.iR * W.iR2;
-    const double nG2 = -W.G2 * iR3, G3r = W.G3 * W.iR2, G4r = W.G4 * W.iR2;
-    cF = __builtin_fma(-W.G1, W.iR, cF);
-    const double t1 = nG2 * g.Rz;
-    const double tz = cDdz + t1;                       // cD d_z + nG2 R_z
-    m.F = cF;
-    m.P = cD + nG2;
-    m.Q3 = tz + G3r;
-    m.Q4 = tz + G4r;
-    // Szz = cF + cD dz^2 + nG2 Rz^2 + (G3r + G4r) Rz + G5 iR
-    m.Szz = __builtin_fma(t1 + (G3r + G4r), g.Rz, __builtin_fma(cDdz, g.dz, __builtin_fma(W.G5, W.iR, cF)));
+    m.Q4 = __builtin_fma(q3, __builtin_fma(-g.Rz, H, zj2), cDdz);
+    m.Q3 = __builtin_fma(q3, __builtin_fma(g.Rz, H - 2.0, zj2), cDdz);
+    m.P = __builtin_fma(-q3, __builtin_fma(Ta, -10.0, H), cD);                     // H - 20 T^2/3
+    const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T, __builtin_fma(U, -2.0, 2.0 / 3.0), __builtin_fma(W, 2.0, 1.0)));
+    m.F = __builtin_fma(-G1, s, cF);
+    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U V/3 - 8/3);  U (10U - 6) = 2U (p5 - 2),  T^2 (...) = Ta (35 U V - 4)
+    const double Zb = __builtin_fma(Ta, __builtin_fma(U * V, 35.0, -4.0),
+                                    __builtin_fma(T, (U + U) * (p5 - 2.0), __builtin_fma(-U, __builtin_fma(W, 6.0, 1.0), 4.0 * W)));
+    m.Szz = __builtin_fma(s, Zb, __builtin_fma(cDdz, g.dz, m.F));
   } else {
     m.F = cF; m.P = cD;          // tt_apply<false> contracts these two directly
     m.Q3 = m.Q4 = m.Szz = 0.0;

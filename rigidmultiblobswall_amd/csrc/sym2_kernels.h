@@ -42,7 +42,7 @@ __device__ __forceinline__ TTPair tt_pair_coefficients(const PairConsts& k, doub
                                                        double zj) {
   TTPair p;
   p.g = make_geom<WALL>(dx, dy, dz, zi, zj);
-  p.c = tt_coeffs<WALL>(k, p.g, zj);
+  p.c = tt_coeffs<WALL>(k, p.g, zi, zj);
   return p;
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, doub
                                             double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                             Vec3& ui, double& tx, double& ty, double& tz) {
   const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-  const TTc c = tt_coeffs<WALL>(k, g, zj);
+  const TTc c = tt_coeffs<WALL>(k, g, zi, zj);
   const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
   double u[3] = {ui.x, ui.y, ui.z}, t[3];
   tt_apply<WALL, false>(c, g, vi, vj, u, t);

@@ -84,7 +84,7 @@ struct OpFusedRow {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
     tt_apply<WALL, false>(a, g, vi, vj, ui, t);
     const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
     tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
@@ -104,7 +104,7 @@ struct OpGrand {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
     tt_apply<WALL, false>(a, g, vi, vj, ui, t);
     const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
     tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
@@ -129,7 +129,7 @@ struct OpColumnF {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zj);
+    const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
     tt_apply<WALL, false>(a, g, vi, vj, ui, t);
     const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
     rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
@@ -153,7 +153,7 @@ struct OpKindK {
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
     if constexpr (KIND == KIND_TT) {
-      const TTc a = tt_coeffs<WALL>(k, g, zj);
+      const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
 #pragma unroll
       for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else if constexpr (KIND == KIND_RR) {
@@ -190,7 +190,7 @@ struct OpFreeSurface {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<true>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<false>(k, g, zj);
+    const TTc a = tt_coeffs<false>(k, g, zi, zj);
     tt_apply<false, false>(a, g, vi, vj, ui, t);
     double cF, cD;
     rpy_tt_coeffs(k, __builtin_fma(g.Rz, g.Rz, g.rho2), g.iR, g.iR2, cF, cD);
