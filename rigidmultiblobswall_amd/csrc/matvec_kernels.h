@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs a) {
   __shared__ double red[(kWaves - 1) * 3 * 64];
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the source loop index stays scalar
   const long blk_t0 = a.tgt_begin + 64L * blockIdx.x;
   const long ti = blk_t0 + lane;
   const bool valid = ti < a.tgt_end;

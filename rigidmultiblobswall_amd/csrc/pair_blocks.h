@@ -168,24 +168,24 @@ __device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, do
     C.c = (g.r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : C.c;
   }
   if constexpr (WALL) {
+    // p = (R_z (1 + 2 tau) - 2 z)/|R|^3,  D = f3/R^2 = (10 R_z tau - 6 z)/|R|^5,
+    // S = s/|R| - c = [1 + (2 - 20 U) tau]/|R|^3 + 12 R_z z/|R|^5 - c      (z = anchoring height, U = R_z^2/R^2)
+    const double q3 = g.iR2 * g.iR, q5 = q3 * g.iR2;
     const double tau = k.a2 * g.iR2;
-    const double ez = g.Rz * g.iR;
-    const double uu = ez * ez;
-    const double eztau = ez * tau;
-    const double p0 = g.iR2 * __builtin_fma(2.0, eztau, ez);                            // p = p0 - 2 iR2 g
-    const double s0 = g.iR2 * __builtin_fma(__builtin_fma(-20.0, uu, 2.0), tau, 1.0);  // s = s0 + 12 iR2 ez g
-    const double f30 = 10.0 * g.iR2 * eztau;                                            // f3 = f30 - 6 iR2 g
-    const double gi = zi * g.iR, gj = zj * g.iR;
-    const double m2 = -2.0 * g.iR2, e12 = 12.0 * g.iR2 * ez, m6 = -6.0 * g.iR2;
-    const double p_i = __builtin_fma(m2, gi, p0), s_i = __builtin_fma(e12, gi, s0), f3_i = __builtin_fma(m6, gi, f30);
-    const double p_j = __builtin_fma(m2, gj, p0), s_j = __builtin_fma(e12, gj, s0), f3_j = __builtin_fma(m6, gj, f30);
-    C.A = __builtin_fma(g.iR2, g.iR, -C.c);
+    const double U = __builtin_fma(-g.rho2, g.iR2, 1.0);
+    const double RT = g.Rz * tau;
+    const double X = __builtin_fma(2.0, RT, g.Rz);
+    const double RT10 = RT * 10.0;
+    const double S0 = __builtin_fma(q3, __builtin_fma(__builtin_fma(U, -20.0, 2.0), tau, 1.0), -C.c);
+    const double w12 = (q5 * g.Rz) * 12.0;
+    const double p_i = q3 * __builtin_fma(-2.0, zi, X), p_j = q3 * __builtin_fma(-2.0, zj, X);
+    C.D_i = q5 * __builtin_fma(zi, -6.0, RT10); C.D_j = q5 * __builtin_fma(zj, -6.0, RT10);
+    C.S_i = __builtin_fma(w12, zi, S0); C.S_j = __builtin_fma(w12, zj, S0);
+    C.E_i = __builtin_fma(C.D_i, g.Rz, C.S_i); C.E_j = __builtin_fma(C.D_j, g.Rz, C.S_j);
+    C.A = q3 - C.c;
     const double cdz = C.c * g.dz;
     C.B_i = cdz + p_i;
     C.Bjp = p_j - cdz;
-    C.D_i = f3_i * g.iR2; C.D_j = f3_j * g.iR2;
-    C.S_i = __builtin_fma(s_i, g.iR, -C.c); C.S_j = __builtin_fma(s_j, g.iR, -C.c);
-    C.E_i = __builtin_fma(C.D_i, g.Rz, C.S_i); C.E_j = __builtin_fma(C.D_j, g.Rz, C.S_j);
   } else {
     C.A = C.B_i = C.Bjp = C.D_i = C.D_j = C.S_i = C.S_j = C.E_i = C.E_j = 0.0;
   }
@@ -347,17 +347,29 @@ __device__ __forceinline__ void pair_coupling_forward(const PairConsts& k, doubl
   u.x = u3[0]; u.y = u3[1]; u.z = u3[2];
 }
 
+// One-sided tt through the same closed-form block (forward direction only; the reversed one is dead code)
+template <bool WALL>
+__device__ __forceinline__ void pair_tt_forward(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
+                                                double vx, double vy, double vz, Vec3& u) {
+  const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+  const TTc c = tt_coeffs<WALL>(k, g, zi, zj);
+  const double vi[3] = {0.0, 0.0, 0.0}, vj[3] = {vx, vy, vz};
+  double u3[3] = {u.x, u.y, u.z}, t[3];
+  tt_apply<WALL, false>(c, g, vi, vj, u3, t);
+  u.x = u3[0]; u.y = u3[1]; u.z = u3[2];
+}
+
 template <int KIND, bool WALL>
 __device__ __forceinline__ void pair_apply(const PairConsts& k, double dx, double dy, double dz, double zi,
                                            double zj, double vx, double vy, double vz, double wx, double wy,
                                            double wz, Vec3& u) {
   const double Rz = zi + zj;
-  if constexpr (KIND == KIND_TT) pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+  if constexpr (KIND == KIND_TT) pair_tt_forward<WALL>(k, dx, dy, dz, zi, zj, vx, vy, vz, u);
   if constexpr (KIND == KIND_TR) pair_coupling_forward<true, WALL>(k, dx, dy, dz, zi, zj, vx, vy, vz, u);
   if constexpr (KIND == KIND_RT) pair_coupling_forward<false, WALL>(k, dx, dy, dz, zi, zj, vx, vy, vz, u);
   if constexpr (KIND == KIND_RR) pair_rr<WALL>(k, dx, dy, dz, Rz, vx, vy, vz, u);
   if constexpr (KIND == KIND_TT_TR) {
-    pair_tt<WALL>(k, dx, dy, dz, Rz, zj, vx, vy, vz, u);
+    pair_tt_forward<WALL>(k, dx, dy, dz, zi, zj, vx, vy, vz, u);
     pair_coupling_forward<true, WALL>(k, dx, dy, dz, zi, zj, wx, wy, wz, u);
   }
   if constexpr (KIND == KIND_TT_FREE) {
