@@ -40,8 +40,9 @@ __device__ __forceinline__ Geom make_geom(double dx, double dy, double dz, doubl
 
 // RPY tt coefficients of separation r:  cF I + cD r r^T   (mobility_numba.py:209-239)
 __device__ __forceinline__ void rpy_tt_coeffs(const PairConsts& k, double r2, double ir, double ir2, double& cF, double& cD) {
-  cF = __builtin_fma(k.tt_k1, ir2, 1.0) * ir;
-  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir2 * ir;
+  const double ir3 = ir2 * ir;
+  cF = __builtin_fma(k.tt_k1, ir3, ir);                       // (1 + 2a^2/(3r^2))/r
+  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir3;               // (1 - 2a^2/r^2)/r^3
   if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
     const double r = r2 * ir;
     const bool near = r2 <= k.four_a2;
@@ -250,83 +251,47 @@ __device__ __forceinline__ void rt_apply(const CPc& C, const Geom& g, const doub
   }
 }
 
-struct RRc { double cF, cD, cFxy, cFzj, cFzi, h5; };
+// rr:  M = cF I + cD d d^T  (+ wall, mobility_numba.py:1292-1321: with e = R/|R|, u = e_z^2
+//   (W v)_xy = {(3.5 - 6u) v - (1.5 e.v + 3 e_par.v) e}/|R|^3,   (W v)_z = {(0.5 - 3u) v_z + 1.5 (e.v) e_z}/|R|^3 ).
+// On the unnormalised R this is the block form with
+//   F = cF + (3.5 - 6U)/|R|^3,  P = cD - 4.5/|R|^5,  Q3 = cD d_z - h,  Q4 = cD d_z + h,  h = 1.5 R_z/|R|^5,
+//   Szz = cF + cD d_z^2 + (0.5 - 1.5U)/|R|^3
+typedef BlockM RRc;
 
 template <bool WALL>
 __device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
-  RRc c;
+  RRc m;
   const double ir3 = g.ir2 * g.ir;
-  c.cF = -0.5 * ir3;
-  c.cD = 1.5 * ir3 * g.ir2;
+  double cF = -0.5 * ir3;
+  double cD = 1.5 * ir3 * g.ir2;
   if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
     const double r = g.r2 * g.ir;
     const double r3 = g.r2 * r;
     const bool near = g.r2 < k.four_a2;
-    c.cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : c.cF;
-    c.cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : c.cD;
+    cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : cF;
+    cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : cD;
   }
   if constexpr (WALL) {
-    const double iR3 = g.iR2 * g.iR;
-    const double uu = g.Rz * g.Rz * g.iR2;
-    c.cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, c.cF);
-    c.cFzj = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, c.cF);
-    c.cFzi = __builtin_fma(0.5, iR3, c.cF);
-    c.h5 = 1.5 * iR3 * g.iR2;
+    const double q3 = g.iR2 * g.iR, q5 = q3 * g.iR2;
+    const double U = __builtin_fma(-g.rho2, g.iR2, 1.0);
+    const double cDdz = cD * g.dz;
+    const double h = (q5 * g.Rz) * 1.5;
+    m.F = __builtin_fma(__builtin_fma(U, -6.0, 4.0) - 0.5, q3, cF);
+    m.P = __builtin_fma(q5, -4.5, cD);
+    m.Q3 = cDdz - h;
+    m.Q4 = cDdz + h;
+    m.Szz = __builtin_fma(q3, __builtin_fma(U, -1.5, 0.5), __builtin_fma(cDdz, g.dz, cF));
   } else {
-    c.cFxy = c.cFzj = c.cFzi = c.h5 = 0.0;
-  }
-  return c;
-}
-
-// rr: ui += M_rr,ij vj ;  t (+)= M_rr,ji vi       (same algebra as pair_rr_sym)
-template <bool WALL, bool ACC>
-__device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
-  const double pj = __builtin_fma(g.dy, vj[1], g.dx * vj[0]);
-  const double pi = __builtin_fma(g.dy, vi[1], g.dx * vi[0]);
-  const double cDj = c.cD * __builtin_fma(g.dz, vj[2], pj);
-  const double cDi = c.cD * __builtin_fma(g.dz, vi[2], pi);
-  if constexpr (!WALL) {
-    ui[0] = __builtin_fma(c.cF, vj[0], ui[0]); ui[0] = __builtin_fma(cDj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cF, vj[1], ui[1]); ui[1] = __builtin_fma(cDj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cF, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    t[0] = __builtin_fma(cDi, g.dx, ACC ? __builtin_fma(c.cF, vi[0], t[0]) : c.cF * vi[0]);
-    t[1] = __builtin_fma(cDi, g.dy, ACC ? __builtin_fma(c.cF, vi[1], t[1]) : c.cF * vi[1]);
-    t[2] = __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cF, vi[2], t[2]) : c.cF * vi[2]);
-  } else {
-    const double zvj = g.Rz * vj[2], zvi = g.Rz * vi[2];
-    const double Rvj = zvj + pj;
-    const double cj = __builtin_fma(-c.h5, __builtin_fma(2.0, pj, Rvj), cDj);
-    ui[0] = __builtin_fma(c.cFxy, vj[0], ui[0]); ui[0] = __builtin_fma(cj, g.dx, ui[0]);
-    ui[1] = __builtin_fma(c.cFxy, vj[1], ui[1]); ui[1] = __builtin_fma(cj, g.dy, ui[1]);
-    ui[2] = __builtin_fma(c.cFzj, vj[2], ui[2]); ui[2] = __builtin_fma(cDj, g.dz, ui[2]);
-    ui[2] = __builtin_fma(c.h5 * Rvj, g.Rz, ui[2]);
-    const double Rvi = zvi + pi;
-    const double ci = __builtin_fma(-c.h5, __builtin_fma(3.0, pi, -zvi), cDi);
-    t[0] = __builtin_fma(ci, g.dx, ACC ? __builtin_fma(c.cFxy, vi[0], t[0]) : c.cFxy * vi[0]);
-    t[1] = __builtin_fma(ci, g.dy, ACC ? __builtin_fma(c.cFxy, vi[1], t[1]) : c.cFxy * vi[1]);
-    t[2] = __builtin_fma(-c.h5 * Rvi, g.Rz, __builtin_fma(cDi, g.dz, ACC ? __builtin_fma(c.cFzi, vi[2], t[2]) : c.cFzi * vi[2]));
-  }
-}
-
-// The same rr block in the form of BlockM (k-vector passes: built once, ten instructions per direction and vector
-// instead of sixteen): F = cF + (3.5 - 6u) iR3, P = cD - 3 h5, Q3 = cD d_z - h5 R_z, Q4 = cD d_z + h5 R_z,
-// Szz = cF + 0.5 iR3 + cD d_z^2 - h5 R_z^2.
-template <bool WALL>
-__device__ __forceinline__ BlockM rr_block(const RRc& c, const Geom& g) {
-  BlockM m;
-  const double cDdz = c.cD * g.dz;
-  if constexpr (WALL) {
-    const double hz = c.h5 * g.Rz;
-    m.F = c.cFxy;
-    m.P = __builtin_fma(-3.0, c.h5, c.cD);
-    m.Q3 = cDdz - hz;
-    m.Q4 = cDdz + hz;
-    m.Szz = __builtin_fma(-hz, g.Rz, __builtin_fma(cDdz, g.dz, c.cFzi));
-  } else {
-    m.F = c.cF; m.P = c.cD; m.Q3 = cDdz; m.Q4 = cDdz;
-    m.Szz = __builtin_fma(cDdz, g.dz, c.cF);
+    m.F = cF; m.P = cD;          // rr_apply<false> contracts these two directly
+    m.Q3 = m.Q4 = m.Szz = 0.0;
   }
   return m;
+}
+
+// rr: ui += M_rr,ij vj ;  t (+)= M_rr,ji vi
+template <bool WALL, bool ACC>
+__device__ __forceinline__ void rr_apply(const RRc& c, const Geom& g, const double* vi, const double* vj, double* ui, double* t) {
+  tt_apply<WALL, ACC>(c, g, vi, vj, ui, t);     // same block form, same contraction
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -69,64 +69,18 @@ __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, doub
   tx = t[0]; ty = t[1]; tz = t[2];
 }
 
-// rr, both directions.  W_rr = f1 I + f2 e e^T + f3 z e^T + f4 Q (Q = xy block, symmetric), so W^T moves f3 to
-// e z^T:  (W v)_xy = iR3{(3.5-6u) v - (1.5E + 3E_par) e},        (W v)_z = iR3{(0.5-3u) v_z + 1.5 E e_z}
-//         (W^T v)_xy = iR3{(3.5-6u) v - (4.5E_par - 1.5 e_z v_z) e}, (W^T v)_z = iR3{0.5 v_z - 1.5 E e_z}.
+// rr, both directions (same block form, pair_blocks.h: rr_coeffs).
 template <bool WALL>
-__device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, double dy, double dz, double Rz,
+__device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                             double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                             Vec3& ui, double& tx, double& ty, double& tz) {
-  const double rho2 = __builtin_fma(dy, dy, dx * dx);
-  const double r2 = __builtin_fma(dz, dz, rho2);
-  const double ir = rsqrt_f64(r2);
-  const double ir2 = ir * ir;
-  const double ir3 = ir2 * ir;
-  double cF = -0.5 * ir3;
-  double cD = 1.5 * ir3 * ir2;
-  if (__builtin_expect(__any(r2 < k.four_a2), 0)) {
-    const double r = r2 * ir;
-    const double r3 = r2 * r;
-    const bool near = r2 < k.four_a2;
-    cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : cF;
-    cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * ir) : cD;
-  }
-  const double pj = __builtin_fma(dy, vjy, dx * vjx);
-  const double pi = __builtin_fma(dy, viy, dx * vix);
-  const double cDj = cD * __builtin_fma(dz, vjz, pj);
-  const double cDi = cD * __builtin_fma(dz, viz, pi);
-  if constexpr (!WALL) {
-    ui.x = __builtin_fma(cF, vjx, ui.x); ui.x = __builtin_fma(cDj, dx, ui.x);
-    ui.y = __builtin_fma(cF, vjy, ui.y); ui.y = __builtin_fma(cDj, dy, ui.y);
-    ui.z = __builtin_fma(cF, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
-    tx = __builtin_fma(cDi, dx, cF * vix);
-    ty = __builtin_fma(cDi, dy, cF * viy);
-    tz = __builtin_fma(cDi, dz, cF * viz);
-  } else {
-    const double R2 = __builtin_fma(Rz, Rz, rho2);
-    const double iR = rsqrt_f64(R2);
-    const double iR2 = iR * iR;
-    const double iR3 = iR2 * iR;
-    const double iR5 = iR3 * iR2;
-    const double uu = Rz * Rz * iR2;
-    const double cFxy = __builtin_fma(__builtin_fma(-6.0, uu, 3.5), iR3, cF);
-    const double cFzj = __builtin_fma(__builtin_fma(-3.0, uu, 0.5), iR3, cF);
-    const double cFzi = __builtin_fma(0.5, iR3, cF);
-    const double zvj = Rz * vjz, zvi = Rz * viz;
-    const double h5 = 1.5 * iR5;
-    // forward
-    const double Rvj = zvj + pj;
-    const double cj = __builtin_fma(-h5, __builtin_fma(2.0, pj, Rvj), cDj);       // cD (d.v) - iR5 (1.5 R.v + 3 p)
-    ui.x = __builtin_fma(cFxy, vjx, ui.x); ui.x = __builtin_fma(cj, dx, ui.x);
-    ui.y = __builtin_fma(cFxy, vjy, ui.y); ui.y = __builtin_fma(cj, dy, ui.y);
-    ui.z = __builtin_fma(cFzj, vjz, ui.z); ui.z = __builtin_fma(cDj, dz, ui.z);
-    ui.z = __builtin_fma(h5 * Rvj, Rz, ui.z);
-    // transposed
-    const double Rvi = zvi + pi;
-    const double ci = __builtin_fma(-h5, __builtin_fma(3.0, pi, -zvi), cDi);      // cD (d.v) - iR5 (4.5 p - 1.5 Rz v_z)
-    tx = __builtin_fma(ci, dx, cFxy * vix);
-    ty = __builtin_fma(ci, dy, cFxy * viy);
-    tz = __builtin_fma(-h5 * Rvi, Rz, __builtin_fma(cDi, dz, cFzi * viz));
-  }
+  const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
+  const RRc c = rr_coeffs<WALL>(k, g);
+  const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
+  double u[3] = {ui.x, ui.y, ui.z}, t[3];
+  rr_apply<WALL, false>(c, g, vi, vj, u, t);
+  ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
+  tx = t[0]; ty = t[1]; tz = t[2];
 }
 
 // Coupling blocks, both directions.  KIND_TR: u = M_tr tau, wall part anchored on the TARGET height of each
@@ -153,7 +107,7 @@ __device__ __forceinline__ void pair_sym(const PairConsts& k, double dx, double 
                                          double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                          Vec3& ui, double& tx, double& ty, double& tz) {
   if constexpr (KIND == KIND_TT) pair_tt_sym<WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
-  if constexpr (KIND == KIND_RR) pair_rr_sym<WALL>(k, dx, dy, dz, zi + zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_RR) pair_rr_sym<WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
   if constexpr (KIND == KIND_TR) pair_coupling_sym<true, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
   if constexpr (KIND == KIND_RT) pair_coupling_sym<false, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
 }

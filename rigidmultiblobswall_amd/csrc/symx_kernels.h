@@ -157,9 +157,9 @@ struct OpKindK {
 #pragma unroll
       for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else if constexpr (KIND == KIND_RR) {
-      const BlockM b = rr_block<WALL>(rr_coeffs<WALL>(k, g), g);
+      const RRc b = rr_coeffs<WALL>(k, g);
 #pragma unroll
-      for (int v = 0; v < K; ++v) block_apply<false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      for (int v = 0; v < K; ++v) rr_apply<WALL, false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else {
       const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
 #pragma unroll

@@ -34,15 +34,16 @@ KERNELS = {
     "sym_rr_wall": "_ZN3rmb10sym_kernelILi3ELb1ELb0EEE",
     "sweep_tt_wall": "_ZN3rmb12sweep_kernelILi0ELb1ELb0EEE",
     "sym2_tt_wall": "_ZN3rmb11sym2_kernelILb1ELb0EEE",
-    "symx_single_tt_wall": "_ZN3rmb11symx_kernelINS_8OpSingleILi0EEELb1ELb0EEE",
-    "symx_fused_wall": "_ZN3rmb11symx_kernelINS_10OpFusedRowELb1ELb0EEE",
-    "symx_grand_wall": "_ZN3rmb11symx_kernelINS_7OpGrandELb1ELb0EEE",
-    "symx_column_wall": "_ZN3rmb11symx_kernelINS_9OpColumnFELb1ELb0EEE",
-    "symx_tt2_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi2EEELb1ELb0EEE",
-    "symx_tt3_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi3EEELb1ELb0EEE",
-    "symx_tt4_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi4EEELb1ELb0EEE",
-    "symx_rr2_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi3ELi2EEELb1ELb0EEE",
-    "symx_free": "_ZN3rmb11symx_kernelINS_13OpFreeSurfaceELb0ELb0EEE",
+    "symx_single_tt_wall": "_ZN3rmb11symx_kernelINS_8OpSingleILi0EEELb1ELb0ELb0EEE",
+    "symx_fused_wall": "_ZN3rmb11symx_kernelINS_10OpFusedRowELb1ELb0ELb0EEE",
+    "symx_grand_wall": "_ZN3rmb11symx_kernelINS_7OpGrandELb1ELb0ELb0EEE",
+    "symx_column_wall": "_ZN3rmb11symx_kernelINS_9OpColumnFELb1ELb0ELb0EEE",
+    "symx_tt2_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi2EEELb1ELb0ELb0EEE",
+    "symx_tt3_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi3EEELb1ELb0ELb0EEE",
+    "symx_tt4_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi0ELi4EEELb1ELb0ELb0EEE",
+    "symx_rr2_wall": "_ZN3rmb11symx_kernelINS_7OpKindKILi3ELi2EEELb1ELb0ELb0EEE",
+    "symx_radii_wall": "_ZN3rmb11symx_kernelINS_9OpRadiiTTELb1ELb0ELb0EEE",
+    "symx_free": "_ZN3rmb11symx_kernelINS_13OpFreeSurfaceELb0ELb0ELb0EEE",
 }
 
 
