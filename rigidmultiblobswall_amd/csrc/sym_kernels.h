@@ -8,7 +8,8 @@
 // cheap contractions are done twice.  With W = f1 I + f2 e e^T + f3 e z^T + f4 z e^T + f5 z z^T,
 //   W v   = f1 v + [f2 (e.v) + f3 v_z] e + [f4 (e.v) + f5 v_z] z
 //   W^T v = f1 v + [f2 (e.v) + f4 v_z] e + [f3 (e.v) + f5 v_z] z          (f3 <-> f4)
-// => ~110 VALU instructions per unordered pair instead of 2 x 93.
+// => 92 VALU instructions per unordered pair (pair_blocks.h: five-entry block + closed-form wall polynomials)
+// instead of 2 x 83 in the one-sided sweep.
 //
 // Work decomposition: blobs are cut into tiles of 64; a work unit is a tile pair (I <= J).  One wave64
 // owns a unit: lane l holds blob i = 64 I + l in registers (position, its own vector v_i, accumulator u_i);

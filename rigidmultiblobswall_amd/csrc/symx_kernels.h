@@ -14,7 +14,9 @@
 //     the free-surface product (:1770-1937: the image block P RPY(R) is reciprocal too).
 // All of them are symmetric operators on the stacked vector, so every unordered pair is still evaluated once and
 // applied to both blobs.  Differences, both inverse square roots, tau, e and the heights are computed once per pair
-// (Geom) and shared by all blocks: the grand product costs ~2.4x one tt pass instead of 4 passes.
+// (Geom) and shared by all blocks: the grand product costs 2.1x one tt pass (220 against 92 + 77 + 77 + 73 VALU
+// instructions per pair) instead of four passes.  OP::NEXTRA adds per-blob scalars to the record (per-blob radii),
+// the DET variant stores per-unit partials for a fixed-order reduction instead of atomic flushes.
 //
 // Skeleton = sym_kernel's: tile pairs (I <= J) of 64 blobs, one wave64 per unit, rotation j = (lane + k) & 63,
 // transposed contributions through ds_add_f64 into a per-wave LDS accumulator, static exactly balanced step
