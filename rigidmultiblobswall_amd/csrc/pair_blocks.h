@@ -38,11 +38,48 @@ __device__ __forceinline__ Geom make_geom(double dx, double dy, double dz, doubl
   return g;
 }
 
-// RPY tt coefficients of separation r:  cF I + cD r r^T   (mobility_numba.py:209-239)
+// Unbounded (RPY) coefficients of the blocks a kernel asks for, far field + the overlap patch behind ONE wave-uniform
+// branch.  An operation that evaluates several blocks of a pair patches them together, so that everything after the
+// patch is a single basic block (instruction selection folds negations into source modifiers only within a block:
+// with one branch per block the fused operations carried ~10 v_xor / v_mov copies per pair).
+//   tt  cF I + cD r r^T       mobility_numba.py:209-239   (overlap: r <= 2a)
+//   tr / rt  c (eps r)        :619-644 / :1010-1033       (overlap: r <  2a)
+//   rr  rF I + rD r r^T       :1260-1286                  (overlap: r <  2a)
+struct Rpy { double cF, cD, c, rF, rD; };
+
+template <bool TT, bool CPL, bool RR>
+__device__ __forceinline__ Rpy rpy_coeffs(const PairConsts& k, const Geom& g) {
+  Rpy p;
+  const double ir3 = g.ir2 * g.ir;
+  p.cF = __builtin_fma(k.tt_k1, ir3, g.ir);                     // (1 + 2a^2/(3r^2))/r
+  p.cD = __builtin_fma(-k.tt_k2, g.ir2, 1.0) * ir3;             // (1 - 2a^2/r^2)/r^3
+  p.c = ir3;
+  p.rF = -0.5 * ir3;
+  p.rD = 1.5 * ir3 * g.ir2;
+  const bool guard = TT ? (g.r2 <= k.four_a2) : (g.r2 < k.four_a2);      // one compare in the loop
+  if (__builtin_expect(__any(guard), 0)) {
+    const double r = g.r2 * g.ir;
+    if constexpr (TT) {
+      const bool near = g.r2 <= k.four_a2;
+      p.cF = near ? __builtin_fma(-k.tt_n1, r, k.tt_n0) : p.cF;
+      p.cD = near ? k.tt_n2 * g.ir : p.cD;
+    }
+    const bool near = TT ? (g.r2 < k.four_a2) : guard;
+    if constexpr (CPL) p.c = near ? __builtin_fma(-k.c_q1, r, k.c_q0) : p.c;
+    if constexpr (RR) {
+      const double r3 = g.r2 * r;
+      p.rF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : p.rF;
+      p.rD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : p.rD;
+    }
+  }
+  return p;
+}
+
+// RPY tt coefficients of an arbitrary separation (the image term of the free-surface operation)
 __device__ __forceinline__ void rpy_tt_coeffs(const PairConsts& k, double r2, double ir, double ir2, double& cF, double& cD) {
   const double ir3 = ir2 * ir;
-  cF = __builtin_fma(k.tt_k1, ir3, ir);                       // (1 + 2a^2/(3r^2))/r
-  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir3;               // (1 - 2a^2/r^2)/r^3
+  cF = __builtin_fma(k.tt_k1, ir3, ir);
+  cD = __builtin_fma(-k.tt_k2, ir2, 1.0) * ir3;
   if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
     const double r = r2 * ir;
     const bool near = r2 <= k.four_a2;
@@ -89,39 +126,44 @@ __device__ __forceinline__ void block_apply(const BlockM& m, const Geom& g, cons
 typedef BlockM TTc;
 
 template <bool WALL>
-__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
+__device__ __forceinline__ TTc tt_block(const PairConsts& k, const Geom& g, double zi, double zj, double cF, double cD) {
   TTc m;
-  double cF, cD;
-  rpy_tt_coeffs(k, g.r2, g.ir, g.ir2, cF, cD);
   if constexpr (WALL) {
     // every fma below has at most one non-inline constant (gfx9 VOP3 reads one SGPR / literal): no v_mov in the loop
     const double s = g.iR, q = g.iR2;
     const double q3 = s * q;
-    const double T = k.a2 * q;
+    const double T2 = k.tt_k2 * q;                            // 2T
     const double U = __builtin_fma(-g.rho2, q, 1.0);
     const double W = (zi * zj) * q;
     const double p5 = __builtin_fma(U, 5.0, -1.0);            // 5U - 1
-    const double V = 1.0 - U;
-    const double Ta = (T * T) * (2.0 / 3.0);                  // (2/3) T^2
-    // H = 1 - 6W + T (10U - 2) + T^2 (10 - 70U/3),   T^2 (10 - 70U/3) = Ta (15 V - 20 U)
-    const double H = __builtin_fma(Ta, __builtin_fma(U, -20.0, V * 15.0),
-                                   __builtin_fma(T, p5 + p5, __builtin_fma(W, -6.0, 1.0)));
+    const double Ta = (T2 * T2) * (1.0 / 6.0);                // (2/3) T^2
+    // H = 1 - 6W + 2T (5U - 1) + T^2 (10 - 70U/3),   T^2 (10 - 70U/3) = Ta (15 - 35U) = Ta (8 - 7 p5)
+    const double H = __builtin_fma(Ta, __builtin_fma(p5, k.m7, 8.0),
+                                   __builtin_fma(T2, p5, __builtin_fma(W, -6.0, 1.0)));
     const double zj2 = zj + zj;
     const double cDdz = cD * g.dz;
     m.Q4 = __builtin_fma(q3, __builtin_fma(-g.Rz, H, zj2), cDdz);
     m.Q3 = __builtin_fma(q3, __builtin_fma(g.Rz, H - 2.0, zj2), cDdz);
     m.P = __builtin_fma(-q3, __builtin_fma(Ta, -10.0, H), cD);                     // H - 20 T^2/3
-    const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T, __builtin_fma(U, -2.0, 2.0 / 3.0), __builtin_fma(W, 2.0, 1.0)));
+    const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T2, (1.0 / 3.0) - U, __builtin_fma(W, 2.0, 1.0)));
     m.F = __builtin_fma(-G1, s, cF);
-    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U V/3 - 8/3);  U (10U - 6) = 2U (p5 - 2),  T^2 (...) = Ta (35 U V - 4)
+    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U V/3 - 8/3),  V = 1 - U
+    //    = W (4 - 6U) - U + 2T U (p5 - 2) + Ta (35 U V - 4)
+    const double V = 1.0 - U;
     const double Zb = __builtin_fma(Ta, __builtin_fma(U * V, 35.0, -4.0),
-                                    __builtin_fma(T, (U + U) * (p5 - 2.0), __builtin_fma(-U, __builtin_fma(W, 6.0, 1.0), 4.0 * W)));
+                                    __builtin_fma(T2, U * (p5 - 2.0), __builtin_fma(W, __builtin_fma(U, -6.0, 4.0), -U)));
     m.Szz = __builtin_fma(s, Zb, __builtin_fma(cDdz, g.dz, m.F));
   } else {
     m.F = cF; m.P = cD;          // tt_apply<false> contracts these two directly
     m.Q3 = m.Q4 = m.Szz = 0.0;
   }
   return m;
+}
+
+template <bool WALL>
+__device__ __forceinline__ TTc tt_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
+  const Rpy p = rpy_coeffs<true, false, false>(k, g);
+  return tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
 }
 
 // ui += M_tt,ij vj ;  t (+)= M_tt,ji vi
@@ -161,13 +203,9 @@ struct CPc {
 };
 
 template <bool WALL>
-__device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
+__device__ __forceinline__ CPc cpl_block(const PairConsts& k, const Geom& g, double zi, double zj, double c) {
   CPc C;
-  C.c = g.ir2 * g.ir;
-  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
-    const double r = g.r2 * g.ir;
-    C.c = (g.r2 < k.four_a2) ? __builtin_fma(-k.c_q1, r, k.c_q0) : C.c;
-  }
+  C.c = c;
   if constexpr (WALL) {
     // p = (R_z (1 + 2 tau) - 2 z)/|R|^3,  D = f3/R^2 = (10 R_z tau - 6 z)/|R|^5,
     // S = s/|R| - c = [1 + (2 - 20 U) tau]/|R|^3 + 12 R_z z/|R|^5 - c      (z = anchoring height, U = R_z^2/R^2)
@@ -178,19 +216,25 @@ __device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, do
     const double X = __builtin_fma(2.0, RT, g.Rz);
     const double RT10 = RT * 10.0;
     const double S0 = __builtin_fma(q3, __builtin_fma(__builtin_fma(U, -20.0, 2.0), tau, 1.0), -C.c);
-    const double w12 = (q5 * g.Rz) * 12.0;
-    const double p_i = q3 * __builtin_fma(-2.0, zi, X), p_j = q3 * __builtin_fma(-2.0, zj, X);
-    C.D_i = q5 * __builtin_fma(zi, -6.0, RT10); C.D_j = q5 * __builtin_fma(zj, -6.0, RT10);
+    const double q5R = q5 * g.Rz;
+    const double w12 = q5R * 12.0;
+    C.D_i = q5 * __builtin_fma(zi, k.m6, RT10); C.D_j = q5 * __builtin_fma(zj, k.m6, RT10);     // k.m6: RT10 is read four times
     C.S_i = __builtin_fma(w12, zi, S0); C.S_j = __builtin_fma(w12, zj, S0);
-    C.E_i = __builtin_fma(C.D_i, g.Rz, C.S_i); C.E_j = __builtin_fma(C.D_j, g.Rz, C.S_j);
+    // E = D R_z + S = q5 R_z (10 R_z tau + 6 z) + S0   (tr alone needs neither S nor w12)
+    C.E_i = __builtin_fma(q5R, __builtin_fma(zi, -k.m6, RT10), S0); C.E_j = __builtin_fma(q5R, __builtin_fma(zj, -k.m6, RT10), S0);
     C.A = q3 - C.c;
     const double cdz = C.c * g.dz;
-    C.B_i = cdz + p_i;
-    C.Bjp = p_j - cdz;
+    C.B_i = __builtin_fma(q3, __builtin_fma(-2.0, zi, X), cdz);          // c d_z + p_i
+    C.Bjp = __builtin_fma(q3, __builtin_fma(-2.0, zj, X), -cdz);         // p_j - c d_z
   } else {
     C.A = C.B_i = C.Bjp = C.D_i = C.D_j = C.S_i = C.S_j = C.E_i = C.E_j = 0.0;
   }
   return C;
+}
+
+template <bool WALL>
+__device__ __forceinline__ CPc cpl_coeffs(const PairConsts& k, const Geom& g, double zi, double zj) {
+  return cpl_block<WALL>(k, g, zi, zj, rpy_coeffs<false, true, false>(k, g).c);
 }
 
 // RPY part alone (no wall): ui += c (vj x d),  t (+)= -c (vi x d)
@@ -259,24 +303,14 @@ __device__ __forceinline__ void rt_apply(const CPc& C, const Geom& g, const doub
 typedef BlockM RRc;
 
 template <bool WALL>
-__device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
+__device__ __forceinline__ RRc rr_block(const PairConsts& k, const Geom& g, double cF, double cD) {
   RRc m;
-  const double ir3 = g.ir2 * g.ir;
-  double cF = -0.5 * ir3;
-  double cD = 1.5 * ir3 * g.ir2;
-  if (__builtin_expect(__any(g.r2 < k.four_a2), 0)) {
-    const double r = g.r2 * g.ir;
-    const double r3 = g.r2 * r;
-    const bool near = g.r2 < k.four_a2;
-    cF = near ? __builtin_fma(k.rr_m2, r3, __builtin_fma(-k.rr_m1, r, k.rr_m0)) : cF;
-    cD = near ? __builtin_fma(-k.rr_m4, r, k.rr_m3 * g.ir) : cD;
-  }
   if constexpr (WALL) {
     const double q3 = g.iR2 * g.iR, q5 = q3 * g.iR2;
     const double U = __builtin_fma(-g.rho2, g.iR2, 1.0);
     const double cDdz = cD * g.dz;
     const double h = (q5 * g.Rz) * 1.5;
-    m.F = __builtin_fma(__builtin_fma(U, -6.0, 4.0) - 0.5, q3, cF);
+    m.F = __builtin_fma(__builtin_fma(U, k.m6, 3.5), q3, cF);
     m.P = __builtin_fma(q5, -4.5, cD);
     m.Q3 = cDdz - h;
     m.Q4 = cDdz + h;
@@ -286,6 +320,12 @@ __device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
     m.Q3 = m.Q4 = m.Szz = 0.0;
   }
   return m;
+}
+
+template <bool WALL>
+__device__ __forceinline__ RRc rr_coeffs(const PairConsts& k, const Geom& g) {
+  const Rpy p = rpy_coeffs<false, false, true>(k, g);
+  return rr_block<WALL>(k, g, p.rF, p.rD);
 }
 
 // rr: ui += M_rr,ij vj ;  t (+)= M_rr,ji vi

@@ -47,6 +47,10 @@ struct PairConsts {
   // tr / rt
   double c_q0;     // 1/(2 a^3)
   double c_q1;     // 3/(16 a^4)
+  // plain numbers handed over as kernel arguments (SGPRs) so that an fma with two non-inline constants reads one
+  // from the scalar file and keeps the other in a loop-invariant VGPR (gfx9 VOP3: one SGPR / literal per instruction)
+  double m7;       // -7
+  double m6;       // -6
 };
 
 struct Vec3 { double x, y, z; };

@@ -121,6 +121,8 @@ rmb::PairConsts make_pair_consts(double a) {
   k.rr_m4 = 3.0 / (64.0 * a6);
   k.c_q0 = 1.0 / (2.0 * a3);
   k.c_q1 = 3.0 / (16.0 * a4);
+  k.m7 = -7.0;
+  k.m6 = -6.0;
   return k;
 }
 

@@ -86,9 +86,10 @@ struct OpFusedRow {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
+    const Rpy p = rpy_coeffs<true, true, false>(k, g);          // one overlap patch for both blocks
+    const TTc a = tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
     tt_apply<WALL, false>(a, g, vi, vj, ui, t);
-    const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+    const CPc C = cpl_block<WALL>(k, g, zi, zj, p.c);
     tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
   }
   template <bool WALL>
@@ -106,12 +107,13 @@ struct OpGrand {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
+    const Rpy p = rpy_coeffs<true, true, true>(k, g);
+    const TTc a = tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
     tt_apply<WALL, false>(a, g, vi, vj, ui, t);
-    const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+    const CPc C = cpl_block<WALL>(k, g, zi, zj, p.c);
     tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
     rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
-    const RRc b = rr_coeffs<WALL>(k, g);
+    const RRc b = rr_block<WALL>(k, g, p.rF, p.rD);
     rr_apply<WALL, true>(b, g, vi + 3, vj + 3, ui + 3, t + 3);
   }
   template <bool WALL>
@@ -131,9 +133,10 @@ struct OpColumnF {
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
-    const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
+    const Rpy p = rpy_coeffs<true, true, false>(k, g);
+    const TTc a = tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
     tt_apply<WALL, false>(a, g, vi, vj, ui, t);
-    const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
+    const CPc C = cpl_block<WALL>(k, g, zi, zj, p.c);
     rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
   }
   template <bool WALL>

@@ -3,6 +3,9 @@ onto the symmetric skeleton against their one-sided sweeps.  Device-resident vec
 per PRODUCT (a product made of several launches counts all of them), clocks primed first.
 
   python tools/bench_ops.py [N ...]      -> gpurun_out/r2_ops_table.json
+  RMB_AB_LIB=<other build of librmb_mobility.so> RMB_AB_OUT=<json>   time that build instead (same-box A/B of two
+  builds: boxes differ by a few per cent, so a change is only priced against a baseline built from the previous
+  commit and timed in the same call)
 """
 import json
 import os
@@ -12,6 +15,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rigidmultiblobswall_amd import _lib as _rmb_lib
+if os.environ.get("RMB_AB_LIB"):
+  _rmb_lib.LIB_PATH = os.path.abspath(os.environ["RMB_AB_LIB"])
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 
@@ -140,4 +146,4 @@ for N in SIZES:
   ctx.close()
 
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open("gpurun_out/r2_ops_table.json", "w"), indent=1)
+json.dump(rows, open(os.environ.get("RMB_AB_OUT", "gpurun_out/r2_ops_table.json"), "w"), indent=1)

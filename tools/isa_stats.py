@@ -84,7 +84,8 @@ def _classify(op):
 def kernel_loop_stats(asm, mangled_prefix):
   """Instruction mix of the pair loop: LLVM annotates every block with the loop it belongs to
   (`; =>This Inner Loop Header` / `; in Loop: Header=BBf_n`); the pair loop is the innermost loop with the most fp64
-  VALU instructions.  Member blocks that are the near-field patch (a handful of instructions around v_cndmask, entered
+  VALU instructions.  Member blocks that are the near-field patch (a handful of instructions around v_cndmask or under
+  s_and_saveexec, entered
   only when some lane has r < 2a, leaving through s_branch) are left out of the per-step count."""
   lines = asm.split("\n")
   start = None
@@ -123,7 +124,7 @@ def kernel_loop_stats(asm, mangled_prefix):
     counts = {}
     valu = flops = lds = patch = 0
     for lb, an, ops in members:
-      is_patch = (lb != label and len(ops) <= 16 and any(o.startswith("v_cndmask") for o in ops) and ops and
+      is_patch = (lb != label and len(ops) <= 16 and any(o.startswith(("v_cndmask", "s_and_saveexec")) for o in ops) and ops and
                   ops[-1] == "s_branch")
       if is_patch:
         patch += len(ops)
