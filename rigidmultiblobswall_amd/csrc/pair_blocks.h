@@ -115,14 +115,14 @@ __device__ __forceinline__ void block_apply(const BlockM& m, const Geom& g, cons
 // polynomials of wall_tt_from_iR).  Substituting e_z = R_z/|R|, g = z_j/|R|, w = z_i z_j/R^2 into the block entries
 // the z_j-dependent parts collapse (the 12 R_z w terms of Q3 cancel):  with s = 1/|R|, q = s^2, T = a^2 q,
 // U = R_z^2 q = 1 - rho^2 q, W = z_i z_j q and
-//   H  = 1 - 6W + T [ (10U - 2) + T (10 - 70U/3) ]                 (= G2 + 20 T^2/3)
+//   H  = 1 - 6W + T [ (10U - 2) + T (10 - 70U/3) ]                 (= G2 + 20 T^2/3;  Q3 + Q4 = 2 (cD - s q) d_z)
 //   F   = cF - s { 1 + 2W + T [ (2/3 - 2U) + T (10U/3 - 2/3) ] }
 //   P   = cD - s q ( H - 20 T^2/3 )
 //   Q3  = cD d_z + s q [ 2 z_j + R_z (H - 2) ]
 //   Q4  = cD d_z + s q [ 2 z_j - R_z H ]
 //   Szz = F + cD d_z^2 + s { 4W - U (1 + 6W) + T [ U (10U - 6) + T (70 U (1 - U)/3 - 8/3) ] }
-// 41 instructions instead of 50 for polynomials + block (checked against the G-form to rounding, and by every parity
-// test).
+// 37 instructions for polynomials + block entries (the G-form needs 50; checked against it to rounding, and by every
+// parity test).
 typedef BlockM TTc;
 
 template <bool WALL>
@@ -134,24 +134,23 @@ __device__ __forceinline__ TTc tt_block(const PairConsts& k, const Geom& g, doub
     const double q3 = s * q;
     const double T2 = k.tt_k2 * q;                            // 2T
     const double U = __builtin_fma(-g.rho2, q, 1.0);
-    const double W = (zi * zj) * q;
+    const double om = __builtin_fma(-g.r2, q, 1.0);           // 4W = 4 z_i z_j / R^2 = 1 - r^2/R^2
     const double p5 = __builtin_fma(U, 5.0, -1.0);            // 5U - 1
     const double Ta = (T2 * T2) * (1.0 / 6.0);                // (2/3) T^2
     // H = 1 - 6W + 2T (5U - 1) + T^2 (10 - 70U/3),   T^2 (10 - 70U/3) = Ta (15 - 35U) = Ta (8 - 7 p5)
-    const double H = __builtin_fma(Ta, __builtin_fma(p5, k.m7, 8.0),
-                                   __builtin_fma(T2, p5, __builtin_fma(W, -6.0, 1.0)));
-    const double zj2 = zj + zj;
+    const double H = __builtin_fma(Ta, __builtin_fma(p5, k.m7, 8.0), __builtin_fma(T2, p5, __builtin_fma(om, -1.5, 1.0)));
     const double cDdz = cD * g.dz;
-    m.Q4 = __builtin_fma(q3, __builtin_fma(-g.Rz, H, zj2), cDdz);
-    m.Q3 = __builtin_fma(q3, __builtin_fma(g.Rz, H - 2.0, zj2), cDdz);
+    // Q3 = cD d_z + s q (R_z H - 2 z_i): 2 z_i does not change along a lane's row of pairs (hoisted);  Q3 + Q4 = 2 (cD - s q) d_z
+    m.Q3 = __builtin_fma(q3, __builtin_fma(g.Rz, H, -(zi + zi)), cDdz);
+    m.Q4 = __builtin_fma(__builtin_fma(-q3, g.dz, cDdz), 2.0, -m.Q3);
     m.P = __builtin_fma(-q3, __builtin_fma(Ta, -10.0, H), cD);                     // H - 20 T^2/3
-    const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T2, (1.0 / 3.0) - U, __builtin_fma(W, 2.0, 1.0)));
+    const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T2, (1.0 / 3.0) - U, __builtin_fma(om, 0.5, 1.0)));
     m.F = __builtin_fma(-G1, s, cF);
-    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U V/3 - 8/3),  V = 1 - U
-    //    = W (4 - 6U) - U + 2T U (p5 - 2) + Ta (35 U V - 4)
-    const double V = 1.0 - U;
-    const double Zb = __builtin_fma(Ta, __builtin_fma(U * V, 35.0, -4.0),
-                                    __builtin_fma(T2, U * (p5 - 2.0), __builtin_fma(W, __builtin_fma(U, -6.0, 4.0), -U)));
+    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U (1 - U)/3 - 8/3)  =  c0 + U (c1 + U c2)  with
+    //   c2 = 10T - 35Ta,  c1 = -1.5 om - 1 - 6T + 35Ta = 4T - 1.5 om - 1 - c2,  c0 = om - 4Ta
+    const double c2 = __builtin_fma(Ta, -35.0, T2 * 5.0);
+    const double c1 = __builtin_fma(T2, 2.0, __builtin_fma(om, -1.5, -1.0)) - c2;
+    const double Zb = __builtin_fma(U, __builtin_fma(U, c2, c1), __builtin_fma(Ta, -4.0, om));
     m.Szz = __builtin_fma(s, Zb, __builtin_fma(cDdz, g.dz, m.F));
   } else {
     m.F = cF; m.P = cD;          // tt_apply<false> contracts these two directly
@@ -210,12 +209,11 @@ __device__ __forceinline__ CPc cpl_block(const PairConsts& k, const Geom& g, dou
     // p = (R_z (1 + 2 tau) - 2 z)/|R|^3,  D = f3/R^2 = (10 R_z tau - 6 z)/|R|^5,
     // S = s/|R| - c = [1 + (2 - 20 U) tau]/|R|^3 + 12 R_z z/|R|^5 - c      (z = anchoring height, U = R_z^2/R^2)
     const double q3 = g.iR2 * g.iR, q5 = q3 * g.iR2;
-    const double tau = k.a2 * g.iR2;
+    const double T2 = k.tt_k2 * g.iR2;                          // 2 tau
     const double U = __builtin_fma(-g.rho2, g.iR2, 1.0);
-    const double RT = g.Rz * tau;
-    const double X = __builtin_fma(2.0, RT, g.Rz);
-    const double RT10 = RT * 10.0;
-    const double S0 = __builtin_fma(q3, __builtin_fma(__builtin_fma(U, -20.0, 2.0), tau, 1.0), -C.c);
+    const double RT2 = g.Rz * T2;                               // 2 R_z tau
+    const double RT10 = RT2 * 5.0;
+    const double S0 = __builtin_fma(q3, __builtin_fma(__builtin_fma(U, -10.0, 1.0), T2, 1.0), -C.c);
     const double q5R = q5 * g.Rz;
     const double w12 = q5R * 12.0;
     C.D_i = q5 * __builtin_fma(zi, k.m6, RT10); C.D_j = q5 * __builtin_fma(zj, k.m6, RT10);     // k.m6: RT10 is read four times
@@ -223,9 +221,10 @@ __device__ __forceinline__ CPc cpl_block(const PairConsts& k, const Geom& g, dou
     // E = D R_z + S = q5 R_z (10 R_z tau + 6 z) + S0   (tr alone needs neither S nor w12)
     C.E_i = __builtin_fma(q5R, __builtin_fma(zi, -k.m6, RT10), S0); C.E_j = __builtin_fma(q5R, __builtin_fma(zj, -k.m6, RT10), S0);
     C.A = q3 - C.c;
-    const double cdz = C.c * g.dz;
-    C.B_i = __builtin_fma(q3, __builtin_fma(-2.0, zi, X), cdz);          // c d_z + p_i
-    C.Bjp = __builtin_fma(q3, __builtin_fma(-2.0, zj, X), -cdz);         // p_j - c d_z
+    // R_z - 2 z_i = -d_z and R_z - 2 z_j = d_z:  c d_z + p_i = 2 R_z tau/|R|^3 - A d_z,   p_j - c d_z = 2 R_z tau/|R|^3 + A d_z
+    const double y2 = q3 * RT2;
+    C.B_i = __builtin_fma(-C.A, g.dz, y2);
+    C.Bjp = __builtin_fma(C.A, g.dz, y2);
   } else {
     C.A = C.B_i = C.Bjp = C.D_i = C.D_j = C.S_i = C.S_j = C.E_i = C.E_j = 0.0;
   }
@@ -309,11 +308,11 @@ __device__ __forceinline__ RRc rr_block(const PairConsts& k, const Geom& g, doub
     const double q3 = g.iR2 * g.iR, q5 = q3 * g.iR2;
     const double U = __builtin_fma(-g.rho2, g.iR2, 1.0);
     const double cDdz = cD * g.dz;
-    const double h = (q5 * g.Rz) * 1.5;
+    const double q5R = q5 * g.Rz;
     m.F = __builtin_fma(__builtin_fma(U, k.m6, 3.5), q3, cF);
     m.P = __builtin_fma(q5, -4.5, cD);
-    m.Q3 = cDdz - h;
-    m.Q4 = cDdz + h;
+    m.Q3 = __builtin_fma(q5R, -k.c15, cDdz);                   // k.c15 from the scalar file: cDdz is read twice
+    m.Q4 = __builtin_fma(q5R, k.c15, cDdz);
     m.Szz = __builtin_fma(q3, __builtin_fma(U, -1.5, 0.5), __builtin_fma(cDdz, g.dz, cF));
   } else {
     m.F = cF; m.P = cD;          // rr_apply<false> contracts these two directly

@@ -51,6 +51,7 @@ struct PairConsts {
   // from the scalar file and keeps the other in a loop-invariant VGPR (gfx9 VOP3: one SGPR / literal per instruction)
   double m7;       // -7
   double m6;       // -6
+  double c15;      // 1.5
 };
 
 struct Vec3 { double x, y, z; };

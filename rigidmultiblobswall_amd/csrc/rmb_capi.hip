@@ -123,6 +123,7 @@ rmb::PairConsts make_pair_consts(double a) {
   k.c_q1 = 3.0 / (16.0 * a4);
   k.m7 = -7.0;
   k.m6 = -6.0;
+  k.c15 = 1.5;
   return k;
 }
 
