@@ -146,11 +146,9 @@ __device__ __forceinline__ TTc tt_block(const PairConsts& k, const Geom& g, doub
     m.P = __builtin_fma(-q3, __builtin_fma(Ta, -10.0, H), cD);                     // H - 20 T^2/3
     const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T2, (1.0 / 3.0) - U, __builtin_fma(om, 0.5, 1.0)));
     m.F = __builtin_fma(-G1, s, cF);
-    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U (1 - U)/3 - 8/3)  =  c0 + U (c1 + U c2)  with
-    //   c2 = 10T - 35Ta,  c1 = -1.5 om - 1 - 6T + 35Ta = 4T - 1.5 om - 1 - c2,  c0 = om - 4Ta
-    const double c2 = __builtin_fma(Ta, -35.0, T2 * 5.0);
-    const double c1 = __builtin_fma(T2, 2.0, __builtin_fma(om, -1.5, -1.0)) - c2;
-    const double Zb = __builtin_fma(U, __builtin_fma(U, c2, c1), __builtin_fma(Ta, -4.0, om));
+    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U (1 - U)/3 - 8/3)  =  (om - 4Ta) + U (H - 2 - 2 (2T - 10Ta))
+    // (the zz polynomial through H: U^2 enters both with the same coefficient 10T - 35Ta)
+    const double Zb = __builtin_fma(U, __builtin_fma(__builtin_fma(Ta, -10.0, T2), -2.0, H - 2.0), __builtin_fma(Ta, -4.0, om));
     m.Szz = __builtin_fma(s, Zb, __builtin_fma(cDdz, g.dz, m.F));
   } else {
     m.F = cF; m.P = cD;          // tt_apply<false> contracts these two directly
