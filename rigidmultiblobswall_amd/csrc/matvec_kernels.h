@@ -258,9 +258,9 @@ __global__ __launch_bounds__(kBlock) void force_sweep_kernel(const ForceArgs a) 
       const double r = r2 * ir;
       // far: -(eps/b) exp(-(r-2a)/b)/r ; near (r <= 2a): -(eps/b)/max(r,1e-25) = -(eps/b) min(1/r, 1e25)
       const double two_a = RADII ? ra + q.w : a.two_a;
-      const bool far = r > two_a;
-      const double e = exp_nonpositive(a.ec, far ? (two_a - r) * a.inv_b : 0.0);
-      double f0 = -a.eps_over_b * (far ? e * ir : fmin(ir, 1e25));
+      // branch-free (sym_kernels.h pair_force): x = 0 exactly for r <= 2a, exp(0) = 1, min(1/r, 1e25) = 1/r beyond
+      const double e = exp_nonpositive(a.ec, fmin((two_a - r) * a.inv_b, 0.0));
+      double f0 = -a.eps_over_b * (e * fmin(ir, 1e25));
       if (j0 + s == ti) f0 = 0.0;  // i == j (r2 = 0 -> ir = inf; select, do not multiply)
       if (j0 + s == ti) { dx = 0.0; dy = 0.0; dz = 0.0; }
       fx = __builtin_fma(f0, dx, fx); fy = __builtin_fma(f0, dy, fy); fz = __builtin_fma(f0, dz, fz);

@@ -341,10 +341,11 @@ __device__ __forceinline__ void pair_force(const SymForceArgs& a, double two_a, 
   const double ir = rsqrt_f64(r2);
   const double r = r2 * ir;
   // far: -(eps/b) exp(-(r-2a)/b) / r ;  near (r <= 2a): -(eps/b) / max(r, 1e-25) = -(eps/b) min(1/r, 1e25)
-  const bool far = r > two_a;
-  const double x = far ? (two_a - r) * a.inv_b : 0.0;
+  // Branch-free: x = min((2a - r)/b, 0) is 0 exactly for r <= 2a (and for r = NaN at coincident points, fmin keeps
+  // the number), exp(0) = 1 exactly, and min(1/r, 1e25) = 1/r for every r > 2a -- one expression serves both ranges.
+  const double x = fmin((two_a - r) * a.inv_b, 0.0);
   const double e = exp_nonpositive(a.ec, x);
-  const double f0 = -a.eps_over_b * (far ? e * ir : fmin(ir, 1e25));
+  const double f0 = -a.eps_over_b * (e * fmin(ir, 1e25));
   fx = f0 * dx; fy = f0 * dy; fz = f0 * dz;
 }
 
@@ -408,9 +409,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
       pair_force<PERIODIC>(a, RADII ? ri + q.w : a.two_a, q.x - xi, q.y - yi, q.z - zi, fx, fy, fz);
       ax += fx; ay += fy; az += fz;
       if (!diag) {   // wave-uniform
-        __hip_atomic_fetch_add(&accj[jj], -fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&accj[64 + jj], -fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&accj[128 + jj], -fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        // the LDS slab collects +f (ds_add_f64 has no negate modifier: -f would cost a v_xor + v_mov per component
+        // and step); the sign of the reaction goes into the flush below
+        __hip_atomic_fetch_add(&accj[jj], fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[64 + jj], fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[128 + jj], fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
     }
     if (!diag) {
@@ -419,9 +422,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const long j = 64L * J + lane;
       if (j < a.n) {
-        __hip_atomic_fetch_add(&a.acc[j], accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&a.acc[a.n_pad + j], accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[j], -accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + j], -accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], -accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __builtin_amdgcn_wave_barrier();
