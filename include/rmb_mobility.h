@@ -208,6 +208,29 @@ int rmb_mobility_source_target_device(rmb_ctx* ctx, long ns, const double* src_d
                                       long nt, const double* tgt_dev, const double* radius_tgt_dev,
                                       const double* force_dev, double eta, const double* L, int wall, double* out_dev);
 
+/* ---- Stokeslet pressure and Stokes double layer, source -> target ---------------------------------------------
+ * The remaining O(N_s N_t) operators of mobility/mobility_numba.py (wrappers mobility/mobility.py:1345-1366,
+ * :1376-1387, :1432-1442).  Plain positions (no height clamp, no radii), stateless like the K13 entry points; the
+ * host variants are synchronous, the device variants enqueue on the context's stream.  Atomic-free, bit-reproducible.
+ *
+ * rmb_pressure_stokeslet: out[nt], p_t = 1/(4 pi) sum_s f_s . r/|r|^3, wall = 1 adds Blake's image system
+ *   (mobility_numba.py:1332-1396, :1399-1476).  The reference's wall routine rescales its running sum inside the
+ *   source loop (:1474); the factor is applied once here (= the reference for one source, = superposition of its
+ *   single-source results).  L must be NULL or zero: the reference's pseudo-periodic branch divides by the unwrapped
+ *   distance (:1374-1375), which is not reproduced -- RMB_ERR_ARG otherwise.
+ * rmb_double_layer: out[3 nt], u_t = -3/(4 pi) sum_s w_s r (r.n_s)(r.v_s)/|r|^5, pairs with r <= 1e-14 skipped;
+ *   wall = 1 adds the image terms of mobility_numba.py:1725-1759 (evaluated for r = 0 too); blob_radius >= 0 selects
+ *   the RPY-regularised unbounded operator (:2095-2168; wall must be 0), blob_radius < 0 the plain one. */
+int rmb_pressure_stokeslet(long ns, const double* src, long nt, const double* tgt, const double* force, const double* L,
+                           int wall, double* out);
+int rmb_pressure_stokeslet_device(rmb_ctx* ctx, long ns, const double* src_dev, long nt, const double* tgt_dev,
+                                  const double* force_dev, const double* L, int wall, double* out_dev);
+int rmb_double_layer(long ns, const double* src, long nt, const double* tgt, const double* normals, const double* vector,
+                     const double* weights, int wall, double blob_radius, double* out);
+int rmb_double_layer_device(rmb_ctx* ctx, long ns, const double* src_dev, long nt, const double* tgt_dev,
+                            const double* normals_dev, const double* vector_dev, const double* weights_dev, int wall,
+                            double blob_radius, double* out_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ def _lib(fast=False):
                                                 _dp, ctypes.c_int, _dp]
     lib.oracle_source_target_matvec.restype = ctypes.c_int
     lib.oracle_num_threads.restype = ctypes.c_int
+    lib.oracle_pressure_stokeslet.argtypes = [ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, ctypes.c_int, _dp]
+    lib.oracle_double_layer.argtypes = [ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp]
     lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
     lib.oracle_set_num_threads.restype = None
     _LIBS[name] = lib
@@ -306,3 +308,40 @@ def calc_blob_blob_forces_radii_oracle(r_vectors, radius_blobs, *args, **kwargs)
   if rc != 0:
     raise RuntimeError("oracle_blob_blob_force_radii failed: %d" % rc)
   return out.reshape(N, 3)
+
+
+# ---- Stokeslet pressure / Stokes double layer, source -> target (mobility/mobility.py:1345-1366, :1376-1387, :1432-1442)
+def _pressure(source, target, force, wall, **kw):
+  L = np.asarray(kw.get("periodic_length", np.zeros(3)), dtype=np.float64)
+  if np.any(L > 0):
+    raise ValueError("pressure: only periodic_length = 0 is restated (the reference divides by the unwrapped distance)")
+  src, tgt, f = _c(np.asarray(source, dtype=np.float64).reshape(-1)), _c(np.asarray(target, dtype=np.float64).reshape(-1)), \
+      _c(np.asarray(force, dtype=np.float64).reshape(-1))
+  p = np.empty(tgt.size // 3)
+  _lib().oracle_pressure_stokeslet(src.size // 3, _p(src), tgt.size // 3, _p(tgt), _p(f), int(wall), _p(p))
+  return p
+
+
+def no_wall_pressure_Stokeslet_oracle(source, target, force, *args, **kw):
+  return _pressure(source, target, force, 0, **kw)
+
+
+def single_wall_pressure_Stokeslet_oracle(source, target, force, *args, **kw):
+  return _pressure(source, target, force, 1, **kw)
+
+
+def _double_layer(source, target, normals, vector, weights, wall, blob_radius):
+  src, tgt = _c(np.asarray(source, dtype=np.float64).reshape(-1)), _c(np.asarray(target, dtype=np.float64).reshape(-1))
+  n, v, w = _c(np.asarray(normals, dtype=np.float64).reshape(-1)), _c(np.asarray(vector, dtype=np.float64).reshape(-1)), \
+      _c(np.asarray(weights, dtype=np.float64).reshape(-1))
+  u = np.empty(tgt.size)
+  _lib().oracle_double_layer(src.size // 3, _p(src), tgt.size // 3, _p(tgt), _p(n), _p(v), _p(w), int(wall), float(blob_radius), _p(u))
+  return u
+
+
+def double_layer_source_target_oracle(source, target, normals, vector, weights, *args, **kw):
+  return _double_layer(source, target, normals, vector, weights, 1 if kw.get("wall", 0) else 0, -1.0)
+
+
+def no_wall_double_layer_source_target_oracle(source, target, normals, vector, weights, blob_radius, *args, **kw):
+  return _double_layer(source, target, normals, vector, weights, 0, blob_radius)

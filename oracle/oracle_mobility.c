@@ -685,6 +685,108 @@ int oracle_wall_regularisation(long N, const double *r, double a, double *r_eff,
   return 0;
 }
 
+/* ---- Stokeslet pressure and Stokes double layer, source -> target ----------------------------------------------
+ * The remaining O(N_s N_t) operators of mobility/mobility_numba.py.  Written as the reference writes them (explicit
+ * divisions, sqrt, the nine-term contraction as (r.n)(r.v) r), unbounded or above a no-slip wall at z = 0.
+ *
+ * oracle_pressure_stokeslet: p_t = 1/(4 pi) sum_s f_s . r / |r|^3  (+ Blake image system, :1399-1476).  Two notes on
+ * the reference's text: (i) its single-wall routine rescales the running sum by 1/(4 pi) INSIDE the source loop
+ * (:1474), so for more than one source its result depends on the source order and decays geometrically; this
+ * restatement applies the factor once, which is what the routine returns for a single source and what superposition
+ * of single-source calls gives (that is how tests/golden pins it); (ii) the pseudo-periodic branch of both routines
+ * divides by the UNWRAPPED distance (:1374-1375 before :1381-1389), so only L = 0 is restated. */
+int oracle_pressure_stokeslet(long Ns, const double *src, long Nt, const double *tgt, const double *force, int wall,
+                              double *p) {
+  const double c = 1.0 / (4.0 * M_PI);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < Nt; ++i) {
+    const double xi = tgt[3 * i], yi = tgt[3 * i + 1], zi = tgt[3 * i + 2];
+    double acc = 0.0;
+    for (long j = 0; j < Ns; ++j) {
+      const double fx = force[3 * j], fy = force[3 * j + 1], fz = force[3 * j + 2];
+      const double rx = xi - src[3 * j], ry = yi - src[3 * j + 1];
+      double rz = zi - src[3 * j + 2];
+      double r = sqrt(rx * rx + ry * ry + rz * rz);
+      double r3 = r * r * r;
+      acc += (fx * rx + fy * ry + fz * rz) / r3;                       /* :1391 / :1459 */
+      if (wall) {                                                      /* :1461-1473 */
+        const double h = src[3 * j + 2];
+        rz = zi + h;
+        r = sqrt(rx * rx + ry * ry + rz * rz);
+        r3 = r * r * r;
+        const double r5 = r3 * r * r;
+        acc += -(fx * rx + fy * ry + fz * rz) / r3;
+        acc += -fx * 2 * h * (-3 * rz * rx / r5);
+        acc += -fy * 2 * h * (-3 * rz * ry / r5);
+        acc += fz * 2 * h * (-3 * rz * rz / r5 + 1.0 / r3);
+      }
+    }
+    p[i] = c * acc;
+  }
+  return 0;
+}
+
+/* oracle_double_layer: u_t = -3/(4 pi) sum_s w_s [ r (r.n_s)(r.v_s) / |r|^5 (r > 1e-14) + wall images ]
+ *   (mobility_numba.py:1662-1766; images after Gimbutas et al. 2015: reflected double layer, derivative dipole /
+ *   quadrupole, dipole, quadrupole -- the image terms are evaluated for r = 0 too).
+ * blob_radius >= 0 selects the RPY-regularised unbounded operator (:2095-2168):
+ *   (1 - 10 a^2/(3 r^2)) r (r.n)(r.v)/|r|^5 + (2 a^2/3) [(n.v) r + (r.v) n + (r.n) v]/|r|^5,  pairs with r < 1e-14 skipped. */
+int oracle_double_layer(long Ns, const double *src, long Nt, const double *tgt, const double *normals,
+                        const double *vector, const double *weights, int wall, double blob_radius, double *u) {
+  const double factor = -3.0 / (4.0 * M_PI);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < Nt; ++i) {
+    const double xi = tgt[3 * i], yi = tgt[3 * i + 1], zi = tgt[3 * i + 2];
+    double ux = 0.0, uy = 0.0, uz = 0.0;
+    for (long j = 0; j < Ns; ++j) {
+      const double nx = normals[3 * j], ny = normals[3 * j + 1], nz = normals[3 * j + 2];
+      const double vx = vector[3 * j], vy = vector[3 * j + 1], vz = vector[3 * j + 2];
+      const double w = weights[j];
+      const double rx = xi - src[3 * j], ry = yi - src[3 * j + 1];
+      double rz = zi - src[3 * j + 2];
+      double r2 = rx * rx + ry * ry + rz * rz;
+      double r = sqrt(r2);
+      double r5 = r2 * r2 * r;
+      if (blob_radius >= 0.0) {
+        if (r < 1e-14) continue;                                        /* :2139-2140 */
+        const double a2 = blob_radius * blob_radius;
+        const double rn = rx * nx + ry * ny + rz * nz, rv = rx * vx + ry * vy + rz * vz, nv = nx * vx + ny * vy + nz * vz;
+        const double c0 = (1 - 10 * a2 / (3 * r2)) * rn * rv * w / r5;
+        const double c1 = (2.0 * a2 / 3.0) * w / r5;
+        ux += c0 * rx + c1 * (nv * rx + rv * nx + rn * vx);
+        uy += c0 * ry + c1 * (nv * ry + rv * ny + rn * vy);
+        uz += c0 * rz + c1 * (nv * rz + rv * nz + rn * vz);
+        continue;
+      }
+      if (r > 1e-14) {                                                  /* :1715-1722 */
+        const double c0 = (rx * nx + ry * ny + rz * nz) * (rx * vx + ry * vy + rz * vz) * w / r5;
+        ux += rx * c0; uy += ry * c0; uz += rz * c0;
+      }
+      if (wall) {                                                       /* :1725-1759 */
+        const double h = src[3 * j + 2];
+        rz = zi + h;
+        r2 = rx * rx + ry * ry + rz * rz;
+        r = sqrt(r2);
+        const double r3 = r2 * r;
+        r5 = r3 * r2;
+        const double rn = rx * nx + ry * ny - rz * nz, rv = rx * vx + ry * vy - rz * vz, nv = nx * vx + ny * vy + nz * vz;
+        const double c0 = rn * rv * w / r5;
+        ux -= rx * c0; uy -= ry * c0; uz -= rz * c0;
+        ux += -2 * zi * nv * (-rx * rz / r2) * w / r3;
+        uy += -2 * zi * nv * (-ry * rz / r2) * w / r3;
+        uz += -2 * zi * nv * (1.0 / 3.0 - rz * rz / r2) * w / r3;
+        ux += -2 * zi * h * (rx * nv + vx * rn + nx * rv - 5 * rx * rv * rn / r2) * w / r5;
+        uy += -2 * zi * h * (ry * nv + vy * rn + ny * rv - 5 * ry * rv * rn / r2) * w / r5;
+        uz += -2 * zi * h * (rz * nv - vz * rn - nz * rv - 5 * rz * rv * rn / r2) * w / r5;
+        uz += 2 * nv * rz * w / (3 * r3);
+        uz += 2 * h * (-nv / 3 + rv * rn / r2) * w / r3;
+      }
+    }
+    u[3 * i] = factor * ux; u[3 * i + 1] = factor * uy; u[3 * i + 2] = factor * uz;
+  }
+  return 0;
+}
+
 /* Cap the OpenMP team (the GPU box exposes every hardware thread of the host but grants a CPU share of a few cores:
    an oversubscribed team makes the baseline slower than it is). */
 void oracle_set_num_threads(int n) {

@@ -64,6 +64,12 @@ SYMBOLS = {
                                                          ctypes.c_double, _vp, ctypes.c_int, _vp]),
     "rmb_forces_oneshot": (ctypes.c_int, [ctypes.c_long, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_double, _vp]),
+    "rmb_pressure_stokeslet": (ctypes.c_int, [ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    "rmb_pressure_stokeslet_device": (ctypes.c_int, [_vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    "rmb_double_layer": (ctypes.c_int, [ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                        ctypes.c_double, _vp]),
+    "rmb_double_layer_device": (ctypes.c_int, [_vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                               ctypes.c_double, _vp]),
 }
 
 _lib = None

@@ -17,6 +17,7 @@
 #include "symx_kernels.h"
 #include "dense_kernels.h"
 #include "st_kernels.h"
+#include "aux_kernels.h"
 #include "diag_kernels.h"
 
 namespace {
@@ -785,6 +786,50 @@ rmb_ctx* g_default_ctx = nullptr;
 
 }  // namespace
 
+// ---- Stokeslet pressure / Stokes double layer, source -> target (aux_kernels.h) ---------------------------------
+namespace {
+template <int MODE>
+int aux_launch(rmb_ctx* c, rmb::AuxArgs a) {
+  typedef void (*aux_fn)(const rmb::AuxArgs);
+  constexpr int NOUT = rmb::AuxShape<MODE>::NOUT;
+  static int occ = 0;
+  aux_fn fn = (aux_fn)rmb::aux_sweep_kernel<MODE>;
+  const long tiles = (a.nt + 63) / 64;
+  a.n_tgt_pad = 64 * tiles;
+  const long slots = c->n_cu * resident_blocks((const void*)fn, &occ);
+  long n_chunks, chunk_len;
+  choose_chunks(a.nt, a.ns, c->opt_chunks, slots, &n_chunks, &chunk_len);
+  if (tiles > 0x7fffffffL || n_chunks > 65535) return fail(RMB_ERR_ARG, "problem too large for one launch");
+  a.chunk_len = chunk_len; a.n_chunks = (int)n_chunks; a.partial = nullptr;
+  if (n_chunks > 1) {
+    if (int rc = c->partial.reserve((size_t)n_chunks * NOUT * a.n_tgt_pad * sizeof(double))) return rc;
+    a.partial = (double*)c->partial.p;
+  }
+  c->last_path = 0; c->last_tiles = tiles; c->last_chunks = n_chunks; c->last_wgs = tiles * n_chunks;
+  int slot;
+  if (int rc = timing_begin(c, &slot)) return rc;
+  hipLaunchKernelGGL(fn, dim3((unsigned)tiles, (unsigned)n_chunks), dim3(rmb::kBlock), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  if (int rc = timing_end(c, slot)) return rc;
+  if (n_chunks > 1) {
+    hipLaunchKernelGGL(rmb::aux_finalize_kernel<NOUT>, dim3((unsigned)((a.nt + 255) / 256)), dim3(256), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// host arrays -> staging buffers of the default context; returns device pointers in dev[]
+int aux_stage(rmb_ctx* c, int n, const double* const* host, const size_t* bytes, const int* slot, const double** dev) {
+  for (int k = 0; k < n; ++k) {
+    if (int rc = c->st[slot[k]].reserve(bytes[k] ? bytes[k] : sizeof(double))) return rc;
+    if (bytes[k]) RMB_HIP(hipMemcpyAsync(c->st[slot[k]].p, host[k], bytes[k], hipMemcpyHostToDevice, c->stream));
+    dev[k] = (const double*)c->st[slot[k]].p;
+  }
+  return 0;
+}
+}  // namespace
+
+
 extern "C" {
 
 const char* rmb_version(void) { return "rmb_mobility 0.1 (gfx950)"; }
@@ -1147,6 +1192,91 @@ int rmb_mobility_source_target(long ns, const double* src, const double* rad_s, 
                                                  (const double*)c->st[6].p, eta, L, wall, (double*)c->st[7].p))
     return rc;
   RMB_HIP(hipMemcpyAsync(out, c->st[7].p, bt3, hipMemcpyDeviceToHost, c->stream));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rmb_pressure_stokeslet_device(rmb_ctx* c, long ns, const double* src_dev, long nt, const double* tgt_dev,
+                                  const double* force_dev, const double* L, int wall, double* out_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (ns < 0 || nt < 0) return fail(RMB_ERR_ARG, "negative size");
+  if (wall != 0 && wall != 1) return fail(RMB_ERR_ARG, "wall must be 0 or 1");
+  if (L && (L[0] > 0 || L[1] > 0 || L[2] > 0))
+    return fail(RMB_ERR_ARG, "pressure: periodic_length must be zero (the reference's periodic branch divides by the unwrapped distance)");
+  if (nt == 0) return 0;
+  if (!out_dev || !tgt_dev || (ns > 0 && (!src_dev || !force_dev))) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  if (ns == 0) { RMB_HIP(hipMemsetAsync(out_dev, 0, (size_t)nt * sizeof(double), c->stream)); return 0; }
+  rmb::AuxArgs a{};
+  a.src = src_dev; a.tgt = tgt_dev; a.v0 = force_dev; a.v1 = nullptr; a.w = nullptr; a.out = out_dev;
+  a.ns = ns; a.nt = nt; a.prefactor = 1.0 / (4.0 * M_PI); a.a2 = 0.0;
+  return wall ? aux_launch<rmb::AUX_P_WALL>(c, a) : aux_launch<rmb::AUX_P_FREE>(c, a);
+}
+
+int rmb_double_layer_device(rmb_ctx* c, long ns, const double* src_dev, long nt, const double* tgt_dev,
+                            const double* normals_dev, const double* vector_dev, const double* weights_dev, int wall,
+                            double blob_radius, double* out_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (ns < 0 || nt < 0) return fail(RMB_ERR_ARG, "negative size");
+  if (wall != 0 && wall != 1) return fail(RMB_ERR_ARG, "wall must be 0 or 1");
+  if (wall && blob_radius >= 0.0) return fail(RMB_ERR_ARG, "the RPY double layer is unbounded only (mobility_numba.py:2095)");
+  if (nt == 0) return 0;
+  if (!out_dev || !tgt_dev || (ns > 0 && (!src_dev || !normals_dev || !vector_dev || !weights_dev)))
+    return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  if (ns == 0) { RMB_HIP(hipMemsetAsync(out_dev, 0, (size_t)3 * nt * sizeof(double), c->stream)); return 0; }
+  rmb::AuxArgs a{};
+  a.src = src_dev; a.tgt = tgt_dev; a.v0 = normals_dev; a.v1 = vector_dev; a.w = weights_dev; a.out = out_dev;
+  a.ns = ns; a.nt = nt; a.prefactor = -3.0 / (4.0 * M_PI); a.a2 = blob_radius >= 0.0 ? blob_radius * blob_radius : 0.0;
+  if (blob_radius >= 0.0) return aux_launch<rmb::AUX_DL_RPY>(c, a);
+  return wall ? aux_launch<rmb::AUX_DL_WALL>(c, a) : aux_launch<rmb::AUX_DL_FREE>(c, a);
+}
+
+int rmb_pressure_stokeslet(long ns, const double* src, long nt, const double* tgt, const double* force, const double* L,
+                           int wall, double* out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default_ctx) {
+    if (int rc = rmb_ctx_create(0, &g_default_ctx)) return rc;
+  }
+  rmb_ctx* c = g_default_ctx;
+  if (ns < 0 || nt < 0) return fail(RMB_ERR_ARG, "negative size");
+  if (nt == 0) return 0;
+  if (!out || !tgt || (ns > 0 && (!src || !force))) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  const size_t b3s = (size_t)3 * ns * sizeof(double), b3t = (size_t)3 * nt * sizeof(double);
+  const double* host[3] = {src, tgt, force};
+  const size_t bytes[3] = {b3s, b3t, b3s};
+  const int slot[3] = {2, 4, 6};
+  const double* dev[3];
+  if (int rc = aux_stage(c, 3, host, bytes, slot, dev)) return rc;
+  if (int rc = c->st[7].reserve((size_t)nt * sizeof(double))) return rc;
+  if (int rc = rmb_pressure_stokeslet_device(c, ns, dev[0], nt, dev[1], dev[2], L, wall, (double*)c->st[7].p)) return rc;
+  RMB_HIP(hipMemcpyAsync(out, c->st[7].p, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RMB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rmb_double_layer(long ns, const double* src, long nt, const double* tgt, const double* normals, const double* vector,
+                     const double* weights, int wall, double blob_radius, double* out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default_ctx) {
+    if (int rc = rmb_ctx_create(0, &g_default_ctx)) return rc;
+  }
+  rmb_ctx* c = g_default_ctx;
+  if (ns < 0 || nt < 0) return fail(RMB_ERR_ARG, "negative size");
+  if (nt == 0) return 0;
+  if (!out || !tgt || (ns > 0 && (!src || !normals || !vector || !weights))) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  const size_t b3s = (size_t)3 * ns * sizeof(double), b3t = (size_t)3 * nt * sizeof(double);
+  const double* host[5] = {src, tgt, normals, vector, weights};
+  const size_t bytes[5] = {b3s, b3t, b3s, b3s, (size_t)ns * sizeof(double)};
+  const int slot[5] = {2, 4, 6, 5, 3};
+  const double* dev[5];
+  if (int rc = aux_stage(c, 5, host, bytes, slot, dev)) return rc;
+  if (int rc = c->st[7].reserve(b3t)) return rc;
+  if (int rc = rmb_double_layer_device(c, ns, dev[0], nt, dev[1], dev[2], dev[3], dev[4], wall, blob_radius, (double*)c->st[7].p))
+    return rc;
+  RMB_HIP(hipMemcpyAsync(out, c->st[7].p, b3t, hipMemcpyDeviceToHost, c->stream));
   RMB_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }

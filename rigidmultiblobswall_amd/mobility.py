@@ -211,6 +211,63 @@ def mobility_radii_trans_times_force(r_vectors, force, eta, a, radius_blobs, fun
 
 
 # ---------------------------------------------------------------------------------------------
+# Stokeslet pressure and Stokes double layer, source -> target
+# ---------------------------------------------------------------------------------------------
+def _flat(x, what, n=None):
+  x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+  if n is not None and x.size != n:
+    raise ValueError("%s must have %d entries" % (what, n))
+  return x
+
+
+def _pressure(source, target, force, wall, kwargs):
+  import ctypes
+  L = np.ascontiguousarray(kwargs.get('periodic_length', np.zeros(3)), dtype=np.float64).reshape(3)
+  src, tgt = _flat(source, "source"), _flat(target, "target")
+  ns, nt = src.size // 3, tgt.size // 3
+  f = _flat(force, "force", 3 * ns)
+  out = np.empty(nt)
+  p = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+  _lib.check(_lib.load().rmb_pressure_stokeslet(ns, p(src), nt, p(tgt), p(f), p(L), int(wall), p(out)))
+  return out
+
+
+def no_wall_pressure_Stokeslet_hip(source, target, force, *args, **kwargs):
+  '''Pressure at the targets created by Stokeslets at the sources, unbounded (mobility/mobility.py:1345-1354;
+  kernel mobility_numba.py:1332-1396).  periodic_length must be zero (see include/rmb_mobility.h).'''
+  return _pressure(source, target, force, 0, kwargs)
+
+
+def single_wall_pressure_Stokeslet_hip(source, target, force, *args, **kwargs):
+  '''Same above a no-slip wall (Blake's image system; mobility/mobility.py:1357-1366, kernel mobility_numba.py:1399-1476).
+  The 1/(4 pi) factor is applied once: the reference rescales its running sum inside the source loop, which equals
+  this result for one source only.'''
+  return _pressure(source, target, force, 1, kwargs)
+
+
+def _double_layer(source, target, normals, vector, weights, wall, blob_radius):
+  import ctypes
+  src, tgt = _flat(source, "source"), _flat(target, "target")
+  ns, nt = src.size // 3, tgt.size // 3
+  n, v, w = _flat(normals, "normals", 3 * ns), _flat(vector, "vector", 3 * ns), _flat(weights, "weights", ns)
+  out = np.empty(3 * nt)
+  p = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+  _lib.check(_lib.load().rmb_double_layer(ns, p(src), nt, p(tgt), p(n), p(v), p(w), int(wall), float(blob_radius), p(out)))
+  return out
+
+
+def double_layer_source_target_hip(source, target, normals, vector, weights, *args, **kwargs):
+  '''Stokes double-layer operator times a vector, diagonal terms zero; kwarg wall = 1 adds the image system of a
+  no-slip wall (mobility/mobility.py:1376-1387, kernel mobility_numba.py:1662-1766).'''
+  return _double_layer(source, target, normals, vector, weights, 1 if kwargs.get('wall', 0) else 0, -1.0)
+
+
+def no_wall_double_layer_source_target_hip(source, target, normals, vector, weights, blob_radius, *args, **kwargs):
+  '''RPY-regularised double layer, unbounded (mobility/mobility.py:1432-1442, kernel mobility_numba.py:2095-2168).'''
+  return _double_layer(source, target, normals, vector, weights, 0, float(blob_radius))
+
+
+# ---------------------------------------------------------------------------------------------
 # dense builders (used per body by the preconditioner / body_mobility scheme in the reference)
 # ---------------------------------------------------------------------------------------------
 def _dense(r_vectors, eta, a, wall):

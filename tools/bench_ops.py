@@ -140,6 +140,17 @@ for N in SIZES:
   sw = timed(ctx, lambda: st(rd2, rad2), reps, 1)
   row(N, "radii mobility, wall (sources == targets)", "one-sided source->target sweep", sw)
   row(N, "radii mobility, wall (sources == targets)", "symmetric (symx OpRadiiTT)", timed(ctx, lambda: st(rd, rad), reps, 1), sw)
+  # Stokeslet pressure / Stokes double layer, N sources -> N targets (one-sided, atomic-free; aux_kernels.h)
+  nrm, vv, ww = dev(rng.randn(N, 3)), dev(rng.randn(N, 3)), dev(0.1 + rng.rand(N))
+  tg = dev(np.asarray(r) + 0.01)
+  po, uo = torch.empty(N, dtype=torch.float64, device="cuda"), torch.empty(3 * N, dtype=torch.float64, device="cuda")
+  for wall in (0, 1):
+    row(N, "Stokeslet pressure, %s" % ("wall" if wall else "unbounded"), "aux_sweep_kernel",
+        timed(ctx, lambda: _lib.check(lib.rmb_pressure_stokeslet_device(ctx._h, N, vp(rd), N, vp(tg), vp(fd), None, wall, vp(po))), reps, None))
+    row(N, "Stokes double layer, %s" % ("wall" if wall else "unbounded"), "aux_sweep_kernel",
+        timed(ctx, lambda: _lib.check(lib.rmb_double_layer_device(ctx._h, N, vp(rd), N, vp(tg), vp(nrm), vp(vv), vp(ww), wall, -1.0, vp(uo))), reps, None))
+  row(N, "Stokes double layer, RPY blobs", "aux_sweep_kernel",
+      timed(ctx, lambda: _lib.check(lib.rmb_double_layer_device(ctx._h, N, vp(rd), N, vp(tg), vp(nrm), vp(vv), vp(ww), 0, a, vp(uo))), reps, None))
   for kind in ("tt", "tr", "rt", "rr"):
     row(N, "no-wall " + kind, "sym_kernel", timed(ctx, lambda: ctx.matvec_device(kind, fd, eta), reps, 1))
   row(N, "no-wall grand", "single symmetric pass (symx OpGrand)", timed(ctx, lambda: ctx.matvec_op_device("grand", (fd, td), eta), reps, 1))
