@@ -44,6 +44,21 @@ def main():
   out["dl_no_wall_self"] = np.asarray(mob.double_layer_source_target_numba(src, src, normals, vector, weights))
   out["dl_wall_self"] = np.asarray(mob.double_layer_source_target_numba(src, src, normals, vector, weights, wall=1))
   out["dl_rpy_self"] = np.asarray(mob.no_wall_double_layer_source_target_numba(src, src, normals, vector, weights, 0.17))
+  # small host-surface members of mobility.py: per-blob-radius clamp / damping (:87-119), dense products (:711-736),
+  # 6 x 6 self mobility of a sphere above the wall (:739-772)
+  rad = 0.05 + 0.3 * rng.rand(ns)
+  out["radii"] = rad
+  out["shift_heights_different_radius"] = mob.shift_heights_different_radius(src, rad)
+  B, overlap = mob.damping_matrix_B_different_radius(src, rad)
+  out["B_different_radius_diag"] = B.diagonal()
+  out["B_different_radius_overlap"] = np.array(overlap)
+  hi = src + np.array([0, 0, 0.4])          # every blob above z = a = 0.2
+  out["dense_src"] = hi
+  out["wall_dense_product"] = mob.single_wall_fluid_mobility_product(hi, force.flatten(), 0.9, 0.2)
+  out["no_wall_dense_product"] = mob.no_wall_fluid_mobility_product(hi, force.flatten(), 0.9, 0.2)
+  for k, h in enumerate((1.05, 1.7, 6.0)):
+    out["self_6x6_h%d" % k] = mob.single_wall_self_mobility_with_rotation(np.array([0.3, -0.2, h * 0.25]), 1.3, 0.25)
+    out["self_6x6_h%d_height" % k] = np.array(h * 0.25)
   np.savez_compressed(os.path.join(out_dir, "g11_aux_operators.npz"), **out)
   print("g11_aux_operators.npz written: %d arrays" % len(out))
 

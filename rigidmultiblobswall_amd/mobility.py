@@ -86,6 +86,24 @@ def damping_matrix_B(r_vectors, blob_radius, *args, **kwargs):
   return (scipy.sparse.dia_matrix((B, 0), shape=(B.size, B.size)), overlap)
 
 
+def shift_heights_different_radius(r_vectors, blob_radius, *args, **kwargs):
+  '''z_effective = maximum(z, blob_radius[k]) per blob; returns a copy (mobility/mobility.py:87-99).'''
+  r_effective = np.copy(r_vectors)
+  rad = np.asarray(blob_radius, dtype=np.float64).reshape(-1)
+  low = ~(r_effective[:, 2] > rad)
+  r_effective[low, 2] = rad[low]
+  return r_effective
+
+
+def damping_matrix_B_different_radius(r_vectors, blob_radius, *args, **kwargs):
+  '''(sparse diagonal B, overlap flag); B_ii = z_i/a_i for z_i < a_i else 1 (mobility/mobility.py:102-119).'''
+  r = np.asarray(r_vectors).reshape(-1, 3)
+  rad = np.asarray(blob_radius, dtype=np.float64).reshape(-1)
+  below = r[:, 2] < rad
+  B = np.repeat(np.where(below, r[:, 2] / rad, 1.0), 3)
+  return (scipy.sparse.dia_matrix((B, 0), shape=(B.size, B.size)), bool(np.any(below)))
+
+
 # ---------------------------------------------------------------------------------------------
 # translation <- force
 # ---------------------------------------------------------------------------------------------
@@ -293,3 +311,37 @@ def single_wall_fluid_mobility_hip(r_vectors, eta, a, *args, **kwargs):
 def rotne_prager_tensor_hip(r_vectors, eta, a, *args, **kwargs):
   '''Dense 3N x 3N unbounded RPY mobility (mobility/mobility.py:967-1013).'''
   return _dense(r_vectors, eta, a, False)
+
+
+def single_wall_fluid_mobility_product_hip(r_vectors, vector, eta, a, *args, **kwargs):
+  '''Dense wall mobility times a vector (mobility/mobility.py:711-724: `single_wall_fluid_mobility(...) @ vector`, no
+  pseudo-PBC).  The dense matrix carries no height clamp in the reference; for blobs with z > a -- the only case in
+  which that matrix is a valid mobility -- this is the matrix-free product, which is what runs.'''
+  return _product('tt', True, False, r_vectors, vector, eta, a, {})
+
+
+def no_wall_fluid_mobility_product_hip(r_vectors, vector, eta, a, *args, **kwargs):
+  '''Dense RPY mobility times a vector (mobility/mobility.py:727-736), evaluated matrix-free.'''
+  return _product('tt', False, False, r_vectors, vector, eta, a, {})
+
+
+def single_wall_self_mobility_with_rotation_hip(location, eta, a, *args, **kwargs):
+  '''6 x 6 self mobility of one sphere of radius a at height location[2] above the wall, force and torque to velocity
+  and angular velocity (Swan & Brady; mobility/mobility.py:739-772).  Built from the device kernels' own self terms:
+  the six columns are the grand-mobility product [[M_tt, M_tr], [M_rt, M_rr]] of a single blob on the unit vectors.'''
+  import torch
+  r = np.ascontiguousarray(location, dtype=np.float64).reshape(1, 3)
+  ctx = MobilityContext(0)
+  try:
+    ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda:0"), a, None, True)
+    M = np.empty((6, 6))
+    for k in range(6):
+      e = np.zeros(6)
+      e[k] = 1.0
+      f, t = torch.as_tensor(e[:3].copy(), device="cuda:0"), torch.as_tensor(e[3:].copy(), device="cuda:0")
+      u, w = ctx.matvec_op_device("grand", (f, t), eta)
+      M[:3, k] = u.cpu().numpy()
+      M[3:, k] = w.cpu().numpy()
+  finally:
+    ctx.close()
+  return M

@@ -192,3 +192,28 @@ def test_hip_wrappers_reject_bad_shapes(mob):
   from rigidmultiblobswall_amd._lib import RmbError
   with pytest.raises(RmbError):
     mob.no_wall_pressure_Stokeslet_hip(src + 1, tgt, np.zeros((4, 3)), periodic_length=np.array([0.0, 5.0, 0.0]))
+
+
+# ---------------------------------------------------------------------------------------------
+# small host-surface members of mobility/mobility.py
+# ---------------------------------------------------------------------------------------------
+def test_per_blob_radius_clamp_and_damping_match_reference(g11):
+  from rigidmultiblobswall_amd import mobility as mob      # host-only helpers: no GPU needed
+  g = g11
+  assert np.array_equal(mob.shift_heights_different_radius(g["source"], g["radii"]), g["shift_heights_different_radius"])
+  B, overlap = mob.damping_matrix_B_different_radius(g["source"], g["radii"])
+  assert np.array_equal(B.diagonal(), g["B_different_radius_diag"]) and overlap == bool(g["B_different_radius_overlap"])
+  assert bool(g["B_different_radius_overlap"])            # the fixture does contain blobs below their radius
+
+
+@pytest.mark.gpu
+def test_hip_dense_products_and_self_mobility_golden(mob, g11):
+  g = g11
+  f = g["force"].flatten()
+  assert rel_err(mob.single_wall_fluid_mobility_product_hip(g["dense_src"], f, 0.9, 0.2), g["wall_dense_product"]) < TOL
+  assert rel_err(mob.no_wall_fluid_mobility_product_hip(g["dense_src"], f, 0.9, 0.2), g["no_wall_dense_product"]) < TOL
+  for k in range(3):
+    M = mob.single_wall_self_mobility_with_rotation_hip(np.array([0.3, -0.2, float(g["self_6x6_h%d_height" % k])]), 1.3, 0.25)
+    ref = g["self_6x6_h%d" % k]
+    assert M.shape == (6, 6)
+    assert np.abs(M - ref).max() < 1e-13 * np.abs(ref).max(), (k, np.abs(M - ref).max())
