@@ -328,7 +328,11 @@ def no_wall_fluid_mobility_product_hip(r_vectors, vector, eta, a, *args, **kwarg
 def single_wall_self_mobility_with_rotation_hip(location, eta, a, *args, **kwargs):
   '''6 x 6 self mobility of one sphere of radius a at height location[2] above the wall, force and torque to velocity
   and angular velocity (Swan & Brady; mobility/mobility.py:739-772).  Built from the device kernels' own self terms:
-  the six columns are the grand-mobility product [[M_tt, M_tr], [M_rt, M_rr]] of a single blob on the unit vectors.'''
+  the six columns are the grand-mobility product [[M_tt, M_tr], [M_rt, M_rr]] of a single blob on the unit vectors.
+  Sign of the coupling blocks: this legacy routine of the reference writes them with epsilon(2, l, m), the OPPOSITE sign
+  to its own product kernels (mobility_numba.py:646-679, :1035-1066: a torque +y above the wall drives the sphere towards
+  +x, like a rolling wheel; the routine returns -x).  The function returns what the reference's routine returns, so the
+  two off-diagonal blocks of the device result are negated; the products themselves are untouched.'''
   import torch
   r = np.ascontiguousarray(location, dtype=np.float64).reshape(1, 3)
   ctx = MobilityContext(0)
@@ -344,4 +348,6 @@ def single_wall_self_mobility_with_rotation_hip(location, eta, a, *args, **kwarg
       M[3:, k] = w.cpu().numpy()
   finally:
     ctx.close()
+  M[:3, 3:] *= -1.0
+  M[3:, :3] *= -1.0
   return M
