@@ -576,6 +576,21 @@ def test_force_edge_separations_elementwise(Ctx, oracle):
   ctx.close()
 
 
+@pytest.mark.parametrize("span,zmax", [(3000.0, 1.2), (30000.0, 1.02), (1e6, 1.0)])
+def test_flat_layer_far_field_cancellation(mob, oracle, span, zmax):
+  """A monolayer on the wall, thousands of radii wide: every far pair is the near-cancellation of the RPY tensor with
+  its image, and the closed-form block works with 1 - rho^2/R^2 and 1 - r^2/R^2 there (pair_blocks.h)."""
+  N = 2500
+  rng = np.random.RandomState(int(span) % 9973)
+  a, eta = 0.5, 1.0
+  r = np.column_stack([rng.rand(N) * span * a, rng.rand(N) * span * a, a * (1.0 + (zmax - 1.0) * rng.rand(N))])
+  f = rng.randn(N, 3)
+  for nm in ("trans_times_force", "trans_times_torque", "rot_times_force", "rot_times_torque"):
+    u = getattr(mob, "single_wall_mobility_" + nm + "_hip")(r, f, eta, a)
+    ref = getattr(oracle, "single_wall_mobility_" + nm + "_oracle")(r, f, eta, a)
+    assert rel_err(u, ref) < 1e-13, (nm, rel_err(u, ref))
+
+
 # ---------------------------------------------------------------------------------------------
 # 7. source -> target products with per-blob radii (K13)
 # ---------------------------------------------------------------------------------------------
