@@ -14,6 +14,7 @@
 #include "matvec_kernels.h"
 #include "sym_kernels.h"
 #include "sym2_kernels.h"
+#include "sym32_kernels.h"
 #include "symx_kernels.h"
 #include "dense_kernels.h"
 #include "st_kernels.h"
@@ -92,6 +93,7 @@ struct rmb_ctx {
   int last_path = 0;           // 0 = sweep, 1 = symmetric
   long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
   long opt_sym_pin = 1;        // pad dynamic LDS so residency is exactly that number
+  long opt_precision = 64;     // 32: M_tt f (open boundaries) in single precision (sym32_kernels.h); everything else fp64
   long opt_sym_min_steps = 64; // floor on rotation steps per wave (a unit is 64 steps)
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
@@ -311,8 +313,16 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
   SymPlan plan;
-  const size_t stat = sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
-  if (int rc = plan_sym(c, (const void*)se.sweep, &se.occ, stat, a.step_end - a.step_begin, true, &plan)) return rc;
+  // single-precision mode (mobility_pycuda.py:7-19 `precision = 'single'`): tt with open boundaries only
+  const bool f32 = c->opt_precision == 32 && kind == RMB_TT && !periodic;
+  typedef void (*sym32_fn)(const rmb::SymArgs, const rmb::PairConsts32);
+  const sym32_fn fn32 = c->wall ? (sym32_fn)rmb::sym32_tt_kernel<true> : (sym32_fn)rmb::sym32_tt_kernel<false>;
+  static int occ32[2] = {0, 0};
+  const size_t stat = f32 ? (sizeof(float) * 6 + sizeof(double) * 3) * rmb::kSymWaves * 64
+                          : sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
+  if (int rc = plan_sym(c, f32 ? (const void*)fn32 : (const void*)se.sweep, f32 ? &occ32[c->wall ? 1 : 0] : &se.occ, stat,
+                        a.step_end - a.step_begin, true, &plan))
+    return rc;
   const long blocks = plan.blocks;
   a.steps_per_wave = plan.steps_per_wave;
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
@@ -326,7 +336,14 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   }
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
+  if (f32) {
+    rmb::PairConsts32 kf;
+    kf.a2 = (float)a.k.a2; kf.four_a2 = (float)a.k.four_a2; kf.tt_k1 = (float)a.k.tt_k1; kf.tt_k2 = (float)a.k.tt_k2;
+    kf.tt_n0 = (float)a.k.tt_n0; kf.tt_n1 = (float)a.k.tt_n1; kf.tt_n2 = (float)a.k.tt_n2; kf.m7 = -7.0f;
+    hipLaunchKernelGGL(fn32, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a, kf);
+  } else {
+    hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
+  }
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
   const dim3 fgrid((unsigned)((n + 255) / 256));
@@ -899,6 +916,11 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "wave_clock")) { c->opt_wave_clock = value; return 0; }
   if (!strcmp(key, "skip_pairs")) { c->opt_skip_pairs = value; return 0; }
   if (!strcmp(key, "sym_pin")) { c->opt_sym_pin = value; return 0; }
+  if (!strcmp(key, "precision")) {
+    if (value != 32 && value != 64) return fail(RMB_ERR_ARG, "precision must be 32 or 64");
+    c->opt_precision = value;
+    return 0;
+  }
   if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_min_steps")) { c->opt_sym_min_steps = value < 1 ? 1 : value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);

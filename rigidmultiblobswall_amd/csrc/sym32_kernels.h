@@ -1,0 +1,187 @@
+// sym32_kernels.h -- single-precision twin of the symmetric translation-translation sweep (gfx950, fp32 VALU).
+//
+// WHAT: the reference's GPU module has a precision switch (`precision = 'single' | 'double'` + `typedef float real`,
+// mobility/mobility_pycuda.py:7-19): the same kernels compiled in fp32.  This is that mode for the product that
+// dominates every caller, u = M_tt f (wall / no wall, open boundaries): context option "precision" = 32.  Everything
+// else keeps running in fp64 whatever the option says.
+//
+// HOW: the schedule, the tile pairs, the rotation and the global accumulators are sym_kernel's (sym_kernels.h); the pair
+// arithmetic is the closed-form block of pair_blocks.h (F, P, Q3, Q4, Szz) written in float:
+//   * positions and vectors are converted once per tile (the reference casts its arrays to float32 the same way);
+//   * v_rsq_f32 is accurate to 1 ulp, so the two inverse square roots need no correction step (fp64: 5 instructions each);
+//   * tile J sits in the wave's LDS slab as six float planes (conflict-free ds_read_b32 under the rotation); the
+//     transposed contribution is converted and added to three fp64 planes with ds_add_f64 -- ds_add_f32 turned out
+//     ~10x slower than ds_add_f64 on gfx950 (PMC: 45 vs 8 busy cycles per LDS instruction, no bank conflicts), which
+//     made the first version of this kernel 5x SLOWER than the fp64 one;
+//   * a wave's partial sums (64 pairs per blob and unit) are flushed into the SAME fp64 global accumulators the fp64
+//     kernel uses, and the self term, the B-damping and the prefactor are applied by the same fp64 finalize kernel --
+//     so the single-precision error is that of the pair arithmetic (~1e-6 relative), not of a long fp32 sum.
+// 76 VALU instructions per unordered pair (73 fp32 + 3 conversions); fp32 issues 1.6x faster than fp64 on this chip (profiles/
+// r1_ubench_fp64_issue_rates.txt: 785 vs 486 G wave-instr/s), so the mode is ~2x the fp64 kernel.
+#pragma once
+#include "sym_kernels.h"
+
+namespace rmb {
+
+struct PairConsts32 {
+  float a2, four_a2, tt_k1, tt_k2, tt_n0, tt_n1, tt_n2, m7;
+};
+
+__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Both directions of one pair in float: ui += M_ij vj, t = M_ij^T vi   (tt_block / block_apply of pair_blocks.h)
+template <bool WALL>
+__device__ __forceinline__ void pair_tt_sym32(const PairConsts32& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+  const float rho2 = fmaf_(dy, dy, dx * dx);
+  const float r2 = fmaf_(dz, dz, rho2);
+  const float ir = __builtin_amdgcn_rsqf(r2);
+  const float ir2 = ir * ir, ir3 = ir2 * ir;
+  float cF = fmaf_(k.tt_k1, ir3, ir);
+  float cD = fmaf_(-k.tt_k2, ir2, 1.0f) * ir3;
+  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
+    const float r = r2 * ir;
+    const bool near = r2 <= k.four_a2;
+    cF = near ? fmaf_(-k.tt_n1, r, k.tt_n0) : cF;
+    cD = near ? k.tt_n2 * ir : cD;
+  }
+  if constexpr (!WALL) {
+    const float cDj = cD * fmaf_(dz, vj[2], fmaf_(dy, vj[1], dx * vj[0]));
+    const float cDi = cD * fmaf_(dz, vi[2], fmaf_(dy, vi[1], dx * vi[0]));
+    ui[0] = fmaf_(cF, vj[0], ui[0]); ui[0] = fmaf_(cDj, dx, ui[0]);
+    ui[1] = fmaf_(cF, vj[1], ui[1]); ui[1] = fmaf_(cDj, dy, ui[1]);
+    ui[2] = fmaf_(cF, vj[2], ui[2]); ui[2] = fmaf_(cDj, dz, ui[2]);
+    t[0] = fmaf_(cDi, dx, cF * vi[0]);
+    t[1] = fmaf_(cDi, dy, cF * vi[1]);
+    t[2] = fmaf_(cDi, dz, cF * vi[2]);
+  } else {
+    const float Rz = zi + zj;
+    const float s = __builtin_amdgcn_rsqf(fmaf_(Rz, Rz, rho2));
+    const float q = s * s, q3 = s * q;
+    const float T2 = k.tt_k2 * q;
+    const float U = fmaf_(-rho2, q, 1.0f);
+    const float om = fmaf_(-r2, q, 1.0f);
+    const float p5 = fmaf_(U, 5.0f, -1.0f);
+    const float Ta = (T2 * T2) * (1.0f / 6.0f);
+    const float H = fmaf_(Ta, fmaf_(p5, k.m7, 8.0f), fmaf_(T2, p5, fmaf_(om, -1.5f, 1.0f)));
+    const float cDdz = cD * dz;
+    const float Q3 = fmaf_(q3, fmaf_(Rz, H, -(zi + zi)), cDdz);
+    const float Q4 = fmaf_(fmaf_(-q3, dz, cDdz), 2.0f, -Q3);
+    const float P = fmaf_(-q3, fmaf_(Ta, -10.0f, H), cD);
+    const float G1 = fmaf_(Ta, p5, fmaf_(T2, (1.0f / 3.0f) - U, fmaf_(om, 0.5f, 1.0f)));
+    const float F = fmaf_(-G1, s, cF);
+    const float Zb = fmaf_(U, fmaf_(fmaf_(Ta, -10.0f, T2), -2.0f, H - 2.0f), fmaf_(Ta, -4.0f, om));
+    const float Szz = fmaf_(s, Zb, fmaf_(cDdz, dz, F));
+    const float pj = fmaf_(dy, vj[1], dx * vj[0]);
+    const float sj = fmaf_(P, pj, Q3 * vj[2]);
+    ui[0] = fmaf_(F, vj[0], ui[0]); ui[0] = fmaf_(sj, dx, ui[0]);
+    ui[1] = fmaf_(F, vj[1], ui[1]); ui[1] = fmaf_(sj, dy, ui[1]);
+    ui[2] = fmaf_(Q4, pj, ui[2]); ui[2] = fmaf_(Szz, vj[2], ui[2]);
+    const float pi = fmaf_(dy, vi[1], dx * vi[0]);
+    const float si = fmaf_(P, pi, Q4 * vi[2]);
+    t[0] = fmaf_(si, dx, F * vi[0]);
+    t[1] = fmaf_(si, dy, F * vi[1]);
+    t[2] = fmaf_(Szz, vi[2], Q3 * pi);
+  }
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs a, const PairConsts32 kf) {
+  __shared__ float rec_all[kSymWaves][6 * 64];     // planes x, y, z, vx, vy, vz of tile J
+  __shared__ double accj_all[kSymWaves][3 * 64];   // fp64: ds_add_f32 is ~10x slower than ds_add_f64 on this chip (see header)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* rec = rec_all[wave];
+  double* accj = accj_all[wave];
+
+  // the static, exactly balanced schedule of sym_kernel
+  const long w = (long)blockIdx.x * kSymWaves + wave;
+  long s = a.step_begin + w * a.steps_per_wave;
+  long s_end = s + a.steps_per_wave;
+  if (s_end > a.step_end) s_end = a.step_end;
+  int I = 0, J = 0;
+  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+
+  int I_cur = -1;
+  long i = 0;
+  bool vi_ok = false;
+  float xi = 0, yi = 0, zi = 1.0f, vi[3] = {0, 0, 0};
+  float ui[3] = {0, 0, 0};
+
+  while (s < s_end) {
+    const int k0 = (int)(s & 63);
+    const long left = s_end - s;
+    const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    s += k1 - k0;
+
+    if (I != I_cur) {
+      if (I_cur >= 0 && vi_ok) {   // flush the previous row: float partial sums into the fp64 accumulators
+        __hip_atomic_fetch_add(&a.acc[i], (double)ui[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + i], (double)ui[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], (double)ui[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      I_cur = I;
+      i = 64L * I + lane;
+      vi_ok = i < a.n;
+      xi = 1e18f; yi = 1e18f; zi = 1.0f; vi[0] = 0; vi[1] = 0; vi[2] = 0;      // padding: far away, 1/r^2 stays finite in float
+      if (vi_ok) {
+        const double4 p = a.pos[i];
+        xi = (float)p.x; yi = (float)p.y; zi = (float)p.z;
+        vi[0] = (float)(a.vec[3 * i] * p.w); vi[1] = (float)(a.vec[3 * i + 1] * p.w); vi[2] = (float)(a.vec[3 * i + 2] * p.w);
+      }
+      ui[0] = 0; ui[1] = 0; ui[2] = 0;
+    }
+    {
+      const long j = 64L * J + lane;
+      float xj = -1e18f, yj = -1e18f, zj = 1.0f, vjx = 0, vjy = 0, vjz = 0;
+      if (j < a.n) {
+        const double4 p = a.pos[j];
+        xj = (float)p.x; yj = (float)p.y; zj = (float)p.z;
+        vjx = (float)(a.vec[3 * j] * p.w); vjy = (float)(a.vec[3 * j + 1] * p.w); vjz = (float)(a.vec[3 * j + 2] * p.w);
+      }
+      rec[lane] = xj; rec[64 + lane] = yj; rec[128 + lane] = zj;
+      rec[192 + lane] = vjx; rec[256 + lane] = vjy; rec[320 + lane] = vjz;
+      accj[lane] = 0; accj[64 + lane] = 0; accj[128 + lane] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const bool diag = I == J;
+    // diagonal units: every ordered pair of the tile once, forward only, step 0 (the blob itself) left to finalize
+    for (int k = (diag && k0 < 1) ? 1 : k0; k < k1; ++k) {
+      const int jj = (lane + k) & 63;
+      const float zj = rec[128 + jj];
+      const float vj[3] = {rec[192 + jj], rec[256 + jj], rec[320 + jj]};
+      float t[3];
+      pair_tt_sym32<WALL>(kf, xi - rec[jj], yi - rec[64 + jj], zi - zj, zi, zj, vi, vj, ui, t);
+      if (!diag) {   // wave-uniform
+        __hip_atomic_fetch_add(&accj[jj], (double)t[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[64 + jj], (double)t[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[128 + jj], (double)t[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    if (!diag) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long j = 64L * J + lane;
+      if (j < a.n) {
+        __hip_atomic_fetch_add(&a.acc[j], accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + j], accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
+    if (k1 == 64) {
+      if (++J == a.n_tiles) { ++I; J = I; }
+    }
+  }
+  if (I_cur >= 0 && vi_ok) {
+    __hip_atomic_fetch_add(&a.acc[i], (double)ui[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[a.n_pad + i], (double)ui[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], (double)ui[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace rmb

@@ -24,6 +24,12 @@ from .context import MobilityContext
 _ctx = None
 _cached = None  # (r copy, a, L tuple, wall)
 
+# The reference's GPU module has a source-level precision switch (`precision = 'single' | 'double'`,
+# mobility/mobility_pycuda.py:7-19).  Same switch here, settable at run time: with 'single' the translation <- force
+# products with open boundaries (wall / no wall) run the fp32 twin of the symmetric kernel (csrc/sym32_kernels.h,
+# ~1e-6 relative accuracy, about twice as fast); every other product keeps running in fp64.
+precision = 'double'
+
 
 def _context():
   global _ctx
@@ -46,6 +52,9 @@ def _bind_positions(r_vectors, a, L, wall):
   r = np.ascontiguousarray(r_vectors, dtype=np.float64).reshape(-1)
   Lt = tuple(float(x) for x in np.asarray(L, dtype=np.float64).reshape(3))
   ctx = _context()
+  if precision not in ('single', 'double'):
+    raise ValueError("mobility.precision must be 'single' or 'double'")
+  ctx.set_option("precision", 32 if precision == 'single' else 64)
   c = _cached
   if (c is not None and c[1] == float(a) and c[2] == Lt and c[3] == bool(wall) and c[0].size == r.size
       and np.array_equal(c[0], r)):

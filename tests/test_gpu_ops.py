@@ -27,6 +27,12 @@ def Ctx():
   return MobilityContext
 
 
+@pytest.fixture(scope="module")
+def mob():
+  from rigidmultiblobswall_amd import mobility
+  return mobility
+
+
 def _dev(torch, x):
   return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64).reshape(-1), device="cuda")
 
@@ -392,3 +398,52 @@ def test_radii_mobility_sources_equal_targets_is_symmetric_pass(Ctx, oracle, tor
   assert rel_err(out.cpu().numpy(), ref) < TOL_D1
   assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < 1e-12
   ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# single-precision mode of the tt product (the reference's `precision = 'single'` build)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wall", [True, False])
+@pytest.mark.parametrize("N", [128, 1000, 10000, 20011])
+def test_single_precision_tt(Ctx, oracle, wall, N):
+  """fp32 pair arithmetic, fp64 accumulation: relative L2 error 1e-5 against the fp64 oracle (measured ~2e-7 on the
+  5 % cloud, ~1e-6 on the dense overlapping one), and nothing else changes."""
+  r, f, eta, a = d1_cloud(N, seed=N) if N == 1000 else d2_cloud(N, seed=N)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, np.zeros(3), wall=wall)
+    u64 = ctx.matvec("tt", f, eta)
+    t64 = ctx.matvec("tr", f, eta)
+    ctx.set_option("precision", 32)
+    u32 = ctx.matvec("tt", f, eta)
+    t32 = ctx.matvec("tr", f, eta)
+    ref = getattr(oracle, ("single_wall" if wall else "no_wall") + "_mobility_trans_times_force_oracle")(r, f, eta, a)
+    e32, e64 = rel_err(u32, ref), rel_err(u64, ref)
+    assert np.all(np.isfinite(u32))
+    assert e64 < 1e-10 and 1e-9 < e32 < 1e-5, (e32, e64)           # the fp32 kernel ran, and is single-precision accurate
+    assert rel_err(t32, t64) < 1e-13                                # other kinds stay fp64
+    # pseudo-periodic domains and the deterministic sweep stay fp64 too
+    ctx.set_option("deterministic", 1)
+    assert rel_err(ctx.matvec("tt", f, eta), ref) < 1e-10
+    ctx.set_option("deterministic", 0)
+    ctx.set_option("precision", 64)
+    assert rel_err(ctx.matvec("tt", f, eta), ref) < 1e-10
+    with pytest.raises(Exception):
+      ctx.set_option("precision", 16)
+  finally:
+    ctx.close()
+
+
+def test_single_precision_switch_of_the_python_surface(mob, oracle):
+  r, f, eta, a = d2_cloud(3000, seed=3)
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  try:
+    mob.precision = 'single'
+    e = rel_err(mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a), ref)
+    assert 1e-9 < e < 1e-5, e
+    mob.precision = 'half'
+    with pytest.raises(ValueError):
+      mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
+  finally:
+    mob.precision = 'double'
+  assert rel_err(mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a), ref) < 1e-12

@@ -70,6 +70,9 @@ for N in SIZES:
   for kind in ("tt", "tr", "rt", "rr"):
     t[kind] = timed(ctx, lambda: ctx.matvec_device(kind, fd, eta), reps, 1)
     row(N, "wall " + kind, "sym_kernel", t[kind])
+  ctx.set_option("precision", 32)
+  row(N, "wall tt, single precision", "sym32_tt_kernel", timed(ctx, lambda: ctx.matvec_device("tt", fd, eta), reps, 1), t["tt"])
+  ctx.set_option("precision", 64)
   ctx.set_option("symx_single", 1)
   row(N, "wall tt", "symx_kernel<OpSingle>", timed(ctx, lambda: ctx.matvec_device("tt", fd, eta), reps, 1), t["tt"])
   ctx.set_option("symx_single", 0)
