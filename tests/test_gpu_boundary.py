@@ -70,3 +70,11 @@ def test_stub_reports_errors_as_exceptions(stub):
   r = np.random.rand(4, 3) + 1.0
   with pytest.raises(RuntimeError):
     stub["single_wall_mobility_trans_times_force_hip"](r, r, -1.0, 0.1)      # eta <= 0 -> RMB_ERR_ARG
+
+
+def test_stub_double_layer_and_pressure_match_reference_fixture(stub):
+  g = load_golden(golden_files("g11_aux_operators.npz")[0])
+  args = (g["source"], g["target"], g["normals"], g["vector"], g["weights"])
+  assert rel_err(stub["double_layer_source_target_hip"](*args), g["dl_no_wall"]) < 1e-12
+  assert rel_err(stub["double_layer_source_target_hip"](*args, wall=1), g["dl_wall"]) < 1e-12
+  assert rel_err(stub["no_wall_pressure_Stokeslet_hip"](g["source"], g["target"], g["force"]), g["p_no_wall"]) < 1e-12
