@@ -258,6 +258,13 @@ class ReplicatedContext(object):
     if ctx is not None:
       ctx.set_stream(stream_ptr)
 
+  def set_option(self, key, value):
+    """Context options of the rank's own MobilityContext ("precision", "deterministic", ...); backends without one
+    (the oracle stand-in of the host tests) ignore them."""
+    ctx = getattr(self.sm.backend, "ctx", None)
+    if ctx is not None:
+      ctx.set_option(key, value)
+
   def sync_scalars(self, t):
     """Make rank 0's copy of a small control tensor (Hessenberg column, Lanczos coefficients) the one every rank acts
     on.  The replicated Krylov loops branch on such scalars; identical hardware and identical inputs already give

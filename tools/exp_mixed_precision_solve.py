@@ -1,0 +1,29 @@
+"""config-3 rigid solve (2048 shells x 12 blobs, tol 1e-8): the reference's GMRES against iterative refinement with fp32
+inner products (RigidSuspension.solve_mixed_precision), for a few inner tolerances."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rigidmultiblobswall_amd import structures as st
+from rigidmultiblobswall_amd.rigid import RigidSuspension
+R, eta = 1.0155, 0.957e-3
+shell = st.icosahedron_shell(0.792079207921 * R)
+a = st.min_blob_separation(shell) / 2
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+loc, q, _ = st.roller_monolayer(nb, radius=R, seed=5)
+FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
+rs = RigidSuspension([shell] * nb, loc, q, a, eta)
+rhs = torch.zeros(rs.size, dtype=torch.float64, device="cuda")
+rhs[3 * rs.n_blobs:] = -torch.as_tensor(FT.reshape(-1), device="cuda")
+def timed(fn, reps=5):
+  fn(); torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(reps): out = fn()
+  torch.cuda.synchronize()
+  return (time.perf_counter() - t0) / reps * 1e3, out
+ms, (x, info) = timed(lambda: rs.solve(rhs, tol=1e-8))
+print("fp64 GMRES            : %.2f ms, %d iterations, residual %.2e" % (ms, info["iterations"], info["residual"]))
+for it in (1e-3, 1e-4, 3e-5, 1e-5):
+  ms, (x2, info2) = timed(lambda: rs.solve_mixed_precision(rhs, tol=1e-8, inner_tol=it))
+  print("mixed, inner tol %.0e : %.2f ms, %d fp32 inner iterations in %d outer steps, fp64 residual %.2e, |x - x64|/|x64| = %.1e"
+        % (it, ms, info2["iterations"], info2["outer_iterations"], info2["residual"], float(torch.linalg.norm(x2 - x) / torch.linalg.norm(x))))
+rs.close()
