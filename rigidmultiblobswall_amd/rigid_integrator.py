@@ -102,6 +102,7 @@ class RigidIntegrator(object):
     # state and counters, names as quaternion_integrator_multi_bodies.py:41-55
     self.velocities_previous_step = None
     self.first_step = True
+    self._precision = 'double'
     self.kT = 0.0
     self.tolerance = 1e-08 if tolerance is None else float(tolerance)
     self.rf_delta = 1e-03
@@ -141,6 +142,23 @@ class RigidIntegrator(object):
     if rng is None:
       self._gen, self.seed = seeded_generator(self.device, seed, ctx)
 
+
+  @property
+  def precision(self):
+    """'double' (default) or 'single' -- the reference GPU module's precision switch (mobility_pycuda.py:7-19) for the
+    blob mobility products of this integrator: with 'single' every single-vector M_tt pass with open boundaries runs
+    the fp32 twin of the pair sweep (csrc/sym32_kernels.h: fp32 pair arithmetic, fp64 accumulation, ~1e-6 relative);
+    k-vector lockstep passes, pseudo-periodic domains, forces and the O(N) rigid algebra stay fp64.  Meant for the
+    Brownian schemes at their loose solver tolerances (1e-3 ... 1e-4), where the product error is two orders below
+    the tolerance; the solvers' stopping rules are unchanged."""
+    return self._precision
+
+  @precision.setter
+  def precision(self, value):
+    if value not in ('single', 'double'):
+      raise ValueError("precision must be 'single' or 'double'")
+    self._precision = value
+    self.susp.ctx.set_option("precision", 32 if value == 'single' else 64)
   def close(self):
     self.susp.close()
 

@@ -60,6 +60,36 @@ def test_brownian_slip_trapz_step_on_a_large_suspension():
   assert np.abs(out[0][0] - loc).max() > 1e-5
 
 
+def test_brownian_step_with_single_precision_products():
+  """The integrator's precision switch: the same Brownian steps with the fp32 twin of the pair sweep.  At the schemes'
+  solver tolerance (1e-4) the solvers take the same number of iterations and the trajectory moves by ~1e-6 of the
+  displacement scale; the switch can be flipped back."""
+  from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+  nb = 400
+  shell, a, loc, quat = _suspension(nb, 5)
+  res = {}
+  for prec in ("double", "single"):
+    integ = RigidIntegrator([shell] * nb, loc, quat, "stochastic_Slip_Trapz", a, 0.957e-3, tolerance=1e-4, device="cuda:0", seed=4)
+    integ.kT, integ.g = 0.0041419464, 0.0024892 * 12
+    integ.repulsion_strength_wall, integ.debye_length_wall = 0.0165677856, 0.0656
+    integ.repulsion_strength, integ.debye_length = 0.0165677856, 0.0656
+    integ.precision = prec
+    assert integ.precision == prec
+    for step in range(2):
+      integ.advance_time_step(0.01, step=step)
+    res[prec] = (integ.location.cpu().numpy(), integ.det_iterations_count, integ.stoch_iterations_count,
+                 integ.invalid_configuration_count)
+    with pytest.raises(ValueError):
+      integ.precision = "half"
+    integ.precision = "double"
+    integ.close()
+  moved = np.abs(res["double"][0] - loc).max()
+  assert res["single"][3] == 0 and res["double"][3] == 0
+  assert abs(res["single"][1] - res["double"][1]) <= 2 and abs(res["single"][2] - res["double"][2]) <= 1
+  diff = np.abs(res["single"][0] - res["double"][0]).max()
+  assert 0 < diff < 1e-3 * moved, (diff, moved)          # fp32 products were used, and only perturb the step
+
+
 def test_deterministic_step_equals_solve_plus_update():
   """deterministic_forward_euler == one RigidSuspension solve with the integrator's own force model + the
   quaternion update formula, on 300 shells."""

@@ -1,4 +1,4 @@
-"""usage: exp_config5_multiblob.py [bodies] [steps] [tol] [rfd_tol|-] [lockstep 0/1] [warm_start 0/1] [lockstep_width]
+"""usage: exp_config5_multiblob.py [bodies] [steps] [tol] [rfd_tol|-] [lockstep 0/1] [warm_start 0/1] [lockstep_width] [single|double]
 configs[4] recipe with rigid multiblobs: 21845 shells x 12 blobs = 262140 blobs, stochastic_Slip_Trapz steps
 (physical parameters of examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat).  Prints per-step timing."""
 import math, os, sys, time
@@ -31,6 +31,8 @@ if len(sys.argv) > 6:
   integ.warm_start = bool(int(sys.argv[6]))
 if len(sys.argv) > 7:
   integ.susp.lockstep_width = int(sys.argv[7])
+if len(sys.argv) > 8:
+  integ.precision = sys.argv[8]
 torch.cuda.synchronize()
 print("setup %.2f s, blobs %d" % (time.perf_counter() - t0, integ.Nblobs), flush=True)
 for step in range(steps):
