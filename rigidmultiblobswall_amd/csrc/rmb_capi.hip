@@ -16,6 +16,7 @@
 #include "sym2_kernels.h"
 #include "sym32_kernels.h"
 #include "symx_kernels.h"
+#include "symx32_kernels.h"
 #include "dense_kernels.h"
 #include "st_kernels.h"
 #include "aux_kernels.h"
@@ -396,22 +397,35 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
 // ---- generic symmetric operations (symx_kernels.h) ---------------------------------------------------------
 typedef void (*symx_fn)(const rmb::SymXArgs);
 typedef void (*symx_combine_fn)(const rmb::SymXArgs, int);
+// single-precision twin of an operation (symx32_kernels.h; open boundaries only), or none
+typedef void (*symx32_fn)(const rmb::SymXArgs, const rmb::f32::PairConsts);
+template <class OP32, bool WALL> struct SymX32 {
+  static symx32_fn fn() { return rmb::symx32_kernel<OP32, WALL>; }
+  static size_t lds() { return rmb::SymX32Lds<OP32>::bytes; }
+};
+template <bool WALL> struct SymX32<void, WALL> {
+  static symx32_fn fn() { return nullptr; }
+  static size_t lds() { return 0; }
+};
 struct SymXEntry { symx_fn sweep; symx_fn fin; int occ; size_t static_lds; int n_in, n_out; symx_fn det_sweep; symx_fn det_reduce;
-                   symx_combine_fn det_combine; int det_occ; };
-template <class OP, bool WALL, bool PER> SymXEntry make_symx_entry() {
+                   symx_combine_fn det_combine; int det_occ; symx32_fn sweep32; size_t static_lds32; int occ32; };
+template <class OP, bool WALL, bool PER, class OP32 = void> SymXEntry make_symx_entry() {
   return SymXEntry{rmb::symx_kernel<OP, WALL, PER, false>, rmb::symx_finalize_kernel<OP, WALL>, 0,
                    sizeof(double2) * rmb::kSymWaves * 64 * rmb::SymXRec<OP::NIN, rmb::SymXExtra<OP>::value>::d2 +
                        sizeof(double) * rmb::kSymWaves * 3 * OP::NOUT * 64,
                    OP::NIN, OP::NOUT, rmb::symx_kernel<OP, WALL, PER, true>, rmb::symx_det_reduce_kernel<OP::NOUT>,
-                   rmb::symx_det_combine_kernel<OP::NOUT>, 0};
+                   rmb::symx_det_combine_kernel<OP::NOUT>, 0,
+                   PER ? nullptr : SymX32<OP32, WALL>::fn(), SymX32<OP32, WALL>::lds(), 0};
 }
 // SX_K2 + 4 (k - 2) + kind: one block on k = 2..4 vectors
 enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_RADII, SX_K2, SX_COUNT = SX_K2 + 12 };
 // [op][wall][periodic]
 #define RMB_SX_ROW(OP) {{make_symx_entry<OP, false, false>(), make_symx_entry<OP, false, true>()}, {make_symx_entry<OP, true, false>(), make_symx_entry<OP, true, true>()}}
+#define RMB_SX_ROW32(OP, OP32) {{make_symx_entry<OP, false, false, OP32>(), make_symx_entry<OP, false, true>()}, {make_symx_entry<OP, true, false, OP32>(), make_symx_entry<OP, true, true>()}}
 SymXEntry g_symx[SX_COUNT][2][2] = {
-    RMB_SX_ROW(rmb::OpSingle<rmb::KIND_TT>), RMB_SX_ROW(rmb::OpSingle<rmb::KIND_TR>), RMB_SX_ROW(rmb::OpSingle<rmb::KIND_RT>),
-    RMB_SX_ROW(rmb::OpSingle<rmb::KIND_RR>), RMB_SX_ROW(rmb::OpFusedRow), RMB_SX_ROW(rmb::OpGrand), RMB_SX_ROW(rmb::OpColumnF),
+    RMB_SX_ROW32(rmb::OpSingle<rmb::KIND_TT>, rmb::OpSingle32<rmb::KIND_TT>), RMB_SX_ROW32(rmb::OpSingle<rmb::KIND_TR>, rmb::OpSingle32<rmb::KIND_TR>),
+    RMB_SX_ROW32(rmb::OpSingle<rmb::KIND_RT>, rmb::OpSingle32<rmb::KIND_RT>), RMB_SX_ROW32(rmb::OpSingle<rmb::KIND_RR>, rmb::OpSingle32<rmb::KIND_RR>),
+    RMB_SX_ROW32(rmb::OpFusedRow, rmb::OpFusedRow32), RMB_SX_ROW32(rmb::OpGrand, rmb::OpGrand32), RMB_SX_ROW32(rmb::OpColumnF, rmb::OpColumnF32),
     // the free-surface operation takes raw heights: only the wall = 0 column is ever launched
     {{make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
      {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
@@ -422,6 +436,16 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
 #undef RMB_SX_K
 #undef RMB_SX_KIND
 #undef RMB_SX_ROW
+#undef RMB_SX_ROW32
+
+rmb::f32::PairConsts pair_consts32(const rmb::PairConsts& k) {
+  rmb::f32::PairConsts f;
+  f.a2 = (float)k.a2; f.four_a2 = (float)k.four_a2; f.tt_k1 = (float)k.tt_k1; f.tt_k2 = (float)k.tt_k2;
+  f.tt_n0 = (float)k.tt_n0; f.tt_n1 = (float)k.tt_n1; f.tt_n2 = (float)k.tt_n2;
+  f.rr_m0 = (float)k.rr_m0; f.rr_m1 = (float)k.rr_m1; f.rr_m2 = (float)k.rr_m2; f.rr_m3 = (float)k.rr_m3; f.rr_m4 = (float)k.rr_m4;
+  f.c_q0 = (float)k.c_q0; f.c_q1 = (float)k.c_q1; f.m7 = (float)k.m7; f.m6 = (float)k.m6; f.c15 = (float)k.c15;
+  return f;
+}
 
 // Configuration a symmetric pass runs on: the context's resident one, or a caller-packed one (per-blob radii)
 struct SymConf { const double4* pos; long n; double L[3]; int wall; const double* extra; };
@@ -453,12 +477,17 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   a.skip_pairs = (int)c->opt_skip_pairs;
   a.k = make_pair_consts(c->a > 0.0 ? c->a : 1.0);   // unused by the per-blob-radii operation
   SymPlan plan;
-  if (int rc = plan_sym(c, (const void*)se.sweep, &se.occ, se.static_lds, a.step_end - a.step_begin, true, &plan)) return rc;
+  // "precision" = 32: the operation's single-precision twin where it has one (open boundaries, no per-blob extras)
+  const bool f32 = c->opt_precision == 32 && se.sweep32 != nullptr && a.extra == nullptr;
+  if (int rc = plan_sym(c, f32 ? (const void*)se.sweep32 : (const void*)se.sweep, f32 ? &se.occ32 : &se.occ,
+                        f32 ? se.static_lds32 : se.static_lds, a.step_end - a.step_begin, true, &plan))
+    return rc;
   a.steps_per_wave = plan.steps_per_wave;
   c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
-  hipLaunchKernelGGL(se.sweep, dim3((unsigned)plan.blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
+  if (f32) hipLaunchKernelGGL(se.sweep32, dim3((unsigned)plan.blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a, pair_consts32(a.k));
+  else     hipLaunchKernelGGL(se.sweep, dim3((unsigned)plan.blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
   hipLaunchKernelGGL(se.fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
@@ -563,7 +592,9 @@ int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, cons
       return symx_det_device(c, sx, in, outs, eta, in_plane);
     }
     if (kind <= rmb::KIND_RR) {
-      if (in_plane || c->opt_symx_single) return symx_device(c, SX_TT + kind, in, outs, eta, in_plane, 0, 1);
+      // tr / rt / rr in single precision run on the generic skeleton's fp32 twin (tt has its own kernel in sym_device)
+      const bool x32 = c->opt_precision == 32 && kind != rmb::KIND_TT && !periodic;
+      if (in_plane || c->opt_symx_single || x32) return symx_device(c, SX_TT + kind, in, outs, eta, in_plane, 0, 1);
       return sym_device(c, kind, v, eta, out);
     }
     if (kind == rmb::KIND_TT_TR) {

@@ -1,0 +1,200 @@
+// symx32_kernels.h -- single-precision twins of the symmetric multi-block operations (gfx950, fp32 VALU).
+//
+// WHAT: context option "precision" = 32 (the reference's `precision = 'single'` build, mobility_pycuda.py:7-19) for the
+// products besides tt: tr / rt / rr, the fused row M_tt f + M_tr tau (K11 / K12), the 6N grand mobility and the force
+// column [M_tt; M_rt] f -- everything the single-blob roller steppers apply per step -- with open boundaries.
+//
+// HOW: symx_kernel's skeleton (symx_kernels.h: tile pairs, rotation, static balanced schedule, pair shards, fp64 global
+// accumulators, fp64 finalize with self terms / B-damping / prefactor) with the pair arithmetic of pair_blocks32.h (the
+// fp64 algebra regenerated in float).  As in sym32_kernels.h: tile J as float planes in LDS, at most 64 pair
+// contributions per blob summed in fp32 before they are added in fp64 (ds_add_f64 / global_atomic_add_f64: ds_add_f32
+// is an order of magnitude slower on this chip), so the error is that of the pair arithmetic, ~1e-6 relative.
+#pragma once
+#include "pair_blocks32.h"
+#include "symx_kernels.h"
+
+namespace rmb {
+
+template <int KIND>
+struct OpSingle32 {
+  static constexpr int NIN = 1, NOUT = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const f32::Geom g = f32::make_geom<WALL>(dx, dy, dz, zi, zj);
+    if constexpr (KIND == KIND_TT) { const f32::TTc c = f32::tt_coeffs<WALL>(k, g, zi, zj); f32::tt_apply<WALL, false>(c, g, vi, vj, ui, t); }
+    if constexpr (KIND == KIND_RR) { const f32::RRc c = f32::rr_coeffs<WALL>(k, g); f32::rr_apply<WALL, false>(c, g, vi, vj, ui, t); }
+    if constexpr (KIND == KIND_TR) { const f32::CPc C = f32::cpl_coeffs<WALL>(k, g, zi, zj); f32::tr_apply<WALL, false>(C, g, vi, vj, ui, t); }
+    if constexpr (KIND == KIND_RT) { const f32::CPc C = f32::cpl_coeffs<WALL>(k, g, zi, zj); f32::rt_apply<WALL, false>(C, g, vi, vj, ui, t); }
+  }
+};
+
+struct OpFusedRow32 {      // u = M_tt f + M_tr tau
+  static constexpr int NIN = 2, NOUT = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const f32::Geom g = f32::make_geom<WALL>(dx, dy, dz, zi, zj);
+    const f32::Rpy p = f32::rpy_coeffs<true, true, false>(k, g);
+    const f32::TTc a = f32::tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
+    f32::tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    const f32::CPc C = f32::cpl_block<WALL>(k, g, zi, zj, p.c);
+    f32::tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
+  }
+};
+
+struct OpGrand32 {         // [u; w] = [[M_tt, M_tr], [M_rt, M_rr]] [f; tau]
+  static constexpr int NIN = 2, NOUT = 2;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const f32::Geom g = f32::make_geom<WALL>(dx, dy, dz, zi, zj);
+    const f32::Rpy p = f32::rpy_coeffs<true, true, true>(k, g);
+    const f32::TTc a = f32::tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
+    f32::tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    const f32::CPc C = f32::cpl_block<WALL>(k, g, zi, zj, p.c);
+    f32::tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
+    f32::rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+    const f32::RRc b = f32::rr_block<WALL>(k, g, p.rF, p.rD);
+    f32::rr_apply<WALL, true>(b, g, vi + 3, vj + 3, ui + 3, t + 3);
+  }
+};
+
+struct OpColumnF32 {       // [u; w] = [M_tt; M_rt] f
+  static constexpr int NIN = 1, NOUT = 2;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const f32::Geom g = f32::make_geom<WALL>(dx, dy, dz, zi, zj);
+    const f32::Rpy p = f32::rpy_coeffs<true, true, false>(k, g);
+    const f32::TTc a = f32::tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
+    f32::tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    const f32::CPc C = f32::cpl_block<WALL>(k, g, zi, zj, p.c);
+    f32::rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+  }
+};
+
+template <class OP> struct SymX32Lds {
+  static constexpr int planes = 3 + 3 * OP::NIN;
+  static constexpr size_t bytes = (sizeof(float) * planes + sizeof(double) * 3 * OP::NOUT) * 64 * kSymWaves;
+};
+
+template <class OP, bool WALL>
+__global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a, const f32::PairConsts kf) {
+  constexpr int NI = OP::NIN, NO = OP::NOUT, NP = 3 + 3 * NI;
+  __shared__ float rec_all[kSymWaves][NP * 64];      // planes x, y, z, then the NIN vectors of tile J
+  __shared__ double accj_all[kSymWaves][3 * NO * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* rec = rec_all[wave];
+  double* accj = accj_all[wave];
+
+  const long w = (long)blockIdx.x * kSymWaves + wave;
+  long s = a.step_begin + w * a.steps_per_wave;
+  long s_end = s + a.steps_per_wave;
+  if (s_end > a.step_end) s_end = a.step_end;
+  int I = 0, J = 0;
+  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+
+  int I_cur = -1;
+  long i = 0;
+  bool vi_ok = false;
+  float xi = 0, yi = 0, zi = 1.0f;
+  float vi[3 * NI], ui[3 * NO];
+#pragma unroll
+  for (int c = 0; c < 3 * NI; ++c) vi[c] = 0;
+#pragma unroll
+  for (int c = 0; c < 3 * NO; ++c) ui[c] = 0;
+
+  auto flush_row = [&]() {
+    if (!vi_ok) return;
+#pragma unroll
+    for (int c = 0; c < 3 * NO; ++c)
+      __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + i], (double)ui[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  while (s < s_end) {
+    const int k0 = (int)(s & 63);
+    const long left = s_end - s;
+    const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    s += k1 - k0;
+
+    if (I != I_cur) {
+      if (I_cur >= 0) flush_row();
+      I_cur = I;
+      i = 64L * I + lane;
+      vi_ok = i < a.n;
+      xi = 1e18f; yi = 1e18f; zi = 1.0f;          // padding: far away, 1/r^2 stays finite in float
+#pragma unroll
+      for (int c = 0; c < 3 * NI; ++c) vi[c] = 0;
+      if (vi_ok) {
+        const double4 p = a.pos[i];
+        xi = (float)p.x; yi = (float)p.y; zi = (float)p.z;
+#pragma unroll
+        for (int v = 0; v < NI; ++v) {
+          vi[3 * v] = (float)(a.in[v][3 * i] * p.w); vi[3 * v + 1] = (float)(a.in[v][3 * i + 1] * p.w);
+          vi[3 * v + 2] = a.in_plane ? 0.0f : (float)(a.in[v][3 * i + 2] * p.w);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3 * NO; ++c) ui[c] = 0;
+    }
+    {
+      const long j = 64L * J + lane;
+      float rd[NP];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) rd[c] = 0;
+      rd[0] = -1e18f; rd[1] = -1e18f; rd[2] = 1.0f;
+      if (j < a.n) {
+        const double4 p = a.pos[j];
+        rd[0] = (float)p.x; rd[1] = (float)p.y; rd[2] = (float)p.z;
+#pragma unroll
+        for (int v = 0; v < NI; ++v) {
+          rd[3 + 3 * v] = (float)(a.in[v][3 * j] * p.w); rd[4 + 3 * v] = (float)(a.in[v][3 * j + 1] * p.w);
+          rd[5 + 3 * v] = a.in_plane ? 0.0f : (float)(a.in[v][3 * j + 2] * p.w);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NP; ++c) rec[c * 64 + lane] = rd[c];
+#pragma unroll
+      for (int c = 0; c < 3 * NO; ++c) accj[c * 64 + lane] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const bool diag = I == J;
+    // diagonal units: every ordered pair of the tile once, forward only; step 0 (the blob itself) is the self term
+    for (int k = (diag && k0 < 1) ? 1 : k0; k < k1; ++k) {
+      const int jj = (lane + k) & 63;
+      float rd[NP];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) rd[c] = rec[c * 64 + jj];
+      float t[3 * NO];
+      OP::template pair<WALL>(kf, xi - rd[0], yi - rd[1], zi - rd[2], zi, rd[2], vi, rd + 3, ui, t);
+      if (!diag) {   // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 3 * NO; ++c)
+          __hip_atomic_fetch_add(&accj[c * 64 + jj], (double)t[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    if (!diag) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long j = 64L * J + lane;
+      if (j < a.n) {
+#pragma unroll
+        for (int c = 0; c < 3 * NO; ++c)
+          __hip_atomic_fetch_add(&a.acc[(long)c * a.n_pad + j], accj[c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
+    if (k1 == 64) {
+      if (++J == a.n_tiles) { ++I; J = I; }
+    }
+  }
+  if (I_cur >= 0) flush_row();
+}
+
+}  // namespace rmb

@@ -84,6 +84,22 @@ class RollersIntegrator(object):
     self.ctx = ctx if ctx is not None else MobilityContext(self.device.index or 0)
     self._own_ctx = ctx is None
     self.mobility_products = 0
+    self._precision = 'double'
+
+  @property
+  def precision(self):
+    """'double' (default) or 'single': the reference GPU module's precision switch (mobility_pycuda.py:7-19) for the
+    products of this stepper -- M_tt F + M_tr T, the four blocks and the 6N grand mobility run their fp32 twins
+    (csrc/sym32_kernels.h, symx32_kernels.h: fp32 pair arithmetic, fp64 accumulation, ~1e-6 relative) with open
+    boundaries; forces, pseudo-periodic domains and the stepper's own algebra stay fp64."""
+    return self._precision
+
+  @precision.setter
+  def precision(self, value):
+    if value not in ('single', 'double'):
+      raise ValueError("precision must be 'single' or 'double'")
+    self._precision = value
+    self.ctx.set_option("precision", 32 if value == 'single' else 64)
 
   def close(self):
     if self._own_ctx:

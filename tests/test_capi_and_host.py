@@ -76,3 +76,13 @@ def test_partition_covers_range_without_overlap():
       short = [i for i, c in enumerate(full) if c < spans[0][2]]
       if short:
         assert all(c == 0 for c in full[short[0] + 1:])
+
+
+def test_generated_single_precision_header_is_current():
+  """csrc/pair_blocks32.h is generated from pair_blocks.h (tools/gen_pair_blocks32.py); a stale copy would make the
+  single-precision mode compute with an older algebra than the double-precision one."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  rc = subprocess.call([sys.executable, os.path.join(root, "tools", "gen_pair_blocks32.py"), "--check"])
+  assert rc == 0, "run `python tools/gen_pair_blocks32.py` after editing csrc/pair_blocks.h"

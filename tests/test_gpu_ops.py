@@ -407,21 +407,18 @@ def test_radii_mobility_sources_equal_targets_is_symmetric_pass(Ctx, oracle, tor
 @pytest.mark.parametrize("N", [128, 1000, 10000, 20011])
 def test_single_precision_tt(Ctx, oracle, wall, N):
   """fp32 pair arithmetic, fp64 accumulation: relative L2 error 1e-5 against the fp64 oracle (measured ~2e-7 on the
-  5 % cloud, ~1e-6 on the dense overlapping one), and nothing else changes."""
+  5 % cloud, ~1e-6 on the dense overlapping one); the deterministic sweep stays fp64."""
   r, f, eta, a = d1_cloud(N, seed=N) if N == 1000 else d2_cloud(N, seed=N)
   ctx = Ctx(0)
   try:
     ctx.set_positions(r, a, np.zeros(3), wall=wall)
     u64 = ctx.matvec("tt", f, eta)
-    t64 = ctx.matvec("tr", f, eta)
     ctx.set_option("precision", 32)
     u32 = ctx.matvec("tt", f, eta)
-    t32 = ctx.matvec("tr", f, eta)
     ref = getattr(oracle, ("single_wall" if wall else "no_wall") + "_mobility_trans_times_force_oracle")(r, f, eta, a)
     e32, e64 = rel_err(u32, ref), rel_err(u64, ref)
     assert np.all(np.isfinite(u32))
     assert e64 < 1e-10 and 1e-9 < e32 < 1e-5, (e32, e64)           # the fp32 kernel ran, and is single-precision accurate
-    assert rel_err(t32, t64) < 1e-13                                # other kinds stay fp64
     # pseudo-periodic domains and the deterministic sweep stay fp64 too
     ctx.set_option("deterministic", 1)
     assert rel_err(ctx.matvec("tt", f, eta), ref) < 1e-10
@@ -447,3 +444,47 @@ def test_single_precision_switch_of_the_python_surface(mob, oracle):
   finally:
     mob.precision = 'double'
   assert rel_err(mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a), ref) < 1e-12
+
+
+@pytest.mark.parametrize("wall", [True, False])
+@pytest.mark.parametrize("N", [128, 1000, 6000])
+def test_single_precision_other_products(Ctx, torch_mod, wall, N):
+  """precision = 32 for tr / rt / rr, the fused row, the grand mobility, the force column and the in-plane products:
+  single-precision accurate against the same context in double precision; pseudo-periodic domains stay fp64."""
+  torch = torch_mod
+  r, f, eta, a = d1_cloud(N, seed=N) if N == 1000 else d2_cloud(N, seed=N)
+  t = np.random.RandomState(N + 7).randn(*f.shape)
+  fd, td = _dev(torch, f), _dev(torch, t)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, np.zeros(3), wall=wall)
+
+    def products():
+      out = {k: ctx.matvec_device(k, fd, eta).cpu().numpy() for k in ("tr", "rt", "rr")}
+      out["fused"] = ctx.matvec_device("tt_tr", fd, eta, vec2=td).cpu().numpy()
+      g = ctx.matvec_op_device("grand", (fd, td), eta)
+      out["grand_u"], out["grand_w"] = g[0].cpu().numpy(), g[1].cpu().numpy()
+      c = ctx.matvec_op_device("force_column", (fd,), eta)
+      out["col_u"], out["col_w"] = c[0].cpu().numpy(), c[1].cpu().numpy()
+      if wall:
+        out["in_plane_tt"] = ctx.matvec_device("tt", fd, eta, in_plane=True).cpu().numpy()
+        out["in_plane_tr"] = ctx.matvec_device("tr", fd, eta, in_plane=True).cpu().numpy()
+      return out
+
+    p64 = products()
+    ctx.set_option("precision", 32)
+    p32 = products()
+    for k in p64:
+      e = rel_err(p32[k], p64[k])
+      assert np.all(np.isfinite(p32[k])) and 1e-9 < e < 2e-5, (k, e)
+    ctx.set_option("precision", 64)
+    p64b = products()
+    for k in p64:
+      assert rel_err(p64b[k], p64[k]) < 1e-13, k
+    # pseudo-periodic: the option is ignored (fp64)
+    ctx.set_positions(r, a, np.array([0.0, 40.0 * a * (N / 1000.0) ** (1 / 3.0), 0.0]), wall=wall)
+    ref = ctx.matvec_device("tr", fd, eta).cpu().numpy()
+    ctx.set_option("precision", 32)
+    assert rel_err(ctx.matvec_device("tr", fd, eta).cpu().numpy(), ref) < 1e-13
+  finally:
+    ctx.close()

@@ -115,3 +115,29 @@ def test_brownian_trajectory_statistics_are_reproducible_with_device_generator()
   # symmetric kernels accumulate with atomics: identical draws, round-off-level differences only
   assert np.abs(out[0] - out[1]).max() < 1e-9
   assert np.abs(out[0] - r0).max() > 1e-4
+
+
+def test_single_precision_products_switch():
+  """The stepper's precision switch (the reference GPU module's `precision = 'single'`): same draws, fp32 twins of the
+  fused row / grand mobility / blocks; at the Lanczos tolerance of the decks (1e-3) the iteration count is unchanged and
+  the step moves by a fraction of the displacement that is at the single-precision level."""
+  from rigidmultiblobswall_amd.rollers import RollersIntegrator
+  N, a, eta = 3000, 0.4, 1.1
+  r0 = _monolayer(N, a, 3)
+  res = {}
+  for prec in ("double", "single"):
+    integ = RollersIntegrator(r0, "stochastic_adams_bashforth_rollers", a, eta, tolerance=1e-3, device="cuda:0", seed=4)
+    integ.kT, integ.g, integ.repulsion_strength_wall, integ.debye_length_wall = 0.0041, 0.8, 0.6, 0.12
+    integ.repulsion_strength, integ.debye_length = 0.5, 0.1
+    integ.omega_one_roller = np.array([0.0, 9.0, 0.0])
+    integ.precision = prec
+    for _ in range(3):
+      integ.advance_time_step(0.01)
+    res[prec] = (integ.location.cpu().numpy(), integ.stoch_iterations_count, integ.invalid_configuration_count)
+    with pytest.raises(ValueError):
+      integ.precision = "half"
+    integ.close()
+  moved = np.abs(res["double"][0] - r0).max()
+  diff = np.abs(res["single"][0] - res["double"][0]).max()
+  assert res["single"][2] == 0 and abs(res["single"][1] - res["double"][1]) <= 1
+  assert 0 < diff < 1e-3 * moved, (diff, moved)

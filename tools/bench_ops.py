@@ -103,6 +103,15 @@ for N in SIZES:
   row(N, "wall [tt; rt] f", "single symmetric pass (symx OpColumnF)",
       timed(ctx, lambda: ctx.matvec_op_device("force_column", (fd,), eta), reps, 1), t["tt"] + t["rt"])
 
+  # single-precision twins of the multi-block operations (symx32_kernels.h)
+  ctx.set_option("precision", 32)
+  row(N, "wall tt+tr, single precision", "symx32_kernel<OpFusedRow32>",
+      timed(ctx, lambda: ctx.matvec_device("tt_tr", fd, eta, vec2=td), reps, 1), fused)
+  row(N, "wall grand [tt tr; rt rr], single precision", "symx32_kernel<OpGrand32>",
+      timed(ctx, lambda: ctx.matvec_op_device("grand", (fd, td), eta), reps, 1))
+  row(N, "wall rr, single precision", "symx32_kernel<OpSingle32>", timed(ctx, lambda: ctx.matvec_device("rr", fd, eta), reps, 1), t["rr"])
+  ctx.set_option("precision", 64)
+
   # k vectors
   row(N, "wall tt x2", "sym2_kernel", timed(ctx, lambda: ctx.matvec2_device("tt", fd, td, eta), reps, 1), 2 * t["tt"])
   for k in (2, 3, 4):
