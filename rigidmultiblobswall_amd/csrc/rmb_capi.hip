@@ -240,6 +240,15 @@ int sym_accumulators(rmb_ctx* c, long n_pad) {
   return 0;
 }
 
+rmb::f32::PairConsts pair_consts32(const rmb::PairConsts& k) {
+  rmb::f32::PairConsts f;
+  f.a2 = (float)k.a2; f.four_a2 = (float)k.four_a2; f.tt_k1 = (float)k.tt_k1; f.tt_k2 = (float)k.tt_k2;
+  f.tt_n0 = (float)k.tt_n0; f.tt_n1 = (float)k.tt_n1; f.tt_n2 = (float)k.tt_n2;
+  f.rr_m0 = (float)k.rr_m0; f.rr_m1 = (float)k.rr_m1; f.rr_m2 = (float)k.rr_m2; f.rr_m3 = (float)k.rr_m3; f.rr_m4 = (float)k.rr_m4;
+  f.c_q0 = (float)k.c_q0; f.c_q1 = (float)k.c_q1; f.m7 = (float)k.m7; f.m6 = (float)k.m6; f.c15 = (float)k.c15;
+  return f;
+}
+
 // Launch plan of a symmetric sweep: `total` rotation steps over `blocks` workgroups of 4 waves.
 struct SymPlan { long blocks; long steps_per_wave; size_t dyn_lds; };
 
@@ -316,7 +325,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   SymPlan plan;
   // single-precision mode (mobility_pycuda.py:7-19 `precision = 'single'`): tt with open boundaries only
   const bool f32 = c->opt_precision == 32 && kind == RMB_TT && !periodic;
-  typedef void (*sym32_fn)(const rmb::SymArgs, const rmb::PairConsts32);
+  typedef void (*sym32_fn)(const rmb::SymArgs, const rmb::f32::PairConsts);
   const sym32_fn fn32 = c->wall ? (sym32_fn)rmb::sym32_tt_kernel<true> : (sym32_fn)rmb::sym32_tt_kernel<false>;
   static int occ32[2] = {0, 0};
   const size_t stat = f32 ? (sizeof(float) * 6 + sizeof(double) * 3) * rmb::kSymWaves * 64
@@ -338,9 +347,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
   if (f32) {
-    rmb::PairConsts32 kf;
-    kf.a2 = (float)a.k.a2; kf.four_a2 = (float)a.k.four_a2; kf.tt_k1 = (float)a.k.tt_k1; kf.tt_k2 = (float)a.k.tt_k2;
-    kf.tt_n0 = (float)a.k.tt_n0; kf.tt_n1 = (float)a.k.tt_n1; kf.tt_n2 = (float)a.k.tt_n2; kf.m7 = -7.0f;
+    const rmb::f32::PairConsts kf = pair_consts32(a.k);
     hipLaunchKernelGGL(fn32, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a, kf);
   } else {
     hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
@@ -437,15 +444,6 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
 #undef RMB_SX_KIND
 #undef RMB_SX_ROW
 #undef RMB_SX_ROW32
-
-rmb::f32::PairConsts pair_consts32(const rmb::PairConsts& k) {
-  rmb::f32::PairConsts f;
-  f.a2 = (float)k.a2; f.four_a2 = (float)k.four_a2; f.tt_k1 = (float)k.tt_k1; f.tt_k2 = (float)k.tt_k2;
-  f.tt_n0 = (float)k.tt_n0; f.tt_n1 = (float)k.tt_n1; f.tt_n2 = (float)k.tt_n2;
-  f.rr_m0 = (float)k.rr_m0; f.rr_m1 = (float)k.rr_m1; f.rr_m2 = (float)k.rr_m2; f.rr_m3 = (float)k.rr_m3; f.rr_m4 = (float)k.rr_m4;
-  f.c_q0 = (float)k.c_q0; f.c_q1 = (float)k.c_q1; f.m7 = (float)k.m7; f.m6 = (float)k.m6; f.c15 = (float)k.c15;
-  return f;
-}
 
 // Configuration a symmetric pass runs on: the context's resident one, or a caller-packed one (per-blob radii)
 struct SymConf { const double4* pos; long n; double L[3]; int wall; const double* extra; };

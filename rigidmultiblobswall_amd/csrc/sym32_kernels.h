@@ -6,7 +6,7 @@
 // else keeps running in fp64 whatever the option says.
 //
 // HOW: the schedule, the tile pairs, the rotation and the global accumulators are sym_kernel's (sym_kernels.h); the pair
-// arithmetic is the closed-form block of pair_blocks.h (F, P, Q3, Q4, Szz) written in float:
+// arithmetic is the closed-form block of pair_blocks.h (F, P, Q3, Q4, Szz) regenerated in float (pair_blocks32.h):
 //   * positions and vectors are converted once per tile (the reference casts its arrays to float32 the same way);
 //   * v_rsq_f32 is accurate to 1 ulp, so the two inverse square roots need no correction step (fp64: 5 instructions each);
 //   * tile J sits in the wave's LDS slab as six float planes (conflict-free ds_read_b32 under the rotation); the
@@ -19,74 +19,23 @@
 // 76 VALU instructions per unordered pair (73 fp32 + 3 conversions); fp32 issues 1.6x faster than fp64 on this chip (profiles/
 // r1_ubench_fp64_issue_rates.txt: 785 vs 486 G wave-instr/s), so the mode is ~2x the fp64 kernel.
 #pragma once
+#include "pair_blocks32.h"
 #include "sym_kernels.h"
 
 namespace rmb {
 
-struct PairConsts32 {
-  float a2, four_a2, tt_k1, tt_k2, tt_n0, tt_n1, tt_n2, m7;
-};
-
-__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-// Both directions of one pair in float: ui += M_ij vj, t = M_ij^T vi   (tt_block / block_apply of pair_blocks.h)
+// Both directions of one pair in float: ui += M_ij vj, t = M_ij^T vi -- the generated single-precision algebra
+// (pair_blocks32.h = pair_blocks.h in float, tools/gen_pair_blocks32.py)
 template <bool WALL>
-__device__ __forceinline__ void pair_tt_sym32(const PairConsts32& k, float dx, float dy, float dz, float zi, float zj,
+__device__ __forceinline__ void pair_tt_sym32(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
                                               const float* vi, const float* vj, float* ui, float* t) {
-  const float rho2 = fmaf_(dy, dy, dx * dx);
-  const float r2 = fmaf_(dz, dz, rho2);
-  const float ir = __builtin_amdgcn_rsqf(r2);
-  const float ir2 = ir * ir, ir3 = ir2 * ir;
-  float cF = fmaf_(k.tt_k1, ir3, ir);
-  float cD = fmaf_(-k.tt_k2, ir2, 1.0f) * ir3;
-  if (__builtin_expect(__any(r2 <= k.four_a2), 0)) {
-    const float r = r2 * ir;
-    const bool near = r2 <= k.four_a2;
-    cF = near ? fmaf_(-k.tt_n1, r, k.tt_n0) : cF;
-    cD = near ? k.tt_n2 * ir : cD;
-  }
-  if constexpr (!WALL) {
-    const float cDj = cD * fmaf_(dz, vj[2], fmaf_(dy, vj[1], dx * vj[0]));
-    const float cDi = cD * fmaf_(dz, vi[2], fmaf_(dy, vi[1], dx * vi[0]));
-    ui[0] = fmaf_(cF, vj[0], ui[0]); ui[0] = fmaf_(cDj, dx, ui[0]);
-    ui[1] = fmaf_(cF, vj[1], ui[1]); ui[1] = fmaf_(cDj, dy, ui[1]);
-    ui[2] = fmaf_(cF, vj[2], ui[2]); ui[2] = fmaf_(cDj, dz, ui[2]);
-    t[0] = fmaf_(cDi, dx, cF * vi[0]);
-    t[1] = fmaf_(cDi, dy, cF * vi[1]);
-    t[2] = fmaf_(cDi, dz, cF * vi[2]);
-  } else {
-    const float Rz = zi + zj;
-    const float s = __builtin_amdgcn_rsqf(fmaf_(Rz, Rz, rho2));
-    const float q = s * s, q3 = s * q;
-    const float T2 = k.tt_k2 * q;
-    const float U = fmaf_(-rho2, q, 1.0f);
-    const float om = fmaf_(-r2, q, 1.0f);
-    const float p5 = fmaf_(U, 5.0f, -1.0f);
-    const float Ta = (T2 * T2) * (1.0f / 6.0f);
-    const float H = fmaf_(Ta, fmaf_(p5, k.m7, 8.0f), fmaf_(T2, p5, fmaf_(om, -1.5f, 1.0f)));
-    const float cDdz = cD * dz;
-    const float Q3 = fmaf_(q3, fmaf_(Rz, H, -(zi + zi)), cDdz);
-    const float Q4 = fmaf_(fmaf_(-q3, dz, cDdz), 2.0f, -Q3);
-    const float P = fmaf_(-q3, fmaf_(Ta, -10.0f, H), cD);
-    const float G1 = fmaf_(Ta, p5, fmaf_(T2, (1.0f / 3.0f) - U, fmaf_(om, 0.5f, 1.0f)));
-    const float F = fmaf_(-G1, s, cF);
-    const float Zb = fmaf_(U, fmaf_(fmaf_(Ta, -10.0f, T2), -2.0f, H - 2.0f), fmaf_(Ta, -4.0f, om));
-    const float Szz = fmaf_(s, Zb, fmaf_(cDdz, dz, F));
-    const float pj = fmaf_(dy, vj[1], dx * vj[0]);
-    const float sj = fmaf_(P, pj, Q3 * vj[2]);
-    ui[0] = fmaf_(F, vj[0], ui[0]); ui[0] = fmaf_(sj, dx, ui[0]);
-    ui[1] = fmaf_(F, vj[1], ui[1]); ui[1] = fmaf_(sj, dy, ui[1]);
-    ui[2] = fmaf_(Q4, pj, ui[2]); ui[2] = fmaf_(Szz, vj[2], ui[2]);
-    const float pi = fmaf_(dy, vi[1], dx * vi[0]);
-    const float si = fmaf_(P, pi, Q4 * vi[2]);
-    t[0] = fmaf_(si, dx, F * vi[0]);
-    t[1] = fmaf_(si, dy, F * vi[1]);
-    t[2] = fmaf_(Szz, vi[2], Q3 * pi);
-  }
+  const f32::Geom g = f32::make_geom<WALL>(dx, dy, dz, zi, zj);
+  const f32::TTc c = f32::tt_coeffs<WALL>(k, g, zi, zj);
+  f32::tt_apply<WALL, false>(c, g, vi, vj, ui, t);
 }
 
 template <bool WALL>
-__global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs a, const PairConsts32 kf) {
+__global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs a, const f32::PairConsts kf) {
   __shared__ float rec_all[kSymWaves][6 * 64];     // planes x, y, z, vx, vy, vz of tile J
   __shared__ double accj_all[kSymWaves][3 * 64];   // fp64: ds_add_f32 is ~10x slower than ds_add_f64 on this chip (see header)
   const int lane = threadIdx.x & 63;
