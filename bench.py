@@ -444,6 +444,28 @@ def rank_main(args):
                                  "mobility_products_per_step": (integ.mobility_products - p0) / n5_steps,
                                  "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
                                  "rejected_steps": integ.invalid_configuration_count}
+      # the same two steps with the reference GPU module's precision switch on 'single' (fp32 twins of the fused row and
+      # the grand mobility, fp64 accumulation): an option, reported beside the double-precision figure
+      integ.precision = "single"
+      l1 = integ.stoch_iterations_count
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      t0 = time.perf_counter()
+      for _ in range(n5_steps):
+        integ.advance_time_step(0.016)
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      dt5s = time.perf_counter() - t0
+      if world > 1:
+        t = torch.tensor([dt5s], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt5s = float(t.item())
+      integ.precision = "double"
+      line["config5_rollers"]["single_precision_option"] = {
+          "s_per_step": round(dt5s / n5_steps, 4), "lanczos_iterations_per_step": (integ.stoch_iterations_count - l1) / n5_steps,
+          "rejected_steps": integ.invalid_configuration_count}
     except Exception as exc:      # an extra must never cost the headline line
       line['config5_rollers'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
@@ -490,6 +512,25 @@ def rank_main(args):
                                             "mobility_products_per_step": ri.susp.matvec_count - m0,
                                             "passes_over_the_pairs_per_step": ri.susp.sweep_count - p0,
                                             "rejected_steps": ri.invalid_configuration_count}
+      ri.precision = "single"       # single-vector M_tt passes in fp32 (the k-vector lockstep passes stay fp64)
+      d1, l1 = ri.det_iterations_count, ri.stoch_iterations_count
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      t0 = time.perf_counter()
+      ri.advance_time_step(0.01, step=2)
+      torch.cuda.synchronize(device)
+      if world > 1:
+        dist.barrier()
+      dt5s = time.perf_counter() - t0
+      if world > 1:
+        t = torch.tensor([dt5s], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt5s = float(t.item())
+      ri.precision = "double"
+      line["config5_multiblob_brownian"]["single_precision_option"] = {
+          "s_per_step": round(dt5s, 4), "gmres_iterations_per_step": ri.det_iterations_count - d1,
+          "lanczos_iterations_per_step": ri.stoch_iterations_count - l1, "rejected_steps": ri.invalid_configuration_count}
     except Exception as exc:      # an extra must never cost the headline line
       line['config5_multiblob_brownian'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
