@@ -691,14 +691,19 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     typedef void (*sforce_fn)(const rmb::SymForceArgs);
     const sforce_fn sfn = radii ? (periodic ? (sforce_fn)rmb::sym_force_kernel<true, true> : (sforce_fn)rmb::sym_force_kernel<false, true>)
                                 : (periodic ? (sforce_fn)rmb::sym_force_kernel<true, false> : (sforce_fn)rmb::sym_force_kernel<false, false>);
-    const void* fn = (const void*)sfn;
-    long blocks = c->n_cu * resident_blocks(fn, &socc[radii ? 1 : 0][periodic ? 1 : 0]) * c->opt_sym_oversub;
+    // "precision" = 32, open boundaries: the single-precision kernel -- the arithmetic of the reference's own GPU force
+    // kernel (forces_pycuda.py:14-21)
+    const bool f32 = c->opt_precision == 32 && !periodic;
+    static int socc32[2] = {0, 0};
+    const sforce_fn sfn32 = radii ? (sforce_fn)rmb::sym_force32_kernel<true> : (sforce_fn)rmb::sym_force32_kernel<false>;
+    const void* fn = f32 ? (const void*)sfn32 : (const void*)sfn;
+    long blocks = c->n_cu * resident_blocks(fn, f32 ? &socc32[radii ? 1 : 0] : &socc[radii ? 1 : 0][periodic ? 1 : 0]) * c->opt_sym_oversub;
     const long need = (a.n_units * 64 + 255) / 256;
     if (blocks > need) blocks = need;
     c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
     int slot;
     if (int rc = timing_begin(c, &slot)) return rc;
-    hipLaunchKernelGGL(sfn, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
+    hipLaunchKernelGGL(f32 ? sfn32 : sfn, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), 0, c->stream, a);
     RMB_HIP(hipGetLastError());
     if (int rc = timing_end(c, slot)) return rc;
     hipLaunchKernelGGL(rmb::sym_force_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);

@@ -133,4 +133,105 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Blob-blob forces in single precision -- what the reference's GPU force kernel always computes in
+// (multi_bodies/forces_pycuda.py:14, :21 `precision = 'single'`, `typedef float real`).  Same unit schedule as
+// sym_force_kernel; pair arithmetic in float with the hardware exponential (v_exp_f32), partial sums of at most 64 pairs
+// in fp32, then added in fp64 (LDS and global accumulators, same finalize).  Open boundaries; uniform radius or per-blob
+// radii (RADII).  Reached through context option "precision" = 32.
+// ---------------------------------------------------------------------------------------------
+template <bool RADII>
+__global__ __launch_bounds__(64 * kSymWaves) void sym_force32_kernel(const SymForceArgs a) {
+  __shared__ float4 rec_all[kSymWaves][64];
+  __shared__ double accj_all[kSymWaves][3 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float4* rec = rec_all[wave];
+  double* accj = accj_all[wave];
+  const long n_waves = (long)gridDim.x * kSymWaves;
+  const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long s_total = a.n_units * 64;
+  const long spw = (s_total + n_waves - 1) / n_waves;
+  long s = w * spw;
+  long s_end = s + spw;
+  if (s_end > s_total) s_end = s_total;
+  int I = 0, J = 0;
+  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  int I_cur = -1;
+  long i = 0;
+  bool vi_ok = false;
+  float xi = 0, yi = 0, zi = 0, ri = 0;
+  float ax = 0, ay = 0, az = 0;
+  const float eps_over_b = (float)a.eps_over_b, inv_b_log2e = (float)(a.inv_b * 1.4426950408889634), two_a0 = (float)a.two_a;
+  auto flush_row = [&]() {
+    if (!vi_ok) return;
+    __hip_atomic_fetch_add(&a.acc[i], (double)ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[a.n_pad + i], (double)ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], (double)az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  while (s < s_end) {
+    const int k0 = (int)(s & 63);
+    const long left = s_end - s;
+    const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
+    s += k1 - k0;
+    if (I != I_cur) {
+      if (I_cur >= 0) flush_row();
+      I_cur = I;
+      i = 64L * I + lane;
+      vi_ok = i < a.n;
+      xi = 1e18f; yi = 1e18f; zi = 1e18f;
+      if (vi_ok) { const double4 p = a.pos[i]; xi = (float)p.x; yi = (float)p.y; zi = (float)p.z; }
+      if constexpr (RADII) ri = vi_ok ? (float)a.radii[i] : 0.0f;
+      ax = 0; ay = 0; az = 0;
+    }
+    {
+      const long j = 64L * J + lane;
+      float4 q = make_float4(-1e18f, -1e18f, -1e18f, 0.0f);
+      if (j < a.n) { const double4 p = a.pos[j]; q.x = (float)p.x; q.y = (float)p.y; q.z = (float)p.z; }
+      if constexpr (RADII) q.w = (j < a.n) ? (float)a.radii[j] : 0.0f;
+      rec[lane] = q;
+      accj[lane] = 0.0; accj[64 + lane] = 0.0; accj[128 + lane] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool diag = (I == J);
+    for (int k = (diag && k0 < 1) ? 1 : k0; k < k1; ++k) {
+      const int jj = (lane + k) & 63;
+      const float4 q = rec[jj];
+      const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
+      const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      const float ir = __builtin_amdgcn_rsqf(r2);
+      const float r = r2 * ir;
+      const float two_a = RADII ? ri + q.w : two_a0;
+      // branch-free as pair_force (sym_kernels.h): exponent 0 exactly for r <= 2a, exp2(0) = 1, min(1/r, 1e25) = 1/r beyond
+      const float e = __builtin_amdgcn_exp2f(__builtin_fminf((two_a - r) * inv_b_log2e, 0.0f));
+      const float f0 = -eps_over_b * (e * __builtin_fminf(ir, 1e25f));
+      const float fx = f0 * dx, fy = f0 * dy, fz = f0 * dz;
+      ax += fx; ay += fy; az += fz;
+      if (!diag) {   // wave-uniform; +f here, the sign of the reaction goes into the flush
+        __hip_atomic_fetch_add(&accj[jj], (double)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[64 + jj], (double)fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[128 + jj], (double)fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    if (!diag) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long j = 64L * J + lane;
+      if (j < a.n) {
+        __hip_atomic_fetch_add(&a.acc[j], -accj[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[a.n_pad + j], -accj[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + j], -accj[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (k1 == 64) {
+      if (++J == a.n_tiles) { ++I; J = I; }
+    }
+  }
+  if (I_cur >= 0) flush_row();
+}
+
 }  // namespace rmb

@@ -488,3 +488,28 @@ def test_single_precision_other_products(Ctx, torch_mod, wall, N):
     assert rel_err(ctx.matvec_device("tr", fd, eta).cpu().numpy(), ref) < 1e-13
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("N", [200, 5000])
+def test_single_precision_forces(Ctx, oracle, N):
+  """precision = 32: the blob-blob forces in fp32 (what the reference's GPU force kernel computes in), uniform and
+  per-blob radii; single-precision accurate against the fp64 oracle, fp64 again after switching back."""
+  r, f, eta, a = d2_cloud(N, seed=N + 1)
+  eps, b = 0.7, 0.15 * a
+  rad = a * (0.6 + 0.8 * np.random.RandomState(N).rand(N))
+  ref = oracle.calc_blob_blob_forces_oracle(r, repulsion_strength=eps, debye_length=b, blob_radius=a, periodic_length=np.zeros(3))
+  ref_r = oracle.calc_blob_blob_forces_radii_oracle(r, rad, repulsion_strength=eps, debye_length=b, periodic_length=np.zeros(3))
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, np.zeros(3), wall=False)
+    ctx.set_option("precision", 32)
+    F = ctx.blob_blob_force(eps, b, a)
+    e = rel_err(F.reshape(-1), ref.reshape(-1))
+    assert np.all(np.isfinite(F)) and 1e-9 < e < 1e-5, e
+    Fr = ctx.blob_blob_force_radii(rad, eps, b)
+    er = rel_err(Fr.reshape(-1), ref_r.reshape(-1))
+    assert 1e-9 < er < 1e-5, er
+    ctx.set_option("precision", 64)
+    assert rel_err(ctx.blob_blob_force(eps, b, a).reshape(-1), ref.reshape(-1)) < 1e-12
+  finally:
+    ctx.close()
