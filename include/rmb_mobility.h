@@ -81,11 +81,11 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *                          (nshards > 1) ignore it.  Forces: 1 and 2 both take the one-sided sweep.
  *   "precision"       [64] 32 = single precision on the default symmetric path with open boundaries (the
  *                          reference's `precision = 'single'` build, mobility_pycuda.py:7-19) for tt / tr / rt / rr,
- *                          RMB_TT_TR, the in-plane products, the grand / force-column operations and the
+ *                          RMB_TT_TR, the in-plane products, the grand / force-column / k-vector operations and the
  *                          blob-blob forces (the reference's GPU force kernel is always single precision,
  *                          forces_pycuda.py:14-21) (sym32_kernels.h, symx32_kernels.h): pair arithmetic in fp32
  *                          (~1e-6 relative), partial sums, self terms and scaling in fp64; 1.7-1.8x faster.
- *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes, k-vector products,
+ *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes, rmb_matvec2_*,
  *                          free-surface / per-blob-radii mobility products, pair shards of kinds other than tt and
  *                          the source->target operators compute in fp64 whatever this says.  Other values:
  *                          RMB_ERR_ARG.

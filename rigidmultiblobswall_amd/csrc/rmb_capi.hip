@@ -437,11 +437,14 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
     {{make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
      {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
     RMB_SX_ROW(rmb::OpRadiiTT),
-#define RMB_SX_K(K) RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_TT, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_TR, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_RT, K)), RMB_SX_ROW(RMB_SX_KIND(rmb::KIND_RR, K))
+#define RMB_SX_K(K) RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_TT, K), RMB_SX_KIND32(rmb::KIND_TT, K)), RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_TR, K), RMB_SX_KIND32(rmb::KIND_TR, K)), \
+                    RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_RT, K), RMB_SX_KIND32(rmb::KIND_RT, K)), RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_RR, K), RMB_SX_KIND32(rmb::KIND_RR, K))
 #define RMB_SX_KIND(KIND, K) rmb::OpKindK<KIND, K>
+#define RMB_SX_KIND32(KIND, K) rmb::OpKindK32<KIND, K>
     RMB_SX_K(2), RMB_SX_K(3), RMB_SX_K(4)};
 #undef RMB_SX_K
 #undef RMB_SX_KIND
+#undef RMB_SX_KIND32
 #undef RMB_SX_ROW
 #undef RMB_SX_ROW32
 

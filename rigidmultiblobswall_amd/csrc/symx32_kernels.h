@@ -2,7 +2,8 @@
 //
 // WHAT: context option "precision" = 32 (the reference's `precision = 'single'` build, mobility_pycuda.py:7-19) for the
 // products besides tt: tr / rt / rr, the fused row M_tt f + M_tr tau (K11 / K12), the 6N grand mobility and the force
-// column [M_tt; M_rt] f -- everything the single-blob roller steppers apply per step -- with open boundaries.
+// column [M_tt; M_rt] f -- everything the single-blob roller steppers apply per step -- and one block on k = 2..4
+// vectors (lockstep solves), with open boundaries.
 //
 // HOW: symx_kernel's skeleton (symx_kernels.h: tile pairs, rotation, static balanced schedule, pair shards, fp64 global
 // accumulators, fp64 finalize with self terms / B-damping / prefactor) with the pair arithmetic of pair_blocks32.h (the
@@ -71,6 +72,32 @@ struct OpColumnF32 {       // [u; w] = [M_tt; M_rt] f
     f32::tt_apply<WALL, false>(a, g, vi, vj, ui, t);
     const f32::CPc C = f32::cpl_block<WALL>(k, g, zi, zj, p.c);
     f32::rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+  }
+};
+
+template <int KIND, int K>
+struct OpKindK32 {         // one block applied to K vectors (lockstep solves): the coefficients are built once
+  static constexpr int NIN = K, NOUT = K;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const f32::Geom g = f32::make_geom<WALL>(dx, dy, dz, zi, zj);
+    if constexpr (KIND == KIND_TT) {
+      const f32::TTc a = f32::tt_coeffs<WALL>(k, g, zi, zj);
+#pragma unroll
+      for (int v = 0; v < K; ++v) f32::tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+    } else if constexpr (KIND == KIND_RR) {
+      const f32::RRc b = f32::rr_coeffs<WALL>(k, g);
+#pragma unroll
+      for (int v = 0; v < K; ++v) f32::rr_apply<WALL, false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+    } else {
+      const f32::CPc C = f32::cpl_coeffs<WALL>(k, g, zi, zj);
+#pragma unroll
+      for (int v = 0; v < K; ++v) {
+        if constexpr (KIND == KIND_TR) f32::tr_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+        else                           f32::rt_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      }
+    }
   }
 };
 

@@ -146,9 +146,9 @@ class RigidIntegrator(object):
   @property
   def precision(self):
     """'double' (default) or 'single' -- the reference GPU module's precision switch (mobility_pycuda.py:7-19) for the
-    blob mobility products of this integrator: with 'single' every single-vector M_tt pass with open boundaries runs
-    the fp32 twin of the pair sweep (csrc/sym32_kernels.h: fp32 pair arithmetic, fp64 accumulation, ~1e-6 relative);
-    k-vector lockstep passes, pseudo-periodic domains, forces and the O(N) rigid algebra stay fp64.  Meant for the
+    blob mobility products of this integrator: with 'single' every M_tt pass with open boundaries (single-vector and k-vector lockstep
+    passes) and the blob-blob forces run the fp32 twins of the pair sweeps (csrc/sym32_kernels.h, symx32_kernels.h: fp32
+    pair arithmetic, fp64 accumulation, ~1e-6 relative); pseudo-periodic domains and the O(N) rigid algebra stay fp64.  Meant for the
     Brownian schemes at their loose solver tolerances (1e-3 ... 1e-4), where the product error is two orders below
     the tolerance; the solvers' stopping rules are unchanged."""
     return self._precision

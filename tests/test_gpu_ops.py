@@ -449,7 +449,7 @@ def test_single_precision_switch_of_the_python_surface(mob, oracle):
 @pytest.mark.parametrize("wall", [True, False])
 @pytest.mark.parametrize("N", [128, 1000, 6000])
 def test_single_precision_other_products(Ctx, torch_mod, wall, N):
-  """precision = 32 for tr / rt / rr, the fused row, the grand mobility, the force column and the in-plane products:
+  """precision = 32 for tr / rt / rr, the fused row, the grand mobility, the force column, k-vector and in-plane products:
   single-precision accurate against the same context in double precision; pseudo-periodic domains stay fp64."""
   torch = torch_mod
   r, f, eta, a = d1_cloud(N, seed=N) if N == 1000 else d2_cloud(N, seed=N)
@@ -466,6 +466,10 @@ def test_single_precision_other_products(Ctx, torch_mod, wall, N):
       out["grand_u"], out["grand_w"] = g[0].cpu().numpy(), g[1].cpu().numpy()
       c = ctx.matvec_op_device("force_column", (fd,), eta)
       out["col_u"], out["col_w"] = c[0].cpu().numpy(), c[1].cpu().numpy()
+      m = ctx.matvec_op_device("tt_multi", (fd, td, fd + td), eta)
+      out["tt3_a"], out["tt3_b"], out["tt3_c"] = (x.cpu().numpy() for x in m)
+      m = ctx.matvec_op_device("rr_multi", (fd, td), eta)
+      out["rr2_a"], out["rr2_b"] = (x.cpu().numpy() for x in m)
       if wall:
         out["in_plane_tt"] = ctx.matvec_device("tt", fd, eta, in_plane=True).cpu().numpy()
         out["in_plane_tr"] = ctx.matvec_device("tr", fd, eta, in_plane=True).cpu().numpy()
