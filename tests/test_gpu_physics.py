@@ -26,6 +26,10 @@ def test_roller_schemes_keep_the_equilibrium_height_distribution():
   assert abs(ab["var"] / ab["analytic_var"] - 1.0) < 0.08, ab
   tr = E.main(scheme="stochastic_trapezoidal_rollers")
   assert abs(tr["mean"] / tr["analytic_mean"] - 1.0) < 0.01, tr
+  # the precision switch must not touch the physics: same check with single-precision mobility products
+  sp = E.main(scheme="stochastic_adams_bashforth_rollers", precision="single")
+  assert sp["rejected"] == 0 and abs(sp["mean"] / sp["analytic_mean"] - 1.0) < 0.01, sp
+  assert abs(sp["mean"] / ab["mean"] - 1.0) < 1e-4, (sp, ab)      # same draws: the two runs track each other
   control = E.main(drift=False)
   assert control["mean"] / control["analytic_mean"] - 1.0 < -0.02, control      # the check has teeth
 

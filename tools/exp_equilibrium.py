@@ -23,7 +23,8 @@ def analytic_moments():
   return m1, m2 - m1 * m1, h, np.cumsum(w) / np.sum(w)
 
 
-def main(N=2048, steps=200, dt=0.016, scheme="stochastic_adams_bashforth_rollers", seed=3, spacing=5.0, drift=True):
+def main(N=2048, steps=200, dt=0.016, scheme="stochastic_adams_bashforth_rollers", seed=3, spacing=5.0, drift=True,
+         precision="double"):
   m1, var, h, cdf = analytic_moments()
   rng = np.random.RandomState(seed)
   side = int(math.ceil(math.sqrt(N)))
@@ -33,6 +34,7 @@ def main(N=2048, steps=200, dt=0.016, scheme="stochastic_adams_bashforth_rollers
   r0[:, 2] = np.interp(rng.rand(N), cdf, h)             # start in equilibrium
   integ = RollersIntegrator(r0, scheme, a, eta, tolerance=1e-4, device="cuda:0", seed=seed)
   integ.kT, integ.g, integ.repulsion_strength_wall, integ.debye_length_wall = kT, mg, ew, bw
+  integ.precision = precision
   if not drift:
     # drop the random-finite-difference term kT div(M): what an integrator without the stochastic drift would do
     integ._random_finite_difference = lambda kinds: [torch.zeros(3 * N, dtype=torch.float64, device="cuda:0") for _ in kinds]
