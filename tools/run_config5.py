@@ -91,6 +91,8 @@ else:
   FT = torch.zeros((nb, 6), dtype=torch.float64, device=dev)
   FT[:, 4] = 8 * math.pi * eta * R ** 3 * 62.8
   ri.external_force_torque = lambda it: FT
+  ri.precision = precision
+  rec["precision_of_the_mobility_products"] = precision
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for step in range(steps):
