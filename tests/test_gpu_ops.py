@@ -517,3 +517,32 @@ def test_single_precision_forces(Ctx, oracle, N):
     assert rel_err(ctx.blob_blob_force(eps, b, a).reshape(-1), ref.reshape(-1)) < 1e-12
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("N", [130, 3000])
+def test_single_precision_pair_shards_sum_to_the_product(Ctx, torch_mod, N):
+  """Multi-GPU layout in single precision: the shards of the unordered pairs (tt kernel, fused row, grand mobility) still
+  partition the work exactly -- their sum is the unsharded single-precision product up to fp32 summation order."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(N, seed=N + 2)
+  t = np.random.RandomState(N).randn(*f.shape)
+  fd, td = _dev(torch, f), _dev(torch, t)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, np.zeros(3), wall=True)
+    ctx.set_option("precision", 32)
+    G = 3
+    whole = ctx.matvec_device("tt", fd, eta)
+    parts = sum(ctx.matvec_pairshard_device("tt", fd, eta, g, G) for g in range(G))
+    assert rel_err(parts.cpu().numpy(), whole.cpu().numpy()) < 1e-6
+    for op, vecs in (("velocity_from_force_torque", (fd, td)), ("grand", (fd, td))):
+      w = ctx.matvec_op_device(op, vecs, eta)
+      p = [ctx.matvec_op_device(op, vecs, eta, shard=g, nshards=G) for g in range(G)]
+      for c in range(len(w)):
+        assert rel_err(sum(x[c] for x in p).cpu().numpy(), w[c].cpu().numpy()) < 1e-6, (op, c)
+    # and they are single-precision results: close to, but not equal to, the double-precision product
+    ctx.set_option("precision", 64)
+    e = rel_err(whole.cpu().numpy(), ctx.matvec_device("tt", fd, eta).cpu().numpy())
+    assert 1e-9 < e < 1e-5, e
+  finally:
+    ctx.close()
