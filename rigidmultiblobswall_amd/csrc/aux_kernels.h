@@ -13,7 +13,8 @@
 // of a workgroup (each wave takes every fourth source), source chunks over blockIdx.y with a fixed-order reduction, no
 // atomics: bit-reproducible.  The nine-term contraction of the reference is (r.n)(r.v) r; divisions become one
 // inverse square root per distance.  HBM traffic is the records once per target tile; the kernel is fp64-VALU bound
-// like every pair sweep here (~35 instructions per pair unbounded, ~90 with the wall images).
+// like every pair sweep here (VALU instructions per source-target pair in this build: pressure 21 / 42 with the wall,
+// double layer 35 / 82 with the wall images / 50 for the RPY form).
 #pragma once
 #include "matvec_kernels.h"
 
