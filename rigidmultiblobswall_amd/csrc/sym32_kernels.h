@@ -18,6 +18,8 @@
 //     so the single-precision error is that of the pair arithmetic (~1e-6 relative), not of a long fp32 sum.
 // 76 VALU instructions per unordered pair (73 fp32 + 3 conversions); fp32 issues 1.6x faster than fp64 on this chip (profiles/
 // r1_ubench_fp64_issue_rates.txt: 785 vs 486 G wave-instr/s), so the mode is ~2x the fp64 kernel.
+// Caveat shared with the reference's float build: positions are rounded to float before they are subtracted, so two
+// blobs closer than ~1e-7 of their coordinates coincide (r = 0 => NaN, as for exactly coincident blobs in fp64).
 #pragma once
 #include "pair_blocks32.h"
 #include "sym_kernels.h"
