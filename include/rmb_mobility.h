@@ -84,7 +84,8 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *                          RMB_TT_TR, the in-plane products, the grand / force-column / k-vector operations and the
  *                          blob-blob forces (the reference's GPU force kernel is always single precision,
  *                          forces_pycuda.py:14-21) (sym32_kernels.h, symx32_kernels.h): pair arithmetic in fp32
- *                          (~1e-6 relative), partial sums, self terms and scaling in fp64; 1.7-1.8x faster.
+ *                          (~1e-6 relative, separations from a head / tail split of the fp64 positions), partial sums,
+ *                          self terms and scaling in fp64; 1.5-1.6x faster.
  *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes, rmb_matvec2_*,
  *                          free-surface / per-blob-radii mobility products, pair shards of kinds other than tt and
  *                          the source->target operators compute in fp64 whatever this says.  Other values:

@@ -328,7 +328,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   typedef void (*sym32_fn)(const rmb::SymArgs, const rmb::f32::PairConsts);
   const sym32_fn fn32 = c->wall ? (sym32_fn)rmb::sym32_tt_kernel<true> : (sym32_fn)rmb::sym32_tt_kernel<false>;
   static int occ32[2] = {0, 0};
-  const size_t stat = f32 ? (sizeof(float) * 6 + sizeof(double) * 3) * rmb::kSymWaves * 64
+  const size_t stat = f32 ? (sizeof(float) * 9 + sizeof(double) * 3) * rmb::kSymWaves * 64
                           : sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
   if (int rc = plan_sym(c, f32 ? (const void*)fn32 : (const void*)se.sweep, f32 ? &occ32[c->wall ? 1 : 0] : &se.occ, stat,
                         a.step_end - a.step_begin, true, &plan))

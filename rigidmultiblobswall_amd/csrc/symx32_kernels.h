@@ -13,6 +13,7 @@
 #pragma once
 #include "pair_blocks32.h"
 #include "symx_kernels.h"
+#include "sym32_kernels.h"
 
 namespace rmb {
 
@@ -102,14 +103,14 @@ struct OpKindK32 {         // one block applied to K vectors (lockstep solves): 
 };
 
 template <class OP> struct SymX32Lds {
-  static constexpr int planes = 3 + 3 * OP::NIN;
+  static constexpr int planes = 6 + 3 * OP::NIN;
   static constexpr size_t bytes = (sizeof(float) * planes + sizeof(double) * 3 * OP::NOUT) * 64 * kSymWaves;
 };
 
 template <class OP, bool WALL>
 __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a, const f32::PairConsts kf) {
-  constexpr int NI = OP::NIN, NO = OP::NOUT, NP = 3 + 3 * NI;
-  __shared__ float rec_all[kSymWaves][NP * 64];      // planes x, y, z, then the NIN vectors of tile J
+  constexpr int NI = OP::NIN, NO = OP::NOUT, NP = 6 + 3 * NI;
+  __shared__ float rec_all[kSymWaves][NP * 64];      // planes x, y, z (float heads), the NIN vectors, then the position tails
   __shared__ double accj_all[kSymWaves][3 * NO * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
   int I_cur = -1;
   long i = 0;
   bool vi_ok = false;
-  float xi = 0, yi = 0, zi = 1.0f;
+  float xi = 0, yi = 0, zi = 1.0f, xil = 0, yil = 0, zil = 0;
   float vi[3 * NI], ui[3 * NO];
 #pragma unroll
   for (int c = 0; c < 3 * NI; ++c) vi[c] = 0;
@@ -151,12 +152,13 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
       I_cur = I;
       i = 64L * I + lane;
       vi_ok = i < a.n;
-      xi = 1e18f; yi = 1e18f; zi = 1.0f;          // padding: far away, 1/r^2 stays finite in float
+      xi = 1e18f; yi = 1e18f; zi = 1.0f; xil = 0; yil = 0; zil = 0;   // padding: far away, 1/r^2 stays finite in float
 #pragma unroll
       for (int c = 0; c < 3 * NI; ++c) vi[c] = 0;
       if (vi_ok) {
         const double4 p = a.pos[i];
         xi = (float)p.x; yi = (float)p.y; zi = (float)p.z;
+        xil = (float)(p.x - (double)xi); yil = (float)(p.y - (double)yi); zil = (float)(p.z - (double)zi);
 #pragma unroll
         for (int v = 0; v < NI; ++v) {
           vi[3 * v] = (float)(a.in[v][3 * i] * p.w); vi[3 * v + 1] = (float)(a.in[v][3 * i + 1] * p.w);
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
       if (j < a.n) {
         const double4 p = a.pos[j];
         rd[0] = (float)p.x; rd[1] = (float)p.y; rd[2] = (float)p.z;
+        rd[3 + 3 * NI] = (float)(p.x - (double)rd[0]); rd[4 + 3 * NI] = (float)(p.y - (double)rd[1]); rd[5 + 3 * NI] = (float)(p.z - (double)rd[2]);
 #pragma unroll
         for (int v = 0; v < NI; ++v) {
           rd[3 + 3 * v] = (float)(a.in[v][3 * j] * p.w); rd[4 + 3 * v] = (float)(a.in[v][3 * j + 1] * p.w);
@@ -198,7 +201,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
 #pragma unroll
       for (int c = 0; c < NP; ++c) rd[c] = rec[c * 64 + jj];
       float t[3 * NO];
-      OP::template pair<WALL>(kf, xi - rd[0], yi - rd[1], zi - rd[2], zi, rd[2], vi, rd + 3, ui, t);
+      // head / tail split of the fp64 positions (sym32_kernels.h): the error of d does not grow with the domain size
+      const v2f xyj = {rd[0], rd[1]}, xyjl = {rd[3 + 3 * NI], rd[4 + 3 * NI]}, xyi = {xi, yi}, xyil = {xil, yil};
+      const v2f dxy = (xyi - xyj) + (xyil - xyjl);
+      const float dz = (zi - rd[2]) + (zil - rd[5 + 3 * NI]);
+      OP::template pair<WALL>(kf, dxy.x, dxy.y, dz, zi, rd[2], vi, rd + 3, ui, t);
       if (!diag) {   // wave-uniform
 #pragma unroll
         for (int c = 0; c < 3 * NO; ++c)

@@ -27,7 +27,7 @@ _cached = None  # (r copy, a, L tuple, wall)
 # The reference's GPU module has a source-level precision switch (`precision = 'single' | 'double'`,
 # mobility/mobility_pycuda.py:7-19).  Same switch here, settable at run time: with 'single' the translation <- force
 # products with open boundaries (wall / no wall) run the fp32 twin of the symmetric kernel (csrc/sym32_kernels.h,
-# ~1e-6 relative accuracy, about twice as fast); every other product keeps running in fp64.
+# ~1e-6 relative accuracy, 1.5-1.6x faster); every other product keeps running in fp64.
 precision = 'double'
 
 

@@ -399,7 +399,7 @@ class RigidSuspension(object):
   def solve_mixed_precision(self, rhs, tol=1e-8, inner_tol=3e-5, restart=60, maxiter=1000, max_outer=8):
     """The same saddle-point solve by iterative refinement with a single-precision inner operator -- MI355X issues
     fp32 1.6x faster than fp64 and the fp32 twin of the pair sweep (csrc/sym32_kernels.h, context option "precision")
-    runs at 1.7-1.8x the fp64 one.  Outer loop in fp64: r = rhs - A x with the fp64 operator; inner loop: the SAME
+    runs at 1.5-1.6x the fp64 one.  Outer loop in fp64: r = rhs - A x with the fp64 operator; inner loop: the SAME
     right-preconditioned GMRES (same preconditioner) on A_32 dx = r to the loose relative tolerance `inner_tol`;
     x += dx.  The returned residual is the true fp64 one, so the result meets `tol` exactly as `solve` does; what
     differs from the reference's flow is the number of Krylov restarts (one per outer step), not the stopping rule.

@@ -546,3 +546,29 @@ def test_single_precision_pair_shards_sum_to_the_product(Ctx, torch_mod, N):
     assert 1e-9 < e < 1e-5, e
   finally:
     ctx.close()
+
+
+def test_single_precision_is_insensitive_to_the_size_of_the_domain(Ctx, oracle):
+  """The float kernels subtract positions through a head / tail split of the fp64 coordinates, so a cloud sitting 4e5
+  radii from the origin (where a float coordinate resolves 0.03 radii) is as accurate as the same cloud at the origin.
+  (The reference's float build subtracts rounded coordinates and would be off by 10 % here.)"""
+  N = 2000
+  r, f, eta, a = d2_cloud(N, seed=21)
+  shift = np.array([4.0e5 * a, -2.5e5 * a, 0.0])
+  eps, b = 0.7, 0.15 * a
+  for origin in (np.zeros(3), shift):
+    rr = r + origin
+    ctx = Ctx(0)
+    try:
+      ctx.set_positions(rr, a, np.zeros(3), wall=True)
+      ctx.set_option("precision", 32)
+      u = ctx.matvec("tt", f, eta)
+      w = ctx.matvec("rr", f, eta)
+      ref_u = oracle.single_wall_mobility_trans_times_force_oracle(rr, f, eta, a)
+      ref_w = oracle.single_wall_mobility_rot_times_torque_oracle(rr, f, eta, a)
+      assert rel_err(u, ref_u) < 2e-6 and rel_err(w, ref_w) < 2e-6, (origin, rel_err(u, ref_u), rel_err(w, ref_w))
+      F = ctx.blob_blob_force(eps, b, a)
+      ref_F = oracle.calc_blob_blob_forces_oracle(rr, repulsion_strength=eps, debye_length=b, blob_radius=a, periodic_length=np.zeros(3))
+      assert rel_err(F.reshape(-1), ref_F.reshape(-1)) < 1e-5, (origin, rel_err(F.reshape(-1), ref_F.reshape(-1)))
+    finally:
+      ctx.close()
