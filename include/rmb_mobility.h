@@ -86,7 +86,7 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *                          forces_pycuda.py:14-21) (sym32_kernels.h, symx32_kernels.h): pair arithmetic in fp32
  *                          (~1e-6 relative, separations from a head / tail split of the fp64 positions), partial sums,
  *                          self terms and scaling in fp64; 1.5-1.6x faster.
- *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes, rmb_matvec2_*,
+ *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes,
  *                          free-surface / per-blob-radii mobility products, pair shards of kinds other than tt and
  *                          the source->target operators compute in fp64 whatever this says.  Other values:
  *                          RMB_ERR_ARG.

@@ -1013,7 +1013,9 @@ int rmb_matvec2_pairshard_device(rmb_ctx* c, int kind, const double* vec_a, cons
   }
   // a pair shard (nshards > 1) always runs the symmetric kernel, whatever n: it is the only kernel that can
   // evaluate a slice of the unordered pairs (rmb_matvec_pairshard_device does the same)
-  if (c->opt_symx_single || (c->opt_deterministic == 2 && nshards == 1)) {
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  const bool x32 = c->opt_precision == 32 && !periodic;     // the generic skeleton has the single-precision twin
+  if (c->opt_symx_single || x32 || (c->opt_deterministic == 2 && nshards == 1)) {
     const double* in[2] = {vec_a, vec_b};
     double* outs[2] = {out_a, out_b};
     if (c->opt_deterministic == 2 && nshards == 1) return symx_det_device(c, SX_K2, in, outs, eta, 0);

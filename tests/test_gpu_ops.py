@@ -470,6 +470,8 @@ def test_single_precision_other_products(Ctx, torch_mod, wall, N):
       out["tt3_a"], out["tt3_b"], out["tt3_c"] = (x.cpu().numpy() for x in m)
       m = ctx.matvec_op_device("rr_multi", (fd, td), eta)
       out["rr2_a"], out["rr2_b"] = (x.cpu().numpy() for x in m)
+      m = ctx.matvec2_device("tt", fd, td, eta)
+      out["mv2_a"], out["mv2_b"] = (x.cpu().numpy() for x in m)
       if wall:
         out["in_plane_tt"] = ctx.matvec_device("tt", fd, eta, in_plane=True).cpu().numpy()
         out["in_plane_tr"] = ctx.matvec_device("tr", fd, eta, in_plane=True).cpu().numpy()
