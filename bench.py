@@ -20,15 +20,19 @@ launch), so `--warmup 5` alone would time the power-management ramp, not the ker
 
 Objects on the line
   roofline      dominant kernel (the pair sweep).  The path is fp64-VALU bound, not HBM bound.
-                `achieved`/`frac` use SURVEY 8(d)'s ALGORITHMIC unit: 211 flops per ORDERED pair (the reference's
-                as-written arithmetic) x N^2 / kernel time -- the symmetric kernel evaluates each unordered pair once
-                with ~154 executed flops, so this fraction can exceed 1 and is a throughput figure, not a utilisation.
-                `executed` is the utilisation view, <= 1 by construction: fp64 flops the kernel really executes per
-                launch (FMA = 2, mul/add/rsq = 1, counted over the pair loop of THIS build's ISA by tools/isa_stats.py)
-                / kernel time / 78.6 TF.  `issue` = VALU wave-instructions per launch from the same ISA count / kernel
-                time against the fp64 issue ceiling measured live in this process (rmb_ubench_fp64_issue).
+                `achieved` / `frac` are the UTILISATION, <= 1 by construction: fp64 flops the kernel really executes
+                per launch (FMA = 2, mul/add/rsq = 1, counted over the pair loop of THIS build's ISA by
+                tools/isa_stats.py) x the real unordered pairs of the launch / kernel time / 78.6 TF (`executed` holds
+                the inputs of that number).  `algorithmic_throughput` is SURVEY 8(d)'s unit -- 211 as-written flops per
+                ORDERED pair x N^2 / kernel time: a speed in the reference's currency that exceeds the peak because
+                the symmetric kernel evaluates each unordered pair once with 123 flops; it is never `frac`.
+                `issue` = VALU wave-instructions per launch from the same ISA count / kernel time against the fp64
+                issue ceiling measured live in this process (rmb_ubench_fp64_issue).
                 `traffic` (HBM bytes per launch) cannot be measured inside this process: it is the figure of the
                 committed rocprofv3 --pmc passes, tagged with its source, or null.
+  value_unprimed  the same W + K steps run first thing, before the declared pre-warm (clock still ramping)
+  host_surface  matvecs/s through single_wall_mobility_trans_times_force_hip with numpy in / out (the reference's
+                call shape, PCIe-inclusive) -- reported beside `value`, never `value`
   cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N = 1 only)
 """
 import argparse
@@ -134,7 +138,8 @@ def timed_region(torch, dist, world, device, backend, step, steps, warmup):
   return dt, kern_ms_avg
 
 
-def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, device, decomposition="pair", prewarm_ms=0.0):
+def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, device, decomposition="pair", prewarm_ms=0.0,
+               unprimed=False):
   """decomposition "pair": every rank holds f, evaluates its slice of the unordered pairs (each once, both blobs
   updated) into a full-length partial, one all-reduce of u.  "target": rank g owns a block of targets, all-gather of
   the f blocks, one-sided sweep of its targets against all sources, no reduction (north_star's layout)."""
@@ -160,7 +165,11 @@ def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, de
     def step():
       sm.matvec_local("tt", f_local, eta, out=out)
   prewarm = None
+  cold = None
   try:
+    if unprimed:
+      # the driver's bare flags on a chip that has not run this kernel yet: W warm-up steps, then the same K steps
+      cold = timed_region(torch, dist, world, device, backend, step, steps, warmup)
     if prewarm_ms > 0:
       t0 = time.perf_counter()
       n_pre = 0
@@ -174,7 +183,7 @@ def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, de
   finally:
     backend.ctx.set_option("deterministic", 0)
   return dict(dt=dt, kern_ms=kern_ms, launch=backend.ctx.last_launch(), out=out, r=r, f=f, eta=eta, a=a,
-              n_local=e - b, begin=b, end=e, prewarm=prewarm)
+              n_local=e - b, begin=b, end=e, prewarm=prewarm, cold=cold)
 
 
 def committed_traffic(N, sym):
@@ -198,6 +207,52 @@ def committed_traffic(N, sym):
   except (OSError, ValueError, KeyError):
     pass
   return None, {"measured_in_this_run": False, "source": None}
+
+
+def load_isa():
+  """Instruction mix of the pair loops of THIS build (tools/isa_stats.py; hashed against csrc/), or None."""
+  try:
+    import isa_stats
+    return isa_stats.load()
+  except Exception:
+    return None
+
+
+def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None):
+  """(executed, issue): what one launch of the wall-tt sweep really executes, priced against the fp64 vector peak
+  and against the live fp64 issue ceiling.  Both <= 1 by construction."""
+  st = isa["kernels"].get("sym_tt_wall" if sym else "sweep_tt_wall") if isa else None
+  if st is None:
+    return None, None
+  if sym:
+    tiles = (N + 63) // 64
+    wave_steps = (tiles * (tiles + 1) // 2 * 64 - tiles) / world       # rotation steps (diagonal units skip k = 0)
+    pair_evals = float(N) * (N - 1) / 2 / world                         # real (unpadded) unordered pairs
+  else:
+    wave_steps = float(-(-n_local // 64)) * N
+    pair_evals = float(n_local) * N
+  ex_tf = st["flops_per_lane_step"] * pair_evals / kern_s / 1e12
+  executed = {"flops_per_pair_evaluation": st["flops_per_lane_step"], "pair_evaluations_per_launch": pair_evals,
+              "achieved": round(ex_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(ex_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+              "source": "FMA = 2, mul/add/rsq = 1 flop, counted over the pair loop of this build's ISA "
+                        "(tools/isa_stats.py, csrc sha1 %s); padded lanes not counted" % isa["source_sha1"][:12],
+              "instruction_mix_per_step": st["classes"]}
+  issue = None
+  if issue_peak:
+    valu = st["valu_per_step"] * wave_steps
+    issue = {"valu_wave_instr_per_launch": valu, "achieved": round(valu / kern_s / 1e9, 1), "peak": round(issue_peak, 1),
+             "unit": "G wave-instr/s", "frac": round(valu / kern_s / 1e9 / issue_peak, 4),
+             "peak_source": "rmb_ubench_fp64_issue: independent v_fma_f64, 4 waves per SIMD on every CU, 40 launches, "
+                            "measured in this process right after the timed loop",
+             "note": "two of the %d VALU instructions per step are v_rsq_f64, which issue at ~0.3x the FMA rate "
+                     "(profiles/r1_ubench_fp64_issue_rates.txt)" % st["valu_per_step"]}
+  return executed, issue
+
+
+def _exec_frac(isa, sym, N, world, n_local, kern_s):
+  ex, _ = executed_views(isa, sym, N, world, n_local, kern_s)
+  return None if ex is None else ex["frac"]
 
 
 def rank_main(args):
@@ -231,7 +286,8 @@ def rank_main(args):
   sm = ShardedMobility(backend, device=device)
 
   N = args.blobs
-  res = run_config(torch, dist, sm, backend, N, args.steps, args.warmup, world, rank, device, "pair", args.prewarm_ms)
+  res = run_config(torch, dist, sm, backend, N, args.steps, args.warmup, world, rank, device, "pair", args.prewarm_ms,
+                   unprimed=True)
   ms_per_step = 1e3 * res["dt"] / args.steps
   value = args.steps / res["dt"]
   sym = res["launch"]["chunks"] == 0
@@ -247,50 +303,32 @@ def rank_main(args):
   alg_tf = FLOPS_PER_PAIR["tt_wall"] * pairs_ordered / kern_s / 1e12
   alg_bytes = 48.0 * N + 24.0 * (res["n_local"] if world == 1 else N)
   traffic, traffic_src = committed_traffic(N, sym) if world == 1 else (None, {"measured_in_this_run": False, "source": None})
-  executed = issue = None
-  try:
-    import isa_stats
-    isa = isa_stats.load()
-    st = isa["kernels"]["sym_tt_wall" if sym else "sweep_tt_wall"] if isa else None
-  except Exception:
-    isa = st = None
-  if st is not None:
-    if sym:
-      tiles = (N + 63) // 64
-      wave_steps = (tiles * (tiles + 1) // 2 * 64 - tiles) / world       # rotation steps (diagonal units skip k = 0)
-      pair_evals = float(N) * (N - 1) / 2 / world                         # real (unpadded) unordered pairs
-    else:
-      wave_steps = float(-(-res["n_local"] // 64)) * N
-      pair_evals = float(res["n_local"]) * N
-    ex_flops = st["flops_per_lane_step"] * pair_evals
-    ex_tf = ex_flops / kern_s / 1e12
-    executed = {"flops_per_pair_evaluation": st["flops_per_lane_step"], "pair_evaluations_per_launch": pair_evals,
-                "achieved": round(ex_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ex_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-                "source": "FMA = 2, mul/add/rsq = 1 flop, counted over the pair loop of this build's ISA "
-                          "(tools/isa_stats.py, csrc sha1 %s); padded lanes not counted" % isa["source_sha1"][:12],
-                "instruction_mix_per_step": st["classes"]}
-    valu = st["valu_per_step"] * wave_steps
-    issue = {"valu_wave_instr_per_launch": valu, "achieved": round(valu / kern_s / 1e9, 1), "peak": round(issue_peak, 1),
-             "unit": "G wave-instr/s", "frac": round(valu / kern_s / 1e9 / issue_peak, 4),
-             "peak_source": "rmb_ubench_fp64_issue: independent v_fma_f64, 4 waves per SIMD on every CU, 40 launches, "
-                            "measured in this process right after the timed loop",
-             "note": "two of the %d VALU instructions per step are v_rsq_f64, which issue at ~0.3x the FMA rate "
-                     "(profiles/r1_ubench_fp64_issue_rates.txt)" % st["valu_per_step"]}
+  isa = load_isa()
+  executed, issue = executed_views(isa, sym, N, world, res["n_local"], kern_s, issue_peak)
+  if executed is None:
+    # no instruction count for this build (tools/isa_stats.py needs hipcc): the utilisation cannot be priced; say so
+    # rather than fall back to the algorithmic unit, which is not a utilisation
+    executed = {"flops_per_pair_evaluation": 0, "pair_evaluations_per_launch": 0, "achieved": None, "frac": None,
+                "error": "librmb_mobility.isa.json missing and could not be regenerated"}
   roofline = {
       "bound": "valu_fp64",
       "kernel": "rmb::sym_kernel<TT,wall> (each unordered pair once, both blobs updated)" if sym else "rmb::sweep_kernel<TT,wall>",
-      "achieved": round(alg_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-      "frac": round(alg_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-      "unit_of_work": "ALGORITHMIC: 211 flops per ordered pair (the reference's as-written count, SURVEY 8d) x N^2 per "
-                      "matvec; the kernel needs fewer (see `executed`), so this fraction may exceed 1 -- it is a "
-                      "throughput in the reference's unit, not a utilisation",
-      "flops_per_pair": FLOPS_PER_PAIR["tt_wall"], "pairs_per_launch": pairs_ordered,
+      # utilisation, <= 1 by construction: fp64 flops this kernel EXECUTES per launch / kernel time / fp64 vector peak
+      "achieved": executed["achieved"], "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed["frac"],
+      "unit_of_work": "EXECUTED: %g fp64 flops per pair evaluation (FMA = 2, mul/add/rsq = 1, counted over the pair loop "
+                      "of this build's ISA) x %.0f pair evaluations per launch (N(N-1)/2 unordered pairs / ranks for the "
+                      "symmetric kernel)" % (executed["flops_per_pair_evaluation"], executed["pair_evaluations_per_launch"]),
       "kernel_ms_avg": round(res["kern_ms"], 5),
       "kernel_ms_avg_source": "HIP events on the launch stream around every %d-th sweep launch of the timed region "
                               "(%d launches sampled)" % (TIMING_STRIDE, -(-args.steps // TIMING_STRIDE)),
       "launch": res["launch"],
-      "executed": executed, "frac_executed": executed["frac"] if executed else None,
+      "executed": executed,
+      # throughput in the reference's unit: 211 as-written flops per ORDERED pair x N^2.  The symmetric
+      # kernel needs 3.4x fewer flops for the same result, so this exceeds the peak: a speed in the reference's
+      # currency, NOT a utilisation -- never read it as `frac`
+      "algorithmic_throughput": {"flops_per_ordered_pair": FLOPS_PER_PAIR["tt_wall"], "ordered_pairs_per_launch": pairs_ordered,
+                                 "value": round(alg_tf, 3), "unit": "TFLOP/s (reference's as-written arithmetic)",
+                                 "ratio_to_fp64_vector_peak": round(alg_tf / FP64_VECTOR_PEAK_TFLOPS, 4)},
       "issue": issue,
       "traffic": traffic, "traffic_provenance": traffic_src,
       "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
@@ -314,6 +352,35 @@ def rank_main(args):
       "prewarm": res["prewarm"],
       "roofline": roofline,
   }
+  if res["cold"] is not None:
+    # the same K steps after the same W warm-up steps, run BEFORE the declared pre-warm on a chip that had not run the
+    # kernel yet: what the driver's bare flags measure without priming (the fp64 clock is still ramping)
+    cdt, ckern = res["cold"]
+    line["value_unprimed"] = {"value": round(args.steps / cdt, 3), "unit": "matvecs/s", "ms_per_step": round(1e3 * cdt / args.steps, 5),
+                              "kernel_ms_avg": round(ckern, 5), "steps": args.steps, "warmup": args.warmup,
+                              "when": "first thing this process ran on the GPU, before `prewarm`"}
+
+  if rank == 0 and world == 1:
+    # End to end through the plugin surface, the call shape of the reference's callers (mobility/mobility.py:222-252,
+    # multi_bodies/multi_bodies.py:445): numpy arrays in, a new numpy array out, synchronous, PCIe-inclusive.  Never
+    # `value`.  The positions stay resident while the caller passes the same r_vectors (one compare per call).
+    try:
+      from rigidmultiblobswall_amd import mobility as mob
+      r_h, f_h = np.ascontiguousarray(res["r"]), np.ascontiguousarray(res["f"])
+      for _ in range(max(args.warmup, 3)):
+        u_h = mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
+      n_host = max(args.steps, 50)
+      t0 = time.perf_counter()
+      for _ in range(n_host):
+        u_h = mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
+      dt_h = time.perf_counter() - t0
+      line["host_surface"] = {"value": round(n_host / dt_h, 3), "unit": "matvecs/s", "ms_per_call": round(1e3 * dt_h / n_host, 5),
+                              "calls": n_host, "function": "single_wall_mobility_trans_times_force_hip(r_vectors, force, eta, a)",
+                              "bytes_over_pcie_per_call": 48 * N,
+                              "max_abs_diff_vs_timed_device_output": float(np.max(np.abs(u_h - res["out"].cpu().numpy())))}
+      mob.reset()
+    except Exception as exc:      # an extra must never cost the headline line
+      line["host_surface"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
   if rank == 0 and world == 1 and not args.no_cpu:
     from oracle import oracle
@@ -358,12 +425,14 @@ def rank_main(args):
             "hbm_traffic_source": prov.get("source"),
             "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
             "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
+            "executed_frac": _exec_frac(isa, rs["launch"]["chunks"] == 0, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
             "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]})
       for nb, st_, wu in ((10000, 50, 5), (100000, 3, 1), (1000000, 1, 1)):
         rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "target", 100.0 if nb == 10000 else 0.0)
         dec["target_shard_allgather"].append({
             "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
             "kernel_ms_avg": round(rs["kern_ms"], 4), "allgather_bytes": 0 if world == 1 else 24 * nb,
+            "executed_frac": _exec_frac(isa, False, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
             "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
             "launch": rs["launch"]})
       line["decompositions"] = dec

@@ -66,8 +66,16 @@ int rmb_ctx_destroy(rmb_ctx* ctx);
 /* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream.
  * A context is SINGLE-STREAM at a time (its accumulators, workspaces and packed positions are re-used from call to
  * call): when the handle changes, the new stream is made to wait (event) for everything already queued on the
- * previous one.  Unchanged handle: no cost. */
+ * previous one.  Unchanged handle: no cost.
+ * LIFETIME: the stream a context is bound to must be alive while calls are enqueued on it AND at the moment the
+ * handle is changed (the switch records an event on it; HIP does not validate stream handles, a destroyed one is a
+ * use-after-free).  A host that destroys its streams (one stream per time step, say) calls rmb_ctx_release_stream()
+ * before hipStreamDestroy: it waits for the context's work on that stream and forgets the handle (the context is then
+ * on the default stream until the next rmb_ctx_set_stream).  If the record on the previous stream fails with an error
+ * code, the switch falls back to a device-wide synchronisation and adopts the new handle all the same: a context
+ * never stays bound to a stream it could not fence. */
 int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
+int rmb_ctx_release_stream(rmb_ctx* ctx);
 /* Options (unknown key -> RMB_ERR_ARG).  Defaults in [].
  *   "timing"          [0]  n >= 1 = bracket every n-th pair-sweep launch with HIP events (rmb_timing_collect); an
  *                          event pair serialises ~4-8 us around the launch, so throughput runs sample (n = 4)
@@ -78,7 +86,9 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *                          ordered pair, fixed summation order, no workspace; ~1.5x the default time);
  *                          2 = the symmetric pass with per-unit partials summed in a fixed order instead of
  *                          atomics (1.06-1.18x; workspace min(0.19 N^2 B, "det_workspace_mb")).  Pair shards
- *                          (nshards > 1) ignore it.  Forces: 1 and 2 both take the one-sided sweep.
+ *                          (nshards > 1) honour 2 -- a shard is then a range of WHOLE tile pairs, so a G-rank run
+ *                          is bit-reproducible whenever its all-reduce is -- and ignore 1 (a slice of the unordered
+ *                          pairs has no one-sided form).  Forces: 1 and 2 both take the one-sided sweep.
  *   "precision"       [64] 32 = single precision on the default symmetric path with open boundaries (the
  *                          reference's `precision = 'single'` build, mobility_pycuda.py:7-19) for tt / tr / rt / rr,
  *                          RMB_TT_TR, the in-plane products, the grand / force-column / k-vector operations and the
@@ -89,7 +99,10 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes,
  *                          free-surface / per-blob-radii mobility products, pair shards of kinds other than tt and
  *                          the source->target operators compute in fp64 whatever this says.  Other values:
- *                          RMB_ERR_ARG.
+ *                          RMB_ERR_ARG.  The "wave_clock" / "skip_pairs" diagnostics exist in the fp64 kernels only:
+ *                          a product that would run an fp32 kernel with one of them set returns RMB_ERR_STATE.
+ *   "force_precision" [0]  blob-blob forces: 0 = follow "precision", 32 / 64 = pinned whatever "precision" says
+ *                          (products in single precision with double-precision forces, or the reverse)
  *   "det_workspace_mb" [8192]  workspace of mode 2; the unit list is processed in chunks that fit
  *   "fused_symmetric" [1]  RMB_TT_TR: 1 = one symmetric pass sharing the pair geometry between both blocks,
  *                          2 = two symmetric passes (tt, then tr accumulated), 0 = the one-sided fused sweep
@@ -104,6 +117,8 @@ int rmb_ctx_set_stream(rmb_ctx* ctx, void* hip_stream);
  *   "skip_pairs"      [0]  diagnostics, results are WRONG: bit 0 = no pair arithmetic, bit 1 = no flush of the
  *                          per-wave LDS accumulators (tools/exp_prewarm.py prices the atomics with it)          */
 int rmb_ctx_set_option(rmb_ctx* ctx, const char* key, long value);
+/* Current value of an option (same keys); lets a caller switch one temporarily and restore what was there. */
+int rmb_ctx_get_option(rmb_ctx* ctx, const char* key, long* value);
 
 /* Upload / pack positions: fuses shift_heights + damping_matrix_B (mobility.py:52-84).
  * r: (n,3).  The *_device variant reads a device pointer and is asynchronous. */

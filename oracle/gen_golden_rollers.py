@@ -108,6 +108,50 @@ def run_trajectory(lib, name, scheme, N, n_steps, out_dir, **over):
   print("  %-44s %-34s N=%-3d steps=%d  %.1fs" % (name, scheme, N, n_steps, time.time() - t0), flush=True)
 
 
+def run_driven_monolayer(lib, out_dir, N=256, n_steps=48, only=False):
+  """configs[4]'s driven recipe in small: a DENSE torque-driven monolayer (area fraction 0.4, heights 1.1-2 a: below
+  the equilibrium height, so it also relaxes upwards) at the reference roller deck's own parameters
+  (multi_bodies/examples/rollers/inputfile_rollers.dat: dt = 0.016, omega = 62.8 rad/s, a = 0.656, eta = 1e-3, kT,
+  gravity and repulsions), stochastic Adams-Bashforth, >= 40 steps.  At this density and dt the contact repulsion is
+  stiff (steps get rejected) and trajectories separate exponentially, so besides the trajectory every step records what
+  is needed to REPLAY THAT STEP ALONE from the reference's own state: the numpy RNG state before the step, the previous
+  deterministic velocity, the first-step flag and the counters."""
+  p = dict(BASE)
+  p.update(a=0.656, eta=1.0e-3, kT=0.0041419464, g=0.0024892, repulsion_strength_wall=0.0165677856,
+           debye_length_wall=0.0656, repulsion_strength=0.0165677856, debye_length=0.0656,
+           omega_one_roller=(0.0, 62.8, 0.0), tolerance=1e-6, dt=0.016, seed=21)
+  t0 = time.time()
+  a = p["a"]
+  rng = np.random.RandomState(7)
+  side = int(np.ceil(np.sqrt(N)))
+  cell = np.sqrt(np.pi * a ** 2 / 0.4)
+  ij = np.array([(i, j) for i in range(side) for j in range(side)][:N], dtype=np.float64)
+  r0 = np.empty((N, 3))
+  r0[:, :2] = (ij + 0.5) * cell + (rng.rand(N, 2) - 0.5) * (cell - 2.0 * a) * 0.9
+  r0[:, 2] = a * (1.1 + 0.9 * rng.rand(N))
+  integ = make_integrator(lib, r0, "stochastic_adams_bashforth_rollers", p)
+  np.random.seed(p["seed"])
+  traj, rng_keys, rng_pos, rng_gauss, prev_vel, first_flag, rejected, overlaps, lanczos = [r0.copy()], [], [], [], [], [], [], [], []
+  for step in range(n_steps):
+    st = np.random.get_state()
+    rng_keys.append(np.asarray(st[1], dtype=np.uint32)); rng_pos.append(int(st[2])); rng_gauss.append((int(st[3]), float(st[4])))
+    prev_vel.append(np.zeros(3 * N) if integ.velocities_previous_step is None else np.array(integ.velocities_previous_step))
+    first_flag.append(bool(integ.first_step))
+    integ.advance_time_step(p["dt"])
+    traj.append(np.array([b.location for b in integ.bodies]))
+    rejected.append(integ.invalid_configuration_count); overlaps.append(integ.wall_overlaps); lanczos.append(integ.stoch_iterations_count)
+    print("    step %2d  %.0f s  mean height %.4f  min height %.4f  rejected %d  lanczos its %d" %
+          (step + 1, time.time() - t0, traj[-1][:, 2].mean(), traj[-1][:, 2].min(), rejected[-1], lanczos[-1]), flush=True)
+  data = {k: (np.asarray(v) if not isinstance(v, str) else v) for k, v in p.items()}
+  np.savez_compressed(os.path.join(out_dir, "g8_driven_dense_monolayer.npz"), scheme="stochastic_adams_bashforth_rollers",
+                      trajectory=np.array(traj), rng_keys=np.array(rng_keys), rng_pos=np.array(rng_pos),
+                      rng_gauss=np.array(rng_gauss), velocities_previous_step=np.array(prev_vel),
+                      first_step=np.array(first_flag), rejected_cumulative=np.array(rejected),
+                      wall_overlaps_cumulative=np.array(overlaps), lanczos_iterations_cumulative=np.array(lanczos),
+                      wall_overlaps=integ.wall_overlaps, invalid_configuration_count=integ.invalid_configuration_count, **data)
+  print("  g8_driven_dense_monolayer N=%d steps=%d  %.1fs" % (N, n_steps, time.time() - t0), flush=True)
+
+
 def run_velocity_pieces(lib, out_dir):
   """Single calls of the velocity builders (no time step): det + stochastic pieces at one configuration."""
   p = dict(BASE)
@@ -157,9 +201,12 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--ref", default="/root/reference")
   ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+  ap.add_argument("--only-driven", action="store_true", help="only the (slow) driven dense monolayer record")
   args = ap.parse_args()
   out_dir = os.path.abspath(args.out)
   lib = load(args.ref)
+  if args.only_driven:
+    return run_driven_monolayer(lib, out_dir)
   kT = 0.0041
   run_trajectory(lib, "g8_rollers_det_euler", "deterministic_forward_euler_rollers", 20, 3, out_dir)
   run_trajectory(lib, "g8_rollers_det_ab", "deterministic_adams_bashforth_rollers", 20, 4, out_dir)
@@ -198,6 +245,7 @@ def main():
                  periodic_length=(12.6, 12.6, 0.0))
   run_velocity_pieces(lib, out_dir)
   run_prescribed_kinematics(lib, out_dir)
+  run_driven_monolayer(lib, out_dir)
 
 
 if __name__ == "__main__":

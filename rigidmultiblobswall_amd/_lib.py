@@ -30,7 +30,9 @@ SYMBOLS = {
     "rmb_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "rmb_ctx_destroy": (ctypes.c_int, [_vp]),
     "rmb_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "rmb_ctx_release_stream": (ctypes.c_int, [_vp]),
     "rmb_ctx_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_long]),
+    "rmb_ctx_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _lp]),
     "rmb_set_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_double, _vp, ctypes.c_int]),
     "rmb_set_positions_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_double, _vp, ctypes.c_int]),
     "rmb_set_target_range": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long]),

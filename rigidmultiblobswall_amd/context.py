@@ -55,6 +55,14 @@ class MobilityContext(object):
     _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)))
     self._user_stream = True
 
+  def release_stream(self):
+    """Call BEFORE destroying a stream this context is bound to: waits for the context's work on it and forgets the
+    handle (rmb_ctx_release_stream).  The next device call follows torch's current stream again unless set_stream()
+    pins another one."""
+    _lib.check(self._lib.rmb_ctx_release_stream(self._h))
+    self._stream_handle = 0
+    self._user_stream = False
+
   # Ordering of the device path against PyTorch: every *_device call is enqueued on the stream that is
   # torch's CURRENT stream at call time (handle passed through the C ABI), so it is ordered after the
   # torch kernels that produced its inputs and before those that consume its outputs -- no events, no
@@ -71,6 +79,11 @@ class MobilityContext(object):
 
   def set_option(self, key, value):
     _lib.check(self._lib.rmb_ctx_set_option(self._h, key.encode(), int(value)))
+
+  def get_option(self, key):
+    v = ctypes.c_long()
+    _lib.check(self._lib.rmb_ctx_get_option(self._h, key.encode(), ctypes.byref(v)))
+    return int(v.value)
 
   def set_positions(self, r_vectors, a, periodic_length=None, wall=True):
     """r_vectors: numpy (N,3)/(3N,) or a CUDA torch float64 tensor (stays on device)."""

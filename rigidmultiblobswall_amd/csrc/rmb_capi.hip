@@ -95,6 +95,7 @@ struct rmb_ctx {
   long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
   long opt_sym_pin = 1;        // pad dynamic LDS so residency is exactly that number
   long opt_precision = 64;     // 32: M_tt f (open boundaries) in single precision (sym32_kernels.h); everything else fp64
+  long opt_force_precision = 0;  // blob-blob forces: 0 = follow "precision", 32 / 64 = pinned
   long opt_sym_min_steps = 64; // floor on rotation steps per wave (a unit is 64 steps)
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
@@ -325,6 +326,8 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   SymPlan plan;
   // single-precision mode (mobility_pycuda.py:7-19 `precision = 'single'`): tt with open boundaries only
   const bool f32 = c->opt_precision == 32 && kind == RMB_TT && !periodic;
+  if (f32 && (c->opt_wave_clock || c->opt_skip_pairs))
+    return fail(RMB_ERR_STATE, "the \"wave_clock\" / \"skip_pairs\" diagnostics exist in the fp64 kernels only: set \"precision\" = 64");
   typedef void (*sym32_fn)(const rmb::SymArgs, const rmb::f32::PairConsts);
   const sym32_fn fn32 = c->wall ? (sym32_fn)rmb::sym32_tt_kernel<true> : (sym32_fn)rmb::sym32_tt_kernel<false>;
   static int occ32[2] = {0, 0};
@@ -480,6 +483,8 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   SymPlan plan;
   // "precision" = 32: the operation's single-precision twin where it has one (open boundaries, no per-blob extras)
   const bool f32 = c->opt_precision == 32 && se.sweep32 != nullptr && a.extra == nullptr;
+  if (f32 && c->opt_skip_pairs)
+    return fail(RMB_ERR_STATE, "the \"skip_pairs\" diagnostic exists in the fp64 kernels only: set \"precision\" = 64");
   if (int rc = plan_sym(c, f32 ? (const void*)se.sweep32 : (const void*)se.sweep, f32 ? &se.occ32 : &se.occ,
                         f32 ? se.static_lds32 : se.static_lds, a.step_end - a.step_begin, true, &plan))
     return rc;
@@ -499,7 +504,10 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
 // Deterministic symmetric pass ("deterministic" = 2): same pair arithmetic as symx_device, but whole units per wave and
 // per-unit partial results in a bounded workspace instead of atomics, summed in a fixed order by
 // symx_det_reduce_kernel; the unit list is processed in chunks that fit the workspace ("det_workspace_mb").
-int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane) {
+// Pair shard `shard` of `nshards`: whole units [n_units shard / nshards, n_units (shard + 1) / nshards) -- the fixed order
+// then holds per rank, and a G-rank run is bit-reproducible as long as the all-reduce is (same ranks, same algorithm).
+int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane,
+                    long shard = 0, long nshards = 1) {
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   SymXEntry& se = g_symx[op][c->wall ? 1 : 0][periodic ? 1 : 0];
   const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
@@ -510,7 +518,9 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
   for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
   a.acc = (double*)c->symbuf.p;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
-  a.self_begin = 0; a.self_end = n;
+  long sb_unused, se_unused;
+  shard_ranges(n, a.n_units, shard, nshards, &sb_unused, &se_unused, &a.self_begin, &a.self_end);
+  const long shard_ub = (long)((__int128)a.n_units * shard / nshards), shard_ue = (long)((__int128)a.n_units * (shard + 1) / nshards);
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
   a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
@@ -526,7 +536,7 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
   const long max_waves = c->n_cu * wps * rmb::kSymWaves * c->opt_sym_oversub;
   const size_t slot = (size_t)3 * se.n_out * 64 * sizeof(double);
   long chunk_units = (long)(((size_t)c->opt_det_workspace_mb << 20) / (2 * slot));
-  if (chunk_units > a.n_units) chunk_units = a.n_units;
+  if (chunk_units > shard_ue - shard_ub) chunk_units = shard_ue - shard_ub;
   if (chunk_units < 1) chunk_units = 1;
   const long upw = (chunk_units + max_waves - 1) / max_waves;
   chunk_units = ((chunk_units + upw - 1) / upw) * upw;
@@ -541,11 +551,11 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
   a.units_per_wave = upw;
   a.steps_per_wave = 64 * upw;
   c->last_path = 2; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = 0;
-  for (long ub = 0; ub < a.n_units; ub += chunk_units) {
-    const long ue = ub + chunk_units < a.n_units ? ub + chunk_units : a.n_units;
+  for (long ub = shard_ub; ub < shard_ue; ub += chunk_units) {
+    const long ue = ub + chunk_units < shard_ue ? ub + chunk_units : shard_ue;
     a.unit_begin = ub; a.unit_end = ue;
     a.step_begin = 64 * ub; a.step_end = 64 * ue;
-    a.first_chunk = ub == 0 ? 1 : 0;
+    a.first_chunk = ub == shard_ub ? 1 : 0;
     const long waves = (ue - ub + upw - 1) / upw;
     const long blocks = (waves + rmb::kSymWaves - 1) / rmb::kSymWaves;
     c->last_wgs += blocks;
@@ -696,7 +706,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
                                 : (periodic ? (sforce_fn)rmb::sym_force_kernel<true, false> : (sforce_fn)rmb::sym_force_kernel<false, false>);
     // "precision" = 32, open boundaries: the single-precision kernel -- the arithmetic of the reference's own GPU force
     // kernel (forces_pycuda.py:14-21)
-    const bool f32 = c->opt_precision == 32 && !periodic;
+    const bool f32 = (c->opt_force_precision ? c->opt_force_precision : c->opt_precision) == 32 && !periodic;
     static int socc32[2] = {0, 0};
     const sforce_fn sfn32 = radii ? (sforce_fn)rmb::sym_force32_kernel<true> : (sforce_fn)rmb::sym_force32_kernel<false>;
     const void* fn = f32 ? (const void*)sfn32 : (const void*)sfn;
@@ -808,7 +818,7 @@ int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* con
   if (c->n == 0) return 0;
   RMB_HIP(hipSetDevice(c->device));
   // a pair shard always writes all n targets, whatever target range is set (as rmb_matvec_pairshard_device)
-  if (nshards == 1 && sym_applies(c) && c->opt_deterministic == 2) return symx_det_device(c, sx, in, out, eta, in_plane);
+  if (c->opt_deterministic == 2 && (nshards > 1 || sym_applies(c))) return symx_det_device(c, sx, in, out, eta, in_plane, shard, nshards);
   if (sym_applies(c) || nshards > 1) return symx_device(c, sx, in, out, eta, in_plane, shard, nshards);
   const long n_tgt = c->tgt_end - c->tgt_begin;
   if (n_tgt == 0) return 0;
@@ -933,10 +943,27 @@ int rmb_ctx_set_stream(rmb_ctx* c, void* s) {
     // to call, so the new stream must not start before what was queued on the previous one has finished.
     RMB_HIP(hipSetDevice(c->device));
     if (!c->stream_switch) RMB_HIP(hipEventCreateWithFlags(&c->stream_switch, hipEventDisableTiming));
-    RMB_HIP(hipEventRecord(c->stream_switch, c->stream));
-    RMB_HIP(hipStreamWaitEvent(next, c->stream_switch, 0));
+    // The previous handle must still be alive here (HIP does not validate stream handles: recording on a destroyed
+    // one is a use-after-free, it crashed in the round-3 test) -- a host that destroys its streams calls
+    // rmb_ctx_release_stream() first.  Whatever the record returns, the new handle is adopted: a context never stays
+    // bound to a stream it failed to fence.
+    hipError_t e = hipEventRecord(c->stream_switch, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(next, c->stream_switch, 0);
     c->stream = next;
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      RMB_HIP(hipDeviceSynchronize());
+    }
   }
+  return 0;
+}
+
+int rmb_ctx_release_stream(rmb_ctx* c) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  RMB_HIP(hipSetDevice(c->device));
+  hipError_t e = hipStreamSynchronize(c->stream);     // the stream is still alive: its owner calls this BEFORE destroying it
+  c->stream = nullptr;                                // from here on the context does not know the old handle any more
+  if (e != hipSuccess) return fail(RMB_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
   return 0;
 }
 
@@ -958,8 +985,27 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
     c->opt_precision = value;
     return 0;
   }
+  if (!strcmp(key, "force_precision")) {
+    if (value != 0 && value != 32 && value != 64) return fail(RMB_ERR_ARG, "force_precision must be 0 (follow \"precision\"), 32 or 64");
+    c->opt_force_precision = value;
+    return 0;
+  }
   if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_min_steps")) { c->opt_sym_min_steps = value < 1 ? 1 : value; return 0; }
+  return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
+}
+
+int rmb_ctx_get_option(rmb_ctx* c, const char* key, long* value) {
+  if (!c || !key || !value) return fail(RMB_ERR_ARG, "null context / key / value");
+  const struct { const char* name; const long* v; } table[] = {
+      {"chunks", &c->opt_chunks}, {"timing", &c->opt_timing}, {"symmetric", &c->opt_symmetric},
+      {"fused_symmetric", &c->opt_fused_symmetric}, {"symx_single", &c->opt_symx_single},
+      {"deterministic", &c->opt_deterministic}, {"det_workspace_mb", &c->opt_det_workspace_mb}, {"sym_wps", &c->opt_sym_wps},
+      {"wave_clock", &c->opt_wave_clock}, {"skip_pairs", &c->opt_skip_pairs}, {"sym_pin", &c->opt_sym_pin},
+      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"sym_oversub", &c->opt_sym_oversub},
+      {"sym_min_steps", &c->opt_sym_min_steps}};
+  for (const auto& e : table)
+    if (!strcmp(key, e.name)) { *value = *e.v; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
 }
 
@@ -1015,10 +1061,10 @@ int rmb_matvec2_pairshard_device(rmb_ctx* c, int kind, const double* vec_a, cons
   // evaluate a slice of the unordered pairs (rmb_matvec_pairshard_device does the same)
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   const bool x32 = c->opt_precision == 32 && !periodic;     // the generic skeleton has the single-precision twin
-  if (c->opt_symx_single || x32 || (c->opt_deterministic == 2 && nshards == 1)) {
+  if (c->opt_symx_single || x32 || c->opt_deterministic == 2) {
     const double* in[2] = {vec_a, vec_b};
     double* outs[2] = {out_a, out_b};
-    if (c->opt_deterministic == 2 && nshards == 1) return symx_det_device(c, SX_K2, in, outs, eta, 0);
+    if (c->opt_deterministic == 2) return symx_det_device(c, SX_K2, in, outs, eta, 0, shard, nshards);
     return symx_device(c, SX_K2, in, outs, eta, 0, shard, nshards);
   }
   return sym2_device(c, vec_a, vec_b, eta, out_a, out_b, shard, nshards);
@@ -1043,6 +1089,11 @@ int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double et
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   RMB_HIP(hipSetDevice(c->device));
   c->last_path = 1;
+  if (c->opt_deterministic == 2) {      // bit-reproducible shard: whole units, ordered reduction (symx_det_device)
+    const double* in[2] = {v, nullptr};
+    double* outs[1] = {out};
+    return symx_det_device(c, SX_TT + kind, in, outs, eta, 0, shard, nshards);
+  }
   return sym_device(c, kind, v, eta, out, shard, nshards);
 }
 

@@ -265,6 +265,11 @@ class ReplicatedContext(object):
     if ctx is not None:
       ctx.set_option(key, value)
 
+  def get_option(self, key):
+    """Current value of a context option, or None for backends without a MobilityContext."""
+    ctx = getattr(self.sm.backend, "ctx", None)
+    return ctx.get_option(key) if ctx is not None else None
+
   def sync_scalars(self, t):
     """Make rank 0's copy of a small control tensor (Hessenberg column, Lanczos coefficients) the one every rank acts
     on.  The replicated Krylov loops branch on such scalars; identical hardware and identical inputs already give

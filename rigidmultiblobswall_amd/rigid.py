@@ -417,23 +417,27 @@ class RigidSuspension(object):
     r = b
     res, its, outer, history = 1.0, 0, 0, []
     sync = getattr(self.ctx, "sync_scalars", None)
-    while res > tol and outer < max_outer and its < maxiter:
-      self.ctx.set_option("precision", 32)
-      try:
+    # the caller's precision (RigidIntegrator.precision = 'single' sets 32) is what the context goes back to afterwards
+    get = getattr(self.ctx, "get_option", None)
+    previous = (get("precision") if get is not None else None) or 64
+    try:
+      while res > tol and outer < max_outer and its < maxiter:
+        self.ctx.set_option("precision", 32)
         dx, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, r / res,
                                               tol=max(inner_tol, 0.25 * tol / res), restart=restart, maxiter=maxiter - its,
                                               sync=sync)
-      finally:
         self.ctx.set_option("precision", 64)
-      its += info["iterations"]
-      history.extend(h * res for h in info["history"])
-      x = x + dx * res
-      r = b - self.apply_operator(x)                    # fp64
-      t = torch.linalg.vector_norm(r).reshape(1)
-      if sync is not None:
-        sync(t)
-      res = float(t)
-      outer += 1
+        its += info["iterations"]
+        history.extend(h * res for h in info["history"])
+        x = x + dx * res
+        r = b - self.apply_operator(x)                    # fp64
+        t = torch.linalg.vector_norm(r).reshape(1)
+        if sync is not None:
+          sync(t)
+        res = float(t)
+        outer += 1
+    finally:
+      self.ctx.set_option("precision", previous)
     return x * nrm, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history, outer_iterations=outer,
                          rhs_norm=nrm)
 
@@ -607,12 +611,33 @@ class RigidSuspension(object):
                                            L_mult=lambda x: self._blockdiag(x, "Lchol"), print_residual=print_residual,
                                            device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
 
-def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync):
+# page-locked staging rows for the Hessenberg columns of running solves (allocated once, handed out per solve)
+_pinned_pool = []
+
+
+def _pinned_columns(rows, cols):
+  for k, t in enumerate(_pinned_pool):
+    if t.shape[0] >= rows and t.shape[1] >= cols:
+      return _pinned_pool.pop(k)
+  return torch.empty((max(rows, 62), max(cols, 63)), dtype=torch.float64).pin_memory()
+
+
+def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
   """GMRES(restart) on A.Minv written as a coroutine: it YIELDS every vector it needs the operator applied to and
   receives A(vector) back, so one driver can serve a single solve (gmres_right_preconditioned) or advance two solves
-  in lockstep and hand both requests to a two-vector operator (gmres_pair_right_preconditioned).  Returns (x, info)."""
+  in lockstep and hand both requests to a two-vector operator (gmres_pair_right_preconditioned).  Returns (x, info).
+
+  On a GPU the host side of an iteration (Givens rotations on the new Hessenberg column, the convergence test) runs ONE
+  ITERATION LATE (`lag`, default on for CUDA tensors): the column is normalised on the device, copied to page-locked
+  memory asynchronously, and read only after the NEXT iteration's preconditioner + operator + Gram-Schmidt have been
+  enqueued -- the device never waits for the host between sweeps.  The iterates, the stopping rule and the iteration
+  count are those of the plain loop; what the lag can cost is one discarded sweep when the solve converges earlier than
+  its own history predicts, so the loop turns synchronous as soon as the last observed reduction rate says the next
+  column may meet the tolerance (normally the last two or three iterations)."""
   dev = b.device
   n = b.numel()
+  if lag is None:
+    lag = dev.type == "cuda"
 
   def host_norm(v):
     t = torch.linalg.vector_norm(v).reshape(1)
@@ -624,62 +649,108 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync):
   y = torch.zeros(n, dtype=torch.float64, device=dev)
   if x0 is not None:
     b = b - (yield x0)
+    beta = host_norm(b)
+  else:
+    beta = bnorm
   r = b.clone()
-  beta = host_norm(r)
   its = 0
   res = beta / bnorm if bnorm > 0 else 0.0
   history = []
-  while its < maxiter and res > tol:
-    m = min(restart, maxiter - its)
-    V = torch.empty((m + 1, n), dtype=torch.float64, device=dev)
-    colbuf = torch.empty(m + 2, dtype=torch.float64, device=dev)
-    V[0] = r / beta
-    H = np.zeros((m + 1, m))
-    cs, sn = np.zeros(m), np.zeros(m)
-    g = np.zeros(m + 1)
-    g[0] = beta
-    k_used = 0
-    for j in range(m):
-      w = yield Minv(V[j])
-      Vj = V[:j + 1]
-      h = Vj @ w
-      w = torch.addmv(w, Vj.t(), h, alpha=-1.0)
-      h2 = Vj @ w
-      w = torch.addmv(w, Vj.t(), h2, alpha=-1.0)
-      torch.add(h, h2, out=colbuf[:j + 1])
-      torch.linalg.vector_norm(w, out=colbuf[j + 1])
-      if sync is not None:                                         # multi-rank: all ranks act on rank 0's numbers
-        sync(colbuf[:j + 2])
-      col = colbuf[:j + 2].cpu().numpy()                          # the one host transfer of the iteration
-      H[:j + 2, j] = col
-      if col[-1] > 0:
-        torch.mul(w, 1.0 / col[-1], out=V[j + 1])
-      for i in range(j):                                           # previous rotations
-        t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
-        H[i + 1, j] = -sn[i] * H[i, j] + cs[i] * H[i + 1, j]
-        H[i, j] = t
-      d = np.hypot(H[j, j], H[j + 1, j])
-      cs[j], sn[j] = (H[j, j] / d, H[j + 1, j] / d) if d > 0 else (1.0, 0.0)
-      H[j, j] = d
-      H[j + 1, j] = 0.0
-      g[j + 1] = -sn[j] * g[j]
-      g[j] = cs[j] * g[j]
-      its += 1
-      k_used = j + 1
-      res = abs(g[j + 1]) / bnorm
-      history.append(res)
-      if res <= tol or col[-1] == 0:
-        break
-    coef = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used]) if k_used > 0 else np.zeros(0)
-    y = y + V[:k_used].t() @ torch.as_tensor(coef, device=dev)
-    if res > tol and its < maxiter:                                # restart: true residual
-      r = b - (yield Minv(y))
-      beta = host_norm(r)
-      res = beta / bnorm
+  wasted = 0
+  host_cols = _pinned_columns(restart + 1, restart + 2) if lag else None
+  events = [torch.cuda.Event(), torch.cuda.Event()] if lag else None
+  try:
+    while its < maxiter and res > tol:
+      m = min(restart, maxiter - its)
+      V = torch.empty((m + 1, n), dtype=torch.float64, device=dev)
+      cols = torch.empty((m, m + 2), dtype=torch.float64, device=dev)      # row j = column j of H, then |w_j|
+      V[0] = r / beta
+      H = np.zeros((m + 1, m))
+      cs, sn = np.zeros(m), np.zeros(m)
+      g = np.zeros(m + 1)
+      g[0] = beta
+      k_used = 0
+      prev_res = None
+
+      def finish(j):
+        """Host side of iteration j: read its column, rotate, test.  True = stop after this column."""
+        nonlocal its, k_used, res, prev_res
+        if lag:
+          events[j & 1].synchronize()
+          col = host_cols[j, :j + 2].numpy()
+        else:
+          col = cols[j, :j + 2].cpu().numpy()                         # the one host transfer of the iteration
+        H[:j + 2, j] = col
+        last_norm[0] = float(col[-1])
+        for i in range(j):                                           # previous rotations
+          t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
+          H[i + 1, j] = -sn[i] * H[i, j] + cs[i] * H[i + 1, j]
+          H[i, j] = t
+        d = np.hypot(H[j, j], H[j + 1, j])
+        cs[j], sn[j] = (H[j, j] / d, H[j + 1, j] / d) if d > 0 else (1.0, 0.0)
+        H[j, j] = d
+        H[j + 1, j] = 0.0
+        g[j + 1] = -sn[j] * g[j]
+        g[j] = cs[j] * g[j]
+        its += 1
+        k_used = j + 1
+        prev_res, res = res, abs(g[j + 1]) / bnorm
+        history.append(res)
+        return res <= tol or col[-1] == 0 or not np.isfinite(col[-1])
+
+      def may_defer():
+        """Whether the pending column can wait until the next iteration has been enqueued: not when the last
+        observed reduction rate says it may already meet the tolerance."""
+        rate = min(1.0, res / prev_res) if prev_res else 1.0
+        return res * rate > 20.0 * tol
+
+      pending, stop, last_norm = None, False, [0.0]
+      for j in range(m):
+        if pending is not None and not may_defer():
+          stop, pending = finish(pending), None
+          if stop:
+            break
+        w = yield Minv(V[j])
+        Vj = V[:j + 1]
+        h = Vj @ w
+        w = torch.addmv(w, Vj.t(), h, alpha=-1.0)
+        h2 = Vj @ w
+        w = torch.addmv(w, Vj.t(), h2, alpha=-1.0)
+        torch.add(h, h2, out=cols[j, :j + 1])
+        torch.linalg.vector_norm(w, out=cols[j, j + 1])
+        if sync is not None:                                         # multi-rank: all ranks act on rank 0's numbers
+          sync(cols[j, :j + 2])
+        if lag:
+          torch.div(w, cols[j, j + 1], out=V[j + 1])                 # normalised on the device: no host value needed
+          host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
+          events[j & 1].record()
+          if pending is not None:
+            stop, pending = finish(pending), None
+            if stop:
+              wasted += 1                                            # iteration j was enqueued for nothing
+              break
+          pending = j
+        else:
+          stop = finish(j)
+          if last_norm[0] > 0:
+            torch.mul(w, 1.0 / last_norm[0], out=V[j + 1])
+          if stop:
+            break
+      if pending is not None and not stop:
+        finish(pending)
+      coef = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used]) if k_used > 0 else np.zeros(0)
+      y = y + V[:k_used].t() @ torch.as_tensor(coef, device=dev)
+      if res > tol and its < maxiter:                                # restart: true residual
+        r = b - (yield Minv(y))
+        beta = host_norm(r)
+        res = beta / bnorm
+  finally:
+    if host_cols is not None:
+      _pinned_pool.append(host_cols)
   x = Minv(y)
   if x0 is not None:
     x = x + x0
-  return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history)
+  return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history, discarded_sweeps=wasted)
 
 
 def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None):

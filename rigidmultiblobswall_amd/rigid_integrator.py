@@ -121,7 +121,10 @@ class RigidIntegrator(object):
     # Numerically neutral: each solve sees exactly its own GMRES iterates.
     self.lockstep_solves = True
     self.print_residual = False
-    self.max_retries = 1000
+    self.max_retries = 1000              # total rejected configurations over the life of the integrator
+    self.max_consecutive_retries = 20    # in a row (one step, or its midpoint / predictor stages)
+    self.consecutive_rejections = 0
+    self.report_rejections = True
     self._pc_built = False
     # force model of multi_bodies_functions.py (gravity + wall repulsion per blob, blob-blob repulsion)
     self.g = 0.0
@@ -150,13 +153,18 @@ class RigidIntegrator(object):
     passes) and the blob-blob forces run the fp32 twins of the pair sweeps (csrc/sym32_kernels.h, symx32_kernels.h: fp32
     pair arithmetic, fp64 accumulation, ~1e-6 relative); pseudo-periodic domains and the O(N) rigid algebra stay fp64.  Meant for the
     Brownian schemes at their loose solver tolerances (1e-3 ... 1e-4), where the product error is two orders below
-    the tolerance; the solvers' stopping rules are unchanged."""
+    the tolerance; the solvers' stopping rules are unchanged.  The random finite differences divide a difference of two
+    products by rf_delta: with ~1e-6-accurate products rf_delta must be >= 1e-4 (doc/README.md:512-523 uses 1e-3 for the
+    reference's single-precision build, 1e-6 for double) -- the setter and every stochastic step raise ValueError otherwise."""
     return self._precision
 
   @precision.setter
   def precision(self, value):
     if value not in ('single', 'double'):
       raise ValueError("precision must be 'single' or 'double'")
+    if value == 'single':
+      from .rollers import _check_rfd_delta_for_single_precision
+      _check_rfd_delta_for_single_precision(self.rf_delta)
     self._precision = value
     self.susp.ctx.set_option("precision", 32 if value == 'single' else 64)
   def close(self):
@@ -184,7 +192,16 @@ class RigidIntegrator(object):
       return True
     r, _ = self.susp.blob_positions_device(location, orientation)
     if bool(torch.any(r[:, 2] < 0.0)):
+      # the reference prints 'Invalid configuration' and redraws without bound (body.check_function + the while True of
+      # every scheme); here every rejection is reported and a step that fails too often in a row raises
       self.invalid_configuration_count += 1
+      self.consecutive_rejections += 1
+      if self.report_rejections:
+        print("Invalid configuration (rejection %d in a row, %d in total, %d blobs)" %
+              (self.consecutive_rejections, self.invalid_configuration_count, r.shape[0]), flush=True)
+      if self.consecutive_rejections > self.max_consecutive_retries:
+        raise RuntimeError("rigid integrator: %d configurations rejected in a row (a blob below the wall plane in every "
+                           "draw): the time step is too large for this configuration" % self.consecutive_rejections)
       if self.invalid_configuration_count > self.max_retries:
         raise RuntimeError("rigid integrator: more than %d rejected configurations" % self.max_retries)
       return False
@@ -282,9 +299,13 @@ class RigidIntegrator(object):
     return noise
 
   def advance_time_step(self, dt, *args, **kwargs):
+    if self._precision == 'single' and self.kT > 0.0 and self.scheme.startswith("stochastic"):
+      from .rollers import _check_rfd_delta_for_single_precision
+      _check_rfd_delta_for_single_precision(self.rf_delta)     # rf_delta may have been set after `precision`
     return getattr(self, self.scheme)(dt, *args, **kwargs)
 
   def _accept(self, location, orientation):
+    self.consecutive_rejections = 0
     self.location, self.orientation = location, orientation
     self._move(location, orientation)
 

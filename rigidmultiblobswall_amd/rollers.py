@@ -32,6 +32,15 @@ from .rigid import gmres_right_preconditioned
 from .stochastic import stochastic_forcing_lanczos
 
 
+def _check_rfd_delta_for_single_precision(rf_delta):
+  """precision = 'single': a random finite difference (M(q + delta W) - M(q)) W / delta of products that carry ~1e-6
+  relative error is noise unless delta is large enough (doc/README.md:512-523: 1e-3 for single, 1e-6 for double)."""
+  if not (float(rf_delta) >= 1e-4):
+    raise ValueError("precision = 'single' needs rf_delta >= 1e-4 (got %g): the random finite differences divide the "
+                     "difference of two ~1e-6-accurate products by rf_delta (doc/README.md:512-523 uses 1e-3 for the "
+                     "single-precision build)" % float(rf_delta))
+
+
 class RollersIntegrator(object):
   """locations: (N,3) array-like or tensor.  `scheme` may carry the reference's `_rollers` suffix."""
 
@@ -62,7 +71,10 @@ class RollersIntegrator(object):
     self.stoch_iterations_count = 0
     self.periodic_length = np.zeros(3)
     self.print_residual = False
-    self.max_retries = 1000
+    self.max_retries = 1000              # total rejected steps over the life of the integrator
+    self.max_consecutive_retries = 20    # rejections of ONE step in a row: beyond this the step size is wrong, not the draw
+    self.consecutive_rejections = 0
+    self.report_rejections = True        # one line per rejected step, like the reference's print('Invalid configuration')
     # force parameters: multi_bodies.py:1326-1336 binds these with functools.partial
     self.g = 0.0
     self.blob_mass = 1.0
@@ -85,21 +97,42 @@ class RollersIntegrator(object):
     self._own_ctx = ctx is None
     self.mobility_products = 0
     self._precision = 'double'
+    self._force_precision = 'follow'
 
   @property
   def precision(self):
     """'double' (default) or 'single': the reference GPU module's precision switch (mobility_pycuda.py:7-19) for the
     products of this stepper -- M_tt F + M_tr T, the four blocks and the 6N grand mobility run their fp32 twins
     (csrc/sym32_kernels.h, symx32_kernels.h: fp32 pair arithmetic, fp64 accumulation, ~1e-6 relative) with open
-    boundaries; forces, pseudo-periodic domains and the stepper's own algebra stay fp64."""
+    boundaries, and so do the blob-blob forces (the reference's GPU force kernel is always single precision; pin them
+    with `force_precision = 'double'`); pseudo-periodic domains and the stepper's own algebra stay fp64.
+    The random finite differences divide a difference of two products by rf_delta, so with ~1e-6-accurate products
+    rf_delta must be >= 1e-4 (the reference's advice for its float build, doc/README.md:512-523): the setter and every
+    stochastic step raise otherwise."""
     return self._precision
 
   @precision.setter
   def precision(self, value):
     if value not in ('single', 'double'):
       raise ValueError("precision must be 'single' or 'double'")
+    if value == 'single':
+      _check_rfd_delta_for_single_precision(self.rf_delta)
     self._precision = value
     self.ctx.set_option("precision", 32 if value == 'single' else 64)
+
+  @property
+  def force_precision(self):
+    """'follow' (default: the blob-blob forces use whatever `precision` says, i.e. the reference GPU force kernel's own
+    float arithmetic with precision = 'single', forces_pycuda.py:14-21), 'single' or 'double' (pinned) -- context
+    option "force_precision".  'double' with precision = 'single' is the products-only single-precision mode."""
+    return self._force_precision
+
+  @force_precision.setter
+  def force_precision(self, value):
+    if value not in ('follow', 'single', 'double'):
+      raise ValueError("force_precision must be 'follow', 'single' or 'double'")
+    self._force_precision = value
+    self.ctx.set_option("force_precision", {'follow': 0, 'single': 32, 'double': 64}[value])
 
   def close(self):
     if self._own_ctx:
@@ -351,11 +384,24 @@ class RollersIntegrator(object):
 
   def _accept(self, r_new):
     self.location = r_new
+    self.consecutive_rejections = 0
     if self.domain == "single_wall":
       self.wall_overlaps += int(torch.count_nonzero(r_new[:, 2] < self.a))
 
   def _rejected(self):
+    """A whole step is redrawn when ANY roller ends below the wall plane (:287-302; the reference prints 'Invalid
+    configuration' and loops without bound).  With N rollers the chance that one of N independent draws fails grows
+    with N, so a step size that a small suspension tolerates can reject nearly every draw of a large one: the
+    rejections are reported as they happen and a step that fails `max_consecutive_retries` times in a row raises
+    instead of spinning silently."""
     self.invalid_configuration_count += 1
+    self.consecutive_rejections += 1
+    if self.report_rejections:
+      print("Invalid configuration (rejection %d of this step, %d in total, %d rollers)" %
+            (self.consecutive_rejections, self.invalid_configuration_count, self.Nblobs), flush=True)
+    if self.consecutive_rejections > self.max_consecutive_retries:
+      raise RuntimeError("rollers: one time step was rejected %d times in a row (a roller below the wall plane in every "
+                         "draw): the time step is too large for this configuration" % self.consecutive_rejections)
     if self.invalid_configuration_count > self.max_retries:
       raise RuntimeError("rollers: more than %d rejected steps" % self.max_retries)
 
@@ -365,6 +411,8 @@ class RollersIntegrator(object):
     return self.compute_deterministic_velocity_and_torque_uncorrelated()
 
   def advance_time_step(self, dt, *args, **kwargs):
+    if self._precision == 'single' and self.kT > 0.0 and self.scheme.startswith("stochastic"):
+      _check_rfd_delta_for_single_precision(self.rf_delta)     # rf_delta may have been set after `precision`
     return getattr(self, self.scheme.replace("_rollers", ""))(dt, *args, **kwargs)
 
   # ---- schemes --------------------------------------------------------------------------------------

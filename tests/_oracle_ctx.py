@@ -12,6 +12,12 @@ class OracleContext(object):
   def set_stream(self, s):
     pass
 
+  def set_option(self, key, value):      # remembered, without effect on the CPU stand-in
+    self.options = dict(getattr(self, "options", {}), **{key: int(value)})
+
+  def get_option(self, key):
+    return getattr(self, "options", {}).get(key, {"precision": 64}.get(key, 0))
+
   def set_positions(self, r, a, L=None, wall=True):
     self.r = (r.detach().cpu().numpy() if isinstance(r, torch.Tensor) else np.asarray(r)).reshape(-1, 3).copy()
     self.a, self.wall = float(a), bool(wall)

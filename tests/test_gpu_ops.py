@@ -6,6 +6,8 @@ is the four separate calls of quaternion_integrator/quaternion_integrator_roller
 mobility_numba.py:291, :690; free surface :1770-1937; radii forces multi_bodies/forces_numba.py:73-122.
 Tolerances as tests/test_gpu_parity.py (relative L2, 1e-12 D2 / 1e-10 D1).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -448,13 +450,22 @@ def test_single_precision_switch_of_the_python_surface(mob, oracle):
 
 @pytest.mark.parametrize("wall", [True, False])
 @pytest.mark.parametrize("N", [128, 1000, 6000])
-def test_single_precision_other_products(Ctx, torch_mod, wall, N):
+def test_single_precision_other_products(Ctx, oracle, torch_mod, wall, N):
   """precision = 32 for tr / rt / rr, the fused row, the grand mobility, the force column, k-vector and in-plane products:
-  single-precision accurate against the same context in double precision; pseudo-periodic domains stay fp64."""
+  single-precision accurate against the fp64 ORACLE (not against its own fp64 twin, with which it shares the algebra);
+  pseudo-periodic domains stay fp64."""
   torch = torch_mod
   r, f, eta, a = d1_cloud(N, seed=N) if N == 1000 else d2_cloud(N, seed=N)
   t = np.random.RandomState(N + 7).randn(*f.shape)
   fd, td = _dev(torch, f), _dev(torch, t)
+  W = lambda kind, v, ip=False: oracle._wrapped(kind, int(wall), r, v, eta, a, periodic_length=np.zeros(3), in_plane=ip)
+  o = dict(tt_f=W("tt", f), tt_t=W("tt", t), tr_f=W("tr", f), tr_t=W("tr", t), rt_f=W("rt", f), rr_f=W("rr", f), rr_t=W("rr", t))
+  ref = {"tr": o["tr_f"], "rt": o["rt_f"], "rr": o["rr_f"], "fused": o["tt_f"] + o["tr_t"],
+         "grand_u": o["tt_f"] + o["tr_t"], "grand_w": o["rt_f"] + o["rr_t"], "col_u": o["tt_f"], "col_w": o["rt_f"],
+         "tt3_a": o["tt_f"], "tt3_b": o["tt_t"], "tt3_c": o["tt_f"] + o["tt_t"], "rr2_a": o["rr_f"], "rr2_b": o["rr_t"],
+         "mv2_a": o["tt_f"], "mv2_b": o["tt_t"]}
+  if wall:
+    ref["in_plane_tt"], ref["in_plane_tr"] = W("tt", f, True), W("tr", f, True)
   ctx = Ctx(0)
   try:
     ctx.set_positions(r, a, np.zeros(3), wall=wall)
@@ -478,11 +489,15 @@ def test_single_precision_other_products(Ctx, torch_mod, wall, N):
       return out
 
     p64 = products()
+    assert set(p64) == set(ref)
+    for k in p64:
+      assert rel_err(p64[k], ref[k]) < (TOL_D1 if N == 1000 else TOL_D2), k
     ctx.set_option("precision", 32)
+    assert ctx.get_option("precision") == 32
     p32 = products()
     for k in p64:
-      e = rel_err(p32[k], p64[k])
-      assert np.all(np.isfinite(p32[k])) and 1e-9 < e < 2e-5, (k, e)
+      e = rel_err(p32[k], ref[k])
+      assert np.all(np.isfinite(p32[k])) and 1e-9 < e < 2e-5, (k, e)      # the fp32 kernel ran and is single-precision accurate
     ctx.set_option("precision", 64)
     p64b = products()
     for k in p64:
@@ -574,3 +589,147 @@ def test_single_precision_is_insensitive_to_the_size_of_the_domain(Ctx, oracle):
       assert rel_err(F.reshape(-1), ref_F.reshape(-1)) < 1e-5, (origin, rel_err(F.reshape(-1), ref_F.reshape(-1)))
     finally:
       ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: options that interact (advisor findings of round 2) and bit-reproducible pair shards
+# ---------------------------------------------------------------------------------------------
+def test_diagnostics_refuse_single_precision_kernels(Ctx, torch_mod):
+  """wave_clock / skip_pairs exist in the fp64 kernels only: with precision = 32 the call fails loudly instead of
+  returning stale stamps or timing the full kernel."""
+  torch = torch_mod
+  from rigidmultiblobswall_amd._lib import RmbError
+  r, f, eta, a = d2_cloud(1000, seed=5)
+  fd = _dev(torch, f)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, np.zeros(3), wall=True)
+    ctx.set_option("precision", 32)
+    for key in ("wave_clock", "skip_pairs"):
+      ctx.set_option(key, 1)
+      with pytest.raises(RmbError):
+        ctx.matvec_device("tt", fd, eta)
+      if key == "skip_pairs":
+        with pytest.raises(RmbError):
+          ctx.matvec_device("rr", fd, eta)
+      ctx.set_option(key, 0)
+    u = ctx.matvec_device("tt", fd, eta)        # and works again once they are off
+    assert bool(torch.isfinite(u).all())
+    assert ctx.get_option("precision") == 32 and ctx.get_option("skip_pairs") == 0 and ctx.get_option("sym_oversub") == 8
+    with pytest.raises(RmbError):
+      ctx.get_option("no_such_option")
+  finally:
+    ctx.close()
+
+
+def test_force_precision_option_pins_the_force_kernel(Ctx, oracle):
+  """"force_precision": 0 follows "precision", 32 / 64 pin the blob-blob force kernel whatever the products run in."""
+  N = 3000
+  r, _, _, a = d2_cloud(N, seed=17)
+  eps, b = 0.3, 0.2 * a
+  ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=np.zeros(3), repulsion_strength=eps, debye_length=b, blob_radius=a)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, np.zeros(3), wall=False)
+    err = {}
+    for prec, fprec in ((64, 0), (32, 0), (32, 64), (64, 32), (64, 64)):
+      ctx.set_option("precision", prec); ctx.set_option("force_precision", fprec)
+      err[(prec, fprec)] = rel_err(ctx.blob_blob_force(eps, b, a), ref)
+    assert err[(64, 0)] < 1e-12 and err[(32, 64)] < 1e-12 and err[(64, 64)] < 1e-12, err
+    assert 1e-9 < err[(32, 0)] < 1e-4 and 1e-9 < err[(64, 32)] < 1e-4, err
+    from rigidmultiblobswall_amd._lib import RmbError
+    with pytest.raises(RmbError):
+      ctx.set_option("force_precision", 16)
+  finally:
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,G", [(1000, 2), (4097, 3), (10000, 8), (100, 4)])
+def test_pair_shards_honour_the_deterministic_symmetric_mode(Ctx, oracle, torch_mod, N, G):
+  """deterministic = 2 on a pair shard: whole tile pairs per shard, ordered reduction -- every shard is bit-identical from
+  launch to launch and from context to context, and the shards still sum to the product (single kinds, the two-vector
+  product and a multi-block operation)."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(N, seed=N + 3)
+  t = np.random.RandomState(N).randn(*f.shape)
+  fd, td = _dev(torch, f), _dev(torch, t)
+  ref_tt = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  ref_rr = oracle.single_wall_mobility_rot_times_torque_oracle(r, t, eta, a)
+  runs = []
+  for rep in range(2):
+    ctx = Ctx(0)
+    try:
+      ctx.set_positions(r, a, np.zeros(3), wall=True)
+      ctx.set_option("deterministic", 2)
+      parts = []
+      for g in range(G):
+        one = [ctx.matvec_pairshard_device("tt", fd, eta, g, G).cpu().numpy(),
+               ctx.matvec_pairshard_device("rr", td, eta, g, G).cpu().numpy()]
+        one += [x.cpu().numpy() for x in ctx.matvec2_device("tt", fd, td, eta, shard=g, nshards=G)]
+        one += [x.cpu().numpy() for x in ctx.matvec_op_device("grand", (fd, td), eta, shard=g, nshards=G)]
+        again = ctx.matvec_pairshard_device("tt", fd, eta, g, G).cpu().numpy()
+        assert np.array_equal(again, one[0])
+        parts.append(one)
+      runs.append(parts)
+      # atomics are back when the option is cleared
+      ctx.set_option("deterministic", 0)
+      full = sum(ctx.matvec_pairshard_device("tt", fd, eta, g, G).cpu().numpy() for g in range(G))
+      assert rel_err(full, ref_tt) < TOL_D2
+    finally:
+      ctx.close()
+  for g in range(G):
+    for x, y in zip(runs[0][g], runs[1][g]):
+      assert np.array_equal(x, y)
+  tot = [sum(runs[0][g][c] for g in range(G)) for c in range(6)]
+  assert rel_err(tot[0], ref_tt) < TOL_D2 and rel_err(tot[1], ref_rr) < TOL_D2
+  assert rel_err(tot[2], ref_tt) < TOL_D2
+  assert rel_err(tot[3], oracle.single_wall_mobility_trans_times_force_oracle(r, t, eta, a)) < TOL_D2
+  o_tr = oracle._wrapped("tr", 1, r, t, eta, a, periodic_length=np.zeros(3), in_plane=False)
+  o_rt = oracle._wrapped("rt", 1, r, f, eta, a, periodic_length=np.zeros(3), in_plane=False)
+  assert rel_err(tot[4], ref_tt + o_tr) < TOL_D2 and rel_err(tot[5], o_rt + ref_rr) < TOL_D2
+
+
+def test_streams_that_are_destroyed_between_steps(Ctx, oracle, torch_mod):
+  """C hosts with one stream per step: rmb_ctx_release_stream() before hipStreamDestroy, then the next stream is
+  adopted without the context ever touching the dead handle (HIP does not validate stream handles).  Switching between
+  two LIVE streams needs nothing from the caller."""
+  import ctypes
+  torch = torch_mod
+  hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+  r, f, eta, a = d2_cloud(2000, seed=9)
+  ref = oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a)
+  fd = _dev(torch, f)
+  out = torch.empty_like(fd)
+  torch.cuda.synchronize()
+  ctx = Ctx(0)
+  try:
+    keep = []
+    for step in range(3):
+      s = ctypes.c_void_p()
+      assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+      keep.append(ctypes.c_void_p())                 # a second live stream, so that the allocator cannot hand the
+      assert hip.hipStreamCreate(ctypes.byref(keep[-1])) == 0   # address of the destroyed one straight back
+      ctx.set_stream(s.value)
+      if step == 0:
+        ctx.set_positions(_dev(torch, r), a, np.zeros(3), wall=True)
+      ctx.matvec_device("tt", fd, eta, out=out)
+      ctx.release_stream()                          # waits for the product, forgets the handle
+      assert rel_err(out.cpu().numpy(), ref) < TOL_D2
+      assert hip.hipStreamDestroy(s) == 0
+    # live -> live switches: fenced by the context itself
+    for s in keep + [ctypes.c_void_p(0)]:
+      out.zero_()
+      torch.cuda.synchronize()
+      ctx.set_stream(s.value)
+      ctx.matvec_device("tt", fd, eta, out=out)
+    ctx.synchronize()
+    assert rel_err(out.cpu().numpy(), ref) < TOL_D2
+    ctx.release_stream()
+    for s in keep:
+      assert hip.hipStreamDestroy(s) == 0
+    out.zero_()
+    ctx.matvec_device("tt", fd, eta, out=out)       # follows torch's current stream again
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref) < TOL_D2
+  finally:
+    ctx.close()

@@ -205,16 +205,29 @@ def test_mixed_precision_solve_meets_the_same_tolerance():
   FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
   rs = RigidSuspension([shell] * nb, loc, quat, a, eta)
   try:
+    # the fp64 product BEFORE any mixed solve is the yardstick for "the option did not leak"
+    x = torch.randn(3 * rs.n_blobs, dtype=torch.float64, device="cuda")
+    y64 = rs.mobility_times_lambda(x).clone()
     U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
     U2, lam2, info2 = rs.solve_mobility_problem(force_torque=FT, tol=1e-8, mixed_precision=True)
     assert info["converged"] and info2["converged"]
     assert info2["residual"] <= 1e-8 and 1 <= info2["outer_iterations"] <= 4
     assert np.linalg.norm(U2 - U) < 1e-6 * np.linalg.norm(U)
     assert np.linalg.norm(lam2 - lam) < 1e-5 * np.linalg.norm(lam)
-    # back in fp64: the plain product is double-precision accurate again
-    x = torch.randn(3 * rs.n_blobs, dtype=torch.float64, device="cuda")
-    y1 = rs.mobility_times_lambda(x)
+    # back in fp64 without anybody resetting the option: the product agrees with the one taken before to rounding
+    assert rs.ctx.get_option("precision") == 64
+    y_after = rs.mobility_times_lambda(x)
+    assert float(torch.linalg.norm(y_after - y64)) <= 1e-13 * float(torch.linalg.norm(y64))
+    # a caller that had selected single precision gets it back (RigidIntegrator.precision = 'single' + mixed solves)
+    rs.ctx.set_option("precision", 32)
+    y32 = rs.mobility_times_lambda(x).clone()
+    e32 = float(torch.linalg.norm(y32 - y64)) / float(torch.linalg.norm(y64))
+    assert 1e-9 < e32 < 1e-4, e32
+    U3, _, info3 = rs.solve_mobility_problem(force_torque=FT, tol=1e-8, mixed_precision=True)
+    assert info3["converged"] and info3["residual"] <= 1e-8         # the refinement's residuals ran in fp64 all the same
+    assert np.linalg.norm(U3 - U) < 1e-6 * np.linalg.norm(U)
+    assert rs.ctx.get_option("precision") == 32
+    assert float(torch.linalg.norm(rs.mobility_times_lambda(x) - y32)) <= 1e-12 * float(torch.linalg.norm(y32))
     rs.ctx.set_option("precision", 64)
-    assert float(torch.linalg.norm(rs.mobility_times_lambda(x) - y1)) <= 1e-13 * float(torch.linalg.norm(y1))
   finally:
     rs.close()

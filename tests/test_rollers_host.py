@@ -8,7 +8,8 @@ import pytest
 
 from conftest import golden_files, load_golden, rel_err
 from _oracle_ctx import OracleContext
-from _rollers_common import integrator_from_golden, run_and_compare
+from _rollers_common import (integrator_from_golden, run_and_compare, replay_driven_steps, driven_factory,
+                             check_driven_replay)
 
 TRAJ = [p for p in golden_files("g8_rollers_*.npz") if "velocity_pieces" not in p and "prescribed" not in p]
 
@@ -163,3 +164,73 @@ def test_input_deck_one_file_output_and_errors(oracle, tmp_path):
   (tmp_path / "blob.vertex").write_text("2\n0 0 0\n1 0 0\n")
   with pytest.raises(ValueError):
     rollers.integrator_from_input(read, device="cpu", ctx=OracleContext(oracle))
+
+
+def test_a_step_rejected_over_and_over_raises_instead_of_spinning(oracle, capsys):
+  """The reference redraws a rejected step without bound and prints one line per rejection
+  (quaternion_integrator_rollers.py:287-302).  Here every rejection is reported too, and a step that fails
+  `max_consecutive_retries` times in a row raises: at 2.6e5 rollers a too-large dt otherwise spins silently for minutes
+  (the run of round 2 that was killed for writing nothing)."""
+  from rigidmultiblobswall_amd.rollers import RollersIntegrator
+  r0 = np.array([[0.0, 0.0, 0.3], [3.0, 0.0, 2.0], [0.0, 3.0, 2.0]])
+  integ = RollersIntegrator(r0, "deterministic_forward_euler_rollers", 0.4, 1.0, device="cpu", ctx=OracleContext(oracle))
+  integ.g = 50.0                      # gravity alone pushes roller 0 through the wall in one step, every time
+  integ.max_consecutive_retries = 3
+  with pytest.raises(RuntimeError, match="rejected 4 times in a row"):
+    integ.advance_time_step(1.0)
+  out = capsys.readouterr().out
+  assert out.count("Invalid configuration") == 4 and "rejection 4 of this step" in out
+  assert integ.invalid_configuration_count == 4 and np.array_equal(integ.location.numpy(), r0)
+  # an accepted step resets the run length
+  integ.g = 0.0
+  integ.advance_time_step(0.01)
+  assert integ.consecutive_rejections == 0
+  integ.report_rejections = False
+  integ.g = 50.0
+  with pytest.raises(RuntimeError):
+    integ.advance_time_step(1.0)
+  assert capsys.readouterr().out == ""
+
+
+def test_single_precision_needs_a_finite_difference_step_that_survives_it(oracle):
+  """precision = 'single': products carry ~1e-6 relative error, so the random finite differences need
+  rf_delta >= 1e-4 (doc/README.md:512-523: 1e-3 single, 1e-6 double)."""
+  from rigidmultiblobswall_amd.rollers import RollersIntegrator
+  r0 = np.array([[0.0, 0.0, 1.0], [3.0, 0.0, 1.5], [0.0, 3.0, 1.2]])
+  integ = RollersIntegrator(r0, "stochastic_adams_bashforth_rollers", 0.4, 1.0, device="cpu", ctx=OracleContext(oracle), seed=1)
+  integ.kT = 0.01
+  integ.rf_delta = 1e-6
+  with pytest.raises(ValueError, match="rf_delta >= 1e-4"):
+    integ.precision = 'single'
+  assert integ.precision == 'double'
+  integ.rf_delta = 1e-3
+  integ.precision = 'single'
+  integ.advance_time_step(0.01)
+  integ.rf_delta = 1e-6               # changed after the switch: caught at the next stochastic step
+  with pytest.raises(ValueError):
+    integ.advance_time_step(0.01)
+  integ.precision = 'double'
+  integ.advance_time_step(0.01)
+  with pytest.raises(ValueError):
+    integ.force_precision = 'half'
+  integ.force_precision = 'double'
+  assert integ.ctx.get_option("force_precision") == 64
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[4]'s driven recipe in small, recorded from the reference's own integrator (g8_driven_dense_monolayer)
+# ---------------------------------------------------------------------------------------------
+def test_driven_dense_monolayer_steps_match_the_reference_integrator(oracle):
+  g = load_golden(golden_files("g8_driven_dense_monolayer.npz")[0])
+  n_steps = len(g["trajectory"]) - 1
+  assert n_steps >= 40 and g["trajectory"].shape[1] >= 200
+  # the record itself: the layer starts below its equilibrium height and rises (physical), the reference's own
+  # whole-step rejections are in the record
+  h = g["trajectory"][:, :, 2].mean(axis=1)
+  assert h[-1] > h[0]
+  steps = list(range(0, n_steps, 4)) + [1, n_steps - 1]   # every fourth step here, all of them on the GPU
+  rejected_at = np.nonzero(np.diff(np.concatenate([[0], g["rejected_cumulative"]])))[0]
+  if len(rejected_at):
+    steps.append(int(rejected_at[0]))
+  res = replay_driven_steps(g, driven_factory(g, lambda: OracleContext(oracle), "cpu"), steps)
+  check_driven_replay(g, res, steps)
