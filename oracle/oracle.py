@@ -56,6 +56,9 @@ def _lib(fast=False):
     lib.oracle_blob_blob_force.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, _dp]
     lib.oracle_blob_blob_force.restype = ctypes.c_int
+    lib.oracle_blob_blob_force_targets.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_double, ctypes.c_double,
+                                                   ctypes.c_double, ctypes.c_long, _lp, _dp]
+    lib.oracle_blob_blob_force_targets.restype = ctypes.c_int
     lib.oracle_blob_blob_force_radii.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp]
     lib.oracle_blob_blob_force_radii.restype = ctypes.c_int
     lib.oracle_wall_regularisation.argtypes = [ctypes.c_long, _dp, ctypes.c_double, _dp, _dp,
@@ -294,6 +297,20 @@ def calc_blob_blob_forces_oracle(r_vectors, *args, **kwargs):
   if rc != 0:
     raise RuntimeError("oracle_blob_blob_force failed: %d" % rc)
   return out.reshape(N, 3)
+
+
+def calc_blob_blob_forces_targets_oracle(r_vectors, targets, *args, **kwargs):
+  """The rows `targets` of calc_blob_blob_forces_oracle (all blobs as sources): full-size spot checks."""
+  L = _c(kwargs.get("periodic_length", np.zeros(3))).reshape(3)
+  r = _c(r_vectors).reshape(-1)
+  tg = np.ascontiguousarray(targets, dtype=np.int64)
+  out = np.zeros(3 * tg.size)
+  rc = _lib().oracle_blob_blob_force_targets(r.size // 3, _p(r), _p(L), float(kwargs.get("repulsion_strength")),
+                                             float(kwargs.get("debye_length")), float(kwargs.get("blob_radius")), tg.size,
+                                             tg.ctypes.data_as(_lp), _p(out))
+  if rc != 0:
+    raise RuntimeError("oracle_blob_blob_force_targets failed: %d" % rc)
+  return out.reshape(-1, 3)
 
 
 def calc_blob_blob_forces_radii_oracle(r_vectors, radius_blobs, *args, **kwargs):

@@ -641,6 +641,35 @@ int oracle_blob_blob_force(long N, const double *r, const double *L, double eps,
   return 0;
 }
 
+/* Subset variant for full-size spot checks (as oracle_mobility_matvec_targets): the force on the listed blobs
+ * only, every other blob as a source.  out has 3*n_targets entries.  Same pair formula, forces_numba.py:12-55. */
+int oracle_blob_blob_force_targets(long N, const double *r, const double *L, double eps, double b, double a,
+                                   long n_targets, const long *targets, double *out) {
+  if (N < 0 || n_targets < 0 || !out) return 1;
+  for (long t = 0; t < n_targets; ++t)
+    if (targets[t] < 0 || targets[t] >= N) return 2;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (long t = 0; t < n_targets; ++t) {
+    const long i = targets[t];
+    double fx = 0, fy = 0, fz = 0;
+    for (long j = 0; j < N; ++j) {
+      if (i == j) continue;
+      double dr[3];
+      for (int k = 0; k < 3; ++k) {
+        dr[k] = r[3 * j + k] - r[3 * i + k];
+        if (L[k] > 0) dr[k] = wrap_nearest(dr[k], L[k]);
+      }
+      double rn = sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+      double f0;
+      if (rn > 2 * a) f0 = -((eps / b) * exp(-(rn - 2.0 * a) / b) / rn);
+      else f0 = -((eps / b) / fmax(rn, 1e-25));
+      fx += f0 * dr[0]; fy += f0 * dr[1]; fz += f0 * dr[2];
+    }
+    out[3 * t] = fx; out[3 * t + 1] = fy; out[3 * t + 2] = fz;
+  }
+  return 0;
+}
+
 /* One radius per blob: contact distance a_i + a_j (multi_bodies/forces_numba.py:73-122). */
 int oracle_blob_blob_force_radii(long N, const double *r, const double *radii, const double *L, double eps, double b,
                                  double *out) {

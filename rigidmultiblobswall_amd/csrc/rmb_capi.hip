@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -97,6 +98,7 @@ struct rmb_ctx {
   long opt_precision = 64;     // 32: M_tt f (open boundaries) in single precision (sym32_kernels.h); everything else fp64
   long opt_force_precision = 0;  // blob-blob forces: 0 = follow "precision", 32 / 64 = pinned
   long opt_sym_min_steps = 64; // floor on rotation steps per wave (a unit is 64 steps)
+  long opt_sym_fine_steps = 32;  // floor on steps per wave when less than one resident round is left (pair shards, small N)
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
   // timing ring (events around the sweep kernel)
@@ -182,6 +184,12 @@ int resident_blocks(const void* fn, int* cache) {
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, rmb::kBlock, 0) != hipSuccess || nb < 1) nb = 4;
   if (nb > 8) nb = 8;
+  if (getenv("RMB_DEBUG_OCC")) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, fn) == hipSuccess)
+      fprintf(stderr, "[rmb] occupancy api %d blocks/CU | numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d localSizeBytes %zu\n", nb,
+              at.numRegs, (size_t)at.sharedSizeBytes, at.maxThreadsPerBlock, (size_t)at.localSizeBytes);
+  }
   *cache = nb;
   return nb;
 }
@@ -256,8 +264,15 @@ struct SymPlan { long blocks; long steps_per_wave; size_t dyn_lds; };
 // Static, exactly balanced schedule (sym_kernels.h): whole multiples of the resident workgroup count so that every
 // SIMD gets the same number of steps.  `pin` pads dynamic LDS so that exactly `wps` workgroups fit a CU (equal steps
 // per wave is then equal work per SIMD); CU count and LDS size come from hipDeviceProp_t (rmb_ctx_create).
-int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long total, bool pin, SymPlan* out) {
+// `declared_waves`: the kernel's amdgpu_waves_per_eu bound (0 = none).  The occupancy API prices a kernel by its
+// ARCHITECTURAL VGPRs only (hipFuncAttributes::numRegs); a kernel compiled under waves_per_eu(4, 4) parks values in
+// AGPRs up to the 128-register budget (sym_kernel<TT>: 86 + 9 -> allocates 104, <RR>: 72 + 25), so the API reports 5
+// and 7 workgroups per CU where the hardware holds 4 (per-wave start stamps, profiles/r3_shard_wave_placement.txt) and
+// every plan built on "whole resident rounds" was off after the kernels lost registers in round 2.
+int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long total, bool pin, SymPlan* out,
+             int declared_waves = 0) {
   int wps = resident_blocks(fn, occ_cache);
+  if (declared_waves > 0 && wps > declared_waves) wps = declared_waves;
   if (c->opt_sym_wps > 0 && c->opt_sym_wps < wps) wps = (int)c->opt_sym_wps;
   size_t pad = 0;
   if (pin && c->opt_sym_pin) {
@@ -272,10 +287,12 @@ int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long
   if (blocks > need) blocks = need;
   if (blocks > round) blocks -= blocks % round;   // whole rounds only: a partial last round is a tail
   if (blocks < round) {
-    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): filling the round with
-    // shorter waves (down to 16 steps) beats leaving SIMDs with one or two waves and no latency hiding
-    // (1/4 shard of 1e4 blobs: 68.9 -> 60.3 us; tools/exp_pairshard.py)
-    const long per_wg_fine = rmb::kSymWaves * 16L;
+    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): shorter waves (down to
+    // "sym_fine_steps" = 32) beat leaving SIMDs with one or two waves and no latency hiding, but every wave pays its
+    // own loads and 384 global atomics on accumulators it shares with the other waves of its tile row, so more and
+    // shorter is worse again: 1/8 shard of 1e4 blobs 39.9 us at 16 steps x 1280 workgroups, 29.3 us at 32 x 776
+    // (tools/exp_shard_plan.py, profiles/r3_shard_plan.txt)
+    const long per_wg_fine = rmb::kSymWaves * c->opt_sym_fine_steps;
     long fine = (total + per_wg_fine - 1) / per_wg_fine;
     if (fine > round) fine = round;
     if (fine > blocks) blocks = fine;
@@ -334,7 +351,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   const size_t stat = f32 ? (sizeof(float) * 9 + sizeof(double) * 3) * rmb::kSymWaves * 64
                           : sizeof(double2) * rmb::kSymWaves * 64 * 3 + sizeof(double) * rmb::kSymWaves * 3 * 64;
   if (int rc = plan_sym(c, f32 ? (const void*)fn32 : (const void*)se.sweep, f32 ? &occ32[c->wall ? 1 : 0] : &se.occ, stat,
-                        a.step_end - a.step_begin, true, &plan))
+                        a.step_end - a.step_begin, true, &plan, f32 ? 0 : rmb::kSymWavesPerEu))
     return rc;
   const long blocks = plan.blocks;
   a.steps_per_wave = plan.steps_per_wave;
@@ -387,7 +404,8 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
   const k2_fn fn = c->wall ? (periodic ? (k2_fn)rmb::sym2_kernel<true, true> : (k2_fn)rmb::sym2_kernel<true, false>)
                            : (periodic ? (k2_fn)rmb::sym2_kernel<false, true> : (k2_fn)rmb::sym2_kernel<false, false>);
   SymPlan plan;
-  if (int rc = plan_sym(c, (const void*)fn, &occ2[c->wall ? 1 : 0][periodic ? 1 : 0], 0, a.step_end - a.step_begin, false, &plan))
+  if (int rc = plan_sym(c, (const void*)fn, &occ2[c->wall ? 1 : 0][periodic ? 1 : 0], 0, a.step_end - a.step_begin, false, &plan,
+                        rmb::kSymWavesPerEu))
     return rc;
   const long blocks = plan.blocks;
   a.steps_per_wave = plan.steps_per_wave;
@@ -990,6 +1008,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
     c->opt_force_precision = value;
     return 0;
   }
+  if (!strcmp(key, "sym_fine_steps")) { c->opt_sym_fine_steps = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_min_steps")) { c->opt_sym_min_steps = value < 1 ? 1 : value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);
@@ -1002,7 +1021,7 @@ int rmb_ctx_get_option(rmb_ctx* c, const char* key, long* value) {
       {"fused_symmetric", &c->opt_fused_symmetric}, {"symx_single", &c->opt_symx_single},
       {"deterministic", &c->opt_deterministic}, {"det_workspace_mb", &c->opt_det_workspace_mb}, {"sym_wps", &c->opt_sym_wps},
       {"wave_clock", &c->opt_wave_clock}, {"skip_pairs", &c->opt_skip_pairs}, {"sym_pin", &c->opt_sym_pin},
-      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"sym_oversub", &c->opt_sym_oversub},
+      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps},
       {"sym_min_steps", &c->opt_sym_min_steps}};
   for (const auto& e : table)
     if (!strcmp(key, e.name)) { *value = *e.v; return 0; }

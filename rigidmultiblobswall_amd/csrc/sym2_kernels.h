@@ -58,7 +58,7 @@ __device__ __forceinline__ void tt_pair_apply(const TTPair& p, double vix, doubl
 }
 
 template <bool WALL, bool PERIODIC>
-__global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void sym2_kernel(const Sym2Args a) {
+__global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(kSymWavesPerEu, kSymWavesPerEu))) void sym2_kernel(const Sym2Args a) {
   __shared__ double2 rec_all[kSymWaves][64 * 5];
   __shared__ double accj_all[kSymWaves][6 * 64];
   const int lane = threadIdx.x & 63;

@@ -8,8 +8,8 @@
 // cheap contractions are done twice.  With W = f1 I + f2 e e^T + f3 e z^T + f4 z e^T + f5 z z^T,
 //   W v   = f1 v + [f2 (e.v) + f3 v_z] e + [f4 (e.v) + f5 v_z] z
 //   W^T v = f1 v + [f2 (e.v) + f4 v_z] e + [f3 (e.v) + f5 v_z] z          (f3 <-> f4)
-// => 92 VALU instructions per unordered pair (pair_blocks.h: five-entry block + closed-form wall polynomials)
-// instead of 2 x 83 in the one-sided sweep.
+// => 81 VALU instructions per unordered pair (77 fp64; pair_blocks.h: five-entry block + closed-form wall
+// polynomials through H) instead of 2 x 78 in the one-sided sweep.
 //
 // Work decomposition: blobs are cut into tiles of 64; a work unit is a tile pair (I <= J).  One wave64
 // owns a unit: lane l holds blob i = 64 I + l in registers (position, its own vector v_i, accumulator u_i);
@@ -52,6 +52,7 @@ struct SymArgs {
 };
 
 constexpr int kSymWaves = 4;
+constexpr int kSymWavesPerEu = 4;   // register budget of sym_kernel / sym2_kernel: 4 waves per SIMD (the launch plan relies on it)
 constexpr int kSymRecBytes = 48;
 
 // Both directions of one pair.  (vix..) = target's own vector, (vjx..) = source vector.
@@ -139,7 +140,7 @@ __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
 }
 
 template <int KIND, bool WALL, bool PERIODIC>
-__global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void sym_kernel(const SymArgs a) {
+__global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(kSymWavesPerEu, kSymWavesPerEu))) void sym_kernel(const SymArgs a) {
   __shared__ double2 rec_all[kSymWaves][64 * 3];
   __shared__ double accj_all[kSymWaves][3 * 64];
   const int lane = threadIdx.x & 63;
