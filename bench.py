@@ -90,6 +90,11 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # The hosts of this pool only support dmabuf IPC: with the legacy mode RCCL's (and torch's) cross-process buffer
+    # registration fails with `hipIpcGetMemHandle: invalid argument`.  The image exports HSA_ENABLE_IPC_MODE_LEGACY=0
+    # already (and a launcher such as torch.distributed.run passes its environment on); setdefault only covers a
+    # shell that dropped it, it never overrides a value the operator chose.  The value every rank ran with is on the
+    # line ("ipc_mode_legacy_env").
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
   rc = 0
@@ -349,6 +354,7 @@ def rank_main(args):
                                  "f replicated, one RCCL all-reduce of u per matvec" % world)},
       "world_size": world,
       "collective_backend": None if world == 1 else ("nccl (RCCL)" if backend_name == "nccl" else backend_name),
+      "ipc_mode_legacy_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
       "prewarm": res["prewarm"],
       "roofline": roofline,
   }

@@ -392,7 +392,7 @@ class RigidSuspension(object):
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
     sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
                                            restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
-                                           sync=getattr(self.ctx, "sync_scalars", None))
+                                           sync=getattr(self.ctx, "sync_scalars", None), lag=getattr(self, "gmres_lag", None))
     info["rhs_norm"] = nrm
     return sol * nrm, info
 
@@ -753,16 +753,17 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
   return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history, discarded_sweeps=wasted)
 
 
-def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None):
+def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None, lag=None):
   """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
   Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after `maxiter` INNER iterations in total -- not restart
   cycles: scipy (and the reference's call, maxiter=1000 with restart=60) counts cycles, i.e. up to 60 000 inner
   iterations; the solves here converge in tens of iterations, so the cap only differs in how soon a diverging solve
   gives up.
-  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host.
+  Arnoldi with two passes of classical Gram-Schmidt (one device GEMV each); Givens rotations on the host, on a GPU one
+  iteration behind the device (`lag`, see _gmres_steps; None = on for CUDA tensors).
   x0: optional initial guess (the roller torque solve warm-starts from the previous step,
   quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
-  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync)
+  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag)
   try:
     request = next(steps)
     while True:

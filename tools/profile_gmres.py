@@ -25,8 +25,15 @@ print("K.U                    %.3f ms" % timed(rs.K_times_U, x[n3:]))
 print("K^T.lambda             %.3f ms" % timed(rs.KT_times_lambda, x[:n3]))
 print("apply_operator         %.3f ms" % timed(rs.apply_operator, x))
 print("apply_preconditioner   %.3f ms" % timed(rs.apply_preconditioner, x))
-for rep in range(3):
-  torch.cuda.synchronize(); t0 = time.perf_counter()
-  U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
-  torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
-  print("solve: %d iterations, %.2f ms total, %.3f ms/iteration" % (info["iterations"], dt, dt / info["iterations"]))
+# host bookkeeping of GMRES one iteration behind the device (round 3) against the synchronous loop of rounds 1-2
+for lag in (False, True, False, True):
+  rs.gmres_lag = lag
+  rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
+  ts = []
+  for rep in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+  print("solve, host bookkeeping %s: %d iterations (%d sweeps discarded), residual %.2e, %.2f ms (min of 5; all: %s), %.3f ms/iteration" %
+        ("one iteration late" if lag else "synchronous       ", info["iterations"], info.get("discarded_sweeps", 0), info["residual"],
+         min(ts), " ".join("%.2f" % t for t in ts), min(ts) / info["iterations"]))

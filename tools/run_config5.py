@@ -10,7 +10,7 @@ M^{1/2} z, random-finite-difference drift; quaternion_integrator/quaternion_inte
                still be the Gibbs-Boltzmann one (check of tests/test_gpu_physics.py at full size)
   multiblob    21 845 twelve-blob shells (262 140 blobs), stochastic_Slip_Trapz: 3 GMRES solves + preconditioned
                Lanczos + forces kernel per step
-Prints a progress line every 10 steps and one JSON record at the end (-> profiles/).
+Prints a progress line every step (and every rejected step, from the integrator) and one JSON record at the end (-> profiles/).
 """
 import json
 import math
@@ -50,7 +50,7 @@ if mode in ("driven", "equilibrium"):
   integ = RollersIntegrator(loc, "stochastic_adams_bashforth_rollers", a, eta, tolerance=1e-3, device=dev, seed=11)
   integ.precision = precision
   rec["precision_of_the_mobility_products"] = precision
-  integ.max_retries = 50          # a step rejected this often aborts the run instead of retrying for minutes
+  integ.max_retries = 200                # in total; a single step rejected max_consecutive_retries (20) times in a row raises
   integ.kT, integ.g = E.kT, E.mg
   integ.repulsion_strength = integ.repulsion_strength_wall = E.ew
   integ.debye_length = integ.debye_length_wall = E.bw
@@ -62,11 +62,10 @@ if mode in ("driven", "equilibrium"):
   for step in range(steps):
     integ.advance_time_step(dt)
     heights.append(float(integ.location[:, 2].mean()))
-    if (step + 1) % 5 == 0:
-      torch.cuda.synchronize()
-      print("step %3d  %.1f s  mean height %.4f  products %d  lanczos its %d  rejected %d" %
-            (step + 1, time.perf_counter() - t0, heights[-1], integ.mobility_products, integ.stoch_iterations_count,
-             integ.invalid_configuration_count), flush=True)
+    torch.cuda.synchronize()      # a line every step: a step takes >= 1 s here, and a silent run is a killed run
+    print("step %3d  %.1f s  mean height %.4f  products %d  lanczos its %d  rejected %d" %
+          (step + 1, time.perf_counter() - t0, heights[-1], integ.mobility_products, integ.stoch_iterations_count,
+           integ.invalid_configuration_count), flush=True)
   torch.cuda.synchronize()
   wall = time.perf_counter() - t0
   tail = heights[steps // 4:]
@@ -97,11 +96,10 @@ else:
   t0 = time.perf_counter()
   for step in range(steps):
     ri.advance_time_step(0.01, step=step)
-    if (step + 1) % 5 == 0:
-      torch.cuda.synchronize()
-      print("step %3d  %.1f s  mean height %.4f  gmres %d  lanczos %d  sweeps %d  rejected %d" %
-            (step + 1, time.perf_counter() - t0, float(ri.location[:, 2].mean()), ri.det_iterations_count,
-             ri.stoch_iterations_count, ri.susp.matvec_count, ri.invalid_configuration_count), flush=True)
+    torch.cuda.synchronize()
+    print("step %3d  %.1f s  mean height %.4f  gmres %d  lanczos %d  sweeps %d  rejected %d" %
+          (step + 1, time.perf_counter() - t0, float(ri.location[:, 2].mean()), ri.det_iterations_count,
+           ri.stoch_iterations_count, ri.susp.matvec_count, ri.invalid_configuration_count), flush=True)
   torch.cuda.synchronize()
   wall = time.perf_counter() - t0
   rec.update(bodies=nb, blobs=ri.Nblobs, scheme=ri.scheme, dt=0.01, solver_tolerance=1e-4, seconds=round(wall, 2),
