@@ -139,7 +139,7 @@ int rmb_matvec(rmb_ctx* ctx, int kind, int in_plane, const double* vec_host, con
 int rmb_matvec_device(rmb_ctx* ctx, int kind, int in_plane, const double* vec_dev, const double* vec2_dev,
                       double eta, double* out_dev);
 
-/* Multi-GPU, symmetric pair sharding (RMB_TT / TR / RT / RR): the unordered blob pairs are cut into
+/* Multi-GPU, symmetric pair sharding (RMB_TT / TR / RT / RR / TT_FREE_SURFACE): the unordered blob pairs are cut into
  * `nshards` equal parts; this call evaluates part `shard` (each pair once, applied to both blobs) and
  * writes its contribution to ALL n targets (3n doubles).  The sum over shards is the full product; the
  * self term of target i is added by the shard that owns i in the contiguous block partition.  The
@@ -193,6 +193,11 @@ int rmb_blob_blob_force(rmb_ctx* ctx, double repulsion_strength, double debye_le
                         double* out_host);
 int rmb_blob_blob_force_device(rmb_ctx* ctx, double repulsion_strength, double debye_length,
                                double blob_radius, double* out_dev);
+/* Pair shard `shard` of `nshards` of the forces (each unordered pair once, F_ji = -F_ij) into a full-length partial
+ * (n,3): the sum over shards is rmb_blob_blob_force_device's result (all-reduce on several GPUs).  Atomic flushes
+ * whatever "deterministic" says. */
+int rmb_blob_blob_force_pairshard_device(rmb_ctx* ctx, double repulsion_strength, double debye_length,
+                                         double blob_radius, double* out_dev, long shard, long nshards);
 /* Same with one radius per blob: contact distance a_i + a_j instead of 2a (multi_bodies/forces_numba.py:73-137,
  * `blob_blob_force_implementation radii_numba`).  radii: double[n], host / device. */
 int rmb_blob_blob_force_radii(rmb_ctx* ctx, const double* radii, double repulsion_strength, double debye_length,

@@ -138,7 +138,7 @@ class MobilityContext(object):
     return out
 
   def matvec_pairshard_device(self, kind, vec, eta, shard, nshards, out=None):
-    """Contribution of pair-shard `shard` of `nshards` to ALL targets (3n entries); tt, non-periodic."""
+    """Contribution of pair-shard `shard` of `nshards` to ALL targets (3n entries): tt / tr / rt / rr / tt_free."""
     import torch
     k = _lib.KINDS[kind] if isinstance(kind, str) else int(kind)
     if not _is_torch_cuda(vec) or vec.numel() != 3 * self.n or not vec.is_contiguous():
@@ -256,6 +256,19 @@ class MobilityContext(object):
     self._follow_torch_stream()
     _lib.check(self._lib.rmb_blob_blob_force_device(self._h, float(repulsion_strength), float(debye_length),
                                                     float(blob_radius), ctypes.c_void_p(out.data_ptr())))
+    return out
+
+  def blob_blob_force_pairshard_device(self, repulsion_strength, debye_length, blob_radius, shard, nshards, out=None, device=None):
+    """Contribution of pair shard `shard` of `nshards` to the forces on ALL blobs (3n entries; sum over shards = forces)."""
+    import torch
+    if out is None:
+      out = torch.empty(3 * self.n, dtype=torch.float64, device=device or ("cuda:%d" % self.device))
+    elif not _is_torch_cuda(out) or out.numel() != 3 * self.n or not out.is_contiguous():
+      raise ValueError("out must be a contiguous CUDA float64 tensor with 3*n entries")
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_blob_blob_force_pairshard_device(self._h, float(repulsion_strength), float(debye_length),
+                                                              float(blob_radius), ctypes.c_void_p(out.data_ptr()), int(shard),
+                                                              int(nshards)))
     return out
 
   # --- measurement -----------------------------------------------------------------------------

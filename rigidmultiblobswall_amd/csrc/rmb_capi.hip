@@ -692,16 +692,20 @@ rmb::ExpConsts exp_consts() {
   return e;
 }
 
-int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out, const double* radii = nullptr) {
+// shard / nshards: pair shard of the unordered pairs (F_ji = -F_ij needs no self term) into a full-length partial; a
+// shard always takes the symmetric kernel, whatever n and the target range (as rmb_matvec_pairshard_device).
+int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out, const double* radii = nullptr,
+                      long shard = 0, long nshards = 1) {
   if (int rc = check_ready(c)) return rc;
-  const long n_tgt = c->tgt_end - c->tgt_begin;
+  const long n_tgt = nshards > 1 ? c->n : c->tgt_end - c->tgt_begin;
   if (n_tgt == 0) return 0;
   if (!out) return fail(RMB_ERR_ARG, "null output pointer");
   if (!(b > 0.0)) return fail(RMB_ERR_ARG, "debye_length must be positive");
+  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
   RMB_HIP(hipSetDevice(c->device));
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   c->last_path = 0;
-  if (sym_applies(c) && c->opt_deterministic == 0) {
+  if (nshards > 1 || (sym_applies(c) && c->opt_deterministic == 0)) {
     // symmetric path: each unordered pair once (F_ji = -F_ij); its flushes are atomics, so both deterministic modes
     // take the one-sided sweep below
     const long n = c->n, tiles = (n + 63) / 64, n_pad = 64 * tiles;
@@ -718,6 +722,11 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     a.eps_over_b = eps / b; a.inv_b = 1.0 / b; a.two_a = 2.0 * blob_radius;
     a.ec = exp_consts();
     a.radii = radii;
+    {
+      const __int128 s_all = (__int128)a.n_units * 64;
+      a.step_begin = (long)(s_all * shard / nshards);
+      a.step_end = (long)(s_all * (shard + 1) / nshards);
+    }
     static int socc[2][2] = {{0, 0}, {0, 0}};
     typedef void (*sforce_fn)(const rmb::SymForceArgs);
     const sforce_fn sfn = radii ? (periodic ? (sforce_fn)rmb::sym_force_kernel<true, true> : (sforce_fn)rmb::sym_force_kernel<false, true>)
@@ -729,7 +738,8 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     const sforce_fn sfn32 = radii ? (sforce_fn)rmb::sym_force32_kernel<true> : (sforce_fn)rmb::sym_force32_kernel<false>;
     const void* fn = f32 ? (const void*)sfn32 : (const void*)sfn;
     long blocks = c->n_cu * resident_blocks(fn, f32 ? &socc32[radii ? 1 : 0] : &socc[radii ? 1 : 0][periodic ? 1 : 0]) * c->opt_sym_oversub;
-    const long need = (a.n_units * 64 + 255) / 256;
+    long need = (a.step_end - a.step_begin + 255) / 256;
+    if (need < 1) need = 1;
     if (blocks > need) blocks = need;
     c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
     int slot;
@@ -1101,18 +1111,22 @@ int rmb_matvec2_device(rmb_ctx* c, int kind, const double* vec_a, const double* 
 
 int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards) {
   if (int rc = check_ready(c)) return rc;
-  if (kind < 0 || kind > rmb::KIND_RR) return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT / TR / RT / RR");
+  if ((kind < 0 || kind > rmb::KIND_RR) && kind != rmb::KIND_TT_FREE)
+    return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT / TR / RT / RR / TT_FREE_SURFACE (RMB_TT_TR: rmb_matvec_op_pairshard_device)");
+  if (kind == rmb::KIND_TT_FREE && c->wall)
+    return fail(RMB_ERR_STATE, "RMB_TT_FREE_SURFACE uses raw heights: call rmb_set_positions with wall = 0");
   if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
   if (c->n == 0) return 0;
   if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
   if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
   RMB_HIP(hipSetDevice(c->device));
   c->last_path = 1;
-  if (c->opt_deterministic == 2) {      // bit-reproducible shard: whole units, ordered reduction (symx_det_device)
-    const double* in[2] = {v, nullptr};
-    double* outs[1] = {out};
-    return symx_det_device(c, SX_TT + kind, in, outs, eta, 0, shard, nshards);
-  }
+  const int sx = kind == rmb::KIND_TT_FREE ? SX_FREE : SX_TT + kind;
+  const double* in[2] = {v, nullptr};
+  double* outs[1] = {out};
+  if (c->opt_deterministic == 2)        // bit-reproducible shard: whole units, ordered reduction (symx_det_device)
+    return symx_det_device(c, sx, in, outs, eta, 0, shard, nshards);
+  if (kind == rmb::KIND_TT_FREE) return symx_device(c, SX_FREE, in, outs, eta, 0, shard, nshards);
   return sym_device(c, kind, v, eta, out, shard, nshards);
 }
 
@@ -1180,6 +1194,11 @@ int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double
 
 int rmb_blob_blob_force_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
   return force_device_impl(c, eps, b, blob_radius, out);
+}
+
+int rmb_blob_blob_force_pairshard_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out, long shard,
+                                         long nshards) {
+  return force_device_impl(c, eps, b, blob_radius, out, nullptr, shard, nshards);
 }
 
 int rmb_blob_blob_force_radii_device(rmb_ctx* c, const double* radii_dev, double eps, double b, double* out) {

@@ -169,11 +169,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force32_kernel(const SymFo
   double* accj = accj_all[wave];
   const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
-  const long s_total = a.n_units * 64;
+  const long s_total = a.step_end - a.step_begin;
   const long spw = (s_total + n_waves - 1) / n_waves;
-  long s = w * spw;
+  long s = a.step_begin + w * spw;
   long s_end = s + spw;
-  if (s_end > s_total) s_end = s_total;
+  if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
   if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
   int I_cur = -1;

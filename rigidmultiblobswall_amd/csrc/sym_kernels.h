@@ -326,6 +326,7 @@ struct SymForceArgs {
   double eps_over_b, inv_b, two_a;
   ExpConsts ec;
   const double* radii;  // RADII variant: one radius per blob, contact distance a_i + a_j (forces_numba.py:73-122)
+  long step_begin, step_end;   // rotation steps [begin, end) of the n_units * 64 this launch covers (pair shard)
 };
 
 // f0(r) dr for one pair; dr = r_j - r_i (minimal image), two_a = contact distance of the pair.
@@ -360,11 +361,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
   double* accj = accj_all[wave];
   const long n_waves = (long)gridDim.x * kSymWaves;
   const long w = (long)blockIdx.x * kSymWaves + wave;
-  const long s_total = a.n_units * 64;
+  const long s_total = a.step_end - a.step_begin;
   const long spw = (s_total + n_waves - 1) / n_waves;
-  long s = w * spw;
+  long s = a.step_begin + w * spw;
   long s_end = s + spw;
-  if (s_end > s_total) s_end = s_total;
+  if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
   if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
   int I_cur = -1;

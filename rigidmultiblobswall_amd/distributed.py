@@ -54,7 +54,10 @@ class HipBackend(object):
     return self.ctx.blob_blob_force_device(eps, b, a, out=out, device=self.device)
 
   def supports_pairshard(self, kind, periodic):
-    return kind in ("tt", "tr", "rt", "rr")
+    return kind in ("tt", "tr", "rt", "rr", "tt_free")
+
+  def blob_blob_force_pairshard(self, eps, b, a, shard, nshards, out=None):
+    return self.ctx.blob_blob_force_pairshard_device(eps, b, a, shard, nshards, out=out, device=self.device)
 
   def matvec_pairshard(self, kind, v_full, eta, shard, nshards, out=None):
     return self.ctx.matvec_pairshard_device(kind, v_full, eta, shard, nshards, out=out)
@@ -161,6 +164,13 @@ class ShardedMobility(object):
       if self.world > 1:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
+    if (vec2_full is None and in_plane and kind in ("tt", "tr") and hasattr(self.backend, "matvec_op_pairshard")):
+      # in-plane products are a row / column mask of the symmetric matrix: pair shard of the one-vector operation
+      part = out if out is not None else torch.empty(3 * self.n, dtype=torch.float64, device=self.device)
+      self.backend.matvec_op_pairshard(kind + "_multi", (v,), eta, self.rank, self.world, in_plane=True, outs=[part])
+      if self.world > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+      return part
     v2 = self._to_dev(vec2_full) if vec2_full is not None else None
     if kind == "tt_tr" and v2 is not None and hasattr(self.backend, "matvec_op_pairshard"):
       # fused M_tt f + M_tr tau: one pass over this rank's pair shard for both blocks, one all-reduce
@@ -234,7 +244,13 @@ class ShardedMobility(object):
     raise ValueError("unknown operation %r" % (op,))
 
   def blob_blob_force_replicated(self, eps, b, a):
-    """Forces on ALL blobs on every rank: each rank sweeps its own target block, blocks are all-gathered."""
+    """Forces on ALL blobs on every rank: pair shard of the symmetric force kernel (F_ji = -F_ij, each unordered pair
+    once) + one all-reduce; backends without it sweep their own target block and all-gather the blocks."""
+    if hasattr(self.backend, "blob_blob_force_pairshard"):
+      part = self.backend.blob_blob_force_pairshard(eps, b, a, self.rank, self.world)
+      if self.world > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+      return part
     f_local = self.backend.blob_blob_force(eps, b, a)
     f_full, _ = self._all_gather_blocks(f_local.view(-1), None)
     return f_full if self.world == 1 else f_full.clone()

@@ -69,11 +69,14 @@ def main():
     if e > b:
       assert rel(u_loc, ref[3 * b:3 * e]) < 1e-12, (N, "target shard")
     checked += 1
-    # forces: own target block + all-gather
+    # forces: pair shard of the symmetric force kernel + all-reduce; free surface: pair shard + all-reduce
     single.set_positions(rd, a, L, wall=False)
     rc.set_positions(rd, a, L, False)
     F = rc.blob_blob_force_device(0.7, 0.15, a)
     assert rel(F, single.blob_blob_force_device(0.7, 0.15, a)) < 1e-12
+    u = rc.matvec_device("tt_free", vs[0], eta)
+    assert rel(u, single.matvec_device("tt_free", vs[0], eta)) < 1e-12
+    checked += 2
   torch.cuda.synchronize()
   dist.barrier()
   if rank == 0:

@@ -61,6 +61,14 @@ class SequentialShardsBackend(HipBackend):
     self.ctx.set_target_range(0, n)
     return torch.cat(blocks)
 
+  def blob_blob_force_pairshard(self, eps, b, a, shard, nshards, out=None):
+    tot = None
+    for g in range(self.G):
+      part = self.ctx.blob_blob_force_pairshard_device(eps, b, a, g, self.G, device=self.device)
+      tot = part if tot is None else tot.add_(part)
+      self.launches += 1
+    return tot
+
   def blob_blob_force(self, eps, b, a, out=None):
     return self._over_target_blocks(lambda: self.ctx.blob_blob_force_device(eps, b, a, device=self.device))
 

@@ -733,3 +733,31 @@ def test_streams_that_are_destroyed_between_steps(Ctx, oracle, torch_mod):
     assert rel_err(out.cpu().numpy(), ref) < TOL_D2
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("N,G,L", [(1000, 2, None), (4097, 3, None), (90, 4, None), (700, 2, (14.0, 16.0, 0.0))])
+def test_force_and_free_surface_pair_shards_sum_to_the_full_result(Ctx, oracle, torch_mod, N, G, L):
+  """rmb_blob_blob_force_pairshard_device and the RMB_TT_FREE_SURFACE pair shard: what the ranks of a G-GPU run each
+  evaluate sums to the oracle's forces / free-surface velocities (also below the 128-blob threshold of the symmetric
+  path and with pseudo-periodic images)."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(N, seed=N + 11)
+  eps, b = 0.4, 0.3 * a
+  Lz = np.zeros(3) if L is None else np.asarray(L, dtype=np.float64)
+  F_ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=Lz, repulsion_strength=eps, debye_length=b, blob_radius=a)
+  fd = _dev(torch, f)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(r, a, Lz, wall=False)
+    parts = [ctx.blob_blob_force_pairshard_device(eps, b, a, g, G).cpu().numpy() for g in range(G)]
+    assert rel_err(sum(parts).reshape(-1, 3), F_ref) < 1e-12
+    assert max(np.abs(p).max() for p in parts) > 0
+    if L is None:
+      u_ref = oracle.free_surface_mobility_trans_times_force_oracle(r, f, eta, a)
+      u = sum(ctx.matvec_pairshard_device("tt_free", fd, eta, g, G).cpu().numpy() for g in range(G))
+      assert rel_err(u, u_ref) < TOL_D2
+    from rigidmultiblobswall_amd._lib import RmbError
+    with pytest.raises(RmbError):
+      ctx.blob_blob_force_pairshard_device(eps, b, a, G, G)
+  finally:
+    ctx.close()

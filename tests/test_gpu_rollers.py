@@ -166,3 +166,21 @@ def test_driven_dense_monolayer_against_the_reference_integrator():
   assert integ.invalid_configuration_count == int(g["invalid_configuration_count"]) == 0
   assert h_ref[-1] > 2.0 * h_ref[0] and worst < 0.02, worst
   integ.close()
+
+
+def test_force_kernel_in_use_follows_the_precision_switches(oracle):
+  """precision = 'single' runs the blob-blob forces in float too (the reference's GPU force kernel is always float,
+  forces_pycuda.py:14-21); force_precision = 'double' pins them to fp64 while the products stay single."""
+  from rigidmultiblobswall_amd.rollers import RollersIntegrator
+  N, a, eta = 3000, 0.4, 1.1
+  r0 = _monolayer(N, a, 5, spacing=2.2)
+  integ = RollersIntegrator(r0, "stochastic_adams_bashforth_rollers", a, eta, tolerance=1e-3, device="cuda:0", seed=4)
+  integ.repulsion_strength, integ.debye_length = 0.5, 0.1
+  ref = oracle.calc_blob_blob_forces_oracle(r0, periodic_length=np.zeros(3), repulsion_strength=0.5, debye_length=0.1, blob_radius=a)
+  err = {}
+  for prec, fprec in (("double", "follow"), ("single", "follow"), ("single", "double"), ("double", "single")):
+    integ.precision, integ.force_precision = prec, fprec
+    err[(prec, fprec)] = rel_err(integ.calc_blob_blob_forces(integ.location).cpu().numpy(), ref)
+  assert err[("double", "follow")] < 1e-12 and err[("single", "double")] < 1e-12, err
+  assert 1e-9 < err[("single", "follow")] < 1e-4 and 1e-9 < err[("double", "single")] < 1e-4, err
+  integ.close()
