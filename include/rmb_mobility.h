@@ -91,13 +91,13 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          pairs has no one-sided form).  Forces: 1 and 2 both take the one-sided sweep.
  *   "precision"       [64] 32 = single precision on the default symmetric path with open boundaries (the
  *                          reference's `precision = 'single'` build, mobility_pycuda.py:7-19) for tt / tr / rt / rr,
- *                          RMB_TT_TR, the in-plane products, the grand / force-column / k-vector operations and the
+ *                          RMB_TT_TR, RMB_TT_FREE_SURFACE, the in-plane products, the grand / force-column / k-vector operations and the
  *                          blob-blob forces (the reference's GPU force kernel is always single precision,
  *                          forces_pycuda.py:14-21) (sym32_kernels.h, symx32_kernels.h): pair arithmetic in fp32
  *                          (~1e-6 relative, separations from a head / tail split of the fp64 positions), partial sums,
  *                          self terms and scaling in fp64; 1.5-1.6x faster.
  *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes,
- *                          free-surface / per-blob-radii mobility products, pair shards of kinds other than tt and
+ *                          per-blob-radii mobility products, pair shards of tr / rt / rr and
  *                          the source->target operators compute in fp64 whatever this says.  Other values:
  *                          RMB_ERR_ARG.  The "wave_clock" / "skip_pairs" diagnostics exist in the fp64 kernels only:
  *                          a product that would run an fp32 kernel with one of them set returns RMB_ERR_STATE.

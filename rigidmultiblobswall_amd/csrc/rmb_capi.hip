@@ -455,8 +455,8 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
     RMB_SX_ROW32(rmb::OpSingle<rmb::KIND_RT>, rmb::OpSingle32<rmb::KIND_RT>), RMB_SX_ROW32(rmb::OpSingle<rmb::KIND_RR>, rmb::OpSingle32<rmb::KIND_RR>),
     RMB_SX_ROW32(rmb::OpFusedRow, rmb::OpFusedRow32), RMB_SX_ROW32(rmb::OpGrand, rmb::OpGrand32), RMB_SX_ROW32(rmb::OpColumnF, rmb::OpColumnF32),
     // the free-surface operation takes raw heights: only the wall = 0 column is ever launched
-    {{make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
-     {make_symx_entry<rmb::OpFreeSurface, false, false>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
+    {{make_symx_entry<rmb::OpFreeSurface, false, false, rmb::OpFreeSurface32>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
+     {make_symx_entry<rmb::OpFreeSurface, false, false, rmb::OpFreeSurface32>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
     RMB_SX_ROW(rmb::OpRadiiTT),
 #define RMB_SX_K(K) RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_TT, K), RMB_SX_KIND32(rmb::KIND_TT, K)), RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_TR, K), RMB_SX_KIND32(rmb::KIND_TR, K)), \
                     RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_RT, K), RMB_SX_KIND32(rmb::KIND_RT, K)), RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_RR, K), RMB_SX_KIND32(rmb::KIND_RR, K))

@@ -2,8 +2,8 @@
 //
 // WHAT: context option "precision" = 32 (the reference's `precision = 'single'` build, mobility_pycuda.py:7-19) for the
 // products besides tt: tr / rt / rr, the fused row M_tt f + M_tr tau (K11 / K12), the 6N grand mobility and the force
-// column [M_tt; M_rt] f -- everything the single-blob roller steppers apply per step -- and one block on k = 2..4
-// vectors (lockstep solves), with open boundaries.
+// column [M_tt; M_rt] f -- everything the single-blob roller steppers apply per step -- one block on k = 2..4
+// vectors (lockstep solves) and the free-surface product, with open boundaries.
 //
 // HOW: symx_kernel's skeleton (symx_kernels.h: tile pairs, rotation, static balanced schedule, pair shards, fp64 global
 // accumulators, fp64 finalize with self terms / B-damping / prefactor) with the pair arithmetic of pair_blocks32.h (the
@@ -99,6 +99,30 @@ struct OpKindK32 {         // one block applied to K vectors (lockstep solves): 
         else                           f32::rt_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
       }
     }
+  }
+};
+
+// Free (stress-free) surface at z = 0 (OpFreeSurface of symx_kernels.h in float; mobility_numba.py:1846-1925, the
+// reference's single-precision build covers it too, mobility_pycuda.py:1974): RPY(d) + RPY(R) P with the image block
+// reciprocal, both directions from one set of coefficients.  Raw heights (set_positions with wall = 0).
+struct OpFreeSurface32 {
+  static constexpr int NIN = 1, NOUT = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts& k, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const f32::Geom g = f32::make_geom<true>(dx, dy, dz, zi, zj);
+    const f32::TTc a = f32::tt_coeffs<false>(k, g, zi, zj);
+    f32::tt_apply<false, false>(a, g, vi, vj, ui, t);
+    float cF, cD;
+    f32::rpy_tt_coeffs(k, __builtin_fmaf(g.Rz, g.Rz, g.rho2), g.iR, g.iR2, cF, cD);
+    const float sj = cD * __builtin_fmaf(-g.Rz, vj[2], __builtin_fmaf(dy, vj[1], dx * vj[0]));
+    const float si = cD * __builtin_fmaf(g.Rz, vi[2], __builtin_fmaf(dy, vi[1], dx * vi[0]));
+    ui[0] = __builtin_fmaf(cF, vj[0], ui[0]); ui[0] = __builtin_fmaf(sj, dx, ui[0]);
+    ui[1] = __builtin_fmaf(cF, vj[1], ui[1]); ui[1] = __builtin_fmaf(sj, dy, ui[1]);
+    ui[2] = __builtin_fmaf(-cF, vj[2], ui[2]); ui[2] = __builtin_fmaf(sj, g.Rz, ui[2]);
+    t[0] = __builtin_fmaf(si, dx, __builtin_fmaf(cF, vi[0], t[0]));
+    t[1] = __builtin_fmaf(si, dy, __builtin_fmaf(cF, vi[1], t[1]));
+    t[2] = __builtin_fmaf(-si, g.Rz, __builtin_fmaf(-cF, vi[2], t[2]));
   }
 };
 

@@ -466,6 +466,8 @@ def test_single_precision_other_products(Ctx, oracle, torch_mod, wall, N):
          "mv2_a": o["tt_f"], "mv2_b": o["tt_t"]}
   if wall:
     ref["in_plane_tt"], ref["in_plane_tr"] = W("tt", f, True), W("tr", f, True)
+  else:
+    ref["free_surface"] = oracle.free_surface_mobility_trans_times_force_oracle(r, f, eta, a)
   ctx = Ctx(0)
   try:
     ctx.set_positions(r, a, np.zeros(3), wall=wall)
@@ -486,6 +488,8 @@ def test_single_precision_other_products(Ctx, oracle, torch_mod, wall, N):
       if wall:
         out["in_plane_tt"] = ctx.matvec_device("tt", fd, eta, in_plane=True).cpu().numpy()
         out["in_plane_tr"] = ctx.matvec_device("tr", fd, eta, in_plane=True).cpu().numpy()
+      else:
+        out["free_surface"] = ctx.matvec_device("tt_free", fd, eta).cpu().numpy()
       return out
 
     p64 = products()
