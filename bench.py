@@ -75,6 +75,8 @@ def parse_args():
                   help="untimed, declared clock pre-warm before the warm-up steps (0 disables)")
   ap.add_argument("--no-sweep", action="store_true", help="skip the N_blobs sweep, decompositions and config extras")
   ap.add_argument("--no-cpu", action="store_true")
+  ap.add_argument("--no-host-surface", action="store_true",
+                  help="skip the host_surface extra (profiling runs: the last K dispatches of the trace are then the timed ones)")
   return ap.parse_args()
 
 
@@ -366,7 +368,7 @@ def rank_main(args):
                               "kernel_ms_avg": round(ckern, 5), "steps": args.steps, "warmup": args.warmup,
                               "when": "first thing this process ran on the GPU, before `prewarm`"}
 
-  if rank == 0 and world == 1:
+  if rank == 0 and world == 1 and not args.no_host_surface:
     # End to end through the plugin surface, the call shape of the reference's callers (mobility/mobility.py:222-252,
     # multi_bodies/multi_bodies.py:445): numpy arrays in, a new numpy array out, synchronous, PCIe-inclusive.  Never
     # `value`.  The positions stay resident while the caller passes the same r_vectors (one compare per call).

@@ -11,7 +11,7 @@ STEPS=${3:-50}
 WARMUP=${4:-5}
 PREWARM=${5:-0}
 OUT=gpurun_out/prof_${TAG}
-ARGS="bench.py --blobs ${BLOBS} --steps ${STEPS} --warmup ${WARMUP} --prewarm-ms ${PREWARM} --no-sweep --no-cpu"
+ARGS="bench.py --blobs ${BLOBS} --steps ${STEPS} --warmup ${WARMUP} --prewarm-ms ${PREWARM} --no-sweep --no-cpu --no-host-surface"
 mkdir -p ${OUT}
 export TMPDIR=/tmp
 echo "python3 ${ARGS}" > ${OUT}/command.txt
