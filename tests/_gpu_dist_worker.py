@@ -54,6 +54,18 @@ def main():
       for g, s in zip(got, ref):
         assert rel(g, s) < TOL, (N, op)
         checked += 1
+    # bit-reproducible multi-rank products: every rank's shard is a fixed-order reduction of whole tile pairs
+    rc.set_option("deterministic", 2)
+    for kind in ("tt", "rr"):
+      u1 = rc.matvec_device(kind, vs[0], eta).clone()
+      u2 = rc.matvec_device(kind, vs[0], eta)
+      assert torch.equal(u1, u2), (N, kind, "not bit-reproducible")
+      assert rel(u1, single.matvec_device(kind, vs[0], eta)) < TOL, (N, kind)
+    g1 = [x.clone() for x in rc.matvec_op_device("grand", vs[:2], eta)]
+    g2 = rc.matvec_op_device("grand", vs[:2], eta)
+    assert all(torch.equal(x, y) for x, y in zip(g1, g2))
+    rc.set_option("deterministic", 0)
+    checked += 3
     ua, ub = rc.matvec2_device("tt", vs[0], vs[1], eta)
     sa, sb = single.matvec2_device("tt", vs[0], vs[1], eta)
     assert rel(ua, sa) < TOL and rel(ub, sb) < TOL
