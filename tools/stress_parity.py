@@ -91,3 +91,50 @@ for case in range(n_cases // 3):
   if max(e1, e2, e3) > 1e-10:
     print("CASE2 %d N=%d L=%s forces %.2e fused %.2e source_target %.2e" % (case, N, L, e1, e2, e3), flush=True)
 print("forces / fused / source-target: %d cases, worst relative error %.3e" % (n_cases // 3, worst2))
+
+# --- round 3: pair shards (what the ranks of a G-GPU run evaluate), atomic and bit-reproducible, forces, free surface ---
+import torch
+rng = np.random.RandomState(1234 + (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+worst_shard = 0.0
+ctx = MobilityContext(0)
+for case in range(max(20, n_cases // 4)):
+  N = int(rng.choice([5, 64, 65, 127, 128, 129, 300, 777, 1500, 4097, 9000]))
+  G = int(rng.choice([2, 3, 5, 8]))
+  kind = str(rng.choice(["tt", "tr", "rt", "rr"]))
+  wall = bool(rng.rand() < 0.7)
+  a, eta = float(0.1 + rng.rand()), float(0.5 + rng.rand())
+  box = a * (N ** (1.0 / 3.0)) * float(rng.choice([6.0, 2.2]))
+  r = rng.rand(N, 3) * box
+  if wall:
+    r[:, 2] += 1.05 * a
+  L = np.zeros(3)
+  if rng.rand() < 0.3:
+    L[0] = box * (1.0 + rng.rand())
+  v = rng.randn(N, 3)
+  pre = "single_wall" if wall else "no_wall"
+  ref = getattr(oracle, "%s_mobility_%s_oracle" % (pre, names[kind]))(r, v, eta, a, periodic_length=L)
+  vd = torch.as_tensor(v.reshape(-1), device="cuda")
+  ctx.set_positions(r, a, L, wall=wall)
+  errs = []
+  for det in (0, 2):
+    ctx.set_option("deterministic", det)
+    tot = sum(ctx.matvec_pairshard_device(kind, vd, eta, g, G).cpu().numpy() for g in range(G))
+    errs.append(np.linalg.norm(tot - ref) / np.linalg.norm(ref))
+    if det == 2:
+      again = sum(ctx.matvec_pairshard_device(kind, vd, eta, g, G).cpu().numpy() for g in range(G))
+      assert np.array_equal(again, tot), "deterministic shards differ between launches"
+  ctx.set_option("deterministic", 0)
+  eps, b = float(0.1 + rng.rand()), float(a * (0.1 + 0.4 * rng.rand()))
+  ctx.set_positions(r, a, L, wall=False)
+  F = sum(ctx.blob_blob_force_pairshard_device(eps, b, a, g, G).cpu().numpy() for g in range(G)).reshape(-1, 3)
+  F_ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=L, repulsion_strength=eps, debye_length=b, blob_radius=a)
+  errs.append(np.linalg.norm(F - F_ref) / max(np.linalg.norm(F_ref), 1e-300))
+  if not np.any(L > 0):
+    u = sum(ctx.matvec_pairshard_device("tt_free", vd, eta, g, G).cpu().numpy() for g in range(G))
+    u_ref = oracle.free_surface_mobility_trans_times_force_oracle(r, v, eta, a)
+    errs.append(np.linalg.norm(u - u_ref) / np.linalg.norm(u_ref))
+  worst_shard = max(worst_shard, max(errs))
+  if max(errs) > 1e-12:
+    print("SHARD CASE %d N=%d G=%d kind=%s wall=%s L=%s errs=%s" % (case, N, G, kind, wall, L, errs), flush=True)
+print("pair-shard cases %d, worst relative error %.3e" % (max(20, n_cases // 4), worst_shard))
+ctx.close()
