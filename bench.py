@@ -422,7 +422,8 @@ def rank_main(args):
     # both decompositions at 1e4 / 1e5 / 1e6 blobs (the metric is "... vs N_blobs at 1/2/4/8 MI355X")
     try:
       dec = {"pair_shard_allreduce": [], "target_shard_allgather": []}
-      for nb, st_, wu in ((10000, 50, 5), (100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
+      # the sizes of SURVEY 8(d): 1e4, 24 576 (configs[2]), 3.2e4, 1e5, 262 144 (configs[4]), 1e6 (configs[3])
+      for nb, st_, wu in ((10000, 50, 5), (24576, 20, 3), (32000, 20, 3), (100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
         rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "pair", 100.0 if nb == 10000 else 0.0)
         tb, prov = committed_traffic(nb, True) if world == 1 else (None, {})
         dec["pair_shard_allreduce"].append({
