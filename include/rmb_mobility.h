@@ -111,8 +111,9 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *   "chunks"          [0]  one-sided sweep: number of source chunks (blockIdx.y); 0 = chosen from the occupancy
  *   "sym_oversub"     [8]  symmetric kernels: launch up to this many times the resident workgroup count
  *   "sym_min_steps"   [64] symmetric kernels: floor on rotation steps per wave (one tile pair = 64 steps)
- *   "sym_fine_steps"  [32] symmetric kernels: floor on rotation steps per wave when the launch is smaller than one
- *                          resident round (one rank's pair shard of a small suspension)
+ *   "sym_fine_steps"  [0]  symmetric kernels: floor on rotation steps per wave when the launch is smaller than one
+ *                          resident round (small suspensions, one rank's pair shard); 0 = 16 while 16-step waves do
+ *                          not fill the chip, 32 beyond
  *   "sym_wps"         [0]  symmetric kernels: cap on resident workgroups per CU (0 = occupancy limit)
  *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
  *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics

@@ -98,7 +98,7 @@ struct rmb_ctx {
   long opt_precision = 64;     // 32: M_tt f (open boundaries) in single precision (sym32_kernels.h); everything else fp64
   long opt_force_precision = 0;  // blob-blob forces: 0 = follow "precision", 32 / 64 = pinned
   long opt_sym_min_steps = 64; // floor on rotation steps per wave (a unit is 64 steps)
-  long opt_sym_fine_steps = 32;  // floor on steps per wave when less than one resident round is left (pair shards, small N)
+  long opt_sym_fine_steps = 0;   // floor on steps per wave when less than one resident round is left (pair shards, small N); 0 = 16 or 32, chosen in plan_sym
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
   // timing ring (events around the sweep kernel)
@@ -287,12 +287,16 @@ int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long
   if (blocks > need) blocks = need;
   if (blocks > round) blocks -= blocks % round;   // whole rounds only: a partial last round is a tail
   if (blocks < round) {
-    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): shorter waves (down to
-    // "sym_fine_steps" = 32) beat leaving SIMDs with one or two waves and no latency hiding, but every wave pays its
-    // own loads and 384 global atomics on accumulators it shares with the other waves of its tile row, so more and
-    // shorter is worse again: 1/8 shard of 1e4 blobs 39.9 us at 16 steps x 1280 workgroups, 29.3 us at 32 x 776
-    // (tools/exp_shard_plan.py, profiles/r3_shard_plan.txt)
-    const long per_wg_fine = rmb::kSymWaves * c->opt_sym_fine_steps;
+    // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): shorter waves beat
+    // leaving SIMDs with one or two waves and no latency hiding, but every wave pays its own loads and 384 global
+    // atomics on accumulators it shares with the other waves of its tile row.
+    // Two regimes (tools/exp_small_n.py, tools/exp_shard_plan.py; profiles/r3_shard_plan.txt): while 16-step waves
+    // do not fill the chip (small N: <= 1500 blobs) the launch is latency-bound and more, shorter waves win
+    // (1000 blobs: 9.6 us at 16 steps, 13.0 at 32); once they would overfill it, every extra wave only adds its
+    // loads and flushes (1/8 shard of 1e4 blobs: 36.6 us at 16 steps x 1024 workgroups, 29.3 at 32 x 776).
+    long fine_steps = c->opt_sym_fine_steps;
+    if (fine_steps <= 0) fine_steps = (total + rmb::kSymWaves * 16L - 1) / (rmb::kSymWaves * 16L) <= round ? 16 : 32;
+    const long per_wg_fine = rmb::kSymWaves * fine_steps;
     long fine = (total + per_wg_fine - 1) / per_wg_fine;
     if (fine > round) fine = round;
     if (fine > blocks) blocks = fine;
@@ -1018,7 +1022,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
     c->opt_force_precision = value;
     return 0;
   }
-  if (!strcmp(key, "sym_fine_steps")) { c->opt_sym_fine_steps = value < 1 ? 1 : value; return 0; }
+  if (!strcmp(key, "sym_fine_steps")) { c->opt_sym_fine_steps = value < 0 ? 0 : value; return 0; }
   if (!strcmp(key, "sym_oversub")) { c->opt_sym_oversub = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_min_steps")) { c->opt_sym_min_steps = value < 1 ? 1 : value; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);

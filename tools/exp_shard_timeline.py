@@ -62,5 +62,5 @@ for extra in opts:
             "last wave ends at %.1f us" % (G, skip, ev, nw, wg, smax, dmed, dmax, emax), flush=True)
     print("G=%d: sweep + finalize end to end %.1f us per call (ideal share of the primed full sweep: see G=1 / G)" % (G, e2e), flush=True)
   for k in extra:
-    ctx.set_option(k, {"sym_min_steps": 64, "sym_oversub": 8, "sym_wps": 0}.get(k, 0))
+    ctx.set_option(k, {"sym_min_steps": 64, "sym_oversub": 8, "sym_wps": 0, "sym_fine_steps": 0}.get(k, 0))
 ctx.close()
