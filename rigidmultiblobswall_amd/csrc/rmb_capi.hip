@@ -76,6 +76,9 @@ struct rmb_ctx {
   DevBuf pos;      // double4[n]
   DevBuf r_stage;  // raw positions staging (host entry)
   DevBuf vec, vec2, out, partial, tmp3n;
+  DevBuf tile_bounds;            // bounding boxes of the 64-blob tiles (force kernel's tile culling); valid for the packed positions
+  bool tile_bounds_valid = false;
+  long opt_force_cull = 1;       // blob-blob forces: skip tile pairs beyond the range of the exponential (bit-exact)
   DevBuf det_ws;                 // per-unit partials of the deterministic symmetric pass
   long opt_det_workspace_mb = 8192;   // cap on the partial-result workspace of deterministic = 2 (symx_det_device)
   DevBuf st[8];    // scratch of the source->target entry point
@@ -731,13 +734,30 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
       a.step_begin = (long)(s_all * shard / nshards);
       a.step_end = (long)(s_all * (shard + 1) / nshards);
     }
+    // "precision" = 32, open boundaries: the single-precision kernel -- the arithmetic of the reference's own GPU force
+    // kernel (forces_pycuda.py:14-21)
+    const bool f32 = (c->opt_force_precision ? c->opt_force_precision : c->opt_precision) == 32 && !periodic;
+    // Tile culling: the force has the range of its exponential.  exp(-(r - 2a)/b) is exactly 0 in double precision
+    // beyond (r - 2a)/b = 745.2 (750 here; 110 for the float kernel), so a tile pair whose bounding boxes are further
+    // apart contributes nothing, bit for bit.  In a 262 144-roller monolayer that is 99 % of the tile pairs -- the
+    // reference's own answer to this is a k-d tree (`blob_blob_force_implementation tree_numba`).
+    a.bounds = nullptr; a.cull2 = 0.0;
+    if (c->opt_force_cull && !periodic && !radii && tiles > 1) {
+      if (!c->tile_bounds_valid) {
+        if (int rc = c->tile_bounds.reserve((size_t)6 * tiles * sizeof(double))) return rc;
+        hipLaunchKernelGGL(rmb::tile_bounds_kernel, dim3((unsigned)tiles), dim3(64), 0, c->stream, (const double4*)c->pos.p, n,
+                           (double*)c->tile_bounds.p);
+        RMB_HIP(hipGetLastError());
+        c->tile_bounds_valid = true;
+      }
+      const double reach = 2.0 * blob_radius + (f32 ? 110.0 : 750.0) * b;
+      a.bounds = (const double*)c->tile_bounds.p;
+      a.cull2 = reach * reach;
+    }
     static int socc[2][2] = {{0, 0}, {0, 0}};
     typedef void (*sforce_fn)(const rmb::SymForceArgs);
     const sforce_fn sfn = radii ? (periodic ? (sforce_fn)rmb::sym_force_kernel<true, true> : (sforce_fn)rmb::sym_force_kernel<false, true>)
                                 : (periodic ? (sforce_fn)rmb::sym_force_kernel<true, false> : (sforce_fn)rmb::sym_force_kernel<false, false>);
-    // "precision" = 32, open boundaries: the single-precision kernel -- the arithmetic of the reference's own GPU force
-    // kernel (forces_pycuda.py:14-21)
-    const bool f32 = (c->opt_force_precision ? c->opt_force_precision : c->opt_precision) == 32 && !periodic;
     static int socc32[2] = {0, 0};
     const sforce_fn sfn32 = radii ? (sforce_fn)rmb::sym_force32_kernel<true> : (sforce_fn)rmb::sym_force32_kernel<false>;
     const void* fn = f32 ? (const void*)sfn32 : (const void*)sfn;
@@ -809,6 +829,7 @@ int set_positions_impl(rmb_ctx* c, const double* r_dev, long n, double a, const 
   }
   c->n = n;
   c->a = a;
+  c->tile_bounds_valid = false;
   for (int k = 0; k < 3; ++k) c->L[k] = L ? L[k] : 0.0;
   c->wall = wall ? 1 : 0;
   c->tgt_begin = 0;
@@ -959,7 +980,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->wave_clock.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release();
+  c->wave_clock.release(); c->tile_bounds.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release();
   if (c->stream_switch) (void)hipEventDestroy(c->stream_switch);
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
@@ -1017,6 +1038,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
     c->opt_precision = value;
     return 0;
   }
+  if (!strcmp(key, "force_cull")) { c->opt_force_cull = value ? 1 : 0; return 0; }
   if (!strcmp(key, "force_precision")) {
     if (value != 0 && value != 32 && value != 64) return fail(RMB_ERR_ARG, "force_precision must be 0 (follow \"precision\"), 32 or 64");
     c->opt_force_precision = value;
@@ -1035,7 +1057,7 @@ int rmb_ctx_get_option(rmb_ctx* c, const char* key, long* value) {
       {"fused_symmetric", &c->opt_fused_symmetric}, {"symx_single", &c->opt_symx_single},
       {"deterministic", &c->opt_deterministic}, {"det_workspace_mb", &c->opt_det_workspace_mb}, {"sym_wps", &c->opt_sym_wps},
       {"wave_clock", &c->opt_wave_clock}, {"skip_pairs", &c->opt_skip_pairs}, {"sym_pin", &c->opt_sym_pin},
-      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps},
+      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"force_cull", &c->opt_force_cull}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps},
       {"sym_min_steps", &c->opt_sym_min_steps}};
   for (const auto& e : table)
     if (!strcmp(key, e.name)) { *value = *e.v; return 0; }

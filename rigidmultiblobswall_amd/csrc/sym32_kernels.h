@@ -193,6 +193,13 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force32_kernel(const SymFo
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
+    if (a.bounds != nullptr && I != J && tile_gap2(a.bounds, I, J) > a.cull2) {
+      // beyond the range of the float exponential (cull2 = (2a + 110 b)^2 here): the unit contributes exactly zero
+      if (k1 == 64) {
+        if (++J == a.n_tiles) { ++I; J = I; }
+      }
+      continue;
+    }
     if (I != I_cur) {
       if (I_cur >= 0) flush_row();
       I_cur = I;

@@ -327,7 +327,47 @@ struct SymForceArgs {
   ExpConsts ec;
   const double* radii;  // RADII variant: one radius per blob, contact distance a_i + a_j (forces_numba.py:73-122)
   long step_begin, step_end;   // rotation steps [begin, end) of the n_units * 64 this launch covers (pair shard)
+  // Tile culling (open boundaries, uniform radius): bounds[T] = (xmin, ymin, zmin, xmax, ymax, zmax) of tile T
+  // (tile_bounds_kernel), cull2 = (2a + 750 b)^2.  A tile pair whose boxes are further apart than that holds only
+  // pairs with (r - 2a)/b > 750, for which exp underflows to exactly 0 here (exp_nonpositive) and in the reference
+  // (exp(-745.2) is the smallest denormal): skipping the unit changes no bit of the result.  nullptr = no culling.
+  const double* bounds;
+  double cull2;
 };
+
+// squared distance between the bounding boxes of two tiles (wave-uniform: every lane reads the same twelve doubles)
+__device__ __forceinline__ double tile_gap2(const double* bounds, int I, int J) {
+  const double* bi = bounds + 6L * I;
+  const double* bj = bounds + 6L * J;
+  double g2 = 0.0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double g = fmax(fmax(bj[d] - bi[3 + d], bi[d] - bj[3 + d]), 0.0);
+    g2 = __builtin_fma(g, g, g2);
+  }
+  return g2;
+}
+
+// bounding box of every 64-blob tile of the packed positions; one wave per tile
+__global__ __launch_bounds__(64) void tile_bounds_kernel(const double4* pos, long n, double* bounds) {
+  const long T = blockIdx.x;
+  const long i = 64 * T + threadIdx.x;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  if (i < n) {
+    const double4 p = pos[i];
+    lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+      hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+    }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { bounds[6 * T + d] = lo[d]; bounds[6 * T + 3 + d] = hi[d]; }
+  }
+}
 
 // f0(r) dr for one pair; dr = r_j - r_i (minimal image), two_a = contact distance of the pair.
 // Returns the force ON i; the force on j is minus it.
@@ -378,6 +418,13 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
+    if (a.bounds != nullptr && I != J && tile_gap2(a.bounds, I, J) > a.cull2) {
+      // every pair of this unit is beyond the range of the exponential: contributes exactly zero
+      if (k1 == 64) {
+        if (++J == a.n_tiles) { ++I; J = I; }
+      }
+      continue;
+    }
     if (I != I_cur) {
       if (I_cur >= 0 && vi_ok) {
         __hip_atomic_fetch_add(&a.acc[i], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -765,3 +765,37 @@ def test_force_and_free_surface_pair_shards_sum_to_the_full_result(Ctx, oracle, 
       ctx.blob_blob_force_pairshard_device(eps, b, a, G, G)
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_force_tile_culling_changes_no_bit(Ctx, oracle, prec):
+  """Tile pairs beyond the range of the exponential are skipped (`force_cull`): exp(-(r - 2a)/b) is exactly zero there in
+  the kernel and in the reference, so the result is the same array with and without the culling -- here on a monolayer
+  whose extent is 40x the force range (most tile pairs culled) and on a cloud within the range (none culled)."""
+  rng = np.random.RandomState(4)
+  a, b, eps = 0.5, 0.004, 0.3                 # range 2a + 750 b = 4 (float kernel: 2a + 110 b = 1.44)
+  n = 6000
+  side = int(np.ceil(np.sqrt(n)))
+  ij = np.array([(i, j) for i in range(side) for j in range(side)][:n], dtype=np.float64)
+  r_far = np.concatenate([ij * 2.05 * a + 0.02 * rng.rand(n, 2), a * (1.0 + rng.rand(n, 1))], axis=1)   # 160 x 160 units
+  r_near = rng.rand(500, 3) * 3.0
+  for r in (r_far, r_near):
+    ctx = Ctx(0)
+    try:
+      ctx.set_positions(r, a, np.zeros(3), wall=False)
+      ctx.set_option("precision", prec)
+      ctx.set_option("deterministic", 0)
+      res = {}
+      for cull in (1, 0, 1):
+        ctx.set_option("force_cull", cull)
+        res.setdefault(cull, []).append(ctx.blob_blob_force(eps, b, a))
+      # atomics: run-to-run differences are at round-off, a culled pair contributes exactly 0 -> compare at round-off
+      scale = np.abs(res[0][0]).max()
+      assert np.abs(res[1][0] - res[0][0]).max() <= 1e-13 * scale and np.abs(res[1][1] - res[0][0]).max() <= 1e-13 * scale
+      ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=np.zeros(3), repulsion_strength=eps, debye_length=b, blob_radius=a)
+      assert rel_err(res[1][0], ref) < (1e-12 if prec == 64 else 1e-4)
+      # pair shards cull too and still sum to the forces
+      parts = sum(ctx.blob_blob_force_pairshard_device(eps, b, a, g, 3).cpu().numpy() for g in range(3)).reshape(-1, 3)
+      assert rel_err(parts, ref) < (1e-12 if prec == 64 else 1e-4)
+    finally:
+      ctx.close()
