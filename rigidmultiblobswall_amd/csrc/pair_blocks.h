@@ -132,23 +132,26 @@ __device__ __forceinline__ TTc tt_block(const PairConsts& k, const Geom& g, doub
     // every fma below has at most one non-inline constant (gfx9 VOP3 reads one SGPR / literal): no v_mov in the loop
     const double s = g.iR, q = g.iR2;
     const double q3 = s * q;
-    const double T2 = k.tt_k2 * q;                            // 2T
+    // Base variables (round 3): Tq = T/3 = a^2 q / 3 and p30 = 30 U - 6 = 6 (5U - 1), so that T^2-terms need ONE multiply
+    // (Tc = Tq^2 = T^2/9;  (2/3) T^2 = 6 Tc) and every product below has coefficient one:
+    //   2T (5U - 1) = Tq p30,   (2/3) T^2 (5U - 1) = Tc p30,   2T (1/3 - U) = Tq (2 - 6U)
+    const double Tq = k.tt_k3 * q;
     const double U = __builtin_fma(-g.rho2, q, 1.0);
     const double om = __builtin_fma(-g.r2, q, 1.0);           // 4W = 4 z_i z_j / R^2 = 1 - r^2/R^2
-    const double p5 = __builtin_fma(U, 5.0, -1.0);            // 5U - 1
-    const double Ta = (T2 * T2) * (1.0 / 6.0);                // (2/3) T^2
-    // H = 1 - 6W + 2T (5U - 1) + T^2 (10 - 70U/3),   T^2 (10 - 70U/3) = Ta (15 - 35U) = Ta (8 - 7 p5)
-    const double H = __builtin_fma(Ta, __builtin_fma(p5, k.m7, 8.0), __builtin_fma(T2, p5, __builtin_fma(om, -1.5, 1.0)));
+    const double p30 = __builtin_fma(U, k.c30, -6.0);         // k.c30 from the scalar file, -6 in a loop-invariant VGPR
+    const double Tc = Tq * Tq;
+    // H = 1 - 6W + 2T (5U - 1) + T^2 (10 - 70U/3),   T^2 (10 - 70U/3) = 6 Tc (15 - 35U) = Tc (48 - 7 p30)
+    const double H = __builtin_fma(Tc, __builtin_fma(p30, k.m7, 48.0), __builtin_fma(Tq, p30, __builtin_fma(om, -1.5, 1.0)));
     const double cDdz = cD * g.dz;
     // Q3 = cD d_z + s q (R_z H - 2 z_i): 2 z_i does not change along a lane's row of pairs (hoisted);  Q3 + Q4 = 2 (cD - s q) d_z
     m.Q3 = __builtin_fma(q3, __builtin_fma(g.Rz, H, -(zi + zi)), cDdz);
     m.Q4 = __builtin_fma(__builtin_fma(-q3, g.dz, cDdz), 2.0, -m.Q3);
-    m.P = __builtin_fma(-q3, __builtin_fma(Ta, -10.0, H), cD);                     // H - 20 T^2/3
-    const double G1 = __builtin_fma(Ta, p5, __builtin_fma(T2, (1.0 / 3.0) - U, __builtin_fma(om, 0.5, 1.0)));
+    m.P = __builtin_fma(-q3, __builtin_fma(Tc, -60.0, H), cD);                     // H - 20 T^2/3
+    const double G1 = __builtin_fma(Tc, p30, __builtin_fma(Tq, __builtin_fma(U, k.m6, 2.0), __builtin_fma(om, 0.5, 1.0)));
     m.F = __builtin_fma(-G1, s, cF);
-    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U (1 - U)/3 - 8/3)  =  (om - 4Ta) + U (H - 2 - 2 (2T - 10Ta))
-    // (the zz polynomial through H: U^2 enters both with the same coefficient 10T - 35Ta)
-    const double Zb = __builtin_fma(U, __builtin_fma(__builtin_fma(Ta, -10.0, T2), -2.0, H - 2.0), __builtin_fma(Ta, -4.0, om));
+    // Zb = 4W - U (1 + 6W) + T U (10U - 6) + T^2 (70 U (1 - U)/3 - 8/3)  =  (om - 24 Tc) + U (H - 2 - 12 Tq + 120 Tc)
+    // (the zz polynomial through H: U^2 enters both with the same coefficient 10T - 35 (2/3) T^2)
+    const double Zb = __builtin_fma(U, __builtin_fma(Tc, 120.0, __builtin_fma(Tq, -12.0, H - 2.0)), __builtin_fma(Tc, -24.0, om));
     m.Szz = __builtin_fma(s, Zb, __builtin_fma(cDdz, g.dz, m.F));
   } else {
     m.F = cF; m.P = cD;          // tt_apply<false> contracts these two directly

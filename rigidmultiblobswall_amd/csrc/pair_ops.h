@@ -35,6 +35,7 @@ struct PairConsts {
   // tt
   double tt_k1;    // 2 a^2 / 3
   double tt_k2;    // 2 a^2
+  double tt_k3;    // a^2 / 3            (Tq = T/3 of the wall tt block, pair_blocks.h)
   double tt_n0;    // 4/(3a)             also the unbounded self term
   double tt_n1;    // 3/(8 a^2)
   double tt_n2;    // 1/(8 a^2)
@@ -52,6 +53,7 @@ struct PairConsts {
   double m7;       // -7
   double m6;       // -6
   double c15;      // 1.5
+  double c30;      // 30
 };
 
 struct Vec3 { double x, y, z; };

@@ -121,6 +121,7 @@ rmb::PairConsts make_pair_consts(double a) {
   k.four_a2 = 4.0 * a2;
   k.tt_k1 = 2.0 * a2 / 3.0;
   k.tt_k2 = 2.0 * a2;
+  k.tt_k3 = a2 / 3.0;
   k.tt_n0 = 4.0 / (3.0 * a);
   k.tt_n1 = 3.0 / (8.0 * a2);
   k.tt_n2 = 1.0 / (8.0 * a2);
@@ -134,6 +135,7 @@ rmb::PairConsts make_pair_consts(double a) {
   k.m7 = -7.0;
   k.m6 = -6.0;
   k.c15 = 1.5;
+  k.c30 = 30.0;
   return k;
 }
 
@@ -254,10 +256,10 @@ int sym_accumulators(rmb_ctx* c, long n_pad) {
 
 rmb::f32::PairConsts pair_consts32(const rmb::PairConsts& k) {
   rmb::f32::PairConsts f;
-  f.a2 = (float)k.a2; f.four_a2 = (float)k.four_a2; f.tt_k1 = (float)k.tt_k1; f.tt_k2 = (float)k.tt_k2;
+  f.a2 = (float)k.a2; f.four_a2 = (float)k.four_a2; f.tt_k1 = (float)k.tt_k1; f.tt_k2 = (float)k.tt_k2; f.tt_k3 = (float)k.tt_k3;
   f.tt_n0 = (float)k.tt_n0; f.tt_n1 = (float)k.tt_n1; f.tt_n2 = (float)k.tt_n2;
   f.rr_m0 = (float)k.rr_m0; f.rr_m1 = (float)k.rr_m1; f.rr_m2 = (float)k.rr_m2; f.rr_m3 = (float)k.rr_m3; f.rr_m4 = (float)k.rr_m4;
-  f.c_q0 = (float)k.c_q0; f.c_q1 = (float)k.c_q1; f.m7 = (float)k.m7; f.m6 = (float)k.m6; f.c15 = (float)k.c15;
+  f.c_q0 = (float)k.c_q0; f.c_q1 = (float)k.c_q1; f.m7 = (float)k.m7; f.m6 = (float)k.m6; f.c15 = (float)k.c15; f.c30 = (float)k.c30;
   return f;
 }
 

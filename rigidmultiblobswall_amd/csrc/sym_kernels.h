@@ -8,7 +8,7 @@
 // cheap contractions are done twice.  With W = f1 I + f2 e e^T + f3 e z^T + f4 z e^T + f5 z z^T,
 //   W v   = f1 v + [f2 (e.v) + f3 v_z] e + [f4 (e.v) + f5 v_z] z
 //   W^T v = f1 v + [f2 (e.v) + f4 v_z] e + [f3 (e.v) + f5 v_z] z          (f3 <-> f4)
-// => 81 VALU instructions per unordered pair (77 fp64; pair_blocks.h: five-entry block + closed-form wall
+// => 80 VALU instructions per unordered pair (76 fp64; pair_blocks.h: five-entry block + closed-form wall
 // polynomials through H) instead of 2 x 78 in the one-sided sweep.
 //
 // Work decomposition: blobs are cut into tiles of 64; a work unit is a tile pair (I <= J).  One wave64
