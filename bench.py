@@ -501,6 +501,7 @@ def rank_main(args):
       integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
       integ.debye_length = integ.debye_length_wall = 0.0656
       integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
+      integ.report_rejections = False     # stdout carries ONE JSON line; rejected steps are counted on it
       integ.advance_time_step(0.016)      # warm-up (first step is forward Euler)
       torch.cuda.synchronize(device)
       if world > 1:
@@ -568,6 +569,7 @@ def rank_main(args):
       FT5 = torch.zeros((nb5, 6), dtype=torch.float64, device=device)
       FT5[:, 4] = 8 * math.pi * eta5 * R5 ** 3 * 62.8
       ri.external_force_torque = lambda it: FT5
+      ri.report_rejections = False
       ri.advance_time_step(0.01, step=0)          # warm-up
       torch.cuda.synchronize(device)
       if world > 1:
