@@ -101,7 +101,7 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          the source->target operators compute in fp64 whatever this says.  Other values:
  *                          RMB_ERR_ARG.  The "wave_clock" / "skip_pairs" diagnostics exist in the fp64 kernels only:
  *                          a product that would run an fp32 kernel with one of them set returns RMB_ERR_STATE.
- *   "force_cull"      [1]  blob-blob forces (open boundaries, uniform radius, symmetric path): skip tile pairs whose
+ *   "force_cull"      [1]  blob-blob forces (uniform radius, symmetric path; open or pseudo-periodic): skip tile pairs whose
  *                          bounding boxes are further apart than 2a + 750 b, where exp(-(r - 2a)/b) underflows to
  *                          exactly 0 in double precision (110 b for the float kernel): no bit of the result changes
  *   "force_precision" [0]  blob-blob forces: 0 = follow "precision", 32 / 64 = pinned whatever "precision" says

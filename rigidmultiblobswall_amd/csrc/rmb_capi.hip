@@ -744,7 +744,7 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
     // apart contributes nothing, bit for bit.  In a 262 144-roller monolayer that is 99 % of the tile pairs -- the
     // reference's own answer to this is a k-d tree (`blob_blob_force_implementation tree_numba`).
     a.bounds = nullptr; a.cull2 = 0.0;
-    if (c->opt_force_cull && !periodic && !radii && tiles > 1) {
+    if (c->opt_force_cull && !radii && tiles > 1) {
       if (!c->tile_bounds_valid) {
         if (int rc = c->tile_bounds.reserve((size_t)6 * tiles * sizeof(double))) return rc;
         hipLaunchKernelGGL(rmb::tile_bounds_kernel, dim3((unsigned)tiles), dim3(64), 0, c->stream, (const double4*)c->pos.p, n,

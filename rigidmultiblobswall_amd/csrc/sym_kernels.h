@@ -327,7 +327,7 @@ struct SymForceArgs {
   ExpConsts ec;
   const double* radii;  // RADII variant: one radius per blob, contact distance a_i + a_j (forces_numba.py:73-122)
   long step_begin, step_end;   // rotation steps [begin, end) of the n_units * 64 this launch covers (pair shard)
-  // Tile culling (open boundaries, uniform radius): bounds[T] = (xmin, ymin, zmin, xmax, ymax, zmax) of tile T
+  // Tile culling (uniform radius; open or pseudo-periodic): bounds[T] = (xmin, ymin, zmin, xmax, ymax, zmax) of tile T
   // (tile_bounds_kernel), cull2 = (2a + 750 b)^2.  A tile pair whose boxes are further apart than that holds only
   // pairs with (r - 2a)/b > 750, for which exp underflows to exactly 0 here (exp_nonpositive) and in the reference
   // (exp(-745.2) is the smallest denormal): skipping the unit changes no bit of the result.  nullptr = no culling.
@@ -335,14 +335,28 @@ struct SymForceArgs {
   double cull2;
 };
 
-// squared distance between the bounding boxes of two tiles (wave-uniform: every lane reads the same twelve doubles)
-__device__ __forceinline__ double tile_gap2(const double* bounds, int I, int J) {
+// Lower bound of the squared distance between any blob of tile I and any blob of tile J (wave-uniform: every lane
+// reads the same twelve doubles).  Per direction the separations x_j - x_i fill the interval [lo_J - hi_I, hi_J - lo_I];
+// in a pseudo-periodic direction (L > 0) the pair force takes the nearest image of every separation
+// (d - rint(d/L) L, positions need not lie in one cell), so the interval is first moved by the multiple of L that
+// centres it: it then lies inside (-L, L), and |nearest image| over it is smallest at the end nearer to zero -- or
+// zero if the interval contains zero or is at least L long.
+__device__ __forceinline__ double tile_gap2(const double* bounds, int I, int J, double Lx = 0.0, double Ly = 0.0, double Lz = 0.0) {
   const double* bi = bounds + 6L * I;
   const double* bj = bounds + 6L * J;
+  const double L[3] = {Lx, Ly, Lz};
   double g2 = 0.0;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const double g = fmax(fmax(bj[d] - bi[3 + d], bi[d] - bj[3 + d]), 0.0);
+    double lo = bj[d] - bi[3 + d], hi = bj[3 + d] - bi[d];
+    if (L[d] > 0.0) {
+      if (hi - lo >= L[d]) { lo = 0.0; hi = 0.0; }
+      else {
+        const double shift = __builtin_rint(0.5 * (lo + hi) / L[d]) * L[d];
+        lo -= shift; hi -= shift;
+      }
+    }
+    const double g = lo > 0.0 ? lo : (hi < 0.0 ? -hi : 0.0);
     g2 = __builtin_fma(g, g, g2);
   }
   return g2;
@@ -418,7 +432,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
     const long left = s_end - s;
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
-    if (a.bounds != nullptr && I != J && tile_gap2(a.bounds, I, J) > a.cull2) {
+    if (a.bounds != nullptr && I != J &&
+        tile_gap2(a.bounds, I, J, PERIODIC ? a.Lx : 0.0, PERIODIC ? a.Ly : 0.0, PERIODIC ? a.Lz : 0.0) > a.cull2) {
       // every pair of this unit is beyond the range of the exponential: contributes exactly zero
       if (k1 == 64) {
         if (++J == a.n_tiles) { ++I; J = I; }

@@ -779,10 +779,17 @@ def test_force_tile_culling_changes_no_bit(Ctx, oracle, prec):
   ij = np.array([(i, j) for i in range(side) for j in range(side)][:n], dtype=np.float64)
   r_far = np.concatenate([ij * 2.05 * a + 0.02 * rng.rand(n, 2), a * (1.0 + rng.rand(n, 1))], axis=1)   # 160 x 160 units
   r_near = rng.rand(500, 3) * 3.0
-  for r in (r_far, r_near):
+  # pseudo-periodic in x and y (fp64 path only): the same monolayer with every roller moved by a random multiple of the
+  # period, so that nearest images -- not raw separations -- decide what is in range
+  Lp = np.array([side * 2.05 * a, side * 2.05 * a, 0.0])
+  r_per = r_far.copy()
+  r_per[:, 0] += Lp[0] * rng.randint(-2, 3, n)
+  r_per[:, 1] += Lp[1] * rng.randint(-2, 3, n)
+  cases = [(r_far, np.zeros(3)), (r_near, np.zeros(3))] + ([(r_per, Lp), (r_far, Lp)] if prec == 64 else [])
+  for r, Lbox in cases:
     ctx = Ctx(0)
     try:
-      ctx.set_positions(r, a, np.zeros(3), wall=False)
+      ctx.set_positions(r, a, Lbox, wall=False)
       ctx.set_option("precision", prec)
       ctx.set_option("deterministic", 0)
       res = {}
@@ -792,7 +799,7 @@ def test_force_tile_culling_changes_no_bit(Ctx, oracle, prec):
       # atomics: run-to-run differences are at round-off, a culled pair contributes exactly 0 -> compare at round-off
       scale = np.abs(res[0][0]).max()
       assert np.abs(res[1][0] - res[0][0]).max() <= 1e-13 * scale and np.abs(res[1][1] - res[0][0]).max() <= 1e-13 * scale
-      ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=np.zeros(3), repulsion_strength=eps, debye_length=b, blob_radius=a)
+      ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=Lbox, repulsion_strength=eps, debye_length=b, blob_radius=a)
       assert rel_err(res[1][0], ref) < (1e-12 if prec == 64 else 1e-4)
       # pair shards cull too and still sum to the forces
       parts = sum(ctx.blob_blob_force_pairshard_device(eps, b, a, g, 3).cpu().numpy() for g in range(3)).reshape(-1, 3)
