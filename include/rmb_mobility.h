@@ -97,7 +97,7 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          (~1e-6 relative, separations from a head / tail split of the fp64 positions), partial sums,
  *                          self terms and scaling in fp64; 1.5-1.6x faster.
  *                          Pseudo-periodic domains, the one-sided sweep, the deterministic modes,
- *                          per-blob-radii mobility products, pair shards of tr / rt / rr and
+ *                           the per-blob-radii product with sources != targets, pair shards of tr / rt / rr and
  *                          the source->target operators compute in fp64 whatever this says.  Other values:
  *                          RMB_ERR_ARG.  The "wave_clock" / "skip_pairs" diagnostics exist in the fp64 kernels only:
  *                          a product that would run an fp32 kernel with one of them set returns RMB_ERR_STATE.
@@ -223,6 +223,11 @@ int rmb_wave_clock_collect(rmb_ctx* ctx, long long* stamps, long max_waves);
 /* launch geometry of the last sweep: target tiles, source chunks, workgroups */
 int rmb_last_launch(rmb_ctx* ctx, long* tiles, long* chunks, long* workgroups);
 int rmb_ctx_synchronize(rmb_ctx* ctx);
+
+/* Options of the library's default context, the one the stateless entry points below run on (rmb_mobility_oneshot,
+ * rmb_forces_oneshot, rmb_mobility_source_target, rmb_pressure_stokeslet, rmb_double_layer): same keys as
+ * rmb_ctx_set_option -- e.g. "precision" = 32 selects the single-precision twins for one-shot callers too. */
+int rmb_default_ctx_set_option(const char* key, long value);
 
 /* ---- stateless one-shot calls: exactly the reference wrapper signature ----------------------
  * r, vec (, vec2) host (n,3); out host (n,3).  Uses a process-wide context on device 0. */

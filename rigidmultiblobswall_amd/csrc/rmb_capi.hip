@@ -466,7 +466,7 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
     // the free-surface operation takes raw heights: only the wall = 0 column is ever launched
     {{make_symx_entry<rmb::OpFreeSurface, false, false, rmb::OpFreeSurface32>(), make_symx_entry<rmb::OpFreeSurface, false, true>()},
      {make_symx_entry<rmb::OpFreeSurface, false, false, rmb::OpFreeSurface32>(), make_symx_entry<rmb::OpFreeSurface, false, true>()}},
-    RMB_SX_ROW(rmb::OpRadiiTT),
+    RMB_SX_ROW32(rmb::OpRadiiTT, rmb::OpRadiiTT32),
 #define RMB_SX_K(K) RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_TT, K), RMB_SX_KIND32(rmb::KIND_TT, K)), RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_TR, K), RMB_SX_KIND32(rmb::KIND_TR, K)), \
                     RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_RT, K), RMB_SX_KIND32(rmb::KIND_RT, K)), RMB_SX_ROW32(RMB_SX_KIND(rmb::KIND_RR, K), RMB_SX_KIND32(rmb::KIND_RR, K))
 #define RMB_SX_KIND(KIND, K) rmb::OpKindK<KIND, K>
@@ -508,8 +508,8 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   a.skip_pairs = (int)c->opt_skip_pairs;
   a.k = make_pair_consts(c->a > 0.0 ? c->a : 1.0);   // unused by the per-blob-radii operation
   SymPlan plan;
-  // "precision" = 32: the operation's single-precision twin where it has one (open boundaries, no per-blob extras)
-  const bool f32 = c->opt_precision == 32 && se.sweep32 != nullptr && a.extra == nullptr;
+  // "precision" = 32: the operation's single-precision twin where it has one (open boundaries)
+  const bool f32 = c->opt_precision == 32 && se.sweep32 != nullptr;
   if (f32 && c->opt_skip_pairs)
     return fail(RMB_ERR_STATE, "the \"skip_pairs\" diagnostic exists in the fp64 kernels only: set \"precision\" = 64");
   if (int rc = plan_sym(c, f32 ? (const void*)se.sweep32 : (const void*)se.sweep, f32 ? &se.occ32 : &se.occ,
@@ -1535,6 +1535,13 @@ static int default_ctx(rmb_ctx** out) {
   }
   *out = g_default_ctx;
   return 0;
+}
+
+int rmb_default_ctx_set_option(const char* key, long value) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  rmb_ctx* c;
+  if (int rc = default_ctx(&c)) return rc;
+  return rmb_ctx_set_option(c, key, value);
 }
 
 int rmb_mobility_oneshot(int kind, int wall, int in_plane, long n, const double* r, const double* vec,

@@ -126,15 +126,105 @@ struct OpFreeSurface32 {
   }
 };
 
+// Translation mobility of blobs with DIFFERENT radii, sources == targets (OpRadiiTT of symx_kernels.h in float; the
+// reference's single-precision build covers K13 too, mobility_pycuda.py:1841-2067 under `typedef float real`).
+// vi[3] / vj[3] = radius of the blob (one extra LDS plane).
+struct STc32 { float C1, C2, alpha, beta, gamma, delta, eps, rz; };
+
+template <bool WALL>
+__device__ __forceinline__ STc32 st_coeffs32(float dx, float dy, float dz, float x3, float y3, float at, float as) {
+  STc32 c;
+  const float rho2 = __builtin_fmaf(dy, dy, dx * dx);
+  const float r2 = __builtin_fmaf(dz, dz, rho2);
+  const float a2 = at * at, b2 = as * as, s = a2 + b2;
+  const float ir = __builtin_amdgcn_rsqf(r2);
+  const float ir2 = ir * ir;
+  c.C1 = __builtin_fmaf(s * (1.0f / 3.0f), ir2, 1.0f) * ir;
+  c.C2 = __builtin_fmaf(-s, ir2, 1.0f) * ir2 * ir;
+  const float sum = at + as;
+  if (__builtin_expect(__any(!(r2 > sum * sum)), 0)) {
+    // overlapping blobs (rare): Zuk et al. regimes 2 and 3
+    const float r = (r2 > 0.0f) ? __builtin_sqrtf(r2) : 0.0f;
+    const float dm = (as - at) * (as - at);
+    const float r3 = r2 * r;
+    const float t = dm + 3.0f * r2, q = dm - r2;
+    const float pre = (4.0f / 3.0f) / (as * at);
+    const float C1m = ((16.0f * sum * r3 - t * t) / (32.0f * r3)) * pre;
+    const float C2m = ((3.0f * q * q / (32.0f * r3)) / r2) * pre;
+    const bool far = r > sum;
+    const bool mid = r > __builtin_fabsf(as - at);
+    c.C1 = far ? c.C1 : (mid ? C1m : (4.0f / 3.0f) / __builtin_fmaxf(at, as));
+    c.C2 = far ? c.C2 : (mid ? C2m : 0.0f);
+  }
+  c.rz = x3 + y3;
+  if constexpr (WALL) {
+    const float rz = c.rz;
+    const float R2 = __builtin_fmaf(rz, rz, rho2);
+    const float i1 = __builtin_amdgcn_rsqf(R2);
+    const float i2 = i1 * i1, i3 = i1 * i2, i5 = i3 * i2, i7 = i5 * i2, i9 = i7 * i2;
+    const float ab = a2 * b2, xy = x3 * y3;
+    const float m = rz * __builtin_fmaf(a2, y3, b2 * x3);
+    const float ab23 = ab * (2.0f / 3.0f);
+    const float rz2 = rz * rz;
+    c.alpha = __builtin_fmaf(ab23, __builtin_fmaf(5.0f * rz2, i7, -i5),
+                             __builtin_fmaf(-2.0f * m, i5, __builtin_fmaf(__builtin_fmaf(2.0f, xy, s * (1.0f / 3.0f)), i3, i1)));
+    c.beta = __builtin_fmaf(ab23, __builtin_fmaf(-35.0f * rz2, i9, 5.0f * i7),
+                            __builtin_fmaf(10.0f * m, i7, __builtin_fmaf(-__builtin_fmaf(6.0f, xy, s), i5, i3)));
+    const float abz = ab * (20.0f / 3.0f) * rz * i7;
+    const float dab = 2.0f * (a2 - b2) * i5;
+    c.gamma = __builtin_fmaf(x3, __builtin_fmaf(-2.0f, i3, dab), abz);
+    c.delta = __builtin_fmaf(y3, -__builtin_fmaf(2.0f, i3, dab), abz);
+    c.eps = -__builtin_fmaf(ab * (4.0f / 3.0f), i5, __builtin_fmaf(s * (2.0f / 3.0f), i3, i1 + i1));
+  } else {
+    c.alpha = c.beta = c.gamma = c.delta = c.eps = 0.0f;
+  }
+  return c;
+}
+
+template <bool WALL>
+__device__ __forceinline__ void st_apply32(const STc32& c, float dx, float dy, float dz, float sx, float gam, float del,
+                                           const float* f, float* u) {
+  const float pxy = __builtin_fmaf(dy, f[1], dx * f[0]);
+  const float cD = c.C2 * __builtin_fmaf(dz, f[2], pxy);
+  if constexpr (!WALL) {
+    u[0] = __builtin_fmaf(c.C1, f[0], u[0]); u[0] = __builtin_fmaf(cD, dx, u[0]);
+    u[1] = __builtin_fmaf(c.C1, f[1], u[1]); u[1] = __builtin_fmaf(cD, dy, u[1]);
+    u[2] = __builtin_fmaf(c.C1, f[2], u[2]); u[2] = __builtin_fmaf(cD, dz, u[2]);
+  } else {
+    const float Rg = __builtin_fmaf(c.rz, f[2], -sx * pxy);
+    const float cR = __builtin_fmaf(c.beta, Rg, gam * f[2]);
+    const float cz = __builtin_fmaf(del, Rg, c.eps * f[2]);
+    const float cFxy = c.C1 - c.alpha, cFz = c.C1 + c.alpha;
+    const float cDR = __builtin_fmaf(sx, cR, cD);
+    u[0] = __builtin_fmaf(cFxy, f[0], u[0]); u[0] = __builtin_fmaf(cDR, dx, u[0]);
+    u[1] = __builtin_fmaf(cFxy, f[1], u[1]); u[1] = __builtin_fmaf(cDR, dy, u[1]);
+    u[2] = __builtin_fmaf(cFz, f[2], u[2]); u[2] = __builtin_fmaf(cD, dz, u[2]);
+    u[2] = __builtin_fmaf(cR, c.rz, u[2]); u[2] += cz;
+  }
+}
+
+struct OpRadiiTT32 {
+  static constexpr int NIN = 1, NOUT = 1, NEXTRA = 1;
+  template <bool WALL>
+  static __device__ __forceinline__ void pair(const f32::PairConsts&, float dx, float dy, float dz, float zi, float zj,
+                                              const float* vi, const float* vj, float* ui, float* t) {
+    const STc32 c = st_coeffs32<WALL>(dx, dy, dz, zi, zj, vi[3], vj[3]);
+    st_apply32<WALL>(c, dx, dy, dz, 1.0f, c.gamma, c.delta, vj, ui);
+    t[0] = 0.0f; t[1] = 0.0f; t[2] = 0.0f;
+    st_apply32<WALL>(c, dx, dy, dz, -1.0f, c.delta, c.gamma, vi, t);
+  }
+};
+
+// planes of a record: x, y, z heads, the NIN vectors, NEXTRA per-blob scalars (radius), then the three position tails
 template <class OP> struct SymX32Lds {
-  static constexpr int planes = 6 + 3 * OP::NIN;
+  static constexpr int planes = 6 + 3 * OP::NIN + SymXExtra<OP>::value;
   static constexpr size_t bytes = (sizeof(float) * planes + sizeof(double) * 3 * OP::NOUT) * 64 * kSymWaves;
 };
 
 template <class OP, bool WALL>
 __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a, const f32::PairConsts kf) {
-  constexpr int NI = OP::NIN, NO = OP::NOUT, NP = 6 + 3 * NI;
-  __shared__ float rec_all[kSymWaves][NP * 64];      // planes x, y, z (float heads), the NIN vectors, then the position tails
+  constexpr int NI = OP::NIN, NO = OP::NOUT, NX = SymXExtra<OP>::value, NV = 3 * NI + NX, NP = 6 + NV;
+  __shared__ float rec_all[kSymWaves][NP * 64];      // planes x, y, z (float heads), the NIN vectors (+ extras), then the position tails
   __shared__ double accj_all[kSymWaves][3 * NO * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -152,9 +242,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
   long i = 0;
   bool vi_ok = false;
   float xi = 0, yi = 0, zi = 1.0f, xil = 0, yil = 0, zil = 0;
-  float vi[3 * NI], ui[3 * NO];
+  float vi[NV], ui[3 * NO];
 #pragma unroll
-  for (int c = 0; c < 3 * NI; ++c) vi[c] = 0;
+  for (int c = 0; c < NV; ++c) vi[c] = 0;
 #pragma unroll
   for (int c = 0; c < 3 * NO; ++c) ui[c] = 0;
 
@@ -178,11 +268,12 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
       vi_ok = i < a.n;
       xi = 1e18f; yi = 1e18f; zi = 1.0f; xil = 0; yil = 0; zil = 0;   // padding: far away, 1/r^2 stays finite in float
 #pragma unroll
-      for (int c = 0; c < 3 * NI; ++c) vi[c] = 0;
+      for (int c = 0; c < NV; ++c) vi[c] = 0;
       if (vi_ok) {
         const double4 p = a.pos[i];
         xi = (float)p.x; yi = (float)p.y; zi = (float)p.z;
         xil = (float)(p.x - (double)xi); yil = (float)(p.y - (double)yi); zil = (float)(p.z - (double)zi);
+        if constexpr (NX > 0) vi[3 * NI] = (float)a.extra[i];
 #pragma unroll
         for (int v = 0; v < NI; ++v) {
           vi[3 * v] = (float)(a.in[v][3 * i] * p.w); vi[3 * v + 1] = (float)(a.in[v][3 * i + 1] * p.w);
@@ -201,7 +292,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
       if (j < a.n) {
         const double4 p = a.pos[j];
         rd[0] = (float)p.x; rd[1] = (float)p.y; rd[2] = (float)p.z;
-        rd[3 + 3 * NI] = (float)(p.x - (double)rd[0]); rd[4 + 3 * NI] = (float)(p.y - (double)rd[1]); rd[5 + 3 * NI] = (float)(p.z - (double)rd[2]);
+        rd[3 + NV] = (float)(p.x - (double)rd[0]); rd[4 + NV] = (float)(p.y - (double)rd[1]); rd[5 + NV] = (float)(p.z - (double)rd[2]);
+        if constexpr (NX > 0) rd[3 + 3 * NI] = (float)a.extra[j];
 #pragma unroll
         for (int v = 0; v < NI; ++v) {
           rd[3 + 3 * v] = (float)(a.in[v][3 * j] * p.w); rd[4 + 3 * v] = (float)(a.in[v][3 * j + 1] * p.w);
@@ -226,9 +318,9 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx32_kernel(const SymXArgs a
       for (int c = 0; c < NP; ++c) rd[c] = rec[c * 64 + jj];
       float t[3 * NO];
       // head / tail split of the fp64 positions (sym32_kernels.h): the error of d does not grow with the domain size
-      const v2f xyj = {rd[0], rd[1]}, xyjl = {rd[3 + 3 * NI], rd[4 + 3 * NI]}, xyi = {xi, yi}, xyil = {xil, yil};
+      const v2f xyj = {rd[0], rd[1]}, xyjl = {rd[3 + NV], rd[4 + NV]}, xyi = {xi, yi}, xyil = {xil, yil};
       const v2f dxy = (xyi - xyj) + (xyil - xyjl);
-      const float dz = (zi - rd[2]) + (zil - rd[5 + 3 * NI]);
+      const float dz = (zi - rd[2]) + (zil - rd[5 + NV]);
       OP::template pair<WALL>(kf, dxy.x, dxy.y, dz, zi, rd[2], vi, rd + 3, ui, t);
       if (!diag) {   // wave-uniform
 #pragma unroll

@@ -207,6 +207,11 @@ def _source_target(source, target, force, radius_source, radius_target, eta, wal
     raise ValueError("force must have 3*N_source entries")
   out = np.empty(3 * nt)
   p = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+  if precision not in ('single', 'double'):
+    raise ValueError("mobility.precision must be 'single' or 'double'")
+  # the stateless entry point runs on the library's default context: hand it the module's precision switch (only the
+  # sources == targets case has a single-precision twin; everything else computes in fp64 whatever it says)
+  _lib.check(_lib.load().rmb_default_ctx_set_option(b"precision", 32 if precision == 'single' else 64))
   _lib.check(_lib.load().rmb_mobility_source_target(ns, p(src), p(rs), nt, p(tgt), p(rt), p(f), float(eta), p(L),
                                                     int(wall), p(out)))
   return out

@@ -806,3 +806,30 @@ def test_force_tile_culling_changes_no_bit(Ctx, oracle, prec):
       assert rel_err(parts, ref) < (1e-12 if prec == 64 else 1e-4)
     finally:
       ctx.close()
+
+
+@pytest.mark.parametrize("wall", [True, False])
+def test_single_precision_per_blob_radii_product(mob, oracle, wall):
+  """precision = 'single' for the per-blob-radii mobility with sources == targets (how the `radii_*` modes call K13,
+  mobility/mobility.py:1369-1374; the reference's float build covers it, mobility_pycuda.py:1841-2067): single-precision
+  accurate against the oracle; sources != targets keep computing in fp64."""
+  rng = np.random.RandomState(12)
+  N = 3000
+  r, f, eta, a = d2_cloud(N, seed=21)
+  radii = a * (0.6 + 0.8 * rng.rand(N))
+  name = "single_wall" if wall else "no_wall"
+  fn_hip = getattr(mob, name + "_mobility_trans_times_force_source_target_hip")
+  fn_ref = getattr(oracle, name + "_mobility_trans_times_force_source_target_oracle")
+  ref = fn_ref(r, r, f, radii, radii, eta)
+  try:
+    e64 = rel_err(mob.mobility_radii_trans_times_force(r, f, eta, a, radii, fn_hip), ref)
+    mob.precision = 'single'
+    e32 = rel_err(mob.mobility_radii_trans_times_force(r, f, eta, a, radii, fn_hip), ref)
+    assert e64 < 1e-12 and 1e-9 < e32 < 2e-5, (e64, e32)
+    # sources != targets: one-sided fp64 kernel whatever the switch says
+    tgt = r[:500] + 0.3 * a
+    e_st = rel_err(fn_hip(r, tgt, f, radii, radii[:500], eta), fn_ref(r, tgt, f, radii, radii[:500], eta))
+    assert e_st < 1e-12, e_st
+  finally:
+    mob.precision = 'double'
+  assert rel_err(mob.mobility_radii_trans_times_force(r, f, eta, a, radii, fn_hip), ref) < 1e-12
