@@ -9,7 +9,7 @@
 //   W v   = f1 v + [f2 (e.v) + f3 v_z] e + [f4 (e.v) + f5 v_z] z
 //   W^T v = f1 v + [f2 (e.v) + f4 v_z] e + [f3 (e.v) + f5 v_z] z          (f3 <-> f4)
 // => 80 VALU instructions per unordered pair (76 fp64; pair_blocks.h: five-entry block + closed-form wall
-// polynomials through H) instead of 2 x 78 in the one-sided sweep.
+// polynomials through H) instead of 2 x 67 in the bulk loop of the one-sided sweep.
 //
 // Work decomposition: blobs are cut into tiles of 64; a work unit is a tile pair (I <= J).  One wave64
 // owns a unit: lane l holds blob i = 64 I + l in registers (position, its own vector v_i, accumulator u_i);
