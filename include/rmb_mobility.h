@@ -61,6 +61,8 @@ int rmb_device_count(void);
 /* ---- persistent context: positions stay resident across the matvecs of one solve ----------
  * (GMRES / Lanczos call M.f many times with fixed r_vectors, multi_bodies.py:445, :599;
  *  the reference re-uploads positions on every call.) */
+/* device: index into the visible devices, or -1 = the default device: the environment variable RMB_DEVICE when it
+ * is set (an index; anything else -> RMB_ERR_ARG), else 0. */
 int rmb_ctx_create(int device, rmb_ctx** ctx);
 int rmb_ctx_destroy(rmb_ctx* ctx);
 /* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream.
@@ -228,9 +230,13 @@ int rmb_ctx_synchronize(rmb_ctx* ctx);
  * rmb_forces_oneshot, rmb_mobility_source_target, rmb_pressure_stokeslet, rmb_double_layer): same keys as
  * rmb_ctx_set_option -- e.g. "precision" = 32 selects the single-precision twins for one-shot callers too. */
 int rmb_default_ctx_set_option(const char* key, long value);
+/* Device of the default context: an index, or -1 = RMB_DEVICE / 0 (the initial state).  An existing default context
+ * on another device is destroyed (its resident positions go with it) and re-created on the next stateless call. */
+int rmb_default_ctx_set_device(int device);
 
 /* ---- stateless one-shot calls: exactly the reference wrapper signature ----------------------
- * r, vec (, vec2) host (n,3); out host (n,3).  Uses a process-wide context on device 0. */
+ * r, vec (, vec2) host (n,3); out host (n,3).  Uses a process-wide context on the default device (RMB_DEVICE, or 0;
+ * rmb_default_ctx_set_device). */
 int rmb_mobility_oneshot(int kind, int wall, int in_plane, long n, const double* r, const double* vec,
                          const double* vec2, double eta, double a, const double* L, double* out);
 int rmb_forces_oneshot(long n, const double* r, const double* L, double repulsion_strength,

@@ -1,7 +1,8 @@
 """MI355X-native blob-mobility engine: RPY + single-wall M.f products and blob-blob forces.
 
 Layout (only what the hot path needs):
-  csrc/         HIP kernels (pair_ops.h, matvec_kernels.h) + C ABI (rmb_capi.hip) -> librmb_mobility.so
+  csrc/         HIP kernels (*_kernels.h, pair_*.h) + C ABI in separately compiled units (rmb_internal.h lists them)
+                -> librmb_mobility.so
   _lib.py       ctypes binding of include/rmb_mobility.h (no CPU fallback)
   context.py    persistent per-GPU context (resident positions, host + device entry points)
   mobility.py   the reference's mobility/mobility.py function surface, `<impl> = hip`

@@ -61,6 +61,7 @@ SYMBOLS = {
     "rmb_last_launch": (ctypes.c_int, [_vp, _lp, _lp, _lp]),
     "rmb_ctx_synchronize": (ctypes.c_int, [_vp]),
     "rmb_default_ctx_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long]),
+    "rmb_default_ctx_set_device": (ctypes.c_int, [ctypes.c_int]),
     "rmb_mobility_oneshot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp, _vp, _vp,
                                             ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "rmb_mobility_source_target": (ctypes.c_int, [ctypes.c_long, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_double, _vp,

@@ -19,8 +19,6 @@
 
 namespace rmb {
 
-constexpr int kWaves = 4;
-constexpr int kBlock = 64 * kWaves;
 constexpr int kTile = 512;  // source records per LDS tile
 
 struct SweepArgs {

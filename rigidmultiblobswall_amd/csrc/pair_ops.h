@@ -26,9 +26,16 @@
 
 namespace rmb {
 
+// Launch geometry shared by the kernels and the host-side plans (rmb_plan.hip): a workgroup of every pair kernel is
+// 4 waves = 256 threads, one wave per SIMD.
+constexpr int kWaves = 4;            // one-sided sweeps (matvec_kernels.h, st_kernels.h, aux_kernels.h)
+constexpr int kBlock = 64 * kWaves;
+constexpr int kSymWaves = 4;         // symmetric kernels (sym*_kernels.h)
+constexpr int kSymWavesPerEu = 4;    // register budget of sym_kernel / sym2_kernel: 4 waves per SIMD (the launch plan relies on it)
+
 enum Kind : int { KIND_TT = 0, KIND_TR = 1, KIND_RT = 2, KIND_RR = 3, KIND_TT_TR = 4, KIND_TT_FREE = 5, KIND_COUNT = 6 };
 
-// Uniform constants (host-computed from the blob radius a; see make_pair_consts in rmb_capi.hip).
+// Uniform constants (host-computed from the blob radius a; see make_pair_consts in rmb_plan.hip).
 struct PairConsts {
   double a2;       // a^2                (tau = a^2/R^2 in the wall corrections)
   double four_a2;  // (2a)^2             far/near switch on r^2

@@ -51,8 +51,6 @@ struct SymArgs {
   PairConsts k;
 };
 
-constexpr int kSymWaves = 4;
-constexpr int kSymWavesPerEu = 4;   // register budget of sym_kernel / sym2_kernel: 4 waves per SIMD (the launch plan relies on it)
 constexpr int kSymRecBytes = 48;
 
 // Both directions of one pair.  (vix..) = target's own vector, (vjx..) = source vector.
@@ -363,7 +361,8 @@ __device__ __forceinline__ double tile_gap2(const double* bounds, int I, int J, 
 }
 
 // bounding box of every 64-blob tile of the packed positions; one wave per tile
-__global__ __launch_bounds__(64) void tile_bounds_kernel(const double4* pos, long n, double* bounds) {
+// (static: this header is part of two translation units, rmb_sym.hip and rmb_sym32.hip)
+static __global__ __launch_bounds__(64) void tile_bounds_kernel(const double4* pos, long n, double* bounds) {
   const long T = blockIdx.x;
   const long i = 64 * T + threadIdx.x;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
   }
 }
 
-__global__ __launch_bounds__(256) void sym_force_finalize_kernel(const SymForceArgs a) {
+static __global__ __launch_bounds__(256) void sym_force_finalize_kernel(const SymForceArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   a.out[3 * i] = a.acc[i]; a.out[3 * i + 1] = a.acc[a.n_pad + i]; a.out[3 * i + 2] = a.acc[2 * a.n_pad + i];

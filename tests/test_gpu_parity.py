@@ -168,7 +168,7 @@ def test_fused_force_torque(mob, oracle, wall):
 @pytest.mark.parametrize("wall", [True, False])
 @pytest.mark.parametrize("L", [(0.0, 0.0, 0.0), (9.0, 8.0, 0.0)])
 def test_fused_force_torque_symmetric_two_pass(Ctx, oracle, wall, L):
-  """K11/K12 at N >= 128 run as two symmetric passes into one output (rmb_capi.hip); must equal the one-sided
+  """K11/K12 at N >= 128 run as two symmetric passes into one output (rmb_entry.hip); must equal the one-sided
   fused sweep (option deterministic) and the oracle."""
   import torch
   r, f, eta, a = d2_cloud(1500, seed=31)

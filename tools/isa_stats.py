@@ -4,7 +4,7 @@
 Why: bench.py prices the dominant kernel two ways that must not exceed 1 by construction --
   executed fp64 flops / time / 78.6 TF   and   issued VALU wave-instructions / time / measured issue ceiling --
 and both need "what one rotation step of one wave executes".  That is a property of the compiled loop body, so it
-is read off the disassembly (hipcc -S --cuda-device-only of csrc/rmb_capi.hip) instead of being replayed from an
+is read off the disassembly (hipcc -S --cuda-device-only of csrc/rmb_sym.hip and rmb_sweep.hip) instead of being replayed from an
 old profile.  `SQ_INSTS_VALU` of the rocprofv3 --pmc passes under profiles/ cross-checks the count.
 
 The pair loop = the innermost loop (label ... backward branch) of the kernel with the most fp64 VALU instructions;
@@ -55,11 +55,19 @@ def source_hash():
   return h.hexdigest()
 
 
+# the translation units that hold the priced kernels (rmb_internal.h: symmetric family / one-sided family)
+ASM_UNITS = ("rmb_sym.hip", "rmb_sweep.hip")
+
+
 def device_asm():
-  out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S",
-                        "--cuda-device-only", "-o", "-", os.path.join(CSRC, "rmb_capi.hip")],
-                       check=True, capture_output=True, text=True)
-  return out.stdout
+  from concurrent.futures import ThreadPoolExecutor
+
+  def one(unit):
+    return subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S",
+                           "--cuda-device-only", "-o", "-", os.path.join(CSRC, unit)],
+                          check=True, capture_output=True, text=True).stdout
+  with ThreadPoolExecutor(max_workers=len(ASM_UNITS)) as pool:
+    return "\n".join(pool.map(one, ASM_UNITS))
 
 
 def _classify(op):
