@@ -234,6 +234,50 @@ int rmb_default_ctx_set_option(const char* key, long value);
  * on another device is destroyed (its resident positions go with it) and re-created on the next stateless call. */
 int rmb_default_ctx_set_device(int device);
 
+/* ---- single-process multi-device engine ------------------------------------------------------------------------
+ * The reference's callers are ONE Python process that calls a module-level function (multi_bodies/multi_bodies.py:
+ * 233-287 selects it, :445 / :599 call it; mobility/mobility.py:222-252 is the call shape): to give that call the
+ * whole node the sharding has to sit behind it.  An engine owns one context per listed device, each with its own
+ * stream.  Per product: inputs go to every device (host entry: one pinned staging copy + G uploads; device entry: every
+ * shard pulls from devices[0] over xGMI), device g evaluates pair shard g of G (each unordered pair once, both blobs
+ * updated) into a full-length partial, then device g sums slice g of the G partials in FIXED order through peer-mapped
+ * reads and stores it where the result is wanted -- reduce-scatter + gather in one kernel per device.  With option
+ * "deterministic" = 2 the product is bit-reproducible for a given device list.  No reference counterpart (single
+ * device); the contract is "equal to the one-context result to rounding" (<= 1e-13).
+ *   - devices: 1..16 indices; the same device may be listed several times (rehearsal of the G-device path on one GPU).
+ *   - without peer access between two listed devices (or with RMB_MULTI_NO_PEER=1) slices travel by hipMemcpyPeerAsync.
+ *   - rmb_multi_set_option: "reduce" 0 [default] = the fixed-order slice reduction, 1 = RCCL all-reduce in place
+ *     (ncclCommInitAll; librccl.so is dlopen()ed on first use; distinct devices only; not bit-reproducible); every other
+ *     key is forwarded to all shard contexts (rmb_ctx_set_option).  rmb_multi_get_option also answers "peer" (1 / 0).
+ *   - host entry points are synchronous.  *_device entry points take pointers on devices[0], are ordered after the work
+ *     already queued on the engine's primary stream (rmb_multi_set_stream; NULL = default stream of devices[0]) and
+ *     order that stream after their own completion; the primary stream must be alive when a call is made, and may be
+ *     destroyed between calls (a switch never touches the previous handle).
+ *   - products: kinds as rmb_matvec (in_plane for TT / TR / RT / RR / TT_TR), operations as rmb_matvec_op_device,
+ *     uniform-radius blob-blob forces.  Target ranges do not apply (every call produces all n targets). */
+typedef struct rmb_multi rmb_multi;
+int rmb_multi_create(const int* devices, int n_devices, rmb_multi** engine);
+int rmb_multi_destroy(rmb_multi* engine);
+int rmb_multi_n_shards(rmb_multi* engine);
+/* the context of shard g (options, rmb_timing_collect, rmb_last_launch of one device); owned by the engine */
+int rmb_multi_shard_ctx(rmb_multi* engine, int shard, rmb_ctx** ctx);
+int rmb_multi_set_stream(rmb_multi* engine, void* hip_stream);
+int rmb_multi_set_option(rmb_multi* engine, const char* key, long value);
+int rmb_multi_get_option(rmb_multi* engine, const char* key, long* value);
+int rmb_multi_set_positions(rmb_multi* engine, const double* r_host, long n, double a, const double* L, int wall);
+int rmb_multi_set_positions_device(rmb_multi* engine, const double* r_dev, long n, double a, const double* L, int wall);
+int rmb_multi_matvec(rmb_multi* engine, int kind, int in_plane, const double* vec_host, const double* vec2_host, double eta,
+                     double* out_host);
+int rmb_multi_matvec_device(rmb_multi* engine, int kind, int in_plane, const double* vec_dev, const double* vec2_dev,
+                            double eta, double* out_dev);
+int rmb_multi_matvec_op_device(rmb_multi* engine, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
+                               double* const* out_dev, double eta);
+int rmb_multi_blob_blob_force(rmb_multi* engine, double repulsion_strength, double debye_length, double blob_radius,
+                              double* out_host);
+int rmb_multi_blob_blob_force_device(rmb_multi* engine, double repulsion_strength, double debye_length, double blob_radius,
+                                     double* out_dev);
+int rmb_multi_synchronize(rmb_multi* engine);
+
 /* ---- stateless one-shot calls: exactly the reference wrapper signature ----------------------
  * r, vec (, vec2) host (n,3); out host (n,3).  Uses a process-wide context on the default device (RMB_DEVICE, or 0;
  * rmb_default_ctx_set_device). */

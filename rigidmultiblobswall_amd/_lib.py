@@ -62,6 +62,22 @@ SYMBOLS = {
     "rmb_ctx_synchronize": (ctypes.c_int, [_vp]),
     "rmb_default_ctx_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long]),
     "rmb_default_ctx_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "rmb_multi_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]),
+    "rmb_multi_destroy": (ctypes.c_int, [_vp]),
+    "rmb_multi_n_shards": (ctypes.c_int, [_vp]),
+    "rmb_multi_shard_ctx": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "rmb_multi_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "rmb_multi_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_long]),
+    "rmb_multi_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _lp]),
+    "rmb_multi_set_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_double, _vp, ctypes.c_int]),
+    "rmb_multi_set_positions_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_double, _vp, ctypes.c_int]),
+    "rmb_multi_matvec": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_multi_matvec_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_multi_matvec_op_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,
+                                                  ctypes.c_double]),
+    "rmb_multi_blob_blob_force": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_multi_blob_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_multi_synchronize": (ctypes.c_int, [_vp]),
     "rmb_mobility_oneshot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp, _vp, _vp,
                                             ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "rmb_mobility_source_target": (ctypes.c_int, [ctypes.c_long, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_double, _vp,

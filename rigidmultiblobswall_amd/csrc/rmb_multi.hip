@@ -1,0 +1,607 @@
+// rmb_multi.hip -- single-process multi-device engine (include/rmb_mobility.h, "rmb_multi_*").
+//
+// The reference's callers are ONE Python process (multi_bodies/multi_bodies.py:233-287 picks a function,
+// :445 / :599 call it; mobility/mobility.py:222-252 is the call shape), so "use the whole node" has to live behind the
+// same call.  One engine owns G shards; shard g = one rmb_ctx on devices[g] with its own stream.  A product is
+//   1. inputs -> every device (host: one pinned staging copy, then G async uploads; device: each shard pulls the vectors
+//      from devices[0] on its own stream -- a peer-read kernel, or hipMemcpyPeerAsync without peer access),
+//   2. shard g sweeps pair shard g of G (rmb_matvec_pairshard_device & co.: each unordered pair once, both blobs updated)
+//      into a full-length partial on its device,
+//   3. device g adds slice g of the G partials IN FIXED ORDER (h = 0 .. G-1) through peer-mapped reads and writes the
+//      sum where the result is wanted (devices[0] for the *_device entry points, a pinned host buffer otherwise) --
+//      reduce-scatter and gather in one kernel per device, no intermediate copy.
+// With "deterministic" = 2 the partials are bit-reproducible and so is the sum.  Option "reduce" = 1 replaces step 3 by a
+// grouped RCCL all-reduce (ncclCommInitAll; librccl is dlopen()ed on first use so the library does not link it).
+// The same device may be listed several times (rehearsal of the G-device code path on one GPU: shards then share the
+// device, the peer reads are local reads).
+#include "rmb_internal.h"
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+using rmbi::DevBuf;
+using rmbi::fail;
+
+constexpr int kMaxShards = 16;
+constexpr int kMaxVec = 4;
+
+struct ReduceArgs {
+  const double* part[kMaxShards];   // partial outputs of every shard: n_out vectors of `len` doubles each
+  double* out[kMaxVec];             // where vector v of the result goes (indexed like the partials)
+  int n_shards, n_out;
+  long len;                         // 3n
+  long lo, hi;                      // this launch's slice of [0, len)
+};
+
+// out[v][i] = sum over shards, ascending shard index: a fixed order, so bit-reproducible partials give a
+// bit-reproducible product.  part[h] may live on a peer device (peer-mapped loads), out[v] too (peer-mapped stores).
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const ReduceArgs a) {
+  const long i = a.lo + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.hi) return;
+  for (int v = 0; v < a.n_out; ++v) {
+    double s = a.part[0][v * a.len + i];
+    for (int h = 1; h < a.n_shards; ++h) s += a.part[h][v * a.len + i];
+    a.out[v][i] = s;
+  }
+}
+
+// dst (local) = src (possibly peer-mapped): how a shard pulls its inputs from devices[0]
+__global__ __launch_bounds__(256) void pull_kernel(double* dst, const double* src, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+struct Shard {
+  int device = 0;
+  rmb_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_partial = nullptr;   // this shard's partial is complete
+  hipEvent_t ev_reduced = nullptr;   // this shard's slice of the result is written
+  DevBuf in[kMaxVec];                // local copies of the input vectors
+  DevBuf part;                       // partial outputs [n_out][3n]
+  DevBuf r_stage;                    // raw positions
+  DevBuf gather;                     // staged path (no peer access): slice of every other shard's partial
+  DevBuf red;                        // staged path / host entry: this shard's reduced slice
+};
+
+// RCCL, resolved at run time (torch bundles its own librccl.so under the same SONAME; dlopen returns the copy that is
+// already mapped, so a process never ends up with two).
+struct Rccl {
+  void* handle = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok() const { return handle && CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce; }
+};
+
+}  // namespace
+
+struct rmb_multi {
+  std::vector<Shard> sh;
+  hipStream_t primary = nullptr;    // the caller's stream on devices[0] (the *_device entry points are ordered on it)
+  hipEvent_t ev_in = nullptr;       // inputs of the current call are ready (recorded on `primary`)
+  hipEvent_t ev_done = nullptr;     // everything the last *_device call enqueued (recorded on `primary`)
+  bool done_recorded = false;
+  bool peer = true;                 // every pair of distinct devices has peer access enabled
+  bool distinct = true;             // no device listed twice (RCCL needs that)
+  long opt_reduce = 0;              // 0 = fixed-order slice reduction (peer reads / staged copies), 1 = RCCL all-reduce
+  long n = 0;
+  bool have_positions = false;
+  void* pinned = nullptr;           // host staging of the synchronous entry points: inputs first, results behind them
+  size_t pinned_cap = 0;
+  double* host_out = nullptr;       // where in `pinned` the current host call's results go
+  Rccl rccl;
+  std::vector<void*> comms;
+};
+
+namespace {
+
+int pinned_reserve(rmb_multi* m, size_t bytes) {
+  if (bytes <= m->pinned_cap) return 0;
+  if (m->pinned) { (void)hipHostFree(m->pinned); m->pinned = nullptr; m->pinned_cap = 0; }
+  const size_t want = bytes + bytes / 8 + 4096;
+  RMB_HIP(hipHostMalloc(&m->pinned, want, hipHostMallocPortable));
+  m->pinned_cap = want;
+  return 0;
+}
+
+int check_multi(rmb_multi* m, bool need_positions) {
+  if (!m) return fail(RMB_ERR_ARG, "null multi-device engine");
+  if (need_positions && !m->have_positions) return fail(RMB_ERR_STATE, "rmb_multi_set_positions has not been called");
+  return 0;
+}
+
+void slice_of(long len, int g, int G, long* lo, long* hi) {
+  *lo = (long)((__int128)len * g / G);
+  *hi = (long)((__int128)len * (g + 1) / G);
+}
+
+int rccl_load(rmb_multi* m) {
+  if (m->rccl.ok()) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    m->rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (m->rccl.handle) break;
+  }
+  if (!m->rccl.handle) return fail(RMB_ERR_STATE, std::string("\"reduce\" = 1 needs librccl.so: ") + dlerror());
+  void* h = m->rccl.handle;
+  *(void**)&m->rccl.CommInitAll = dlsym(h, "ncclCommInitAll");
+  *(void**)&m->rccl.CommDestroy = dlsym(h, "ncclCommDestroy");
+  *(void**)&m->rccl.GroupStart = dlsym(h, "ncclGroupStart");
+  *(void**)&m->rccl.GroupEnd = dlsym(h, "ncclGroupEnd");
+  *(void**)&m->rccl.AllReduce = dlsym(h, "ncclAllReduce");
+  *(void**)&m->rccl.GetErrorString = dlsym(h, "ncclGetErrorString");
+  if (!m->rccl.ok()) return fail(RMB_ERR_STATE, "librccl.so lacks the ncclCommInitAll / ncclAllReduce entry points");
+  return 0;
+}
+
+int rccl_fail(rmb_multi* m, const char* what, int rc) {
+  return fail(RMB_ERR_HIP, std::string(what) + ": " + (m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : "RCCL error"));
+}
+
+int rccl_comms(rmb_multi* m) {
+  if (!m->comms.empty()) return 0;
+  if (!m->distinct) return fail(RMB_ERR_ARG, "\"reduce\" = 1 (RCCL) needs distinct devices: a communicator holds one rank per device");
+  if (int rc = rccl_load(m)) return rc;
+  std::vector<int> devs;
+  for (const Shard& s : m->sh) devs.push_back(s.device);
+  m->comms.assign(devs.size(), nullptr);
+  const int rc = m->rccl.CommInitAll(m->comms.data(), (int)devs.size(), devs.data());
+  if (rc != 0) { m->comms.clear(); return rccl_fail(m, "ncclCommInitAll", rc); }
+  return 0;
+}
+
+// What one product is, seen by the engine: inputs (3n doubles each), outputs (3n each), and how shard g of G launches
+// its pair shard on its own context with LOCAL input pointers into a LOCAL full-length partial.
+struct Product {
+  int n_in = 0, n_out = 0;
+  int (*launch)(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long shard, long nshards) = nullptr;
+  int kind = 0, op = 0, in_plane = 0;
+  double eta = 1.0, eps = 0.0, b = 1.0, a = 0.0;
+};
+
+int launch_kind(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long g, long G) {
+  return rmb_matvec_pairshard_device(c, p.kind, in[0], p.eta, out[0], g, G);
+}
+int launch_op(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long g, long G) {
+  return rmbi::matvec_op_impl(c, p.op, p.in_plane, p.n_in, in, p.n_out, out, p.eta, g, G);
+}
+int launch_force(rmb_ctx* c, const Product& p, const double* const*, double* const* out, long g, long G) {
+  return rmbi::force_device_impl(c, p.eps, p.b, p.a, out[0], nullptr, g, G);
+}
+
+// Steps 2 and 3 of the header comment.  `in_local[g][v]`: input v as shard g sees it (already ordered on its stream).
+// Results: device entry -> out_primary[v] on devices[0], made visible to `m->primary`;
+//          host entry (out_primary == nullptr) -> slice g lands in pinned memory at m->host_out + (v * len + lo_g).
+int sweep_and_reduce(rmb_multi* m, const Product& p, const double* const in_local[][kMaxVec], double* const* out_primary) {
+  const int G = (int)m->sh.size();
+  const long len = 3 * m->n;
+  for (int g = 0; g < G; ++g) {
+    Shard& s = m->sh[g];
+    RMB_HIP(hipSetDevice(s.device));
+    if (int rc = s.part.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
+    double* outs[kMaxVec];
+    for (int v = 0; v < p.n_out; ++v) outs[v] = (double*)s.part.p + v * len;
+    if (int rc = p.launch(s.ctx, p, in_local[g], outs, g, G)) return rc;
+    RMB_HIP(hipEventRecord(s.ev_partial, s.stream));
+  }
+  if (m->opt_reduce == 1) {
+    // RCCL: every device ends up with the whole sum in its partial; the primary shard hands it over
+    if (int rc = rccl_comms(m)) return rc;
+    if (int rc = m->rccl.GroupStart()) return rccl_fail(m, "ncclGroupStart", rc);
+    for (int g = 0; g < G; ++g) {
+      Shard& s = m->sh[g];
+      const int rc = m->rccl.AllReduce(s.part.p, s.part.p, (size_t)p.n_out * len, /*ncclFloat64*/ 8, /*ncclSum*/ 0, m->comms[g], s.stream);
+      if (rc != 0) { (void)m->rccl.GroupEnd(); return rccl_fail(m, "ncclAllReduce", rc); }
+    }
+    if (int rc = m->rccl.GroupEnd()) return rccl_fail(m, "ncclGroupEnd", rc);
+    Shard& s0 = m->sh[0];
+    RMB_HIP(hipSetDevice(s0.device));
+    for (int v = 0; v < p.n_out; ++v) {
+      if (out_primary) RMB_HIP(hipMemcpyAsync(out_primary[v], (double*)s0.part.p + v * len, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s0.stream));
+      else RMB_HIP(hipMemcpyAsync(m->host_out + v * len, (double*)s0.part.p + v * len, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, s0.stream));
+    }
+    for (int g = 0; g < G; ++g) {
+      RMB_HIP(hipSetDevice(m->sh[g].device));
+      RMB_HIP(hipEventRecord(m->sh[g].ev_reduced, m->sh[g].stream));
+    }
+    return 0;
+  }
+  for (int g = 0; g < G; ++g) {
+    Shard& s = m->sh[g];
+    RMB_HIP(hipSetDevice(s.device));
+    for (int h = 0; h < G; ++h)
+      if (h != g) RMB_HIP(hipStreamWaitEvent(s.stream, m->sh[h].ev_partial, 0));
+    long lo, hi;
+    slice_of(len, g, G, &lo, &hi);
+    const long cnt = hi - lo;
+    ReduceArgs ra;
+    ra.n_shards = G; ra.n_out = p.n_out; ra.len = len; ra.lo = lo; ra.hi = hi;
+    const bool direct = m->peer || !out_primary || s.device == m->sh[0].device;   // may this device store into the result?
+    if (m->peer) {
+      for (int h = 0; h < G; ++h) ra.part[h] = (const double*)m->sh[h].part.p;
+    } else {
+      // no peer access: bring slice g of every other shard's partial here with copies the runtime routes itself
+      if (cnt > 0) {
+        if (int rc = s.gather.reserve((size_t)G * p.n_out * len * sizeof(double))) return rc;   // indexed like a partial: no offset arithmetic in the kernel
+        for (int h = 0; h < G; ++h) {
+          if (m->sh[h].device == s.device) { ra.part[h] = (const double*)m->sh[h].part.p; continue; }
+          double* base = (double*)s.gather.p + (size_t)h * p.n_out * len;
+          for (int v = 0; v < p.n_out; ++v)
+            RMB_HIP(hipMemcpyPeerAsync(base + v * len + lo, s.device, (const double*)m->sh[h].part.p + v * len + lo, m->sh[h].device,
+                                       (size_t)cnt * sizeof(double), s.stream));
+          ra.part[h] = base;
+        }
+      } else {
+        for (int h = 0; h < G; ++h) ra.part[h] = (const double*)m->sh[h].part.p;
+      }
+    }
+    if (!out_primary || !direct) {
+      if (int rc = s.red.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
+      for (int v = 0; v < p.n_out; ++v) ra.out[v] = (double*)s.red.p + v * len;
+    } else {
+      for (int v = 0; v < p.n_out; ++v) ra.out[v] = out_primary[v];
+    }
+    if (cnt > 0) {
+      hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s.stream, ra);
+      RMB_HIP(hipGetLastError());
+      for (int v = 0; v < p.n_out; ++v) {
+        if (!out_primary)
+          RMB_HIP(hipMemcpyAsync(m->host_out + v * len + lo, ra.out[v] + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+        else if (!direct)
+          RMB_HIP(hipMemcpyPeerAsync(out_primary[v] + lo, m->sh[0].device, ra.out[v] + lo, s.device, (size_t)cnt * sizeof(double), s.stream));
+      }
+    }
+    RMB_HIP(hipEventRecord(s.ev_reduced, s.stream));
+  }
+  return 0;
+}
+
+// device entry: order the shards after the caller's stream, run, order the caller's stream after the shards
+int run_device(rmb_multi* m, const Product& p, const double* const* in_dev, double* const* out_dev) {
+  const int G = (int)m->sh.size();
+  const long len = 3 * m->n;
+  Shard& s0 = m->sh[0];
+  RMB_HIP(hipSetDevice(s0.device));
+  RMB_HIP(hipEventRecord(m->ev_in, m->primary));
+  const double* in_local[kMaxShards][kMaxVec];
+  for (int g = 0; g < G; ++g) {
+    Shard& s = m->sh[g];
+    RMB_HIP(hipSetDevice(s.device));
+    RMB_HIP(hipStreamWaitEvent(s.stream, m->ev_in, 0));
+    for (int v = 0; v < p.n_in; ++v) {
+      if (s.device == s0.device) { in_local[g][v] = in_dev[v]; continue; }     // same memory: no copy
+      if (int rc = s.in[v].reserve((size_t)len * sizeof(double))) return rc;
+      if (m->peer) {
+        hipLaunchKernelGGL(pull_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s.stream, (double*)s.in[v].p, in_dev[v], len);
+        RMB_HIP(hipGetLastError());
+      } else {
+        RMB_HIP(hipMemcpyPeerAsync(s.in[v].p, s.device, in_dev[v], s0.device, (size_t)len * sizeof(double), s.stream));
+      }
+      in_local[g][v] = (const double*)s.in[v].p;
+    }
+  }
+  if (int rc = sweep_and_reduce(m, p, in_local, out_dev)) return rc;
+  RMB_HIP(hipSetDevice(s0.device));
+  for (int g = 0; g < G; ++g) RMB_HIP(hipStreamWaitEvent(m->primary, m->sh[g].ev_reduced, 0));
+  RMB_HIP(hipEventRecord(m->ev_done, m->primary));
+  m->done_recorded = true;
+  return 0;
+}
+
+// host entry: synchronous, like the reference's wrappers
+int run_host(rmb_multi* m, const Product& p, const double* const* in_host, double* const* out_host) {
+  const int G = (int)m->sh.size();
+  const long len = 3 * m->n;
+  const size_t vb = (size_t)len * sizeof(double);
+  if (int rc = pinned_reserve(m, (size_t)(p.n_in + p.n_out) * vb)) return rc;
+  m->host_out = (double*)m->pinned + (size_t)p.n_in * len;
+  // everything a previous *_device call left in flight must be through before the staging buffer and the partials
+  // are re-used from the host side
+  if (m->done_recorded) { RMB_HIP(hipEventSynchronize(m->ev_done)); }
+  for (int v = 0; v < p.n_in; ++v) memcpy((char*)m->pinned + v * vb, in_host[v], vb);
+  const double* in_local[kMaxShards][kMaxVec];
+  for (int g = 0; g < G; ++g) {
+    Shard& s = m->sh[g];
+    RMB_HIP(hipSetDevice(s.device));
+    for (int v = 0; v < p.n_in; ++v) {
+      if (int rc = s.in[v].reserve(vb)) return rc;
+      RMB_HIP(hipMemcpyAsync(s.in[v].p, (char*)m->pinned + v * vb, vb, hipMemcpyHostToDevice, s.stream));
+      in_local[g][v] = (const double*)s.in[v].p;
+    }
+  }
+  if (int rc = sweep_and_reduce(m, p, in_local, nullptr)) return rc;
+  for (int g = 0; g < G; ++g) {
+    RMB_HIP(hipSetDevice(m->sh[g].device));
+    RMB_HIP(hipStreamSynchronize(m->sh[g].stream));
+  }
+  for (int v = 0; v < p.n_out; ++v) memcpy(out_host[v], m->host_out + v * len, vb);
+  return 0;
+}
+
+int product_of_kind(rmb_multi* m, int kind, int in_plane, bool have_vec2, double eta, Product* p) {
+  if (kind < 0 || kind >= rmb::KIND_COUNT) return fail(RMB_ERR_ARG, "kind must be 0..5");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  if (kind == rmb::KIND_TT_TR && !have_vec2) return fail(RMB_ERR_ARG, "RMB_TT_TR needs vec2 (torque)");
+  p->eta = eta; p->in_plane = in_plane ? 1 : 0; p->kind = kind;
+  p->n_in = kind == rmb::KIND_TT_TR ? 2 : 1;
+  p->n_out = 1;
+  if (kind == rmb::KIND_TT_TR) { p->op = RMB_OP_VELOCITY_FROM_FORCE_TORQUE; p->launch = launch_op; }
+  else if (in_plane && kind <= rmb::KIND_RR) { p->op = RMB_OP_TT_MULTI + kind; p->launch = launch_op; }   // row / column mask of the symmetric block
+  else p->launch = launch_kind;
+  (void)m;
+  return 0;
+}
+
+int product_of_op(int op, int in_plane, int n_in, int n_out, double eta, Product* p) {
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  if (n_in < 1 || n_in > kMaxVec || n_out < 1 || n_out > kMaxVec) return fail(RMB_ERR_ARG, "an operation takes 1..4 vectors");
+  p->op = op; p->in_plane = in_plane ? 1 : 0; p->n_in = n_in; p->n_out = n_out; p->eta = eta; p->launch = launch_op;
+  return 0;    // the shard launch checks op / counts (matvec_op_impl)
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmb_multi_create(const int* devices, int n_dev, rmb_multi** out) {
+  if (!out) return fail(RMB_ERR_ARG, "null engine out pointer");
+  if (!devices || n_dev < 1 || n_dev > kMaxShards) return fail(RMB_ERR_ARG, "device list must hold 1..16 entries");
+  int n_vis = 0;
+  hipError_t e = hipGetDeviceCount(&n_vis);
+  if (e != hipSuccess || n_vis == 0) return fail(RMB_ERR_NO_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + ")");
+  for (int g = 0; g < n_dev; ++g)
+    if (devices[g] < 0 || devices[g] >= n_vis) return fail(RMB_ERR_ARG, "device index out of range");
+  rmb_multi* m = new rmb_multi();
+  m->sh.resize(n_dev);
+  int rc = 0;
+  for (int g = 0; g < n_dev && rc == 0; ++g) {
+    Shard& s = m->sh[g];
+    s.device = devices[g];
+    for (int h = 0; h < g; ++h) if (devices[h] == devices[g]) m->distinct = false;
+    if ((rc = rmb_ctx_create(s.device, &s.ctx))) break;
+    if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev_partial, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev_reduced, hipEventDisableTiming) != hipSuccess) {
+      rc = fail(RMB_ERR_HIP, "stream / event creation failed");
+      break;
+    }
+    rc = rmb_ctx_set_stream(s.ctx, s.stream);
+  }
+  if (rc == 0) {
+    if (hipSetDevice(m->sh[0].device) != hipSuccess || hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess)
+      rc = fail(RMB_ERR_HIP, "event creation failed");
+  }
+  if (rc == 0) {
+    // peer access between every pair of distinct devices (xGMI on an MI355X node); without it the engine stages
+    // through copies.  RMB_MULTI_NO_PEER=1 forces the staged path (rehearsal of that path on any box).
+    const char* np = getenv("RMB_MULTI_NO_PEER");
+    if (np && *np && *np != '0') m->peer = false;
+    for (int g = 0; g < n_dev && m->peer; ++g)
+      for (int h = 0; h < n_dev && m->peer; ++h) {
+        const int a = devices[g], b = devices[h];
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { m->peer = false; break; }
+        if (hipSetDevice(a) != hipSuccess) { m->peer = false; break; }
+        const hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) m->peer = false;
+        (void)hipGetLastError();
+      }
+  }
+  if (rc != 0) { rmb_multi_destroy(m); return rc; }
+  *out = m;
+  return 0;
+}
+
+int rmb_multi_destroy(rmb_multi* m) {
+  if (!m) return 0;
+  for (Shard& s : m->sh) {
+    (void)hipSetDevice(s.device);
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+  }
+  if (!m->comms.empty() && m->rccl.CommDestroy)
+    for (void* c : m->comms) if (c) (void)m->rccl.CommDestroy(c);
+  for (Shard& s : m->sh) {
+    (void)hipSetDevice(s.device);
+    if (s.ctx) { s.ctx->stream = nullptr; rmb_ctx_destroy(s.ctx); }     // its stream goes next: forget the handle first
+    for (auto& b : s.in) b.release();
+    s.part.release(); s.r_stage.release(); s.gather.release(); s.red.release();
+    if (s.ev_partial) (void)hipEventDestroy(s.ev_partial);
+    if (s.ev_reduced) (void)hipEventDestroy(s.ev_reduced);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  if (m->ev_in) (void)hipEventDestroy(m->ev_in);
+  if (m->ev_done) (void)hipEventDestroy(m->ev_done);
+  if (m->pinned) (void)hipHostFree(m->pinned);
+  delete m;
+  return 0;
+}
+
+int rmb_multi_n_shards(rmb_multi* m) { return m ? (int)m->sh.size() : 0; }
+
+int rmb_multi_shard_ctx(rmb_multi* m, int shard, rmb_ctx** ctx) {
+  if (!m || !ctx || shard < 0 || shard >= (int)m->sh.size()) return fail(RMB_ERR_ARG, "bad engine / shard index");
+  *ctx = m->sh[shard].ctx;
+  return 0;
+}
+
+int rmb_multi_set_stream(rmb_multi* m, void* hip_stream) {
+  if (int rc = check_multi(m, false)) return rc;
+  const hipStream_t next = (hipStream_t)hip_stream;
+  if (next != m->primary) {
+    // the new stream continues after what the last call enqueued; the event was recorded while the previous stream was
+    // alive, so nothing here touches the old handle (it may have been destroyed since)
+    if (m->done_recorded) {
+      RMB_HIP(hipSetDevice(m->sh[0].device));
+      RMB_HIP(hipStreamWaitEvent(next, m->ev_done, 0));
+    }
+    m->primary = next;
+  }
+  return 0;
+}
+
+int rmb_multi_set_option(rmb_multi* m, const char* key, long value) {
+  if (int rc = check_multi(m, false)) return rc;
+  if (!key) return fail(RMB_ERR_ARG, "null key");
+  if (!strcmp(key, "reduce")) {
+    if (value != 0 && value != 1) return fail(RMB_ERR_ARG, "reduce must be 0 (fixed-order slices) or 1 (RCCL all-reduce)");
+    if (value == 1 && !m->distinct) return fail(RMB_ERR_ARG, "\"reduce\" = 1 (RCCL) needs distinct devices");
+    m->opt_reduce = value;
+    return 0;
+  }
+  for (Shard& s : m->sh)
+    if (int rc = rmb_ctx_set_option(s.ctx, key, value)) return rc;
+  return 0;
+}
+
+int rmb_multi_get_option(rmb_multi* m, const char* key, long* value) {
+  if (int rc = check_multi(m, false)) return rc;
+  if (!key || !value) return fail(RMB_ERR_ARG, "null key / value");
+  if (!strcmp(key, "reduce")) { *value = m->opt_reduce; return 0; }
+  if (!strcmp(key, "peer")) { *value = m->peer ? 1 : 0; return 0; }
+  return rmb_ctx_get_option(m->sh[0].ctx, key, value);
+}
+
+int rmb_multi_set_positions(rmb_multi* m, const double* r_host, long n, double a, const double* L, int wall) {
+  if (int rc = check_multi(m, false)) return rc;
+  if (n < 0) return fail(RMB_ERR_ARG, "negative n");
+  if (n > 0 && !r_host) return fail(RMB_ERR_ARG, "null positions");
+  if (!(a > 0.0)) return fail(RMB_ERR_ARG, "blob radius must be positive");
+  const size_t rb = (size_t)3 * n * sizeof(double);
+  if (m->done_recorded) { RMB_HIP(hipEventSynchronize(m->ev_done)); }
+  if (n > 0) {
+    if (int rc = pinned_reserve(m, rb)) return rc;
+    memcpy(m->pinned, r_host, rb);
+  }
+  for (Shard& s : m->sh) {
+    RMB_HIP(hipSetDevice(s.device));
+    if (n > 0) {
+      if (int rc = s.r_stage.reserve(rb)) return rc;
+      RMB_HIP(hipMemcpyAsync(s.r_stage.p, m->pinned, rb, hipMemcpyHostToDevice, s.stream));
+    }
+    if (int rc = rmb_set_positions_device(s.ctx, (const double*)s.r_stage.p, n, a, L, wall)) return rc;
+  }
+  for (Shard& s : m->sh) {
+    RMB_HIP(hipSetDevice(s.device));
+    RMB_HIP(hipStreamSynchronize(s.stream));
+  }
+  m->n = n;
+  m->have_positions = true;
+  return 0;
+}
+
+int rmb_multi_set_positions_device(rmb_multi* m, const double* r_dev, long n, double a, const double* L, int wall) {
+  if (int rc = check_multi(m, false)) return rc;
+  if (n < 0) return fail(RMB_ERR_ARG, "negative n");
+  if (n > 0 && !r_dev) return fail(RMB_ERR_ARG, "null positions");
+  if (!(a > 0.0)) return fail(RMB_ERR_ARG, "blob radius must be positive");
+  const long len = 3 * n;
+  Shard& s0 = m->sh[0];
+  RMB_HIP(hipSetDevice(s0.device));
+  RMB_HIP(hipEventRecord(m->ev_in, m->primary));
+  for (Shard& s : m->sh) {
+    RMB_HIP(hipSetDevice(s.device));
+    RMB_HIP(hipStreamWaitEvent(s.stream, m->ev_in, 0));
+    // every shard keeps its OWN copy of the raw positions (the caller may overwrite r_dev as soon as this returns
+    // and its stream moves on: the copy below is ordered before that by ev_reduced -> primary)
+    if (n > 0) {
+      if (int rc = s.r_stage.reserve((size_t)len * sizeof(double))) return rc;
+      if (s.device == s0.device)
+        RMB_HIP(hipMemcpyAsync(s.r_stage.p, r_dev, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
+      else if (m->peer) {
+        hipLaunchKernelGGL(pull_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s.stream, (double*)s.r_stage.p, r_dev, len);
+        RMB_HIP(hipGetLastError());
+      } else {
+        RMB_HIP(hipMemcpyPeerAsync(s.r_stage.p, s.device, r_dev, s0.device, (size_t)len * sizeof(double), s.stream));
+      }
+    }
+    if (int rc = rmb_set_positions_device(s.ctx, (const double*)s.r_stage.p, n, a, L, wall)) return rc;
+    RMB_HIP(hipEventRecord(s.ev_reduced, s.stream));
+  }
+  RMB_HIP(hipSetDevice(s0.device));
+  for (Shard& s : m->sh) RMB_HIP(hipStreamWaitEvent(m->primary, s.ev_reduced, 0));
+  RMB_HIP(hipEventRecord(m->ev_done, m->primary));
+  m->done_recorded = true;
+  m->n = n;
+  m->have_positions = true;
+  return 0;
+}
+
+int rmb_multi_matvec(rmb_multi* m, int kind, int in_plane, const double* vec_host, const double* vec2_host, double eta,
+                     double* out_host) {
+  if (int rc = check_multi(m, true)) return rc;
+  if (m->n == 0) return 0;
+  if (!vec_host || !out_host) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  Product p;
+  if (int rc = product_of_kind(m, kind, in_plane, vec2_host != nullptr, eta, &p)) return rc;
+  const double* in[2] = {vec_host, vec2_host};
+  double* out[1] = {out_host};
+  return run_host(m, p, in, out);
+}
+
+int rmb_multi_matvec_device(rmb_multi* m, int kind, int in_plane, const double* vec_dev, const double* vec2_dev, double eta,
+                            double* out_dev) {
+  if (int rc = check_multi(m, true)) return rc;
+  if (m->n == 0) return 0;
+  if (!vec_dev || !out_dev) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  Product p;
+  if (int rc = product_of_kind(m, kind, in_plane, vec2_dev != nullptr, eta, &p)) return rc;
+  const double* in[2] = {vec_dev, vec2_dev};
+  double* out[1] = {out_dev};
+  return run_device(m, p, in, out);
+}
+
+int rmb_multi_matvec_op_device(rmb_multi* m, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
+                               double* const* out_dev, double eta) {
+  if (int rc = check_multi(m, true)) return rc;
+  if (!in_dev || !out_dev) return fail(RMB_ERR_ARG, "null vector / output list");
+  Product p;
+  if (int rc = product_of_op(op, in_plane, n_in, n_out, eta, &p)) return rc;
+  for (int v = 0; v < n_in; ++v) if (!in_dev[v]) return fail(RMB_ERR_ARG, "null input vector");
+  for (int v = 0; v < n_out; ++v) if (!out_dev[v]) return fail(RMB_ERR_ARG, "null output vector");
+  if (m->n == 0) return 0;
+  return run_device(m, p, in_dev, out_dev);
+}
+
+int rmb_multi_blob_blob_force(rmb_multi* m, double repulsion_strength, double debye_length, double blob_radius, double* out_host) {
+  if (int rc = check_multi(m, true)) return rc;
+  if (m->n == 0) return 0;
+  if (!out_host) return fail(RMB_ERR_ARG, "null output pointer");
+  Product p;
+  p.n_in = 0; p.n_out = 1; p.eps = repulsion_strength; p.b = debye_length; p.a = blob_radius; p.launch = launch_force;
+  double* out[1] = {out_host};
+  return run_host(m, p, nullptr, out);
+}
+
+int rmb_multi_blob_blob_force_device(rmb_multi* m, double repulsion_strength, double debye_length, double blob_radius,
+                                     double* out_dev) {
+  if (int rc = check_multi(m, true)) return rc;
+  if (m->n == 0) return 0;
+  if (!out_dev) return fail(RMB_ERR_ARG, "null output pointer");
+  Product p;
+  p.n_in = 0; p.n_out = 1; p.eps = repulsion_strength; p.b = debye_length; p.a = blob_radius; p.launch = launch_force;
+  double* out[1] = {out_dev};
+  return run_device(m, p, nullptr, out);
+}
+
+int rmb_multi_synchronize(rmb_multi* m) {
+  if (int rc = check_multi(m, false)) return rc;
+  for (Shard& s : m->sh) {
+    RMB_HIP(hipSetDevice(s.device));
+    RMB_HIP(hipStreamSynchronize(s.stream));
+  }
+  RMB_HIP(hipSetDevice(m->sh[0].device));
+  if (m->done_recorded) { RMB_HIP(hipEventSynchronize(m->ev_done)); }
+  return 0;
+}
+
+}  // extern "C"

@@ -12,13 +12,36 @@ import numpy as np
 from .context import MobilityContext
 
 _ctx = None
+_mctx = None
 
 
-def _context():
-  global _ctx
-  if _ctx is None:
-    _ctx = MobilityContext(0)
+def _context(n=0):
+  """Own contexts (the forces use raw positions, the products clamped ones: sharing would re-pack on every call), on
+  the devices mobility.py is configured with (mobility.set_devices / RMB_DEVICES / RMB_DEVICE)."""
+  global _ctx, _mctx
+  from . import mobility
+  devs = mobility.devices()
+  if len(devs) > 1 and n >= mobility.multi_min_blobs:
+    if _mctx is None or _mctx.devices != devs:
+      if _mctx is not None:
+        _mctx.close()
+      from .multi import MultiContext
+      _mctx = MultiContext(devs)
+    return _mctx
+  if _ctx is None or _ctx.device != devs[0]:
+    if _ctx is not None:
+      _ctx.close()
+    _ctx = MobilityContext(devs[0])
   return _ctx
+
+
+def reset():
+  """Drop the module-level contexts (frees device memory)."""
+  global _ctx, _mctx
+  for c in (_ctx, _mctx):
+    if c is not None:
+      c.close()
+  _ctx = _mctx = None
 
 
 def calc_blob_blob_forces_hip(r_vectors, *args, **kwargs):
@@ -28,7 +51,7 @@ def calc_blob_blob_forces_hip(r_vectors, *args, **kwargs):
   a = kwargs.get('blob_radius')
   if L is None:
     L = np.zeros(3)
-  ctx = _context()
+  ctx = _context(np.asarray(r_vectors).size // 3)
   # wall=False: raw positions, no height clamp (the reference passes r_vectors untouched)
   ctx.set_positions(r_vectors, a, L, wall=False)
   return ctx.blob_blob_force(eps, b, a)
@@ -40,6 +63,6 @@ def calc_blob_blob_forces_radii_hip(r_vectors, radius_blobs, *args, **kwargs):
   L = kwargs.get('periodic_length')
   if L is None:
     L = np.zeros(3)
-  ctx = _context()
+  ctx = _context(0)      # per-blob radii: one device
   ctx.set_positions(r_vectors, 1.0, L, wall=False)
   return ctx.blob_blob_force_radii(radius_blobs, kwargs.get('repulsion_strength'), kwargs.get('debye_length'))

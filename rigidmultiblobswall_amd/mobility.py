@@ -15,14 +15,18 @@ Differences in HOW, not WHAT:
     in the reference (callers pass step=, update_PC= ...).
 There is no CPU fallback: without the HIP library or a GPU these functions raise.
 """
+import os
+
 import numpy as np
 import scipy.sparse
 
 from . import _lib
 from .context import MobilityContext
 
-_ctx = None
-_cached = None  # (r copy, a, L tuple, wall)
+_ctx = None       # one-device context on devices()[0]
+_mctx = None      # multi-device engine over devices() (created when it is first needed)
+_cached = {}      # id of the bound context -> (r copy, a, L tuple, wall)
+_devices = None   # set_devices() / set_device(); None = environment
 
 # The reference's GPU module has a source-level precision switch (`precision = 'single' | 'double'`,
 # mobility/mobility_pycuda.py:7-19).  Same switch here, settable at run time: with 'single' the translation <- force
@@ -30,39 +34,93 @@ _cached = None  # (r copy, a, L tuple, wall)
 # ~1e-6 relative accuracy, 1.5-1.6x faster); every other product keeps running in fp64.
 precision = 'double'
 
+# With more than one device the products of this module (and forces.calc_blob_blob_forces_hip) run on the
+# single-process multi-device engine (multi.MultiContext: pair shards + fixed-order slice reduction over xGMI) once a
+# configuration has at least this many blobs; smaller ones stay on devices()[0], where one launch is already shorter
+# than the cross-device hand-offs.  Environment: RMB_MULTI_MIN_BLOBS.
+multi_min_blobs = int(os.environ.get("RMB_MULTI_MIN_BLOBS", "20000"))
 
-def _context():
-  global _ctx
+
+def devices():
+  """Devices the module-level products use: set_devices() / set_device(), else RMB_DEVICES="0,1,2,3", else
+  RMB_DEVICE="2", else [0]."""
+  if _devices is not None:
+    return list(_devices)
+  env = os.environ.get("RMB_DEVICES", "").strip()
+  if env:
+    return [int(x) for x in env.replace(";", ",").split(",") if x.strip() != ""]
+  env = os.environ.get("RMB_DEVICE", "").strip()
+  if env:
+    return [int(env)]
+  return [0]
+
+
+def set_devices(device_list):
+  """Use these devices (indices into the visible ones) for every product of this module and of forces.py from now
+  on: one entry = that GPU; several = the whole list behind every call, in this one process (a reference-side
+  `elif implementation == 'hip'` then uses the node).  None = back to the environment / device 0."""
+  global _devices
+  reset()
+  _devices = None if device_list is None else [int(d) for d in device_list]
+  if _devices is not None and not _devices:
+    raise ValueError("set_devices needs at least one device")
+  # the stateless C entry points (source -> target, pressure, double layer) run on the library's default context
+  _lib.check(_lib.load().rmb_default_ctx_set_device(-1 if _devices is None else _devices[0]))
+
+
+def set_device(index):
+  """Use this one device (see set_devices)."""
+  set_devices([index])
+
+
+def _context(n=0):
+  """The context a configuration of n blobs is bound to: the engine over all devices when there are several and the
+  configuration is large enough, the one-device context otherwise."""
+  global _ctx, _mctx
+  devs = devices()
+  if len(devs) > 1 and n >= multi_min_blobs:
+    if _mctx is None:
+      from .multi import MultiContext
+      _mctx = MultiContext(devs)
+    return _mctx
   if _ctx is None:
-    _ctx = MobilityContext(0)
+    _ctx = MobilityContext(devs[0])
   return _ctx
 
 
+def active_devices(n):
+  """Devices a product on n blobs runs on right now (bench.py reports it as host_surface.devices)."""
+  devs = devices()
+  return devs if (len(devs) > 1 and n >= multi_min_blobs) else devs[:1]
+
+
 def reset():
-  """Drop the module-level context (frees device memory)."""
-  global _ctx, _cached
+  """Drop the module-level contexts (frees device memory)."""
+  global _ctx, _mctx
   if _ctx is not None:
     _ctx.close()
+  if _mctx is not None:
+    _mctx.close()
   _ctx = None
-  _cached = None
+  _mctx = None
+  _cached.clear()
 
 
 def _bind_positions(r_vectors, a, L, wall):
-  global _cached
   r = np.ascontiguousarray(r_vectors, dtype=np.float64).reshape(-1)
   Lt = tuple(float(x) for x in np.asarray(L, dtype=np.float64).reshape(3))
-  ctx = _context()
+  ctx = _context(r.size // 3)
   if precision not in ('single', 'double'):
     raise ValueError("mobility.precision must be 'single' or 'double'")
   ctx.set_option("precision", 32 if precision == 'single' else 64)
-  c = _cached
+  c = _cached.get(id(ctx))
   if (c is not None and c[1] == float(a) and c[2] == Lt and c[3] == bool(wall) and c[0].size == r.size
       and np.array_equal(c[0], r)):
     if ctx.target_range != (0, ctx.n):
       ctx.set_target_range(0, ctx.n)
     return ctx
   ctx.set_positions(r, a, Lt, wall)
-  _cached = (r.copy(), float(a), Lt, bool(wall))
+  _cached[id(ctx)] = (r.copy(), float(a), Lt, bool(wall))
   return ctx
 
 
@@ -306,10 +364,11 @@ def _dense(r_vectors, eta, a, wall):
   import torch
   r = np.ascontiguousarray(r_vectors, dtype=np.float64).reshape(-1, 3)
   n = len(r)
-  ctx = MobilityContext(0)
+  dev = "cuda:%d" % devices()[0]
+  ctx = MobilityContext(devices()[0])
   try:
-    ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda:0"), a, None, wall)
-    first = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    ctx.set_positions(torch.as_tensor(r.reshape(-1), device=dev), a, None, wall)
+    first = torch.zeros(1, dtype=torch.int64, device=dev)
     M = ctx.body_mobility_dense_device(first, n, eta)[0].cpu().numpy()
   finally:
     ctx.close()
@@ -349,14 +408,15 @@ def single_wall_self_mobility_with_rotation_hip(location, eta, a, *args, **kwarg
   two off-diagonal blocks of the device result are negated; the products themselves are untouched.'''
   import torch
   r = np.ascontiguousarray(location, dtype=np.float64).reshape(1, 3)
-  ctx = MobilityContext(0)
+  dev = "cuda:%d" % devices()[0]
+  ctx = MobilityContext(devices()[0])
   try:
-    ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda:0"), a, None, True)
+    ctx.set_positions(torch.as_tensor(r.reshape(-1), device=dev), a, None, True)
     M = np.empty((6, 6))
     for k in range(6):
       e = np.zeros(6)
       e[k] = 1.0
-      f, t = torch.as_tensor(e[:3].copy(), device="cuda:0"), torch.as_tensor(e[3:].copy(), device="cuda:0")
+      f, t = torch.as_tensor(e[:3].copy(), device=dev), torch.as_tensor(e[3:].copy(), device=dev)
       u, w = ctx.matvec_op_device("grand", (f, t), eta)
       M[:3, k] = u.cpu().numpy()
       M[3:, k] = w.cpu().numpy()

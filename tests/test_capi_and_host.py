@@ -86,3 +86,29 @@ def test_generated_single_precision_header_is_current():
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   rc = subprocess.call([sys.executable, os.path.join(root, "tools", "gen_pair_blocks32.py"), "--check"])
   assert rc == 0, "run `python tools/gen_pair_blocks32.py` after editing csrc/pair_blocks.h"
+
+
+def test_multi_engine_and_device_selection_fail_loudly_without_a_gpu(monkeypatch):
+  """rmb_multi_create / mobility.set_devices never fall back: no device -> error; the device list comes from
+  set_devices, RMB_DEVICES, RMB_DEVICE, in that order."""
+  import torch
+  from rigidmultiblobswall_amd import _lib, mobility
+  monkeypatch.delenv("RMB_DEVICES", raising=False)
+  monkeypatch.delenv("RMB_DEVICE", raising=False)
+  assert mobility.devices() == [0]
+  monkeypatch.setenv("RMB_DEVICE", "3")
+  assert mobility.devices() == [3]
+  monkeypatch.setenv("RMB_DEVICES", "0, 1,2;3")
+  assert mobility.devices() == [0, 1, 2, 3]
+  assert mobility.active_devices(mobility.multi_min_blobs) == [0, 1, 2, 3] and mobility.active_devices(10) == [0]
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  lib = _lib.load()
+  h = ctypes.c_void_p()
+  devs = (ctypes.c_int * 2)(0, 1)
+  assert lib.rmb_multi_create(devs, 2, ctypes.byref(h)) == -4     # RMB_ERR_NO_DEVICE
+  assert lib.rmb_multi_create(devs, 0, ctypes.byref(h)) == -1
+  assert lib.rmb_multi_matvec(None, 0, 0, None, None, 1.0, None) == -1
+  from rigidmultiblobswall_amd.multi import MultiContext
+  with pytest.raises(_lib.RmbError):
+    MultiContext([0, 1])
