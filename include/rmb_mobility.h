@@ -248,7 +248,11 @@ int rmb_default_ctx_set_device(int device);
  *   - without peer access between two listed devices (or with RMB_MULTI_NO_PEER=1) slices travel by hipMemcpyPeerAsync.
  *   - rmb_multi_set_option: "reduce" 0 [default] = the fixed-order slice reduction, 1 = RCCL all-reduce in place
  *     (ncclCommInitAll; librccl.so is dlopen()ed on first use; distinct devices only; not bit-reproducible); every other
- *     key is forwarded to all shard contexts (rmb_ctx_set_option).  rmb_multi_get_option also answers "peer" (1 / 0).
+ *     key is forwarded to all shard contexts (rmb_ctx_set_option).  rmb_multi_get_option also answers "peer" (1 / 0)
+ *     and "threads".
+ *   - with several shards every shard has a worker thread that issues its HIP calls (~25 us per shard and product from
+ *     one thread otherwise); RMB_MULTI_THREADS=0 keeps everything on the calling thread.  An engine is used from one
+ *     thread at a time.
  *   - host entry points are synchronous.  *_device entry points take pointers on devices[0], are ordered after the work
  *     already queued on the engine's primary stream (rmb_multi_set_stream; NULL = default stream of devices[0]) and
  *     order that stream after their own completion; the primary stream must be alive when a call is made, and may be

@@ -18,8 +18,11 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -66,6 +69,8 @@ struct Shard {
   DevBuf r_stage;                    // raw positions
   DevBuf gather;                     // staged path (no peer access): slice of every other shard's partial
   DevBuf red;                        // staged path / host entry: this shard's reduced slice
+  int rc = 0;                        // status of this shard's part of the current job (worker thread -> caller)
+  std::string err;
 };
 
 // RCCL, resolved at run time (torch bundles its own librccl.so under the same SONAME; dlopen returns the copy that is
@@ -79,6 +84,25 @@ struct Rccl {
   int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok() const { return handle && CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce; }
+};
+
+// What one product is, seen by the engine: inputs (3n doubles each), outputs (3n each), and how shard g of G launches
+// its pair shard on its own context with LOCAL input pointers into a LOCAL full-length partial.
+struct Product {
+  int n_in = 0, n_out = 0;
+  int (*launch)(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long shard, long nshards) = nullptr;
+  int kind = 0, op = 0, in_plane = 0;
+  double eta = 1.0, eps = 0.0, b = 1.0, a = 0.0;
+};
+
+// One call in flight: the product, where its inputs are and where its results go.
+//   device entry: in[v] / out[v] are pointers on devices[0]; results are made visible to m->primary
+//   host entry  : in[v] = staged copy in m->pinned, results land at m->host_out + v * len (out[] unused)
+struct Job {
+  Product p;
+  bool host = false;
+  const double* in[kMaxVec] = {nullptr, nullptr, nullptr, nullptr};
+  double* out[kMaxVec] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -99,6 +123,14 @@ struct rmb_multi {
   double* host_out = nullptr;       // where in `pinned` the current host call's results go
   Rccl rccl;
   std::vector<void*> comms;
+  // worker threads (one per shard when there are several): job hand-over, phase barrier, completion
+  std::vector<std::thread> workers;
+  std::mutex mu, mu_done;
+  std::condition_variable cv, cv_done;
+  std::atomic<unsigned long> job_seq{0};
+  std::atomic<int> quit{0}, failed{0}, done_count{0}, bar_count{0};
+  std::atomic<unsigned> bar_gen{0};
+  Job job;
 };
 
 namespace {
@@ -158,15 +190,6 @@ int rccl_comms(rmb_multi* m) {
   return 0;
 }
 
-// What one product is, seen by the engine: inputs (3n doubles each), outputs (3n each), and how shard g of G launches
-// its pair shard on its own context with LOCAL input pointers into a LOCAL full-length partial.
-struct Product {
-  int n_in = 0, n_out = 0;
-  int (*launch)(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long shard, long nshards) = nullptr;
-  int kind = 0, op = 0, in_plane = 0;
-  double eta = 1.0, eps = 0.0, b = 1.0, a = 0.0;
-};
-
 int launch_kind(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long g, long G) {
   return rmb_matvec_pairshard_device(c, p.kind, in[0], p.eta, out[0], g, G);
 }
@@ -177,120 +200,219 @@ int launch_force(rmb_ctx* c, const Product& p, const double* const*, double* con
   return rmbi::force_device_impl(c, p.eps, p.b, p.a, out[0], nullptr, g, G);
 }
 
-// Steps 2 and 3 of the header comment.  `in_local[g][v]`: input v as shard g sees it (already ordered on its stream).
-// Results: device entry -> out_primary[v] on devices[0], made visible to `m->primary`;
-//          host entry (out_primary == nullptr) -> slice g lands in pinned memory at m->host_out + (v * len + lo_g).
-int sweep_and_reduce(rmb_multi* m, const Product& p, const double* const in_local[][kMaxVec], double* const* out_primary) {
+// Phase 1 of shard g: inputs -> this device, sweep pair shard g of G into the local partial, record ev_partial.
+int shard_sweep(rmb_multi* m, int g, const Job& job) {
   const int G = (int)m->sh.size();
   const long len = 3 * m->n;
+  const Product& p = job.p;
+  Shard& s = m->sh[g];
+  Shard& s0 = m->sh[0];
+  RMB_HIP(hipSetDevice(s.device));
+  const double* in_local[kMaxVec] = {nullptr, nullptr, nullptr, nullptr};
+  if (!job.host) RMB_HIP(hipStreamWaitEvent(s.stream, m->ev_in, 0));
+  for (int v = 0; v < p.n_in; ++v) {
+    if (!job.host && s.device == s0.device) { in_local[v] = job.in[v]; continue; }     // same memory: no copy
+    if (int rc = s.in[v].reserve((size_t)len * sizeof(double))) return rc;
+    if (job.host) {
+      RMB_HIP(hipMemcpyAsync(s.in[v].p, job.in[v], (size_t)len * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    } else if (m->peer) {
+      hipLaunchKernelGGL(pull_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s.stream, (double*)s.in[v].p, job.in[v], len);
+      RMB_HIP(hipGetLastError());
+    } else {
+      RMB_HIP(hipMemcpyPeerAsync(s.in[v].p, s.device, job.in[v], s0.device, (size_t)len * sizeof(double), s.stream));
+    }
+    in_local[v] = (const double*)s.in[v].p;
+  }
+  if (int rc = s.part.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
+  double* outs[kMaxVec];
+  for (int v = 0; v < p.n_out; ++v) outs[v] = (double*)s.part.p + v * len;
+  if (int rc = p.launch(s.ctx, p, in_local, outs, g, G)) return rc;
+  RMB_HIP(hipEventRecord(s.ev_partial, s.stream));
+  return 0;
+}
+
+// Phase 2 of shard g (every shard has RECORDED its ev_partial by now): slice g of the sum, stored where it is wanted.
+int shard_reduce(rmb_multi* m, int g, const Job& job) {
+  const int G = (int)m->sh.size();
+  const long len = 3 * m->n;
+  const Product& p = job.p;
+  Shard& s = m->sh[g];
+  RMB_HIP(hipSetDevice(s.device));
+  for (int h = 0; h < G; ++h)
+    if (h != g) RMB_HIP(hipStreamWaitEvent(s.stream, m->sh[h].ev_partial, 0));
+  long lo, hi;
+  slice_of(len, g, G, &lo, &hi);
+  const long cnt = hi - lo;
+  ReduceArgs ra;
+  ra.n_shards = G; ra.n_out = p.n_out; ra.len = len; ra.lo = lo; ra.hi = hi;
+  const bool direct = !job.host && (m->peer || s.device == m->sh[0].device);   // may this device store into the result?
+  for (int h = 0; h < G; ++h) ra.part[h] = (const double*)m->sh[h].part.p;
+  if (!m->peer && cnt > 0) {
+    // no peer access: bring slice g of every other device's partial here with copies the runtime routes itself
+    if (int rc = s.gather.reserve((size_t)G * p.n_out * len * sizeof(double))) return rc;   // indexed like a partial: no offset arithmetic in the kernel
+    for (int h = 0; h < G; ++h) {
+      if (m->sh[h].device == s.device) continue;
+      double* base = (double*)s.gather.p + (size_t)h * p.n_out * len;
+      for (int v = 0; v < p.n_out; ++v)
+        RMB_HIP(hipMemcpyPeerAsync(base + v * len + lo, s.device, (const double*)m->sh[h].part.p + v * len + lo, m->sh[h].device,
+                                   (size_t)cnt * sizeof(double), s.stream));
+      ra.part[h] = base;
+    }
+  }
+  if (direct) {
+    for (int v = 0; v < p.n_out; ++v) ra.out[v] = job.out[v];
+  } else {
+    if (int rc = s.red.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
+    for (int v = 0; v < p.n_out; ++v) ra.out[v] = (double*)s.red.p + v * len;
+  }
+  if (cnt > 0) {
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s.stream, ra);
+    RMB_HIP(hipGetLastError());
+    for (int v = 0; v < p.n_out; ++v) {
+      if (job.host)
+        RMB_HIP(hipMemcpyAsync(m->host_out + v * len + lo, ra.out[v] + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+      else if (!direct)
+        RMB_HIP(hipMemcpyPeerAsync(job.out[v] + lo, m->sh[0].device, ra.out[v] + lo, s.device, (size_t)cnt * sizeof(double), s.stream));
+    }
+  }
+  RMB_HIP(hipEventRecord(s.ev_reduced, s.stream));
+  if (job.host) RMB_HIP(hipStreamSynchronize(s.stream));     // synchronous entry: the shards wait in parallel
+  return 0;
+}
+
+// "reduce" = 1: RCCL all-reduce of the partials in place (one grouped call from the calling thread), then the primary
+// shard hands the sum over.  Every shard has recorded its ev_partial; RCCL orders itself on the shard streams.
+int rccl_reduce(rmb_multi* m, const Job& job) {
+  const int G = (int)m->sh.size();
+  const long len = 3 * m->n;
+  const Product& p = job.p;
+  if (int rc = rccl_comms(m)) return rc;
+  if (int rc = m->rccl.GroupStart()) return rccl_fail(m, "ncclGroupStart", rc);
   for (int g = 0; g < G; ++g) {
     Shard& s = m->sh[g];
-    RMB_HIP(hipSetDevice(s.device));
-    if (int rc = s.part.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
-    double* outs[kMaxVec];
-    for (int v = 0; v < p.n_out; ++v) outs[v] = (double*)s.part.p + v * len;
-    if (int rc = p.launch(s.ctx, p, in_local[g], outs, g, G)) return rc;
-    RMB_HIP(hipEventRecord(s.ev_partial, s.stream));
+    const int rc = m->rccl.AllReduce(s.part.p, s.part.p, (size_t)p.n_out * len, /*ncclFloat64*/ 8, /*ncclSum*/ 0, m->comms[g], s.stream);
+    if (rc != 0) { (void)m->rccl.GroupEnd(); return rccl_fail(m, "ncclAllReduce", rc); }
   }
-  if (m->opt_reduce == 1) {
-    // RCCL: every device ends up with the whole sum in its partial; the primary shard hands it over
-    if (int rc = rccl_comms(m)) return rc;
-    if (int rc = m->rccl.GroupStart()) return rccl_fail(m, "ncclGroupStart", rc);
-    for (int g = 0; g < G; ++g) {
-      Shard& s = m->sh[g];
-      const int rc = m->rccl.AllReduce(s.part.p, s.part.p, (size_t)p.n_out * len, /*ncclFloat64*/ 8, /*ncclSum*/ 0, m->comms[g], s.stream);
-      if (rc != 0) { (void)m->rccl.GroupEnd(); return rccl_fail(m, "ncclAllReduce", rc); }
+  if (int rc = m->rccl.GroupEnd()) return rccl_fail(m, "ncclGroupEnd", rc);
+  Shard& s0 = m->sh[0];
+  RMB_HIP(hipSetDevice(s0.device));
+  for (int v = 0; v < p.n_out; ++v) {
+    if (!job.host) RMB_HIP(hipMemcpyAsync(job.out[v], (double*)s0.part.p + v * len, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s0.stream));
+    else RMB_HIP(hipMemcpyAsync(m->host_out + v * len, (double*)s0.part.p + v * len, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, s0.stream));
+  }
+  for (int g = 0; g < G; ++g) {
+    RMB_HIP(hipSetDevice(m->sh[g].device));
+    RMB_HIP(hipEventRecord(m->sh[g].ev_reduced, m->sh[g].stream));
+    if (job.host) RMB_HIP(hipStreamSynchronize(m->sh[g].stream));
+  }
+  return 0;
+}
+
+// ---- executors ---------------------------------------------------------------------------------------------------
+// Enqueueing one shard's part of a product is ~25 us of HIP calls (waits, two or three launches, records); issued from
+// one thread that is 25 us x G before the last device even starts (tools/experiments/exp_multi_engine.py).  With more
+// than one shard every shard therefore has a worker thread that issues its own calls; the calling thread publishes the
+// job and waits.  Between the two phases all workers meet at a barrier: hipStreamWaitEvent refers to the event's most
+// recent RECORD, so every ev_partial has to be recorded before any shard waits on it.
+
+void spin_pause() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
+
+// every worker calls this once per phase; returns when all `n` have arrived
+void workers_barrier(rmb_multi* m) {
+  const int n = (int)m->sh.size();
+  const unsigned gen = m->bar_gen.load(std::memory_order_acquire);
+  if (m->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+    m->bar_count.store(0, std::memory_order_relaxed);
+    m->bar_gen.fetch_add(1, std::memory_order_release);
+  } else {
+    int spins = 0;
+    while (m->bar_gen.load(std::memory_order_acquire) == gen) {
+      if (++spins < 4096) spin_pause(); else std::this_thread::yield();
     }
-    if (int rc = m->rccl.GroupEnd()) return rccl_fail(m, "ncclGroupEnd", rc);
-    Shard& s0 = m->sh[0];
-    RMB_HIP(hipSetDevice(s0.device));
-    for (int v = 0; v < p.n_out; ++v) {
-      if (out_primary) RMB_HIP(hipMemcpyAsync(out_primary[v], (double*)s0.part.p + v * len, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s0.stream));
-      else RMB_HIP(hipMemcpyAsync(m->host_out + v * len, (double*)s0.part.p + v * len, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, s0.stream));
+  }
+}
+
+void worker_main(rmb_multi* m, int g) {
+  (void)hipSetDevice(m->sh[g].device);
+  unsigned long seen = 0;
+  for (;;) {
+    {
+      // short spin first (a Krylov loop calls every few hundred microseconds), then sleep
+      int spins = 0;
+      while (m->job_seq.load(std::memory_order_acquire) == seen && !m->quit.load(std::memory_order_acquire) && ++spins < 20000) spin_pause();
+      if (m->job_seq.load(std::memory_order_acquire) == seen && !m->quit.load(std::memory_order_acquire)) {
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv.wait(lk, [&] { return m->job_seq.load(std::memory_order_acquire) != seen || m->quit.load(std::memory_order_acquire); });
+      }
     }
-    for (int g = 0; g < G; ++g) {
-      RMB_HIP(hipSetDevice(m->sh[g].device));
-      RMB_HIP(hipEventRecord(m->sh[g].ev_reduced, m->sh[g].stream));
+    if (m->quit.load(std::memory_order_acquire)) return;
+    seen = m->job_seq.load(std::memory_order_acquire);
+    const Job& job = m->job;
+    int rc = shard_sweep(m, g, job);
+    if (rc != 0) { m->sh[g].rc = rc; m->sh[g].err = rmb_last_error(); m->failed.store(1, std::memory_order_release); }
+    workers_barrier(m);
+    if (!m->failed.load(std::memory_order_acquire) && m->opt_reduce == 0) {
+      rc = shard_reduce(m, g, job);
+      if (rc != 0) { m->sh[g].rc = rc; m->sh[g].err = rmb_last_error(); m->failed.store(1, std::memory_order_release); }
     }
+    if (m->done_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (int)m->sh.size()) {
+      std::lock_guard<std::mutex> lk(m->mu_done);
+      m->cv_done.notify_one();
+    }
+  }
+}
+
+int run_shards(rmb_multi* m, const Job& job) {
+  const int G = (int)m->sh.size();
+  if (m->workers.empty()) {
+    // one shard, or RMB_MULTI_THREADS=0: everything from the calling thread
+    for (int g = 0; g < G; ++g)
+      if (int rc = shard_sweep(m, g, job)) return rc;
+    if (m->opt_reduce == 1) return rccl_reduce(m, job);
+    for (int g = 0; g < G; ++g)
+      if (int rc = shard_reduce(m, g, job)) return rc;
     return 0;
   }
-  for (int g = 0; g < G; ++g) {
-    Shard& s = m->sh[g];
-    RMB_HIP(hipSetDevice(s.device));
-    for (int h = 0; h < G; ++h)
-      if (h != g) RMB_HIP(hipStreamWaitEvent(s.stream, m->sh[h].ev_partial, 0));
-    long lo, hi;
-    slice_of(len, g, G, &lo, &hi);
-    const long cnt = hi - lo;
-    ReduceArgs ra;
-    ra.n_shards = G; ra.n_out = p.n_out; ra.len = len; ra.lo = lo; ra.hi = hi;
-    const bool direct = m->peer || !out_primary || s.device == m->sh[0].device;   // may this device store into the result?
-    if (m->peer) {
-      for (int h = 0; h < G; ++h) ra.part[h] = (const double*)m->sh[h].part.p;
-    } else {
-      // no peer access: bring slice g of every other shard's partial here with copies the runtime routes itself
-      if (cnt > 0) {
-        if (int rc = s.gather.reserve((size_t)G * p.n_out * len * sizeof(double))) return rc;   // indexed like a partial: no offset arithmetic in the kernel
-        for (int h = 0; h < G; ++h) {
-          if (m->sh[h].device == s.device) { ra.part[h] = (const double*)m->sh[h].part.p; continue; }
-          double* base = (double*)s.gather.p + (size_t)h * p.n_out * len;
-          for (int v = 0; v < p.n_out; ++v)
-            RMB_HIP(hipMemcpyPeerAsync(base + v * len + lo, s.device, (const double*)m->sh[h].part.p + v * len + lo, m->sh[h].device,
-                                       (size_t)cnt * sizeof(double), s.stream));
-          ra.part[h] = base;
-        }
-      } else {
-        for (int h = 0; h < G; ++h) ra.part[h] = (const double*)m->sh[h].part.p;
-      }
-    }
-    if (!out_primary || !direct) {
-      if (int rc = s.red.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
-      for (int v = 0; v < p.n_out; ++v) ra.out[v] = (double*)s.red.p + v * len;
-    } else {
-      for (int v = 0; v < p.n_out; ++v) ra.out[v] = out_primary[v];
-    }
-    if (cnt > 0) {
-      hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s.stream, ra);
-      RMB_HIP(hipGetLastError());
-      for (int v = 0; v < p.n_out; ++v) {
-        if (!out_primary)
-          RMB_HIP(hipMemcpyAsync(m->host_out + v * len + lo, ra.out[v] + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-        else if (!direct)
-          RMB_HIP(hipMemcpyPeerAsync(out_primary[v] + lo, m->sh[0].device, ra.out[v] + lo, s.device, (size_t)cnt * sizeof(double), s.stream));
-      }
-    }
-    RMB_HIP(hipEventRecord(s.ev_reduced, s.stream));
+  m->job = job;
+  m->failed.store(0, std::memory_order_relaxed);
+  m->done_count.store(0, std::memory_order_relaxed);
+  for (Shard& s : m->sh) s.rc = 0;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->job_seq.fetch_add(1, std::memory_order_release);
   }
+  m->cv.notify_all();
+  {
+    int spins = 0;
+    while (m->done_count.load(std::memory_order_acquire) != G && ++spins < 200000) spin_pause();
+    if (m->done_count.load(std::memory_order_acquire) != G) {
+      std::unique_lock<std::mutex> lk(m->mu_done);
+      m->cv_done.wait(lk, [&] { return m->done_count.load(std::memory_order_acquire) == G; });
+    }
+  }
+  if (m->failed.load(std::memory_order_acquire))
+    for (Shard& s : m->sh)
+      if (s.rc != 0) return fail(s.rc, s.err);
+  if (m->opt_reduce == 1) return rccl_reduce(m, job);
   return 0;
 }
 
 // device entry: order the shards after the caller's stream, run, order the caller's stream after the shards
 int run_device(rmb_multi* m, const Product& p, const double* const* in_dev, double* const* out_dev) {
-  const int G = (int)m->sh.size();
-  const long len = 3 * m->n;
   Shard& s0 = m->sh[0];
   RMB_HIP(hipSetDevice(s0.device));
   RMB_HIP(hipEventRecord(m->ev_in, m->primary));
-  const double* in_local[kMaxShards][kMaxVec];
-  for (int g = 0; g < G; ++g) {
-    Shard& s = m->sh[g];
-    RMB_HIP(hipSetDevice(s.device));
-    RMB_HIP(hipStreamWaitEvent(s.stream, m->ev_in, 0));
-    for (int v = 0; v < p.n_in; ++v) {
-      if (s.device == s0.device) { in_local[g][v] = in_dev[v]; continue; }     // same memory: no copy
-      if (int rc = s.in[v].reserve((size_t)len * sizeof(double))) return rc;
-      if (m->peer) {
-        hipLaunchKernelGGL(pull_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s.stream, (double*)s.in[v].p, in_dev[v], len);
-        RMB_HIP(hipGetLastError());
-      } else {
-        RMB_HIP(hipMemcpyPeerAsync(s.in[v].p, s.device, in_dev[v], s0.device, (size_t)len * sizeof(double), s.stream));
-      }
-      in_local[g][v] = (const double*)s.in[v].p;
-    }
-  }
-  if (int rc = sweep_and_reduce(m, p, in_local, out_dev)) return rc;
+  Job job;
+  job.p = p; job.host = false;
+  for (int v = 0; v < p.n_in; ++v) job.in[v] = in_dev[v];
+  for (int v = 0; v < p.n_out; ++v) job.out[v] = out_dev[v];
+  if (int rc = run_shards(m, job)) return rc;
   RMB_HIP(hipSetDevice(s0.device));
-  for (int g = 0; g < G; ++g) RMB_HIP(hipStreamWaitEvent(m->primary, m->sh[g].ev_reduced, 0));
+  for (Shard& s : m->sh) RMB_HIP(hipStreamWaitEvent(m->primary, s.ev_reduced, 0));
   RMB_HIP(hipEventRecord(m->ev_done, m->primary));
   m->done_recorded = true;
   return 0;
@@ -298,30 +420,19 @@ int run_device(rmb_multi* m, const Product& p, const double* const* in_dev, doub
 
 // host entry: synchronous, like the reference's wrappers
 int run_host(rmb_multi* m, const Product& p, const double* const* in_host, double* const* out_host) {
-  const int G = (int)m->sh.size();
   const long len = 3 * m->n;
   const size_t vb = (size_t)len * sizeof(double);
   if (int rc = pinned_reserve(m, (size_t)(p.n_in + p.n_out) * vb)) return rc;
   m->host_out = (double*)m->pinned + (size_t)p.n_in * len;
-  // everything a previous *_device call left in flight must be through before the staging buffer and the partials
-  // are re-used from the host side
+  // everything a previous *_device call left in flight must be through before the partials are re-used
   if (m->done_recorded) { RMB_HIP(hipEventSynchronize(m->ev_done)); }
-  for (int v = 0; v < p.n_in; ++v) memcpy((char*)m->pinned + v * vb, in_host[v], vb);
-  const double* in_local[kMaxShards][kMaxVec];
-  for (int g = 0; g < G; ++g) {
-    Shard& s = m->sh[g];
-    RMB_HIP(hipSetDevice(s.device));
-    for (int v = 0; v < p.n_in; ++v) {
-      if (int rc = s.in[v].reserve(vb)) return rc;
-      RMB_HIP(hipMemcpyAsync(s.in[v].p, (char*)m->pinned + v * vb, vb, hipMemcpyHostToDevice, s.stream));
-      in_local[g][v] = (const double*)s.in[v].p;
-    }
+  Job job;
+  job.p = p; job.host = true;
+  for (int v = 0; v < p.n_in; ++v) {
+    memcpy((char*)m->pinned + v * vb, in_host[v], vb);
+    job.in[v] = (const double*)((char*)m->pinned + v * vb);
   }
-  if (int rc = sweep_and_reduce(m, p, in_local, nullptr)) return rc;
-  for (int g = 0; g < G; ++g) {
-    RMB_HIP(hipSetDevice(m->sh[g].device));
-    RMB_HIP(hipStreamSynchronize(m->sh[g].stream));
-  }
+  if (int rc = run_shards(m, job)) return rc;      // every shard stream is synchronised when this returns
   for (int v = 0; v < p.n_out; ++v) memcpy(out_host[v], m->host_out + v * len, vb);
   return 0;
 }
@@ -398,12 +509,31 @@ int rmb_multi_create(const int* devices, int n_dev, rmb_multi** out) {
       }
   }
   if (rc != 0) { rmb_multi_destroy(m); return rc; }
+  // one worker thread per shard issues that shard's HIP calls (RMB_MULTI_THREADS=0: everything from the calling thread)
+  const char* th = getenv("RMB_MULTI_THREADS");
+  if (n_dev > 1 && !(th && *th == '0')) {
+    try {
+      for (int g = 0; g < n_dev; ++g) m->workers.emplace_back(worker_main, m, g);
+    } catch (...) {
+      rmb_multi_destroy(m);
+      return fail(RMB_ERR_STATE, "could not start the shard worker threads");
+    }
+  }
   *out = m;
   return 0;
 }
 
 int rmb_multi_destroy(rmb_multi* m) {
   if (!m) return 0;
+  if (!m->workers.empty()) {
+    {
+      std::lock_guard<std::mutex> lk(m->mu);
+      m->quit.store(1, std::memory_order_release);
+    }
+    m->cv.notify_all();
+    for (std::thread& t : m->workers) if (t.joinable()) t.join();
+    m->workers.clear();
+  }
   for (Shard& s : m->sh) {
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -468,6 +598,7 @@ int rmb_multi_get_option(rmb_multi* m, const char* key, long* value) {
   if (!key || !value) return fail(RMB_ERR_ARG, "null key / value");
   if (!strcmp(key, "reduce")) { *value = m->opt_reduce; return 0; }
   if (!strcmp(key, "peer")) { *value = m->peer ? 1 : 0; return 0; }
+  if (!strcmp(key, "threads")) { *value = (long)m->workers.size(); return 0; }
   return rmb_ctx_get_option(m->sh[0].ctx, key, value);
 }
 
