@@ -15,7 +15,7 @@ decompositions (pair shard + all-reduce; target shard + all-gather of f, the one
 1e6 blobs.  Rank 0 prints ONE JSON line.
 
 Before the W warm-up steps every rank primes the clocks with an untimed, DECLARED pre-warm (`prewarm` in the line):
-from idle the fp64 clock needs ~100 launches / 25 ms to settle (tools/exp_prewarm.py: 0.207 -> 0.230 -> 0.189 ms per
+from idle the fp64 clock needs ~100 launches / 25 ms to settle (tools/experiments/exp_prewarm.py: 0.207 -> 0.230 -> 0.189 ms per
 launch), so `--warmup 5` alone would time the power-management ramp, not the kernel.
 
 Objects on the line
@@ -33,7 +33,18 @@ Objects on the line
   value_unprimed  the same W + K steps run first thing, before the declared pre-warm (clock still ramping)
   host_surface  matvecs/s through single_wall_mobility_trans_times_force_hip with numpy in / out (the reference's
                 call shape, PCIe-inclusive) -- reported beside `value`, never `value`
-  cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N = 1 only)
+                `devices` = what the call ran on (mobility.set_devices / RMB_DEVICES), `breakdown_us` = where one call's
+                time goes (position compare, upload, enqueue, sweep by HIP events, download + sync, Python)
+  multi_device_surface  one-rank run with several devices visible: the same call on the single-process multi-device
+                engine over all of them (child process with a timeout, tools/multi_surface_probe.py)
+  cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N = 1 only); `by_size`: every
+                size of SURVEY 8(d) up to 1e5 blobs measured (bounded repetitions), 262 144 / 1e6 extrapolated with N^2
+  build         what __graft_entry__.build() did for the library this run loaded (compiled / reused)
+
+The run cannot hang and cannot lose its headline (class Guard): the headline goes to stderr and to a file the moment
+it exists; every later stage is started only if all ranks agree that it fits the wall-clock budget (--budget-s, 420 s);
+a rank whose stage raises drops a marker file and every rank's watchdog thread ends the run within a second -- rank 0
+prints the line with what exists plus `extras_aborted`; the same watchdog cuts a stage that never returns at the budget.
 """
 import argparse
 import json
@@ -75,6 +86,9 @@ def parse_args():
                   help="untimed, declared clock pre-warm before the warm-up steps (0 disables)")
   ap.add_argument("--no-sweep", action="store_true", help="skip the N_blobs sweep, decompositions and config extras")
   ap.add_argument("--no-cpu", action="store_true")
+  ap.add_argument("--budget-s", type=float, default=420.0,
+                  help="wall-clock budget of the whole run: stages that would not fit are skipped on all ranks, and at the "
+                       "budget the watchdog prints the line with what exists and ends the run (the driver's limit is 600 s)")
   ap.add_argument("--no-host-surface", action="store_true",
                   help="skip the host_surface extra (profiling runs: the last K dispatches of the trace are then the timed ones)")
   return ap.parse_args()
@@ -87,6 +101,8 @@ def spawn_ranks(args):
   with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
+  import tempfile
+  run_dir = tempfile.mkdtemp(prefix="rmb_bench_")      # side channel of the ranks' watchdogs (Guard)
   procs = []
   for rank in range(args.gpus):
     env = dict(os.environ)
@@ -98,6 +114,7 @@ def spawn_ranks(args):
     # shell that dropped it, it never overrides a value the operator chose.  The value every rank ran with is on the
     # line ("ipc_mode_legacy_env").
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["RMB_BENCH_RUN_DIR"] = run_dir
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
   rc = 0
   alive = set(range(len(procs)))
@@ -262,7 +279,138 @@ def _exec_frac(isa, sym, N, world, n_local, kern_s):
   return None if ex is None else ex["frac"]
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# never hang, never lose the headline
+# ---------------------------------------------------------------------------------------------------------------
+class Guard(object):
+  """Keeps a run from hanging and from losing its headline (one rank that leaves a collective sequence
+  strands the others until the driver's limit, and the line was only printed at the very end).
+
+    * the headline is written to stderr and to <run dir>/headline.json the moment it exists;
+    * every stage after it is announced with begin(): the ranks agree (MAX of their clocks) whether it still fits the
+      wall-clock budget, otherwise it is skipped on all of them;
+    * a rank whose stage raises calls fail(): it drops a marker file in the run directory (a side channel that needs
+      neither the GPU nor a collective);
+    * a watchdog thread on every rank polls for markers and the budget four times a second; on either, rank 0 prints
+      the line with what it has (plus `extras_aborted`) and every rank leaves with os._exit -- whatever collective
+      the main thread is stuck in."""
+
+  def __init__(self, rank, world, budget_s, run_dir, t0):
+    import threading
+    self.rank, self.world, self.budget, self.run_dir, self.t0 = rank, world, float(budget_s), run_dir, t0
+    self.line = None
+    self.stage = "headline"
+    self._lock = threading.Lock()
+    self._finished = False
+    self._stop = threading.Event()
+    os.makedirs(run_dir, exist_ok=True)
+    self._thread = threading.Thread(target=self._watch, name="bench-watchdog", daemon=True)
+    self._thread.start()
+
+  def elapsed(self):
+    return time.time() - self.t0
+
+  def publish_headline(self, line):
+    self.line = line
+    if self.rank == 0:
+      txt = json.dumps({k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline")
+                        if k in line})
+      sys.stderr.write("[bench headline] %s\n" % txt)
+      sys.stderr.flush()
+      for path in (os.path.join(self.run_dir, "headline.json"), os.path.join(ROOT, "gpurun_out", "bench_headline_last.json")):
+        try:
+          if os.path.isdir(os.path.dirname(path)):
+            with open(path, "w") as fh:
+              fh.write(txt + "\n")
+        except OSError:
+          pass
+
+  def begin(self, stage, expect_s, torch=None, dist=None, device=None):
+    """All ranks: may `stage` (expected to take `expect_s`) still start?  Decided on the slowest rank's clock."""
+    el = self.elapsed()
+    if self.world > 1:
+      t = torch.tensor([el], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      el = float(t.item())
+    ok = el + expect_s < self.budget
+    if ok:
+      self.stage = stage
+    return ok
+
+  def fail(self, stage, exc):
+    """A stage raised on this rank of a multi-rank run: tell every rank's watchdog, then wait to be taken down."""
+    try:
+      with open(os.path.join(self.run_dir, "abort_rank%d" % self.rank), "w") as fh:
+        fh.write("rank %d failed in stage %r: %s: %s" % (self.rank, stage, type(exc).__name__, exc))
+    except OSError:
+      os._exit(3)
+    time.sleep(3600)
+
+  def _emit(self, reason):
+    if self.rank == 0:
+      code = 3
+      for _ in range(5):
+        try:
+          line = dict(self.line) if self.line is not None else {"error": "aborted before the headline existed"}
+          line["extras_aborted"] = {"reason": reason, "stage": self.stage, "elapsed_s": round(self.elapsed(), 1),
+                                    "budget_s": self.budget}
+          sys.stdout.write(json.dumps(line) + "\n")
+          sys.stdout.flush()
+          code = 0 if "value" in line else 3
+          break
+        except RuntimeError:      # the main thread added a key while we copied: again
+          time.sleep(0.01)
+      os._exit(code)
+    time.sleep(2.0)               # let rank 0 print first: a launcher may stop everybody when the first rank leaves
+    os._exit(0)
+
+  def _watch(self):
+    import glob
+    while not self._stop.wait(0.25):
+      reason = None
+      if self.elapsed() > self.budget:
+        reason = "wall-clock budget exhausted"
+      else:
+        marks = sorted(glob.glob(os.path.join(self.run_dir, "abort_rank*")))
+        if marks:
+          try:
+            with open(marks[0]) as fh:
+              reason = fh.read() or "a rank failed"
+          except OSError:
+            reason = "a rank failed"
+      if reason:
+        with self._lock:
+          if self._finished:
+            return
+          self._finished = True
+        self._emit(reason)
+
+  def finish(self):
+    """Main thread, normal end: True if it may print (the watchdog has not taken over)."""
+    with self._lock:
+      if self._finished:
+        time.sleep(3600)
+      self._finished = True
+    self._stop.set()
+    return True
+
+
+def _inject(stage, rank):
+  """Test hook (tests/test_gpu_distributed.py): RMB_BENCH_INJECT="fail:<rank>:<stage>" raises in that rank's stage,
+  "hang:<rank>:<stage>" blocks it."""
+  spec = os.environ.get("RMB_BENCH_INJECT", "")
+  if not spec:
+    return
+  what, r, st = spec.split(":")
+  if int(r) == rank and st == stage:
+    if what == "fail":
+      raise RuntimeError("injected failure")
+    if what == "hang":
+      time.sleep(3600)
+
+
 def rank_main(args):
+  t_start = time.time()
   import torch
   import torch.distributed as dist
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,6 +427,9 @@ def rank_main(args):
     raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, n_dev))
   device = torch.device("cuda:%d" % (local_rank % n_dev))
   torch.cuda.set_device(device)
+  run_dir = os.environ.get("RMB_BENCH_RUN_DIR") or os.path.join(
+      "/tmp", "rmb_bench_%d_%s" % (os.getppid() if world > 1 else os.getpid(), os.environ.get("MASTER_PORT", "0")))
+  guard = Guard(rank, world, args.budget_s, run_dir, t_start)
   if world > 1:
     if backend_name == "nccl":
       dist.init_process_group("nccl", device_id=device)
@@ -288,7 +439,7 @@ def rank_main(args):
   from rigidmultiblobswall_amd.distributed import HipBackend, ShardedMobility
   backend = HipBackend(device)
   # HIP events around every 4th sweep of the timed region: an event pair serialises 4-8 us around a 190 us launch
-  # (tools/exp_graph.py), so bracketing every launch would lower `value` by ~4 %; the sample gives kernel_ms_avg
+  # (tools/experiments/exp_graph.py), so bracketing every launch would lower `value` by ~4 %; the sample gives kernel_ms_avg
   backend.ctx.set_option("timing", TIMING_STRIDE)
   sm = ShardedMobility(backend, device=device)
 
@@ -359,6 +510,7 @@ def rank_main(args):
       "ipc_mode_legacy_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
       "prewarm": res["prewarm"],
       "roofline": roofline,
+      "build": build_record(),
   }
   if res["cold"] is not None:
     # the same K steps after the same W warm-up steps, run BEFORE the declared pre-warm on a chip that had not run the
@@ -367,30 +519,96 @@ def rank_main(args):
     line["value_unprimed"] = {"value": round(args.steps / cdt, 3), "unit": "matvecs/s", "ms_per_step": round(1e3 * cdt / args.steps, 5),
                               "kernel_ms_avg": round(ckern, 5), "steps": args.steps, "warmup": args.warmup,
                               "when": "first thing this process ran on the GPU, before `prewarm`"}
+  # From here on nothing can cost the headline: it is on stderr and on disk, and the watchdog prints the line if a
+  # later stage hangs or a rank fails.
+  guard.publish_headline(line)
 
-  if rank == 0 and world == 1 and not args.no_host_surface:
+  def stage(key, expect_s, fn, single_rank_only=False):
+    """One extra.  world == 1: an exception is recorded and the run goes on.  world > 1: the failing rank raises the
+    abort marker and every rank leaves within a second -- no rank ever skips ahead of the others' collectives."""
+    if single_rank_only and not (rank == 0 and world == 1):
+      return
+    if not guard.begin(key, expect_s, torch, dist, device):
+      line[key] = {"skipped": "would not fit the wall-clock budget (%.0f s of %.0f s used)" % (guard.elapsed(), guard.budget)}
+      return
+    try:
+      _inject(key, rank)
+      out = fn()
+      if out is not None:
+        line[key] = out
+    except Exception as exc:      # an extra must never cost the headline line
+      line[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+      if world > 1:
+        guard.fail(key, exc)
+
+  # ---- extras ---------------------------------------------------------------------------------------------------
+  def host_surface():
     # End to end through the plugin surface, the call shape of the reference's callers (mobility/mobility.py:222-252,
     # multi_bodies/multi_bodies.py:445): numpy arrays in, a new numpy array out, synchronous, PCIe-inclusive.  Never
     # `value`.  The positions stay resident while the caller passes the same r_vectors (one compare per call).
-    try:
-      from rigidmultiblobswall_amd import mobility as mob
-      r_h, f_h = np.ascontiguousarray(res["r"]), np.ascontiguousarray(res["f"])
-      for _ in range(max(args.warmup, 3)):
-        u_h = mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
-      n_host = max(args.steps, 50)
+    from rigidmultiblobswall_amd import mobility as mob
+    r_h, f_h = np.ascontiguousarray(res["r"]), np.ascontiguousarray(res["f"])
+    for _ in range(max(args.warmup, 3)):
+      u_h = mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
+    n_host = max(args.steps, 50)
+    t0 = time.perf_counter()
+    for _ in range(n_host):
+      u_h = mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
+    dt_h = time.perf_counter() - t0
+    out = {"value": round(n_host / dt_h, 3), "unit": "matvecs/s", "ms_per_call": round(1e3 * dt_h / n_host, 5),
+           "calls": n_host, "function": "single_wall_mobility_trans_times_force_hip(r_vectors, force, eta, a)",
+           "devices": mob.active_devices(N), "bytes_over_pcie_per_call": 48 * N,
+           "max_abs_diff_vs_timed_device_output": float(np.max(np.abs(u_h - res["out"].cpu().numpy())))}
+    # where the time of one call goes: the position compare + option set of the Python wrapper, the C call split by
+    # the library's own host clock (rmb_last_host_timing), the sweep by HIP events, the rest is Python / ctypes
+    ctx = mob._context(N)
+    if hasattr(ctx, "last_host_timing"):
+      n_b = 200
       t0 = time.perf_counter()
-      for _ in range(n_host):
-        u_h = mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
-      dt_h = time.perf_counter() - t0
-      line["host_surface"] = {"value": round(n_host / dt_h, 3), "unit": "matvecs/s", "ms_per_call": round(1e3 * dt_h / n_host, 5),
-                              "calls": n_host, "function": "single_wall_mobility_trans_times_force_hip(r_vectors, force, eta, a)",
-                              "bytes_over_pcie_per_call": 48 * N,
-                              "max_abs_diff_vs_timed_device_output": float(np.max(np.abs(u_h - res["out"].cpu().numpy())))}
-      mob.reset()
-    except Exception as exc:      # an extra must never cost the headline line
-      line["host_surface"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+      for _ in range(n_b):
+        mob._bind_positions(r_h, res["a"], np.zeros(3), True)
+      bind_us = (time.perf_counter() - t0) / n_b * 1e6
+      ctx.set_option("timing", 1)
+      ctx.timing_reset()
+      acc = np.zeros(4)
+      for _ in range(n_b):
+        mob.single_wall_mobility_trans_times_force_hip(r_h, f_h, res["eta"], res["a"])
+        ht = ctx.last_host_timing()
+        acc += [ht["upload_us"], ht["launch_us"], ht["wait_and_download_us"], ht["c_call_us"]]
+      acc /= n_b
+      k_us = float(np.mean(ctx.timing_collect(n_b))) * 1e3
+      ctx.set_option("timing", 0)
+      total_us = 1e3 * out["ms_per_call"]
+      out["breakdown_us"] = {
+          "position_compare_and_options": round(bind_us, 1),
+          "upload_24N_bytes": round(acc[0], 1), "kernel_enqueue": round(acc[1], 1),
+          "sweep_kernel_hip_events": round(k_us, 1),
+          "finalize_download_24N_bytes_and_sync": round(max(acc[2] - k_us, 0.0), 1),
+          "python_ctypes_numpy_alloc": round(max(total_us - bind_us - acc[3], 0.0), 1),
+          "c_call_total": round(acc[3], 1), "call_total": round(total_us, 1),
+          "note": "upload / enqueue / wait+download: host wall clock inside rmb_matvec (rmb_last_host_timing), measured with "
+                  "per-launch HIP events on (adds ~5 us); the pageable upload is staged, so the call returns when it is done"}
+    mob.reset()
+    return out
+  if not args.no_host_surface:
+    stage("host_surface", 10, host_surface, single_rank_only=True)
 
-  if rank == 0 and world == 1 and not args.no_cpu:
+  def multi_device_surface():
+    # More than one device visible to a one-rank run (a whole node): the same plugin call on the single-process
+    # multi-device engine (mobility.set_devices(all): pair shards on every GPU, fixed-order slice reduction over xGMI).
+    # Run in a CHILD process with a timeout: it touches devices this process does not own, and a fault there must not
+    # take the line down with it.
+    if n_dev < 2:
+      return None
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "multi_surface_probe.py"), str(n_dev)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+    rows = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    if p.returncode != 0 or not rows:
+      return {"error": "probe exited with %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])}
+    return json.loads(rows[-1])
+  stage("multi_device_surface", 160, multi_device_surface, single_rank_only=True)
+
+  def parity_and_cpu():
     from oracle import oracle
     r, f, eta, a = res["r"], res["f"], res["eta"], res["a"]
     # parity guard on the very output that was timed (subset of targets, all sources)
@@ -406,218 +624,235 @@ def rank_main(args):
     oracle.set_num_threads(cores)
     oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a, fast=True)   # warm-up
     times = []
-    t_start = time.perf_counter()
-    while len(times) < 40 and (time.perf_counter() - t_start < 12.0 or len(times) < 3):
+    t_start_ = time.perf_counter()
+    while len(times) < 40 and (time.perf_counter() - t_start_ < 12.0 or len(times) < 3):
       t0 = time.perf_counter()
       oracle.single_wall_mobility_trans_times_force_oracle(r, f, eta, a, fast=True)
       times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    line["cpu_baseline"] = {"value": round(1.0 / med, 4), "unit": "matvecs/s", "cores": cores,
-                            "kind": "port",
-                            "sample": "%d full matvecs of the same %d-blob workload (median), oracle C port "
-                                      "-O3 -ffast-math -fopenmp, %d OpenMP threads (host exposes %d hardware threads)"
-                                      % (len(times), N, cores, hw_threads)}
+    cb = {"value": round(1.0 / med, 4), "unit": "matvecs/s", "cores": cores, "kind": "port",
+          "sample": "%d full matvecs of the same %d-blob workload (median), oracle C port "
+                    "-O3 -ffast-math -fopenmp, %d OpenMP threads (host exposes %d hardware threads)"
+                    % (len(times), N, cores, hw_threads)}
+    # the CPU baseline at every size <= 1e5, 1e6 extrapolated with N^2 and flagged.  Bounded: the
+    # larger sizes run fewer repetitions (one matvec at 1e5 blobs is ~10-15 s on 16 cores).
+    by_size = [{"n_blobs": N, "matvecs_per_s": cb["value"], "reps": len(times), "extrapolated": False}]
+    if not args.no_sweep:
+      last = None
+      for nb, reps in ((24576, 3), (32000, 3), (100000, 2)):
+        if guard.elapsed() + reps * med * (nb / float(N)) ** 2 * 1.3 > 0.6 * guard.budget:
+          by_size.append({"n_blobs": nb, "matvecs_per_s": round(1.0 / (med * (nb / float(N)) ** 2), 5), "reps": 0, "extrapolated": True})
+          continue
+        rb, fb, eb, ab = d2_cloud(nb, seed=0)
+        ts = []
+        for _ in range(reps):
+          t0 = time.perf_counter()
+          oracle.single_wall_mobility_trans_times_force_oracle(rb, fb, eb, ab, fast=True)
+          ts.append(time.perf_counter() - t0)
+        last = (nb, float(np.median(ts)))
+        by_size.append({"n_blobs": nb, "matvecs_per_s": round(1.0 / last[1], 5), "reps": reps, "extrapolated": False})
+      base_n, base_t = last if last is not None else (N, med)
+      for nb in (262144, 1000000):
+        by_size.append({"n_blobs": nb, "matvecs_per_s": round(1.0 / (base_t * (nb / float(base_n)) ** 2), 6), "reps": 0,
+                        "extrapolated": True, "from_n_blobs": base_n})
+    cb["by_size"] = by_size
+    line["cpu_baseline"] = cb
+    return None
+  if not args.no_cpu:
+    stage("cpu_baseline", 75 if not args.no_sweep else 20, parity_and_cpu, single_rank_only=True)
 
-  if not args.no_sweep:
+  def decompositions():
     # both decompositions at 1e4 / 1e5 / 1e6 blobs (the metric is "... vs N_blobs at 1/2/4/8 MI355X")
-    try:
-      dec = {"pair_shard_allreduce": [], "target_shard_allgather": []}
-      # the sizes of SURVEY 8(d): 1e4, 24 576 (configs[2]), 3.2e4, 1e5, 262 144 (configs[4]), 1e6 (configs[3])
-      for nb, st_, wu in ((10000, 50, 5), (24576, 20, 3), (32000, 20, 3), (100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
-        rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "pair", 100.0 if nb == 10000 else 0.0)
-        tb, prov = committed_traffic(nb, True) if world == 1 else (None, {})
-        dec["pair_shard_allreduce"].append({
-            "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
-            # HBM-side traffic of one launch from the committed rocprofv3 --pmc passes (not measured in this run) over
-            # this run's kernel time: what the metric's "HBM GB/s vs N_blobs" is for a VALU-bound kernel
-            "hbm_traffic_gbps": None if tb is None else round(tb / (rs["kern_ms"] * 1e-3) / 1e9, 1),
-            "hbm_traffic_source": prov.get("source"),
-            "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
-            "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
-            "executed_frac": _exec_frac(isa, rs["launch"]["chunks"] == 0, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
-            "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]})
-      for nb, st_, wu in ((10000, 50, 5), (100000, 3, 1), (1000000, 1, 1)):
-        rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "target", 100.0 if nb == 10000 else 0.0)
-        dec["target_shard_allgather"].append({
-            "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
-            "kernel_ms_avg": round(rs["kern_ms"], 4), "allgather_bytes": 0 if world == 1 else 24 * nb,
-            "executed_frac": _exec_frac(isa, False, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
-            "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
-            "launch": rs["launch"]})
-      line["decompositions"] = dec
-    except Exception as exc:      # an extra must never cost the headline line
-      line["decompositions"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-
-  if world == 1 and not args.no_sweep:
-    try:
-      # BASELINE.json configs[2]: 2048 rollers x 12-blob shells, full GMRES mobility solve on 1 GPU (reported
-      # beside the headline, not part of `value`)
-      from rigidmultiblobswall_amd import structures as st
-      from rigidmultiblobswall_amd.rigid import RigidSuspension
-      R, eta3 = 1.0155, 0.957e-3
-      shell = st.icosahedron_shell(0.792079207921 * R)
-      a3 = st.min_blob_separation(shell) / 2
-      nb = 2048
-      loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
-      FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
-      rs = RigidSuspension([shell] * nb, loc, quat, a3, eta3, device=device)
-      rs.solve_mobility_problem(force_torque=FT, tol=1e-8)        # warm-up (library initialisation)
-      torch.cuda.synchronize(device)
-      t0 = time.perf_counter()
-      U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
-      torch.cuda.synchronize(device)
-      line["config3_gmres"] = {"bodies": nb, "blobs": rs.n_blobs, "tolerance": 1e-8, "iterations": info["iterations"],
-                               "residual": float(info["residual"]), "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3)}
-      # the same solve by iterative refinement with fp32 inner products (RigidSuspension.solve_mixed_precision): same
-      # tolerance on the true fp64 residual; an option, reported beside the reference's algorithm above
-      rs.solve_mobility_problem(force_torque=FT, tol=1e-8, mixed_precision=True)
-      torch.cuda.synchronize(device)
-      t0 = time.perf_counter()
-      U2, lam2, info2 = rs.solve_mobility_problem(force_torque=FT, tol=1e-8, mixed_precision=True)
-      torch.cuda.synchronize(device)
-      line["config3_gmres"]["mixed_precision_option"] = {
-          "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3), "inner_iterations_fp32": info2["iterations"],
-          "outer_iterations_fp64": info2["outer_iterations"], "residual_fp64": float(info2["residual"]),
-          "velocity_rel_diff_vs_fp64_solve": float(np.linalg.norm(U2 - U) / np.linalg.norm(U))}
-      rs.close()
-    except Exception as exc:      # an extra must never cost the headline line
-      line['config3_gmres'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-
+    dec = {"pair_shard_allreduce": [], "target_shard_allgather": []}
+    # the sizes of SURVEY 8(d): 1e4, 24 576 (configs[2]), 3.2e4, 1e5, 262 144 (configs[4]), 1e6 (configs[3])
+    for nb, st_, wu in ((10000, 50, 5), (24576, 20, 3), (32000, 20, 3), (100000, 5, 1), (262144, 3, 1), (1000000, 2, 1)):
+      rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "pair", 100.0 if nb == 10000 else 0.0)
+      tb, prov = committed_traffic(nb, True) if world == 1 else (None, {})
+      row = {
+          "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
+          "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
+          "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
+          "executed_frac": _exec_frac(isa, rs["launch"]["chunks"] == 0, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
+          "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]}
+      if tb is not None:
+        # HBM-side traffic of one launch from the committed rocprofv3 --pmc passes (not measured in this run) over
+        # this run's kernel time: what the metric's "HBM GB/s vs N_blobs" is for a VALU-bound kernel
+        row["hbm_traffic_gbps"] = round(tb / (rs["kern_ms"] * 1e-3) / 1e9, 1)
+        row["hbm_traffic_source"] = prov.get("source")
+      dec["pair_shard_allreduce"].append(row)
+    for nb, st_, wu in ((10000, 50, 5), (100000, 3, 1), (1000000, 1, 1)):
+      rs = run_config(torch, dist, sm, backend, nb, st_, wu, world, rank, device, "target", 100.0 if nb == 10000 else 0.0)
+      dec["target_shard_allgather"].append({
+          "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
+          "kernel_ms_avg": round(rs["kern_ms"], 4), "allgather_bytes": 0 if world == 1 else 24 * nb,
+          "executed_frac": _exec_frac(isa, False, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
+          "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
+          "launch": rs["launch"]})
+    return dec
   if not args.no_sweep:
-    try:
-      # BASELINE.json configs[4] recipe: 2.6e5 single-blob rollers, Brownian Adams-Bashforth steps = forces kernel +
-      # M_tt F + M_tr T + Lanczos M^{1/2} z + 2 random-finite-difference products per step; physical parameters of
-      # multi_bodies/examples/rollers/inputfile_rollers.dat.  On N ranks the same replicated stepper runs on every
-      # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline; the full
-      # 100-step run is tools/run_config5.py (profiles/).
-      from rigidmultiblobswall_amd import structures as st
-      from rigidmultiblobswall_amd.distributed import ReplicatedContext
-      from rigidmultiblobswall_amd.rollers import RollersIntegrator
-      n5, a5 = 262144, 0.656
-      loc5, _, _ = st.roller_monolayer(n5, radius=a5, seed=7)
-      integ = RollersIntegrator(loc5, "stochastic_adams_bashforth_rollers", a5, 1.0e-3, tolerance=1e-3, device=device,
-                                ctx=ReplicatedContext(sm), seed=11)
-      integ.kT, integ.g = 0.0041419464, 0.0024892
-      integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
-      integ.debye_length = integ.debye_length_wall = 0.0656
-      integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
-      integ.report_rejections = False     # stdout carries ONE JSON line; rejected steps are counted on it
-      integ.advance_time_step(0.016)      # warm-up (first step is forward Euler)
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      p0, l0, n5_steps = integ.mobility_products, integ.stoch_iterations_count, 2
-      t0 = time.perf_counter()
-      for _ in range(n5_steps):
-        integ.advance_time_step(0.016)
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      dt5 = time.perf_counter() - t0
-      if world > 1:
-        t = torch.tensor([dt5], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt5 = float(t.item())
-      line["config5_rollers"] = {"rollers": n5, "scheme": integ.scheme, "lanczos_tolerance": 1e-3, "steps": n5_steps,
-                                 "s_per_step": round(dt5 / n5_steps, 4),
-                                 "mobility_products_per_step": (integ.mobility_products - p0) / n5_steps,
-                                 "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
-                                 "rejected_steps": integ.invalid_configuration_count}
-      # the same two steps with the reference GPU module's precision switch on 'single' (fp32 twins of the fused row and
-      # the grand mobility, fp64 accumulation): an option, reported beside the double-precision figure
-      integ.precision = "single"
-      l1 = integ.stoch_iterations_count
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      t0 = time.perf_counter()
-      for _ in range(n5_steps):
-        integ.advance_time_step(0.016)
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      dt5s = time.perf_counter() - t0
-      if world > 1:
-        t = torch.tensor([dt5s], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt5s = float(t.item())
-      integ.precision = "double"
-      line["config5_rollers"]["single_precision_option"] = {
-          "s_per_step": round(dt5s / n5_steps, 4), "lanczos_iterations_per_step": (integ.stoch_iterations_count - l1) / n5_steps,
-          "rejected_steps": integ.invalid_configuration_count}
-    except Exception as exc:      # an extra must never cost the headline line
-      line['config5_rollers'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    stage("decompositions", 40, decompositions)
 
+  def config3_gmres():
+    # BASELINE.json configs[2]: 2048 rollers x 12-blob shells, full GMRES mobility solve on 1 GPU (reported
+    # beside the headline, not part of `value`)
+    from rigidmultiblobswall_amd import structures as st
+    from rigidmultiblobswall_amd.rigid import RigidSuspension
+    R, eta3 = 1.0155, 0.957e-3
+    shell = st.icosahedron_shell(0.792079207921 * R)
+    a3 = st.min_blob_separation(shell) / 2
+    nb = 2048
+    loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
+    FT = np.zeros((nb, 6)); FT[:, 2] = -0.05; FT[:, 4] = 1.0
+    rs = RigidSuspension([shell] * nb, loc, quat, a3, eta3, device=device)
+    rs.solve_mobility_problem(force_torque=FT, tol=1e-8)        # warm-up (library initialisation)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    U, lam, info = rs.solve_mobility_problem(force_torque=FT, tol=1e-8)
+    torch.cuda.synchronize(device)
+    out = {"bodies": nb, "blobs": rs.n_blobs, "tolerance": 1e-8, "iterations": info["iterations"],
+           "residual": float(info["residual"]), "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3)}
+    # the same solve by iterative refinement with fp32 inner products (RigidSuspension.solve_mixed_precision): same
+    # tolerance on the true fp64 residual; an option, reported beside the reference's algorithm above
+    rs.solve_mobility_problem(force_torque=FT, tol=1e-8, mixed_precision=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    U2, lam2, info2 = rs.solve_mobility_problem(force_torque=FT, tol=1e-8, mixed_precision=True)
+    torch.cuda.synchronize(device)
+    out["mixed_precision_option"] = {
+        "ms_per_solve": round(1e3 * (time.perf_counter() - t0), 3), "inner_iterations_fp32": info2["iterations"],
+        "outer_iterations_fp64": info2["outer_iterations"], "residual_fp64": float(info2["residual"]),
+        "velocity_rel_diff_vs_fp64_solve": float(np.linalg.norm(U2 - U) / np.linalg.norm(U))}
+    rs.close()
+    return out
   if not args.no_sweep:
-    try:
-      # The same config with rigid multiblobs instead of single-blob rollers: 21845 shells x 12 blobs = 262140 blobs,
-      # stochastic_Slip_Trapz (3 GMRES rigid solves + preconditioned Lanczos + forces kernel per step), parameters of
-      # multi_bodies/examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat (tolerance 1e-4, constant torque).
-      import math
-      from rigidmultiblobswall_amd import structures as st
-      from rigidmultiblobswall_amd.distributed import ReplicatedContext
-      from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
-      R5, eta5, nb5 = 1.0155, 0.957e-3, 21845
-      shell5 = st.icosahedron_shell(0.792079207921 * R5)
-      a5b = st.min_blob_separation(shell5) / 2
-      loc5, quat5, _ = st.roller_monolayer(nb5, radius=R5, seed=5)
-      ri = RigidIntegrator([shell5] * nb5, loc5, quat5, "stochastic_Slip_Trapz", a5b, eta5, tolerance=1e-4, device=device,
-                           ctx=ReplicatedContext(sm), seed=1)
-      ri.kT, ri.g = 0.0040749841, 0.0303 / 12
-      ri.repulsion_strength_wall = ri.repulsion_strength = 0.0326
-      ri.debye_length_wall = ri.debye_length = 0.0406
-      FT5 = torch.zeros((nb5, 6), dtype=torch.float64, device=device)
-      FT5[:, 4] = 8 * math.pi * eta5 * R5 ** 3 * 62.8
-      ri.external_force_torque = lambda it: FT5
-      ri.report_rejections = False
-      ri.advance_time_step(0.01, step=0)          # warm-up
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      d0, l0, m0, p0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count, ri.susp.sweep_count
-      t0 = time.perf_counter()
-      ri.advance_time_step(0.01, step=1)
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      dt5 = time.perf_counter() - t0
-      if world > 1:
-        t = torch.tensor([dt5], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt5 = float(t.item())
-      line["config5_multiblob_brownian"] = {"bodies": nb5, "blobs": ri.Nblobs, "scheme": ri.scheme, "solver_tolerance": 1e-4,
-                                            "steps": 1, "s_per_step": round(dt5, 4),
-                                            "gmres_iterations_per_step": ri.det_iterations_count - d0,
-                                            "lanczos_iterations_per_step": ri.stoch_iterations_count - l0,
-                                            "mobility_products_per_step": ri.susp.matvec_count - m0,
-                                            "passes_over_the_pairs_per_step": ri.susp.sweep_count - p0,
-                                            "rejected_steps": ri.invalid_configuration_count}
-      ri.precision = "single"       # single-vector M_tt passes in fp32 (the k-vector lockstep passes stay fp64)
-      d1, l1 = ri.det_iterations_count, ri.stoch_iterations_count
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      t0 = time.perf_counter()
-      ri.advance_time_step(0.01, step=2)
-      torch.cuda.synchronize(device)
-      if world > 1:
-        dist.barrier()
-      dt5s = time.perf_counter() - t0
-      if world > 1:
-        t = torch.tensor([dt5s], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt5s = float(t.item())
-      ri.precision = "double"
-      line["config5_multiblob_brownian"]["single_precision_option"] = {
-          "s_per_step": round(dt5s, 4), "gmres_iterations_per_step": ri.det_iterations_count - d1,
-          "lanczos_iterations_per_step": ri.stoch_iterations_count - l1, "rejected_steps": ri.invalid_configuration_count}
-    except Exception as exc:      # an extra must never cost the headline line
-      line['config5_multiblob_brownian'] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    stage("config3_gmres", 15, config3_gmres, single_rank_only=True)
 
+  def sync_max(dt):
+    if world > 1:
+      t = torch.tensor([dt], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      return float(t.item())
+    return dt
+
+  def fence():
+    torch.cuda.synchronize(device)
+    if world > 1:
+      dist.barrier()
+
+  def config5_rollers():
+    # BASELINE.json configs[4] recipe: 2.6e5 single-blob rollers, Brownian Adams-Bashforth steps = forces kernel +
+    # M_tt F + M_tr T + Lanczos M^{1/2} z + 2 random-finite-difference products per step; physical parameters of
+    # multi_bodies/examples/rollers/inputfile_rollers.dat.  On N ranks the same replicated stepper runs on every
+    # rank and only the pair sweeps are divided (ReplicatedContext).  Reported beside the headline; the full
+    # 100-step run is tools/run_config5.py (profiles/).
+    from rigidmultiblobswall_amd import structures as st
+    from rigidmultiblobswall_amd.distributed import ReplicatedContext
+    from rigidmultiblobswall_amd.rollers import RollersIntegrator
+    n5, a5 = 262144, 0.656
+    loc5, _, _ = st.roller_monolayer(n5, radius=a5, seed=7)
+    integ = RollersIntegrator(loc5, "stochastic_adams_bashforth_rollers", a5, 1.0e-3, tolerance=1e-3, device=device,
+                              ctx=ReplicatedContext(sm), seed=11)
+    integ.kT, integ.g = 0.0041419464, 0.0024892
+    integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
+    integ.debye_length = integ.debye_length_wall = 0.0656
+    integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
+    integ.report_rejections = False     # stdout carries ONE JSON line; rejected steps are counted on it
+    integ.advance_time_step(0.016)      # warm-up (first step is forward Euler)
+    fence()
+    p0, l0, n5_steps = integ.mobility_products, integ.stoch_iterations_count, 2
+    t0 = time.perf_counter()
+    for _ in range(n5_steps):
+      integ.advance_time_step(0.016)
+    fence()
+    dt5 = sync_max(time.perf_counter() - t0)
+    out = {"rollers": n5, "scheme": integ.scheme, "lanczos_tolerance": 1e-3, "steps": n5_steps,
+           "s_per_step": round(dt5 / n5_steps, 4),
+           "mobility_products_per_step": (integ.mobility_products - p0) / n5_steps,
+           "lanczos_iterations_per_step": (integ.stoch_iterations_count - l0) / n5_steps,
+           "rejected_steps": integ.invalid_configuration_count}
+    # the same two steps with the reference GPU module's precision switch on 'single' (fp32 twins of the fused row and
+    # the grand mobility, fp64 accumulation): an option, reported beside the double-precision figure
+    integ.precision = "single"
+    l1 = integ.stoch_iterations_count
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(n5_steps):
+      integ.advance_time_step(0.016)
+    fence()
+    dt5s = sync_max(time.perf_counter() - t0)
+    integ.precision = "double"
+    out["single_precision_option"] = {
+        "s_per_step": round(dt5s / n5_steps, 4), "lanczos_iterations_per_step": (integ.stoch_iterations_count - l1) / n5_steps,
+        "rejected_steps": integ.invalid_configuration_count}
+    return out
+  if not args.no_sweep:
+    stage("config5_rollers", 40, config5_rollers)
+
+  def config5_multiblob():
+    # The same config with rigid multiblobs instead of single-blob rollers: 21845 shells x 12 blobs = 262140 blobs,
+    # stochastic_Slip_Trapz (3 GMRES rigid solves + preconditioned Lanczos + forces kernel per step), parameters of
+    # multi_bodies/examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat (tolerance 1e-4, constant torque).
+    import math
+    from rigidmultiblobswall_amd import structures as st
+    from rigidmultiblobswall_amd.distributed import ReplicatedContext
+    from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+    R5, eta5, nb5 = 1.0155, 0.957e-3, 21845
+    shell5 = st.icosahedron_shell(0.792079207921 * R5)
+    a5b = st.min_blob_separation(shell5) / 2
+    loc5, quat5, _ = st.roller_monolayer(nb5, radius=R5, seed=5)
+    ri = RigidIntegrator([shell5] * nb5, loc5, quat5, "stochastic_Slip_Trapz", a5b, eta5, tolerance=1e-4, device=device,
+                         ctx=ReplicatedContext(sm), seed=1)
+    ri.kT, ri.g = 0.0040749841, 0.0303 / 12
+    ri.repulsion_strength_wall = ri.repulsion_strength = 0.0326
+    ri.debye_length_wall = ri.debye_length = 0.0406
+    FT5 = torch.zeros((nb5, 6), dtype=torch.float64, device=device)
+    FT5[:, 4] = 8 * math.pi * eta5 * R5 ** 3 * 62.8
+    ri.external_force_torque = lambda it: FT5
+    ri.report_rejections = False
+    ri.advance_time_step(0.01, step=0)          # warm-up
+    fence()
+    d0, l0, m0, p0 = ri.det_iterations_count, ri.stoch_iterations_count, ri.susp.matvec_count, ri.susp.sweep_count
+    t0 = time.perf_counter()
+    ri.advance_time_step(0.01, step=1)
+    fence()
+    dt5 = sync_max(time.perf_counter() - t0)
+    out = {"bodies": nb5, "blobs": ri.Nblobs, "scheme": ri.scheme, "solver_tolerance": 1e-4,
+           "steps": 1, "s_per_step": round(dt5, 4),
+           "gmres_iterations_per_step": ri.det_iterations_count - d0,
+           "lanczos_iterations_per_step": ri.stoch_iterations_count - l0,
+           "mobility_products_per_step": ri.susp.matvec_count - m0,
+           "passes_over_the_pairs_per_step": ri.susp.sweep_count - p0,
+           "rejected_steps": ri.invalid_configuration_count}
+    ri.precision = "single"       # single-vector M_tt passes in fp32 (the k-vector lockstep passes stay fp64)
+    d1, l1 = ri.det_iterations_count, ri.stoch_iterations_count
+    fence()
+    t0 = time.perf_counter()
+    ri.advance_time_step(0.01, step=2)
+    fence()
+    dt5s = sync_max(time.perf_counter() - t0)
+    ri.precision = "double"
+    out["single_precision_option"] = {
+        "s_per_step": round(dt5s, 4), "gmres_iterations_per_step": ri.det_iterations_count - d1,
+        "lanczos_iterations_per_step": ri.stoch_iterations_count - l1, "rejected_steps": ri.invalid_configuration_count}
+    return out
+  if not args.no_sweep:
+    stage("config5_multiblob_brownian", 60, config5_multiblob)
+
+  line["wall_s"] = round(guard.elapsed(), 1)
+  guard.finish()
   if rank == 0:
     print(json.dumps(line), flush=True)
   if world > 1:
     dist.destroy_process_group()
+
+
+def build_record():
+  """What __graft_entry__.build() did for the library this run loads: compiled or reused (librmb_mobility.build.json)."""
+  try:
+    with open(os.path.join(ROOT, "rigidmultiblobswall_amd", "librmb_mobility.build.json")) as fh:
+      return json.load(fh)
+  except (OSError, ValueError):
+    return {"mode": "unknown (no build record next to the library)"}
 
 
 def main():

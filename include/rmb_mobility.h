@@ -222,6 +222,10 @@ int rmb_ubench_fp64_issue(rmb_ctx* ctx, int launches, double* g_wave_instr_per_s
 /* Schedule diagnostics: with option "wave_clock" = 1 the symmetric kernel stamps every wave's start and end
  * (100 MHz wall clock); copies (start, end) pairs of the last launch into stamps[2*max_waves], returns count. */
 int rmb_wave_clock_collect(rmb_ctx* ctx, long long* stamps, long max_waves);
+/* Host wall clock of the last rmb_matvec call on this context, microseconds: us4 = {upload of the vector(s) (pageable
+ * host memory: the copy is staged, the call returns when it is done), enqueue of the kernels, wait for them + download
+ * of the result, the whole call}.  What the reference's synchronous call shape costs beyond the kernel. */
+int rmb_last_host_timing(rmb_ctx* ctx, double* us4);
 /* launch geometry of the last sweep: target tiles, source chunks, workgroups */
 int rmb_last_launch(rmb_ctx* ctx, long* tiles, long* chunks, long* workgroups);
 int rmb_ctx_synchronize(rmb_ctx* ctx);

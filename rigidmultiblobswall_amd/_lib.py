@@ -58,6 +58,7 @@ SYMBOLS = {
     "rmb_timing_reset": (ctypes.c_int, [_vp]),
     "rmb_ubench_fp64_issue": (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
     "rmb_wave_clock_collect": (ctypes.c_int, [_vp, _vp, ctypes.c_long]),
+    "rmb_last_host_timing": (ctypes.c_int, [_vp, _dp]),
     "rmb_last_launch": (ctypes.c_int, [_vp, _lp, _lp, _lp]),
     "rmb_ctx_synchronize": (ctypes.c_int, [_vp]),
     "rmb_default_ctx_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long]),

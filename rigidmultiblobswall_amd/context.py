@@ -294,6 +294,12 @@ class MobilityContext(object):
     _lib.check(self._lib.rmb_ubench_fp64_issue(self._h, int(launches), ctypes.byref(out)))
     return float(out.value)
 
+  def last_host_timing(self):
+    """Host wall clock (us) of the last matvec() on this context: upload, launch, wait + download, whole C call."""
+    buf = (ctypes.c_double * 4)()
+    _lib.check(self._lib.rmb_last_host_timing(self._h, buf))
+    return dict(upload_us=buf[0], launch_us=buf[1], wait_and_download_us=buf[2], c_call_us=buf[3])
+
   def timing_reset(self):
     _lib.check(self._lib.rmb_timing_reset(self._h))
 

@@ -2,6 +2,7 @@
 // and the one-sided kernel families (rmb_sym.hip / rmb_sweep.hip), host staging of the synchronous entry points.
 #include "rmb_internal.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -262,6 +263,9 @@ int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double
   if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
   if (kind == rmb::KIND_TT_TR && !v2) return fail(RMB_ERR_ARG, "RMB_TT_TR needs vec2 (torque)");
   RMB_HIP(hipSetDevice(c->device));
+  // host wall clock of the four stages of this synchronous call (rmb_last_host_timing): where the time through the
+  // reference's call shape goes beyond the kernel
+  const auto t0 = std::chrono::steady_clock::now();
   const size_t vb = (size_t)3 * n * sizeof(double), ob = (size_t)3 * n_tgt * sizeof(double);
   if (int rc = c->vec.reserve(vb)) return rc;
   if (int rc = c->out.reserve(ob)) return rc;
@@ -272,9 +276,22 @@ int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double
     RMB_HIP(hipMemcpyAsync(c->vec2.p, v2, vb, hipMemcpyHostToDevice, c->stream));
     v2d = (const double*)c->vec2.p;
   }
+  const auto t1 = std::chrono::steady_clock::now();
   if (int rc = matvec_device_impl(c, kind, in_plane, (const double*)c->vec.p, v2d, eta, (double*)c->out.p)) return rc;
+  const auto t2 = std::chrono::steady_clock::now();
   RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
   RMB_HIP(hipStreamSynchronize(c->stream));
+  const auto t3 = std::chrono::steady_clock::now();
+  const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::micro>(b - a).count();
+  };
+  c->host_us[0] = us(t0, t1); c->host_us[1] = us(t1, t2); c->host_us[2] = us(t2, t3); c->host_us[3] = us(t0, t3);
+  return 0;
+}
+
+int rmb_last_host_timing(rmb_ctx* c, double* us4) {
+  if (!c || !us4) return fail(RMB_ERR_ARG, "null context / output");
+  for (int k = 0; k < 4; ++k) us4[k] = c->host_us[k];
   return 0;
 }
 

@@ -97,6 +97,7 @@ struct rmb_ctx {
   long timing_launches = 0;  // sweeps seen since the last reset (sampling stride of the "timing" option)
   // last launch
   long last_tiles = 0, last_chunks = 0, last_wgs = 0;
+  double host_us[4] = {0, 0, 0, 0};   // last rmb_matvec: upload, launch, wait + download, whole call (host wall clock, us)
 };
 
 namespace rmbi {

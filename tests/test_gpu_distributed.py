@@ -65,3 +65,44 @@ def test_bench_spawns_its_own_ranks():
     assert res.returncode != 0        # 2 RCCL ranks on a 1-GPU box: refused before any collective
   else:
     assert res.returncode == 0
+
+
+def _bench(args, env_extra, timeout):
+  import json
+  import time
+  env = dict(os.environ, RMB_BENCH_BACKEND="gloo", **env_extra)
+  env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+  t0 = time.time()
+  res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+  rows = [l for l in res.stdout.split("\n") if l.startswith("{")]
+  return res, (json.loads(rows[-1]) if rows else None), time.time() - t0
+
+
+def test_bench_rank_failure_in_an_extra_ends_the_run_within_seconds_and_keeps_the_headline():
+  """One rank raises inside a multi-rank extra (whose other ranks are inside collectives): the run must end within
+  seconds, with the headline on the line and the failure recorded -- never a hang."""
+  res, line, took = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--prewarm-ms", "20", "--no-cpu", "--no-host-surface"],
+                           {"RMB_BENCH_INJECT": "fail:1:decompositions"}, 240)
+  assert took < 120, took
+  assert line is not None, res.stdout[-2000:] + res.stderr[-3000:]
+  assert line["value"] > 0 and line["n_gpus"] == 2
+  assert "extras_aborted" in line and "rank 1 failed in stage 'decompositions'" in line["extras_aborted"]["reason"]
+  assert "[bench headline]" in res.stderr            # the headline was out before any extra started
+
+
+def test_bench_hang_in_an_extra_is_cut_at_the_wall_clock_budget():
+  """One rank never comes back from a stage: at the budget rank 0 prints the line with what exists and all ranks leave."""
+  res, line, took = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--prewarm-ms", "20", "--no-cpu", "--no-host-surface",
+                            "--budget-s", "45"], {"RMB_BENCH_INJECT": "hang:1:decompositions"}, 240)
+  assert took < 100, took
+  assert line is not None and line["value"] > 0
+  assert line["extras_aborted"]["reason"] == "wall-clock budget exhausted" and line["extras_aborted"]["stage"] == "decompositions"
+
+
+def test_bench_single_rank_extra_failure_is_recorded_and_the_run_goes_on():
+  res, line, took = _bench(["--steps", "5", "--warmup", "2", "--prewarm-ms", "20", "--no-cpu", "--no-sweep"],
+                           {"RMB_BENCH_INJECT": "fail:0:host_surface"}, 240)
+  assert res.returncode == 0 and line is not None
+  assert line["host_surface"] == {"error": "RuntimeError: injected failure"} and "extras_aborted" not in line
+  assert line["build"]["mode"] in ("compiled", "reused")
