@@ -78,3 +78,22 @@ def test_stub_double_layer_and_pressure_match_reference_fixture(stub):
   assert rel_err(stub["double_layer_source_target_hip"](*args), g["dl_no_wall"]) < 1e-12
   assert rel_err(stub["double_layer_source_target_hip"](*args, wall=1), g["dl_wall"]) < 1e-12
   assert rel_err(stub["no_wall_pressure_Stokeslet_hip"](g["source"], g["target"], g["force"]), g["p_no_wall"]) < 1e-12
+
+
+def test_node_stub_runs_the_multi_device_engine(stub, monkeypatch):
+  """The second block of section B -- the same stub on the multi-device engine (rmb_multi_*), executed as written in
+  the first block's namespace with RMB_DEVICES listing this box's GPU three times -- against the reference's fixture."""
+  text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+  sect = text[text.index("## B. "):text.index("## Build")]
+  code = re.findall(r"```python\n(.*?)```", sect, re.S)[1]
+  assert "rmb_multi_create" in code and "rmb_multi_matvec" in code
+  monkeypatch.setenv("RMB_DEVICES", "0,0,0")
+  ns = dict(stub)
+  exec(compile(code, "INTEGRATION.md#B-node", "exec"), ns)
+  g = load_golden([p for p in golden_files("g[123]_*.npz") if "wall_tt" in load_golden(p)][0])
+  r, v, eta, a, L = g["r_vectors"], g["vector"], float(g["eta"]), float(g["a"]), g["periodic_length"]
+  u = ns["single_wall_mobility_trans_times_force_hip_node"](r, v, eta, a, periodic_length=L)
+  assert rel_err(u, g["wall_tt"]) < 1e-10
+  u1 = stub["single_wall_mobility_trans_times_force_hip"](r, v, eta, a, periodic_length=L)
+  assert rel_err(u, u1) < 1e-13
+  ns["_lib"].rmb_multi_destroy(ns["_engine"])
