@@ -85,6 +85,8 @@ def parse_args():
   ap.add_argument("--prewarm-ms", type=float, default=300.0,
                   help="untimed, declared clock pre-warm before the warm-up steps (0 disables)")
   ap.add_argument("--no-sweep", action="store_true", help="skip the N_blobs sweep, decompositions and config extras")
+  ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=VALUE",
+                  help="context option for this run (A/B and profiling passes), e.g. sym_coop=2; recorded on the line")
   ap.add_argument("--no-cpu", action="store_true")
   ap.add_argument("--budget-s", type=float, default=420.0,
                   help="wall-clock budget of the whole run: stages that would not fit are skipped on all ranks, and at the "
@@ -206,7 +208,8 @@ def run_config(torch, dist, sm, backend, n_blobs, steps, warmup, world, rank, de
     dt, kern_ms = timed_region(torch, dist, world, device, backend, step, steps, warmup)
   finally:
     backend.ctx.set_option("deterministic", 0)
-  return dict(dt=dt, kern_ms=kern_ms, launch=backend.ctx.last_launch(), out=out, r=r, f=f, eta=eta, a=a,
+  return dict(dt=dt, kern_ms=kern_ms, launch=backend.ctx.last_launch(), path=backend.ctx.get_option("last_path"), out=out, r=r, f=f,
+              eta=eta, a=a,
               n_local=e - b, begin=b, end=e, prewarm=prewarm, cold=cold)
 
 
@@ -242,10 +245,15 @@ def load_isa():
     return None
 
 
-def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None):
+def isa_key(path):
+  """librmb_mobility.isa.json entry of the kernel family a product ran on (context option "last_path")."""
+  return {0: "sweep_tt_wall", 1: "sym_tt_wall", 2: "symx_single_tt_wall", 3: "sym_coop_tt_wall"}.get(path, "sym_tt_wall")
+
+
+def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None, key=None):
   """(executed, issue): what one launch of the wall-tt sweep really executes, priced against the fp64 vector peak
   and against the live fp64 issue ceiling.  Both <= 1 by construction."""
-  st = isa["kernels"].get("sym_tt_wall" if sym else "sweep_tt_wall") if isa else None
+  st = isa["kernels"].get(key or ("sym_tt_wall" if sym else "sweep_tt_wall")) if isa else None
   if st is None:
     return None, None
   if sym:
@@ -274,8 +282,8 @@ def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None):
   return executed, issue
 
 
-def _exec_frac(isa, sym, N, world, n_local, kern_s):
-  ex, _ = executed_views(isa, sym, N, world, n_local, kern_s)
+def _exec_frac(isa, sym, N, world, n_local, kern_s, key=None):
+  ex, _ = executed_views(isa, sym, N, world, n_local, kern_s, key=key)
   return None if ex is None else ex["frac"]
 
 
@@ -441,6 +449,9 @@ def rank_main(args):
   # HIP events around every 4th sweep of the timed region: an event pair serialises 4-8 us around a 190 us launch
   # (tools/experiments/exp_graph.py), so bracketing every launch would lower `value` by ~4 %; the sample gives kernel_ms_avg
   backend.ctx.set_option("timing", TIMING_STRIDE)
+  for kv in args.ctx_option:
+    k_, v_ = kv.split("=")
+    backend.ctx.set_option(k_, int(v_))
   sm = ShardedMobility(backend, device=device)
 
   N = args.blobs
@@ -462,7 +473,7 @@ def rank_main(args):
   alg_bytes = 48.0 * N + 24.0 * (res["n_local"] if world == 1 else N)
   traffic, traffic_src = committed_traffic(N, sym) if world == 1 else (None, {"measured_in_this_run": False, "source": None})
   isa = load_isa()
-  executed, issue = executed_views(isa, sym, N, world, res["n_local"], kern_s, issue_peak)
+  executed, issue = executed_views(isa, sym, N, world, res["n_local"], kern_s, issue_peak, key=isa_key(res["path"]))
   if executed is None:
     # no instruction count for this build (tools/isa_stats.py needs hipcc): the utilisation cannot be priced; say so
     # rather than fall back to the algorithmic unit, which is not a utilisation
@@ -470,7 +481,9 @@ def rank_main(args):
                 "error": "librmb_mobility.isa.json missing and could not be regenerated"}
   roofline = {
       "bound": "valu_fp64",
-      "kernel": "rmb::sym_kernel<TT,wall> (each unordered pair once, both blobs updated)" if sym else "rmb::sweep_kernel<TT,wall>",
+      "kernel": {3: "rmb::sym_coop_kernel<TT,wall> (each unordered pair once, both blobs updated; the four waves of a workgroup "
+                    "share one staged tile and one flush per tile)",
+                 1: "rmb::sym_kernel<TT,wall> (each unordered pair once, both blobs updated)"}.get(res["path"], "rmb::sweep_kernel<TT,wall>"),
       # utilisation, <= 1 by construction: fp64 flops this kernel EXECUTES per launch / kernel time / fp64 vector peak
       "achieved": executed["achieved"], "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed["frac"],
       "unit_of_work": "EXECUTED: %g fp64 flops per pair evaluation (FMA = 2, mul/add/rsq = 1, counted over the pair loop "
@@ -512,6 +525,8 @@ def rank_main(args):
       "roofline": roofline,
       "build": build_record(),
   }
+  if args.ctx_option:
+    line["ctx_options"] = list(args.ctx_option)      # not the defaults: an A/B or profiling pass
   if res["cold"] is not None:
     # the same K steps after the same W warm-up steps, run BEFORE the declared pre-warm on a chip that had not run the
     # kernel yet: what the driver's bare flags measure without priming (the fp64 clock is still ramping)
@@ -672,7 +687,8 @@ def rank_main(args):
           "n_blobs": nb, "matvecs_per_s": round(st_ / rs["dt"], 4), "ms_per_step": round(1e3 * rs["dt"] / st_, 4),
           "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
           "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
-          "executed_frac": _exec_frac(isa, rs["launch"]["chunks"] == 0, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3),
+          "executed_frac": _exec_frac(isa, rs["launch"]["chunks"] == 0, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3, isa_key(rs["path"])),
+          "kernel_family": {0: "one-sided sweep", 1: "symmetric, per wave", 3: "symmetric, workgroup-cooperative"}.get(rs["path"]),
           "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]}
       if tb is not None:
         # HBM-side traffic of one launch from the committed rocprofv3 --pmc passes (not measured in this run) over

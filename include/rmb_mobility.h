@@ -119,13 +119,20 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *   "sym_fine_steps"  [0]  symmetric kernels: floor on rotation steps per wave when the launch is smaller than one
  *                          resident round (small suspensions, one rank's pair shard); 0 = 16 while 16-step waves do
  *                          not fill the chip, 32 beyond
+ *   "sym_coop"        [1]  tt / tr / rt / rr on the dedicated symmetric kernel: the workgroup-cooperative variant
+ *                          (the four waves of a workgroup share one staged tile and one flush per tile instead of each
+ *                          staging and flushing its own): 0 = never, 1 = launches of at most four resident rounds of
+ *                          workgroups (small suspensions, one rank's pair shard, products up to ~1e4 blobs: faster below
+ *                          one round, same time with half the atomic flush traffic up to four), 2 = always
  *   "sym_wps"         [0]  symmetric kernels: cap on resident workgroups per CU (0 = occupancy limit)
  *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
  *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics
  *   "skip_pairs"      [0]  diagnostics, results are WRONG: bit 0 = no pair arithmetic, bit 1 = no flush of the
  *                          per-wave LDS accumulators (tools/exp_prewarm.py prices the atomics with it)          */
 int rmb_ctx_set_option(rmb_ctx* ctx, const char* key, long value);
-/* Current value of an option (same keys); lets a caller switch one temporarily and restore what was there. */
+/* Current value of an option (same keys); lets a caller switch one temporarily and restore what was there.  Read-only
+ * key "last_path": the kernel family of the last product (0 one-sided sweep, 1 symmetric per wave, 2 deterministic
+ * symmetric, 3 symmetric workgroup-cooperative). */
 int rmb_ctx_get_option(rmb_ctx* ctx, const char* key, long* value);
 
 /* Upload / pack positions: fuses shift_heights + damping_matrix_B (mobility.py:52-84).

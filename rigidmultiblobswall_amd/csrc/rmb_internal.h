@@ -82,13 +82,15 @@ struct rmb_ctx {
   long opt_fused_symmetric = 1;  // tt+tr: 1 = single symmetric pass (symx_kernels.h), 2 = two symmetric passes, 0 = one-sided fused sweep
   long opt_symx_single = 0;      // route tt / tr / rt / rr through the generic skeleton (A/B against sym_kernel)
   long opt_deterministic = 0;  // force the atomic-free sweep kernel everywhere
-  int last_path = 0;           // 0 = sweep, 1 = symmetric
+  int last_path = 0;           // 0 = sweep, 1 = symmetric (per wave), 2 = deterministic symmetric, 3 = symmetric, workgroup-cooperative
   long opt_sym_wps = 0;        // cap on resident workgroups per CU for the symmetric kernel (0 = occupancy limit)
   long opt_sym_pin = 1;        // pad dynamic LDS so residency is exactly that number
   long opt_precision = 64;     // 32: M_tt f (open boundaries) in single precision (sym32_kernels.h); everything else fp64
   long opt_force_precision = 0;  // blob-blob forces: 0 = follow "precision", 32 / 64 = pinned
   long opt_sym_min_steps = 64; // floor on rotation steps per wave (a unit is 64 steps)
   long opt_sym_fine_steps = 0;   // floor on steps per wave when less than one resident round is left (pair shards, small N); 0 = 16 or 32, chosen in plan_sym
+  long opt_sym_coop = 1;       // workgroup-cooperative symmetric kernel (sym_coop_kernels.h): 0 = never, 1 = launches of at most
+                               // kCoopMaxRounds resident rounds (small suspensions, pair shards, up to ~1e4 blobs), 2 = always
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
   // timing ring (events around the sweep kernel)
@@ -116,9 +118,9 @@ rmb::ExpConsts exp_consts();
 void choose_chunks(long n_tgt, long n_src, long forced, long slots, long* n_chunks, long* chunk_len);
 int resident_blocks(const void* fn, int* cache);   // workgroups of 256 threads per CU, capped at 8
 // Launch plan of a symmetric sweep: `total` rotation steps over `blocks` workgroups of 4 waves.
-struct SymPlan { long blocks; long steps_per_wave; size_t dyn_lds; };
+struct SymPlan { long blocks; long steps_per_wave; size_t dyn_lds; bool sub_round; long round; };   // round: resident workgroups; sub_round: less work than that
 int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long total, bool pin, SymPlan* out,
-             int declared_waves = 0);
+             int declared_waves = 0, long fine_auto = 0);
 void shard_ranges(long n, long n_units, long shard, long nshards, long* step_begin, long* step_end, long* self_begin,
                   long* self_end);
 int sym_accumulators(rmb_ctx* c, long n_pad);

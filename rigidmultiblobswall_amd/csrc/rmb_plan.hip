@@ -112,7 +112,7 @@ int sym_accumulators(rmb_ctx* c, long n_pad) {
 // and 7 workgroups per CU where the hardware holds 4 (per-wave start stamps, profiles/r3_shard_wave_placement.txt) and
 // every plan built on "whole resident rounds" was off after the kernels lost registers in round 2.
 int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long total, bool pin, SymPlan* out,
-             int declared_waves) {
+             int declared_waves, long fine_auto) {
   int wps = resident_blocks(fn, occ_cache);
   if (declared_waves > 0 && wps > declared_waves * kSimdsPerCu / rmb::kSymWaves) wps = declared_waves * kSimdsPerCu / rmb::kSymWaves;
   if (c->opt_sym_wps > 0 && c->opt_sym_wps < wps) wps = (int)c->opt_sym_wps;
@@ -128,6 +128,8 @@ int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long
   const long need = (total + per_wg - 1) / per_wg > 0 ? (total + per_wg - 1) / per_wg : 1;
   if (blocks > need) blocks = need;
   if (blocks > round) blocks -= blocks % round;   // whole rounds only: a partial last round is a tail
+  out->sub_round = blocks < round;
+  out->round = round;
   if (blocks < round) {
     // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): shorter waves beat
     // leaving SIMDs with one or two waves and no latency hiding, but every wave pays its own loads and 384 global
@@ -137,6 +139,9 @@ int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long
     // (1000 blobs: 9.6 us at 16 steps, 13.0 at 32); once they would overfill it, every extra wave only adds its
     // loads and flushes (1/8 shard of 1e4 blobs: 36.6 us at 16 steps x 1024 workgroups, 29.3 at 32 x 776).
     long fine_steps = c->opt_sym_fine_steps;
+    // `fine_auto` > 0: the caller's own default (the workgroup-cooperative kernel shares loads and flushes between
+    // the waves of a workgroup, so shorter waves cost it nothing: 8 steps per wave, tools/experiments/exp_coop.py)
+    if (fine_steps <= 0 && fine_auto > 0) fine_steps = fine_auto;
     if (fine_steps <= 0) fine_steps = (total + rmb::kSymWaves * 16L - 1) / (rmb::kSymWaves * 16L) <= round ? 16 : 32;
     const long per_wg_fine = rmb::kSymWaves * fine_steps;
     long fine = (total + per_wg_fine - 1) / per_wg_fine;

@@ -6,6 +6,7 @@
 #include <cmath>
 
 #include "sym_kernels.h"
+#include "sym_coop_kernels.h"
 #include "sym2_kernels.h"
 #include "symx_kernels.h"
 
@@ -13,9 +14,9 @@ namespace rmbi {
 
 namespace {
 typedef void (*sym_fn)(const rmb::SymArgs);
-struct SymEntry { sym_fn sweep; sym_fn fin; int occ; };
+struct SymEntry { sym_fn sweep; sym_fn fin; int occ; sym_fn coop; int coop_occ; };
 template <int KIND, bool WALL, bool PER> SymEntry make_sym_entry() {
-  return SymEntry{rmb::sym_kernel<KIND, WALL, PER>, rmb::sym_finalize_kernel<KIND, WALL>, 0};
+  return SymEntry{rmb::sym_kernel<KIND, WALL, PER>, rmb::sym_finalize_kernel<KIND, WALL>, 0, rmb::sym_coop_kernel<KIND, WALL, PER>, 0};
 }
 // [kind tt,tr,rt,rr][wall][periodic]
 #define RMB_SYM_ROW(K) {{make_sym_entry<K, false, false>(), make_sym_entry<K, false, true>()}, {make_sym_entry<K, true, false>(), make_sym_entry<K, true, true>()}}
@@ -57,9 +58,24 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   if (int rc = plan_sym(c, f32 ? k32.fn : (const void*)se.sweep, f32 ? k32.occ : &se.occ, stat,
                         a.step_end - a.step_begin, true, &plan, f32 ? 0 : rmb::kSymWavesPerEu))
     return rc;
+  // Workgroup-cooperative variant (sym_coop_kernels.h): the workgroup owns the step range, its four waves share one
+  // staged tile J and one flush per tile.  Faster below one resident round (1/8 pair shard of 1e4 blobs 29.6 -> 25.0 us,
+  // 1000 blobs 10.4 -> 9.0 us), the same time up to a few rounds with HALF the atomic flush traffic (1e4 blobs:
+  // WRITE_SIZE 54.4 -> 27.4 MB per launch, 146.7 vs 147.8 us), 0.5-1 % slower at >= 8 rounds
+  // (profiles/r4_coop_kernel_ab.txt): by default up to kCoopMaxRounds.
+  constexpr long kCoopMaxRounds = 4;
+  const bool coop = !f32 && !c->opt_wave_clock &&
+                    (c->opt_sym_coop == 2 || (c->opt_sym_coop == 1 && (plan.sub_round || plan.blocks <= kCoopMaxRounds * plan.round)));
+  if (coop) {
+    const size_t coop_lds = sizeof(double2) * 64 * 3 + sizeof(double) * 2 * 3 * 64;
+    if (int rc = plan_sym(c, (const void*)se.coop, &se.coop_occ, coop_lds, a.step_end - a.step_begin, true, &plan, rmb::kSymWavesPerEu, 8))
+      return rc;
+  }
   const long blocks = plan.blocks;
-  a.steps_per_wave = plan.steps_per_wave;
+  const long total_steps = a.step_end - a.step_begin;
+  a.steps_per_wave = coop ? (total_steps + blocks - 1) / blocks : plan.steps_per_wave;    // coop: steps per WORKGROUP
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+  c->last_path = coop ? 3 : 1;
   a.skip_pairs = (int)c->opt_skip_pairs;
   a.accumulate = accumulate ? 1 : 0;
   a.wave_clock = nullptr;
@@ -73,7 +89,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   if (f32) {
     k32.launch(&a, a.k, (unsigned)blocks, plan.dyn_lds, c->stream);
   } else {
-    hipLaunchKernelGGL(se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
+    hipLaunchKernelGGL(coop ? se.coop : se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
   }
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;

@@ -833,3 +833,43 @@ def test_single_precision_per_blob_radii_product(mob, oracle, wall):
   finally:
     mob.precision = 'double'
   assert rel_err(mob.mobility_radii_trans_times_force(r, f, eta, a, radii, fn_hip), ref) < 1e-12
+
+
+@pytest.mark.parametrize("n", [130, 1000, 5000])
+def test_workgroup_cooperative_kernel_matches_the_per_wave_kernel_and_the_oracle(oracle, n):
+  """Option "sym_coop": the four waves of a workgroup share one staged tile and one flush per tile
+  (csrc/sym_coop_kernels.h).  Default for launches below one resident round; forced here (2) for every kind, wall /
+  no wall / pseudo-periodic, full products and pair shards, against the per-wave kernel (0) and the oracle."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  rng = np.random.RandomState(n)
+  a, eta = 0.37, 0.9
+  box = (n * (4.0 / 3.0) * np.pi * a ** 3 / 0.05) ** (1.0 / 3.0)
+  r = rng.rand(n, 3) * box
+  r[:, 2] += 0.8 * a                                    # some blobs below z = a: B-damping on load and store
+  v = rng.randn(n, 3)
+  rd, vd = torch.as_tensor(r.reshape(-1), device="cuda"), torch.as_tensor(v.reshape(-1), device="cuda")
+  ctx = MobilityContext(0)
+  try:
+    for wall, L in ((True, None), (False, None), (True, np.array([box, 0.0, 0.0]))):
+      ctx.set_positions(rd, a, L, wall)
+      for kind in ("tt", "tr", "rt", "rr"):
+        ctx.set_option("sym_coop", 0)
+        ref = ctx.matvec_device(kind, vd, eta).cpu().numpy()
+        ctx.set_option("sym_coop", 2)
+        got = ctx.matvec_device(kind, vd, eta).cpu().numpy()
+        assert ctx.last_launch()["chunks"] == 0 or n < 128
+        assert rel_err(got, ref) < 1e-13, (kind, wall, L, rel_err(got, ref))
+        parts = sum(ctx.matvec_pairshard_device(kind, vd, eta, g, 3).cpu().numpy() for g in range(3))
+        assert rel_err(parts, ref) < 1e-13, (kind, wall, "shards")
+      if L is None:
+        stem = {"tt": "trans_times_force", "rr": "rot_times_torque"}
+        for kind in ("tt", "rr"):
+          uo = getattr(oracle, ("single_wall" if wall else "no_wall") + "_mobility_" + stem[kind] + "_oracle")(r, v, eta, a)
+          assert rel_err(ctx.matvec_device(kind, vd, eta).cpu().numpy(), uo) < 1e-12
+    ctx.set_option("sym_coop", 1)
+    ctx.set_positions(rd, a, None, True)
+    ctx.matvec_device("tt", vd, eta)
+    assert ctx.get_option("sym_coop") == 1
+  finally:
+    ctx.close()

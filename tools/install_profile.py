@@ -23,14 +23,16 @@ shutil.copy(os.path.join(src, "bench_line_under_trace.json"), base + "_line_unde
 
 with open(os.path.join(src, "summary.json")) as fh:
   summ = json.load(fh)
-kern = [v for k, v in summ.items() if "sym_kernel<0, true, false>" in k]
+kern = [v for k, v in summ.items() if "sym_kernel<0, true, false>" in k or "sym_coop_kernel<0, true, false>" in k]
 if not kern:
-  raise SystemExit("no rmb::sym_kernel<0, true, false> in %s/summary.json" % src)
+  raise SystemExit("no rmb::sym_kernel / sym_coop_kernel<0, true, false> in %s/summary.json" % src)
+kern.sort(key=lambda v: -v.get("trace_n", 0))     # the one the timed steps ran
 k = kern[0]
 ub = [v for kk, v in summ.items() if "ubench_fma64_kernel" in kk]
 with open(os.path.join(src, "bench_line_under_trace.json")) as fh:
   line = json.loads(fh.read().strip().splitlines()[-1])
 entry = {
+    "kernel": [kk for kk, v in summ.items() if v is k][0],
     "FETCH_SIZE_kb": k.get("FETCH_SIZE"), "WRITE_SIZE_kb": k.get("WRITE_SIZE"),
     "traffic_bytes": int(round(k["hbm_traffic_bytes_per_launch"])),
     "SQ_INSTS_VALU_per_launch": k.get("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU_per_launch": k.get("SQ_ACTIVE_INST_VALU"),

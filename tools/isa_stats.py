@@ -28,6 +28,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # name in the JSON -> mangled-name prefix of the kernel
 KERNELS = {
     "sym_tt_wall": "_ZN3rmb10sym_kernelILi0ELb1ELb0EEE",
+    "sym_coop_tt_wall": "_ZN3rmb15sym_coop_kernelILi0ELb1ELb0EEE",
     "sym_tt_nowall": "_ZN3rmb10sym_kernelILi0ELb0ELb0EEE",
     "sym_tr_wall": "_ZN3rmb10sym_kernelILi1ELb1ELb0EEE",
     "sym_rt_wall": "_ZN3rmb10sym_kernelILi2ELb1ELb0EEE",

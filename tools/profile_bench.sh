@@ -11,7 +11,8 @@ STEPS=${3:-50}
 WARMUP=${4:-5}
 PREWARM=${5:-0}
 OUT=gpurun_out/prof_${TAG}
-ARGS="bench.py --blobs ${BLOBS} --steps ${STEPS} --warmup ${WARMUP} --prewarm-ms ${PREWARM} --no-sweep --no-cpu --no-host-surface"
+# BENCH_EXTRA: further bench.py arguments of this pass, e.g. BENCH_EXTRA="--ctx-option sym_coop=2"
+ARGS="bench.py --blobs ${BLOBS} --steps ${STEPS} --warmup ${WARMUP} --prewarm-ms ${PREWARM} --no-sweep --no-cpu --no-host-surface ${BENCH_EXTRA}"
 mkdir -p ${OUT}
 export TMPDIR=/tmp
 echo "python3 ${ARGS}" > ${OUT}/command.txt
@@ -23,4 +24,4 @@ python3 tools/summarize_profile.py ${OUT} ${STEPS} > ${OUT}/summary.txt 2>&1
 grep "^{" ${OUT}/trace.log | tail -1 > ${OUT}/bench_line_under_trace.json
 # keep the merge-back small: the raw per-dispatch CSVs of the large passes are not needed once summarised
 find ${OUT} -name "*.csv" -size +2M -delete
-grep -E "sym_kernel|ubench|sym_finalize" ${OUT}/summary.txt | head -40
+grep -E "sym_kernel|sym_coop_kernel|ubench|sym_finalize" ${OUT}/summary.txt | head -40
