@@ -106,6 +106,11 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *   "force_cull"      [1]  blob-blob forces (uniform radius, symmetric path; open or pseudo-periodic): skip tile pairs whose
  *                          bounding boxes are further apart than 2a + 750 b, where exp(-(r - 2a)/b) underflows to
  *                          exactly 0 in double precision (110 b for the float kernel): no bit of the result changes
+ *   "force_sort"      [1]  with "force_cull", from 2048 blobs on: sort the blobs along a Morton curve once per configuration
+ *                          (on the device) and run the force kernel on the sorted copy, results written back to the caller's
+ *                          indices -- the culling then skips the same tile pairs whatever order the caller lists the blobs in
+ *                          (262 144 rollers listed at random: 48 -> 4 ms).  Same pair terms in another summation order:
+ *                          equal to rounding; 0 = keep the caller's order
  *   "force_precision" [0]  blob-blob forces: 0 = follow "precision", 32 / 64 = pinned whatever "precision" says
  *                          (products in single precision with double-precision forces, or the reverse)
  *   "det_workspace_mb" [8192]  workspace of mode 2; the unit list is processed in chunks that fit

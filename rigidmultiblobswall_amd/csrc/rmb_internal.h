@@ -7,6 +7,7 @@
 //   rmb_sym.hip      launchers of the symmetric (each unordered pair once) fp64 kernels: sym / sym2 / symx / symx_det,
 //                    the symmetric force kernel
 //   rmb_sym32.hip    their single-precision twins (handed over as launch thunks)
+//   rmb_sort.hip     Morton ordering of the blobs for the force kernel's tile culling (rocPRIM radix sort)
 //   rmb_sweep.hip    launchers of the one-sided kernels: sweep, force sweep, source->target, pressure / double layer,
 //                    dense body blocks, position packing
 //   rmb_entry.hip    the extern "C" products: argument checks, routing between the two families, host staging
@@ -66,6 +67,10 @@ struct rmb_ctx {
   rmbi::DevBuf tile_bounds;      // bounding boxes of the 64-blob tiles (force kernel's tile culling); valid for the packed positions
   bool tile_bounds_valid = false;
   long opt_force_cull = 1;       // blob-blob forces: skip tile pairs beyond the range of the exponential (bit-exact)
+  // spatially sorted copy of the configuration for the force kernel (rmb_sort.hip): valid together with tile_bounds
+  rmbi::DevBuf fpos, fperm, fsort_keys, fsort_vals, fsort_tmp, fsort_box;
+  bool force_sorted = false;     // tile_bounds / fpos / fperm describe the SORTED configuration
+  long opt_force_sort = 1;       // sort the blobs along a Morton curve for the force kernel's tile culling
   rmbi::DevBuf det_ws;           // per-unit partials of the deterministic symmetric pass
   long opt_det_workspace_mb = 8192;   // cap on the partial-result workspace of deterministic = 2 (symx_det_device)
   rmbi::DevBuf st[8];    // scratch of the source->target entry point
@@ -142,6 +147,9 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
                     long shard = 0, long nshards = 1);
 int sym_force_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out, const double* radii, long shard,
                      long nshards);
+
+// ---- rmb_sort.hip ------------------------------------------------------------------------------------------
+int force_sort_positions(rmb_ctx* c);
 
 // ---- rmb_sym32.hip: single-precision twins as launch thunks ---------------------------------------------------
 // fn = host handle of the kernel (occupancy / attributes), nullptr when the operation has no fp32 twin;

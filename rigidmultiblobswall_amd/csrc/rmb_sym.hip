@@ -324,14 +324,27 @@ int sym_force_device(rmb_ctx* c, double eps, double b, double blob_radius, doubl
   // beyond (r - 2a)/b = 745.2 (750 here; 110 for the float kernel), so a tile pair whose bounding boxes are further
   // apart contributes nothing, bit for bit.  In a 262 144-roller monolayer that is 99 % of the tile pairs -- the
   // reference's own answer to this is a k-d tree (`blob_blob_force_implementation tree_numba`).
-  a.bounds = nullptr; a.cull2 = 0.0;
+  a.bounds = nullptr; a.cull2 = 0.0; a.perm = nullptr;
   if (c->opt_force_cull && !radii && tiles > 1) {
-    if (!c->tile_bounds_valid) {
-      if (int rc = c->tile_bounds.reserve((size_t)6 * tiles * sizeof(double))) return rc;
-      hipLaunchKernelGGL(rmb::tile_bounds_kernel, dim3((unsigned)tiles), dim3(64), 0, c->stream, (const double4*)c->pos.p, n,
-                         (double*)c->tile_bounds.p);
-      RMB_HIP(hipGetLastError());
+    // Spatial order first ("force_sort"): how much the culling skips depends on how compact a 64-blob tile is, i.e. on
+    // the order in which the caller lists the blobs; from 32 tiles on the blobs are sorted along a Morton curve once
+    // per configuration (rmb_sort.hip) and the kernel runs on the sorted copy.
+    const bool want_sorted = c->opt_force_sort && tiles >= 32;
+    if (!c->tile_bounds_valid || c->force_sorted != want_sorted) {
+      if (want_sorted) {
+        if (int rc = force_sort_positions(c)) return rc;
+      } else {
+        if (int rc = c->tile_bounds.reserve((size_t)6 * tiles * sizeof(double))) return rc;
+        hipLaunchKernelGGL(rmb::tile_bounds_kernel, dim3((unsigned)tiles), dim3(64), 0, c->stream, (const double4*)c->pos.p, n,
+                           (double*)c->tile_bounds.p);
+        RMB_HIP(hipGetLastError());
+      }
+      c->force_sorted = want_sorted;
       c->tile_bounds_valid = true;
+    }
+    if (c->force_sorted) {
+      a.pos = (const double4*)c->fpos.p;
+      a.perm = (const unsigned*)c->fperm.p;
     }
     const double reach = 2.0 * blob_radius + (f32 ? 110.0 : 750.0) * b;
     a.bounds = (const double*)c->tile_bounds.p;

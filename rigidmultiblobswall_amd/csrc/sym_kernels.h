@@ -331,6 +331,9 @@ struct SymForceArgs {
   // (exp(-745.2) is the smallest denormal): skipping the unit changes no bit of the result.  nullptr = no culling.
   const double* bounds;
   double cull2;
+  // Spatially sorted configuration (rmb_sort.hip): `pos` is then the sorted copy and perm[s] the caller's index of
+  // sorted slot s; the finalize kernel writes slot s to out[perm[s]].  nullptr = the caller's order.
+  const unsigned* perm;
 };
 
 // Lower bound of the squared distance between any blob of tile I and any blob of tile J (wave-uniform: every lane
@@ -505,7 +508,8 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
 static __global__ __launch_bounds__(256) void sym_force_finalize_kernel(const SymForceArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  a.out[3 * i] = a.acc[i]; a.out[3 * i + 1] = a.acc[a.n_pad + i]; a.out[3 * i + 2] = a.acc[2 * a.n_pad + i];
+  const long o = a.perm ? (long)a.perm[i] : i;
+  a.out[3 * o] = a.acc[i]; a.out[3 * o + 1] = a.acc[a.n_pad + i]; a.out[3 * o + 2] = a.acc[2 * a.n_pad + i];
   a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;
 }
 

@@ -792,6 +792,7 @@ def test_force_tile_culling_changes_no_bit(Ctx, oracle, prec):
       ctx.set_positions(r, a, Lbox, wall=False)
       ctx.set_option("precision", prec)
       ctx.set_option("deterministic", 0)
+      ctx.set_option("force_sort", 0)      # the culling alone: the caller's order on both sides (same summation order per tile)
       res = {}
       for cull in (1, 0, 1):
         ctx.set_option("force_cull", cull)
@@ -871,5 +872,54 @@ def test_workgroup_cooperative_kernel_matches_the_per_wave_kernel_and_the_oracle
     ctx.set_positions(rd, a, None, True)
     ctx.matvec_device("tt", vd, eta)
     assert ctx.get_option("sym_coop") == 1
+  finally:
+    ctx.close()
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_force_culling_does_not_depend_on_the_order_of_the_blobs(oracle, periodic):
+  """Option "force_sort": the blobs are sorted along a Morton curve on the device before the force kernel's tile
+  culling (csrc/rmb_sort.hip), results go back to the caller's indices.  A monolayer listed in lattice order and the
+  same monolayer listed in random order give the same forces (to rounding), equal to the oracle; the reference's own
+  answer to the short range of the force is a tree (multi_bodies/forces_numba.py:141-271)."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  rng = np.random.RandomState(9)
+  a, b, eps = 0.5, 0.01, 0.4
+  n = 9000
+  side = int(np.ceil(np.sqrt(n)))
+  ij = np.array([(i, j) for i in range(side) for j in range(side)][:n], dtype=np.float64)
+  r = np.concatenate([ij * 2.02 * a + 0.03 * rng.rand(n, 2), a * (1.0 + 0.5 * rng.rand(n, 1))], axis=1)
+  L = np.array([side * 2.02 * a, side * 2.02 * a, 0.0]) if periodic else np.zeros(3)
+  if periodic:
+    r[:, 0] += L[0] * rng.randint(-1, 2, n)              # positions need not lie in one cell
+  perm = rng.permutation(n)
+  ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=L, repulsion_strength=eps, debye_length=b, blob_radius=a)
+  ctx = MobilityContext(0)
+  try:
+    out = {}
+    for label, rr, sort in (("lattice", r, 1), ("random", r[perm], 1), ("random_unsorted", r[perm], 0)):
+      ctx.set_option("force_sort", sort)
+      ctx.set_positions(rr, a, L, wall=False)
+      out[label] = ctx.blob_blob_force(eps, b, a)
+    assert rel_err(out["lattice"], ref) < 1e-12
+    assert rel_err(out["random"], ref[perm]) < 1e-12
+    assert rel_err(out["random"], out["random_unsorted"]) < 1e-13
+    # device entry, pair shards (full-length partials in the CALLER's order), and a new configuration on the same context
+    ctx.set_option("force_sort", 1)
+    rd = torch.as_tensor(r[perm].reshape(-1), device="cuda")
+    ctx.set_positions(rd, a, L, wall=False)
+    fd = ctx.blob_blob_force_device(eps, b, a).cpu().numpy().reshape(-1, 3)
+    assert rel_err(fd, ref[perm]) < 1e-12
+    parts = sum(ctx.blob_blob_force_pairshard_device(eps, b, a, g, 4).cpu().numpy() for g in range(4)).reshape(-1, 3)
+    assert rel_err(parts, ref[perm]) < 1e-12
+    r2 = r.copy(); r2[:, :2] *= 1.01
+    ctx.set_positions(r2[perm], a, L * 1.01, wall=False)
+    ref2 = oracle.calc_blob_blob_forces_oracle(r2, periodic_length=L * 1.01, repulsion_strength=eps, debye_length=b, blob_radius=a)
+    assert rel_err(ctx.blob_blob_force(eps, b, a), ref2[perm]) < 1e-12
+    # single-precision force kernel on the sorted copy
+    ctx.set_option("force_precision", 32)
+    if not periodic:
+      assert rel_err(ctx.blob_blob_force(eps, b, a), ref2[perm]) < 1e-4
   finally:
     ctx.close()
