@@ -7,6 +7,7 @@
 //   rmb_sym.hip      launchers of the symmetric (each unordered pair once) fp64 kernels: sym / sym2 / symx / symx_det,
 //                    the symmetric force kernel
 //   rmb_sym32.hip    their single-precision twins (handed over as launch thunks)
+//   rmb_symx_coop.hip  workgroup-cooperative instances of the generic symmetric skeleton (launch thunks too)
 //   rmb_sort.hip     Morton ordering of the blobs for the force kernel's tile culling (rocPRIM radix sort)
 //   rmb_sweep.hip    launchers of the one-sided kernels: sweep, force sweep, source->target, pressure / double layer,
 //                    dense body blocks, position packing
@@ -164,6 +165,8 @@ struct Kernel32 {
 Kernel32 sym32_tt(bool wall);
 Kernel32 symx32(int sx, bool wall);
 Kernel32 sym_force32(bool radii);
+// ---- rmb_symx_coop.hip: workgroup-cooperative instances of the generic skeleton, same thunk shape (fp64) ---------
+Kernel32 symx_coop(int sx, bool wall, bool periodic);
 
 // ---- rmb_sweep.hip -----------------------------------------------------------------------------------------
 int pack_positions(rmb_ctx* c, const double* r_dev, long n, double a, const double* L, int wall);

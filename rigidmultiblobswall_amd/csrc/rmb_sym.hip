@@ -208,11 +208,27 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   if (int rc = plan_sym(c, f32 ? k32.fn : (const void*)se.sweep, f32 ? k32.occ : &se.occ,
                         f32 ? k32.static_lds : se.static_lds, a.step_end - a.step_begin, true, &plan))
     return rc;
-  a.steps_per_wave = plan.steps_per_wave;
-  c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
+  // Workgroup-cooperative instance (symx_coop_kernels.h).  Measured (profiles/r4_coop_kernel_ab.txt): faster below one
+  // resident round (pair shards, small suspensions); for the three-vector passes at every size (their per-wave slabs,
+  // 47 KB per workgroup, hold residency at three workgroups per CU where the registers allow four: -7 % at 1e4 blobs,
+  // -1.6 % at 1e5); no gain for the other operations above one round, and 2-7 % SLOWER for four vectors at 1e5 blobs
+  // (those passes are bound by the LDS pipe itself -- 20 LDS instructions per step -- and a third wave per SIMD only
+  // adds contention).
+  const bool three_vectors = op >= SX_K2 + 4 && op < SX_K2 + 8;
+  Kernel32 kc{nullptr, 0, nullptr, nullptr};
+  if (!f32 && (c->opt_sym_coop == 2 || (c->opt_sym_coop == 1 && (plan.sub_round || three_vectors))))
+    kc = symx_coop(op, cf.wall != 0, periodic);
+  const bool coop = kc.fn != nullptr;
+  if (coop) {
+    if (int rc = plan_sym(c, kc.fn, kc.occ, kc.static_lds, a.step_end - a.step_begin, true, &plan, 0, 8)) return rc;
+  }
+  const long total_steps = a.step_end - a.step_begin;
+  a.steps_per_wave = coop ? (total_steps + plan.blocks - 1) / plan.blocks : plan.steps_per_wave;     // coop: steps per WORKGROUP
+  c->last_path = coop ? 3 : 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
   if (f32) k32.launch(&a, a.k, (unsigned)plan.blocks, plan.dyn_lds, c->stream);
+  else if (coop) kc.launch(&a, a.k, (unsigned)plan.blocks, plan.dyn_lds, c->stream);
   else     hipLaunchKernelGGL(se.sweep, dim3((unsigned)plan.blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;

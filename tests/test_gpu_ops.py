@@ -923,3 +923,43 @@ def test_force_culling_does_not_depend_on_the_order_of_the_blobs(oracle, periodi
       assert rel_err(ctx.blob_blob_force(eps, b, a), ref2[perm]) < 1e-4
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [200, 3000])
+def test_cooperative_generic_skeleton_matches_the_per_wave_one(n):
+  """symx_coop_kernel (csrc/symx_coop_kernels.h): every multi-block / multi-vector operation, forced cooperative
+  (sym_coop = 2) against per wave (0): wall / no wall / pseudo-periodic, in-plane, pair shards, free surface."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  rng = np.random.RandomState(n + 1)
+  a, eta = 0.4, 1.1
+  box = (n * (4.0 / 3.0) * np.pi * a ** 3 / 0.05) ** (1.0 / 3.0)
+  r = rng.rand(n, 3) * box
+  r[:, 2] += 0.9 * a
+  rd = torch.as_tensor(r.reshape(-1), device="cuda")
+  vs = [torch.as_tensor(rng.randn(3 * n), device="cuda") for _ in range(4)]
+  ctx = MobilityContext(0)
+  try:
+    for wall, L in ((True, None), (False, None), (True, np.array([0.0, box, 0.0]))):
+      ctx.set_positions(rd, a, L, wall)
+      cases = [("velocity_from_force_torque", vs[:2], False), ("grand", vs[:2], False), ("force_column", vs[:1], False),
+               ("tt_multi", vs[:2], False), ("tt_multi", vs[:3], False), ("rr_multi", vs[:4], False), ("tr_multi", vs[:1], True),
+               ("velocity_from_force_torque", vs[:2], True)]
+      for op, vecs, in_plane in cases:
+        ctx.set_option("sym_coop", 0)
+        ref = [o.cpu().numpy() for o in ctx.matvec_op_device(op, vecs, eta, in_plane=in_plane)]
+        ctx.set_option("sym_coop", 2)
+        got = [o.cpu().numpy() for o in ctx.matvec_op_device(op, vecs, eta, in_plane=in_plane)]
+        assert ctx.get_option("last_path") == 3
+        for x, y in zip(got, ref):
+          assert rel_err(x, y) < 1e-13, (op, wall, L, in_plane)
+        parts = [ctx.matvec_op_device(op, vecs, eta, in_plane=in_plane, shard=g, nshards=3) for g in range(3)]
+        for c in range(len(ref)):
+          assert rel_err(sum(p[c].cpu().numpy() for p in parts), ref[c]) < 1e-13, (op, "shards")
+      if not wall:
+        ctx.set_option("sym_coop", 0)
+        ref = ctx.matvec_device("tt_free", vs[0], eta).cpu().numpy()
+        ctx.set_option("sym_coop", 2)
+        assert rel_err(ctx.matvec_device("tt_free", vs[0], eta).cpu().numpy(), ref) < 1e-13
+  finally:
+    ctx.close()
