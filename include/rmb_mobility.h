@@ -133,7 +133,7 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
  *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics
  *   "skip_pairs"      [0]  diagnostics, results are WRONG: bit 0 = no pair arithmetic, bit 1 = no flush of the
- *                          per-wave LDS accumulators (tools/exp_prewarm.py prices the atomics with it)          */
+ *                          per-wave LDS accumulators (tools/experiments/exp_prewarm.py prices the atomics with it)          */
 int rmb_ctx_set_option(rmb_ctx* ctx, const char* key, long value);
 /* Current value of an option (same keys); lets a caller switch one temporarily and restore what was there.  Read-only
  * key "last_path": the kernel family of the last product (0 one-sided sweep, 1 symmetric per wave, 2 deterministic
@@ -258,7 +258,8 @@ int rmb_default_ctx_set_device(int device);
  * shard pulls from devices[0] over xGMI), device g evaluates pair shard g of G (each unordered pair once, both blobs
  * updated) into a full-length partial, then device g sums slice g of the G partials in FIXED order through peer-mapped
  * reads and stores it where the result is wanted -- reduce-scatter + gather in one kernel per device.  With option
- * "deterministic" = 2 the product is bit-reproducible for a given device list.  No reference counterpart (single
+ * "deterministic" = 2 the mobility products are bit-reproducible for a given device list (the forces' pair shards
+ * flush with atomics whatever the option says).  No reference counterpart (single
  * device); the contract is "equal to the one-context result to rounding" (<= 1e-13).
  *   - devices: 1..16 indices; the same device may be listed several times (rehearsal of the G-device path on one GPU).
  *   - without peer access between two listed devices (or with RMB_MULTI_NO_PEER=1) slices travel by hipMemcpyPeerAsync.

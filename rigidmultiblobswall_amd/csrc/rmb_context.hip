@@ -29,7 +29,7 @@ int timing_begin(rmb_ctx* c, int* slot) {
   *slot = -1;
   if (!c->opt_timing) return 0;
   // "timing" = n > 1: bracket every n-th sweep only.  An event pair costs ~4-8 us of serialisation around a launch
-  // (tools/exp_graph.py: 188 us per 1e4-blob step without events, 199 us with), so a throughput measurement samples.
+  // (tools/experiments/exp_graph.py: 188 us per 1e4-blob step without events, 199 us with), so a throughput measurement samples.
   if (c->opt_timing > 1 && (c->timing_launches++ % c->opt_timing) != 0) return 0;
   if (c->ev0.empty()) {
     c->ev0.resize(kTimingRing);

@@ -134,7 +134,7 @@ int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long
     // Less than one resident round at 64 steps per wave (small N, or one rank's pair shard): shorter waves beat
     // leaving SIMDs with one or two waves and no latency hiding, but every wave pays its own loads and 384 global
     // atomics on accumulators it shares with the other waves of its tile row.
-    // Two regimes (tools/exp_small_n.py, tools/exp_shard_plan.py; profiles/r3_shard_plan.txt): while 16-step waves
+    // Two regimes (tools/experiments/exp_small_n.py, tools/experiments/exp_shard_plan.py; profiles/r3_shard_plan.txt): while 16-step waves
     // do not fill the chip (small N: <= 1500 blobs) the launch is latency-bound and more, shorter waves win
     // (1000 blobs: 9.6 us at 16 steps, 13.0 at 32); once they would overfill it, every extra wave only adds its
     // loads and flushes (1/8 shard of 1e4 blobs: 36.6 us at 16 steps x 1024 workgroups, 29.3 at 32 x 776).

@@ -1,22 +1,24 @@
-"""Target-sharded blob mobility over several GPUs (one process per GPU, torch.distributed).
+"""Blob mobility over several GPUs, one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).
 
-The reference is single-device; this layer has no counterpart there.  Its
-contract is "equal to the 1-GPU result to rounding".
+The reference is single-device; this layer has no counterpart there.  Its contract is "equal to
+the 1-GPU result to rounding".  (One process driving several GPUs -- the reference's own call shape -- is
+multi.MultiContext / rmb_multi_*.)  Two decompositions:
 
-Sharding: blob index range [0, N) is cut into G contiguous blocks of ceil(N/G); rank g OWNS
-block g: it holds r_local, v_local and produces u_local for those targets.  Every rank needs all
-N sources, so there is exactly one exchange step per product:
-  * positions: all-gather once per configuration (set_positions), then packed on the device;
-  * source vector: all-gather (24 N bytes in total) before each matvec  -- RCCL over xGMI when the
-    process group's backend is "nccl";
-  * output: none (each rank keeps the targets it owns).
-The pair sweep on each rank is the same kernel as single-GPU, restricted to its target range
-(rmb_set_target_range), so per-target summation order does not depend on G beyond the source
-chunking.
+  * SYMMETRIC PAIR SHARDING (default of the replicated API: matvec_replicated, matvec_op_replicated,
+    matvec2_replicated, blob_blob_force_replicated -- every product of the surface, open or pseudo-periodic): every
+    rank holds all positions and the full source vector(s); rank g evaluates the g-th slice of the unordered blob
+    pairs once each (rmb_matvec_pairshard_device & co.) into a full-length partial; ONE all-reduce (sum) of 24 N bytes
+    per output vector completes the product on every rank.  Keeps the 2x arithmetic saving of the symmetric kernel at
+    any G.  Bit-reproducible per rank with the context option "deterministic" = 2 (forces: own target block + all-gather).
+  * TARGET SHARDING (the block-distributed API: set_local_positions / matvec_local, north_star's layout): blob index
+    range [0, N) is cut into G contiguous blocks of ceil(N/G); rank g OWNS block g: it holds r_local, v_local and
+    produces u_local.  Positions are all-gathered once per configuration, the source vector (24 N bytes in total)
+    before each matvec; outputs need no reduction.  The per-rank kernel is the one-sided sweep restricted to the
+    rank's targets (rmb_set_target_range): every ordered pair of its rows, 1.6x the work per pair of the default.
 
-The compute backend is injected (`backend=`): the product default is the HIP context
-(`HipBackend`); the CPU test-suite injects an oracle-backed one to exercise partitioning and
-collectives under gloo.  There is no implicit CPU fallback.
+The compute backend is injected (`backend=`): the product default is the HIP context (`HipBackend`); the CPU
+test-suite injects an oracle-backed one to exercise partitioning and collectives under gloo.  There is no implicit
+CPU fallback.
 """
 import numpy as np
 import torch
@@ -73,7 +75,8 @@ class HipBackend(object):
 
 
 class ShardedMobility(object):
-  """M.v with targets sharded over the ranks of a process group."""
+  """M.v over the ranks of a process group: unordered pairs sharded + all-reduce (replicated API) or targets sharded +
+  all-gather (block-distributed API); see the module docstring."""
 
   def __init__(self, backend, group=None, device=None):
     self.backend = backend
@@ -152,10 +155,10 @@ class ShardedMobility(object):
   def matvec_replicated(self, kind, v_full, eta, vec2_full=None, in_plane=False, out=None):
     """Every rank holds the full source vector and receives the full product (the layout a replicated
     Krylov loop wants: its dot products / axpys on 3N-vectors are negligible next to the O(N^2) sweep).
-      * tt, non-periodic: SYMMETRIC PAIR SHARDING -- rank g evaluates the g-th slice of the unordered
-        pairs once each (rmb_matvec_pairshard_device) into a full-length partial, then ONE all-reduce
-        (sum) of 24 N bytes.  Half the arithmetic of target sharding.
-      * other kinds / periodic: target sharding on the rank's block, then all-gather of the blocks."""
+    Symmetric pair sharding for every kind the backend shards (tt / tr / rt / rr / free surface, the fused tt+tr row and
+    the in-plane products; open or pseudo-periodic): rank g evaluates the g-th slice of the unordered pairs once each
+    into a full-length partial, then ONE all-reduce (sum) of 24 N bytes.  Backends without the pair-shard entry points:
+    target sharding on the rank's block, then all-gather of the blocks."""
     v = self._to_dev(v_full)
     periodic = bool(self._periodic)
     if (vec2_full is None and not in_plane and hasattr(self.backend, "supports_pairshard")
@@ -245,8 +248,13 @@ class ShardedMobility(object):
 
   def blob_blob_force_replicated(self, eps, b, a):
     """Forces on ALL blobs on every rank: pair shard of the symmetric force kernel (F_ji = -F_ij, each unordered pair
-    once) + one all-reduce; backends without it sweep their own target block and all-gather the blocks."""
-    if hasattr(self.backend, "blob_blob_force_pairshard"):
+    once) + one all-reduce; with the "deterministic" option, and for backends without the pair shard, every rank sweeps
+    its own target block (atomic-free, bit-reproducible) and the blocks are all-gathered."""
+    # The pair shard flushes with atomics.  With the context's "deterministic" option on (1 or 2) the forces stay
+    # bit-reproducible across runs: own target block with the one-sided sweep (fixed summation order) + all-gather.
+    ctx = getattr(self.backend, "ctx", None)
+    deterministic = bool(ctx.get_option("deterministic")) if ctx is not None and hasattr(ctx, "get_option") else False
+    if hasattr(self.backend, "blob_blob_force_pairshard") and not deterministic:
       part = self.backend.blob_blob_force_pairshard(eps, b, a, self.rank, self.world)
       if self.world > 1:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)

@@ -405,7 +405,7 @@ class RigidSuspension(object):
     differs from the reference's flow is the number of Krylov restarts (one per outer step), not the stopping rule.
     Where the fp32 kernel does not apply (pseudo-periodic domain, fewer than 128 blobs) the inner products fall back to
     fp64 and this is plain restarted GMRES.  Not used by default: `solve` is the reference's algorithm.
-    Measured (2048 shells x 12 blobs, tol 1e-8, tools/exp_mixed_precision_solve.py): 15.8 ms against 18.5 ms -- 21 fp32
+    Measured (2048 shells x 12 blobs, tol 1e-8, tools/experiments/exp_mixed_precision_solve.py): 15.8 ms against 18.5 ms -- 21 fp32
     sweeps + 3 fp64 ones instead of 19 fp64 sweeps; at this size the per-iteration host work limits the gain to 1.17x."""
     if self.groups[0].Lchol is None:
       self.build_preconditioner()
@@ -723,7 +723,9 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
         if lag:
           torch.div(w, cols[j, j + 1], out=V[j + 1])                 # normalised on the device: no host value needed
           host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
-          events[j & 1].record()
+          # fence on the stream the copy was enqueued on: the current stream of the VECTORS' device, which need not
+          # be the process's current device (a suspension built on cuda:1 while cuda:0 is current)
+          events[j & 1].record(torch.cuda.current_stream(dev))
           if pending is not None:
             stop, pending = finish(pending), None
             if stop:

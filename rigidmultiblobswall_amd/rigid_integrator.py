@@ -155,14 +155,15 @@ class RigidIntegrator(object):
     Brownian schemes at their loose solver tolerances (1e-3 ... 1e-4), where the product error is two orders below
     the tolerance; the solvers' stopping rules are unchanged.  The random finite differences divide a difference of two
     products by rf_delta: with ~1e-6-accurate products rf_delta must be >= 1e-4 (doc/README.md:512-523 uses 1e-3 for the
-    reference's single-precision build, 1e-6 for double) -- the setter and every stochastic step raise ValueError otherwise."""
+    reference's single-precision build, 1e-6 for double) -- the setter (for a stochastic scheme with kT > 0) and every stochastic step raise ValueError otherwise."""
     return self._precision
 
   @precision.setter
   def precision(self, value):
     if value not in ('single', 'double'):
       raise ValueError("precision must be 'single' or 'double'")
-    if value == 'single':
+    if value == 'single' and self.kT > 0.0 and self.scheme.startswith("stochastic"):
+      # only the stochastic schemes form random finite differences (the per-step check covers later changes)
       from .rollers import _check_rfd_delta_for_single_precision
       _check_rfd_delta_for_single_precision(self.rf_delta)
     self._precision = value

@@ -107,15 +107,17 @@ class RollersIntegrator(object):
     boundaries, and so do the blob-blob forces (the reference's GPU force kernel is always single precision; pin them
     with `force_precision = 'double'`); pseudo-periodic domains and the stepper's own algebra stay fp64.
     The random finite differences divide a difference of two products by rf_delta, so with ~1e-6-accurate products
-    rf_delta must be >= 1e-4 (the reference's advice for its float build, doc/README.md:512-523): the setter and every
-    stochastic step raise otherwise."""
+    rf_delta must be >= 1e-4 (the reference's advice for its float build, doc/README.md:512-523): the setter (for a stochastic scheme
+    with kT > 0) and every stochastic step raise otherwise."""
     return self._precision
 
   @precision.setter
   def precision(self, value):
     if value not in ('single', 'double'):
       raise ValueError("precision must be 'single' or 'double'")
-    if value == 'single':
+    if value == 'single' and self.kT > 0.0 and self.scheme.startswith("stochastic"):
+      # only the stochastic schemes form random finite differences; a deterministic scheme (or kT = 0) with the
+      # reference's double-precision rf_delta = 1e-6 may select single precision (the per-step check covers later changes)
       _check_rfd_delta_for_single_precision(self.rf_delta)
     self._precision = value
     self.ctx.set_option("precision", 32 if value == 'single' else 64)

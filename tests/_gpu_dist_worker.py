@@ -86,6 +86,15 @@ def main():
     rc.set_positions(rd, a, L, False)
     F = rc.blob_blob_force_device(0.7, 0.15, a)
     assert rel(F, single.blob_blob_force_device(0.7, 0.15, a)) < 1e-12
+    # with "deterministic" on, multi-rank forces are bit-reproducible: own target block (one-sided sweep) + all-gather
+    for mode in (1, 2):
+      rc.set_option("deterministic", mode)
+      F1 = rc.blob_blob_force_device(0.7, 0.15, a).clone()
+      F2 = rc.blob_blob_force_device(0.7, 0.15, a)
+      assert torch.equal(F1, F2), (N, mode, "forces not bit-reproducible")
+      assert rel(F1.view(-1), F.view(-1)) < 1e-12
+    rc.set_option("deterministic", 0)
+    checked += 2
     u = rc.matvec_device("tt_free", vs[0], eta)
     assert rel(u, single.matvec_device("tt_free", vs[0], eta)) < 1e-12
     checked += 2

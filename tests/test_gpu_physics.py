@@ -2,7 +2,7 @@
 Gibbs-Boltzmann height distribution P(h) ~ exp(-U(h)/kT) whatever their hydrodynamic interactions.  That holds only if
 the noise has covariance 2 kT M / dt AND the stochastic drift kT div(M) is right -- dropping the drift term moves the mean
 height by -3 % within 200 steps (control below), the correct integrators stay within 1 %.
-(tools/exp_equilibrium.py is the stand-alone version; parameters of multi_bodies/examples/rollers/inputfile_rollers.dat.)"""
+(tools/experiments/exp_equilibrium.py is the stand-alone version; parameters of multi_bodies/examples/rollers/inputfile_rollers.dat.)"""
 import math
 import os
 import sys

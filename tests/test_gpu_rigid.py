@@ -231,3 +231,49 @@ def test_mixed_precision_solve_meets_the_same_tolerance():
     rs.ctx.set_option("precision", 64)
   finally:
     rs.close()
+
+
+def test_lagged_gmres_bookkeeping_equals_the_synchronous_loop():
+  """The host side of GMRES (Givens rotations, convergence test) runs one iteration behind the device by default on a
+  GPU (`lag`): iterates, stopping rule and iteration counts must be those of the synchronous loop
+  (general_application_utils.py:514-635) -- with restarts, with an initial guess, when the solve converges exactly at
+  a restart boundary, and on a solve that converges in very few iterations (where the loop turns synchronous early)."""
+  import torch
+  from rigidmultiblobswall_amd.rigid import gmres_right_preconditioned
+  dev = torch.device("cuda:0")
+  rng = np.random.RandomState(5)
+  n = 400
+  Q, _ = np.linalg.qr(rng.randn(n, n))
+  eig = np.concatenate([np.linspace(1.0, 3.0, n - 30), 10.0 ** rng.uniform(-2, 1.5, 30)])
+  A_h = (Q * eig) @ Q.T + 0.05 * rng.randn(n, n) / np.sqrt(n)          # non-symmetric, a few outlying eigenvalues
+  A = torch.as_tensor(A_h, device=dev)
+  Pinv = torch.as_tensor(np.diag(1.0 / np.diag(A_h)), device=dev)
+  b = torch.as_tensor(rng.randn(n), device=dev)
+  x0 = torch.as_tensor(0.1 * rng.randn(n), device=dev)
+  op = lambda v: A @ v
+  pc = lambda v: Pinv @ v
+
+  def both(**kw):
+    out = []
+    for lag in (False, True):
+      x, info = gmres_right_preconditioned(op, pc, b, lag=lag, **kw)
+      torch.cuda.synchronize()
+      out.append((x.cpu().numpy(), info))
+    (xs, i_s), (xl, i_l) = out
+    assert i_l["iterations"] == i_s["iterations"], (kw, i_s["iterations"], i_l["iterations"])
+    assert i_l["converged"] == i_s["converged"]
+    assert np.allclose(i_l["history"], i_s["history"], rtol=1e-9, atol=0)
+    # same iterates up to the rounding of w / |w| (device scalar) against w * (1 / |w|) (host scalar), amplified by the
+    # conditioning of the system (~3e3 here)
+    assert rel_err(xl, xs) < 1e-9, rel_err(xl, xs)
+    assert i_l["discarded_sweeps"] <= 1 and i_s["discarded_sweeps"] == 0
+    return i_s
+
+  full = both(tol=1e-10, restart=200)
+  assert full["converged"] and full["iterations"] > 20
+  both(tol=1e-10, restart=7)                                  # many restart cycles
+  both(tol=1e-10, restart=7, x0=x0)                           # warm start + restarts
+  both(tol=1e-10, restart=full["iterations"])                 # converges exactly when the cycle ends
+  both(tol=1e-10, restart=full["iterations"] - 1)             # one iteration into the next cycle
+  both(tol=1e-1, restart=60)                                  # a handful of iterations
+  both(tol=1e-10, restart=60, maxiter=9)                      # stops on the iteration cap, not converged

@@ -61,7 +61,7 @@ for N in SIZES:
   ctx = MobilityContext(0)
   ctx.set_option("timing", 1)
   ctx.set_positions(rd, a, wall=True)
-  # prime the clocks (tools/exp_prewarm.py: ~100 launches / 25 ms until the fp64 clock settles)
+  # prime the clocks (tools/experiments/exp_prewarm.py: ~100 launches / 25 ms until the fp64 clock settles)
   for _ in range(300 if N <= 20000 else 3):
     ctx.matvec_device("tt", fd, eta)
   torch.cuda.synchronize()

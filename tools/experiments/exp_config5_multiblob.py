@@ -3,7 +3,7 @@ configs[4] recipe with rigid multiblobs: 21845 shells x 12 blobs = 262140 blobs,
 (physical parameters of examples/Spectral_Multiblob_Roller/inputfile_2048_rollers.dat).  Prints per-step timing."""
 import math, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rigidmultiblobswall_amd import structures as st
 from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator

@@ -1,7 +1,7 @@
 """Price of the two bit-reproducible modes against the default (atomic flushes): wall tt, clocks primed."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 for N in (10000, 24576, 100000, 262144):

@@ -3,7 +3,7 @@ distribution P(h) ~ exp(-U(h)/kT), U = m g h + wall repulsion, whatever the hydr
 holds if the stochastic drift kT div(M) (random finite difference) and the noise amplitude are right."""
 import math, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rigidmultiblobswall_amd.rollers import RollersIntegrator
 

@@ -2,7 +2,7 @@
 deck's debye length) and on the 5 % cloud; HIP events around the force kernel, clocks primed."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext, structures as st
 from bench import d2_cloud
 ctx = MobilityContext(0)

@@ -4,7 +4,7 @@ times vs a captured graph of 20 steps replayed 10 times.  torch.cuda.CUDAGraph c
 enqueues on torch's current stream."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 

@@ -2,7 +2,7 @@
 first call) against the kernel time: what a RigidMultiblobsWall caller that keeps its vectors on the host pays."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import mobility as mob
 from bench import d2_cloud
 for N in (1000, 10000, 24576, 100000):

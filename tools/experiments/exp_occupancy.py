@@ -4,7 +4,7 @@ the 86 architectural VGPRs of sym_kernel and says 5 waves per SIMD; with its 9 A
 with the residency capped ("sym_wps"), for the library in RMB_AB_LIB (default: the in-tree build)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import _lib as _rmb_lib
 if os.environ.get("RMB_AB_LIB"):
   _rmb_lib.LIB_PATH = os.path.abspath(os.environ["RMB_AB_LIB"])

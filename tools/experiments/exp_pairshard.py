@@ -2,7 +2,7 @@
 several values of the sym_min_steps option."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud

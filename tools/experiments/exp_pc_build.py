@@ -1,7 +1,7 @@
 """Where the preconditioner build spends its time (per-body dense M, Cholesky, inverse, (K^T M^-1 K)^+)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import structures as st
 from rigidmultiblobswall_amd.rigid import RigidSuspension
 R, eta = 1.0155, 0.957e-3

@@ -1,7 +1,7 @@
 """Pseudo-periodic products (3^d image boxes): kernel time of the symmetric path vs the open-boundary one."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud

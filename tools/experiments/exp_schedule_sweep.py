@@ -1,10 +1,10 @@
 """Schedule knobs of the symmetric kernel with primed clocks: rounds of resident workgroups (sym_oversub), minimum
 rotation steps per wave (sym_min_steps), resident workgroups per CU (sym_wps).
-  python tools/exp_schedule_sweep.py [N]            headline size: the full grid
-  python tools/exp_schedule_sweep.py N coarse       other sizes: oversub x min_steps at the default residency"""
+  python tools/experiments/exp_schedule_sweep.py [N]            headline size: the full grid
+  python tools/experiments/exp_schedule_sweep.py N coarse       other sizes: oversub x min_steps at the default residency"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 

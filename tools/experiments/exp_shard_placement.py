@@ -2,7 +2,7 @@
 (tools/ubench_dispatch.hip)?  Per-wave start / end stamps + placement (XCC, SE, CU, SIMD) of one G = 8 shard at 1e4."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 

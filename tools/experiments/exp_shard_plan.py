@@ -2,7 +2,7 @@
 wave ("sym_fine_steps").  HIP events around every sweep, clocks primed."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000

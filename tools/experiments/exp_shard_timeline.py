@@ -5,7 +5,7 @@ the same with skip_pairs = 1 (prologue + epilogue only, no pair arithmetic), and
 sweep + finalize per call without events (what a rank really spends before its all-reduce)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 

@@ -2,7 +2,7 @@
 wave at 16 / 32 / 64 against the one-sided sweep; sweep + finalize end to end per call, no events, clocks primed."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 ctx = MobilityContext(0)

@@ -1,7 +1,7 @@
 """Timing of the source->target product (K13) through the host surface: ns = nt = N, per-blob radii."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import mobility as mob
 from bench import d2_cloud
 for N in (10000, 100000):

@@ -1,7 +1,7 @@
 """GPU experiment: symmetric-kernel residency (waves per SIMD) and pinning vs kernel time."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud

@@ -1,7 +1,7 @@
 """Cost of the two-vector symmetric tt sweep against two single sweeps (kernel time, HIP events)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud

@@ -1,7 +1,7 @@
 """Where does the symmetric kernel's wall time go at small N?  Per-wave start/end stamps."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
 from bench import d2_cloud
 for N in (10000, 24576):
