@@ -68,7 +68,10 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
                     (c->opt_sym_coop == 2 || (c->opt_sym_coop == 1 && (plan.sub_round || plan.blocks <= kCoopMaxRounds * plan.round)));
   if (coop) {
     const size_t coop_lds = sizeof(double2) * 64 * 3 + sizeof(double) * 2 * 3 * 64;
-    if (int rc = plan_sym(c, (const void*)se.coop, &se.coop_occ, coop_lds, a.step_end - a.step_begin, true, &plan, rmb::kSymWavesPerEu, 8))
+    // steps per wave below one resident round: 8, and 4 for the smallest launches (<= 12288 rotation steps, i.e. up to
+    // ~1200 blobs: 1000 blobs 8.98 -> 8.26 us; profiles/r4_coop_kernel_ab.txt)
+    const long fine = (a.step_end - a.step_begin) <= 12288 ? 4 : 8;
+    if (int rc = plan_sym(c, (const void*)se.coop, &se.coop_occ, coop_lds, a.step_end - a.step_begin, true, &plan, rmb::kSymWavesPerEu, fine))
       return rc;
   }
   const long blocks = plan.blocks;
@@ -220,7 +223,8 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
     kc = symx_coop(op, cf.wall != 0, periodic);
   const bool coop = kc.fn != nullptr;
   if (coop) {
-    if (int rc = plan_sym(c, kc.fn, kc.occ, kc.static_lds, a.step_end - a.step_begin, true, &plan, 0, 8)) return rc;
+    const long fine = (a.step_end - a.step_begin) <= 12288 ? 4 : 8;     // as sym_device
+    if (int rc = plan_sym(c, kc.fn, kc.occ, kc.static_lds, a.step_end - a.step_begin, true, &plan, 0, fine)) return rc;
   }
   const long total_steps = a.step_end - a.step_begin;
   a.steps_per_wave = coop ? (total_steps + plan.blocks - 1) / plan.blocks : plan.steps_per_wave;     // coop: steps per WORKGROUP
