@@ -336,3 +336,33 @@ def test_rigid_solver_runs_on_the_engine(torch_mod):
     assert rel_err(UG, U1) < 1e-8
   finally:
     multi.close()
+
+
+def test_bench_probe_of_the_multi_device_surface_runs(tmp_path):
+  """tools/multi_surface_probe.py is what bench.py's `multi_device_surface` extra runs in a child process when a one-rank
+  run sees several devices; here with this box's GPU listed three times."""
+  import json
+  import subprocess
+  import sys
+  from conftest import ROOT
+  res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multi_surface_probe.py"), "0,0,0", "3000"],
+                       capture_output=True, text=True, timeout=240)
+  assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+  row = json.loads([l for l in res.stdout.split("\n") if l.startswith("{")][-1])["sizes"][0]
+  assert row["n_blobs"] == 3000 and row["all_devices"]["devices"] == [0, 0, 0] and row["one_device"]["devices"] == [0]
+  assert row["rel_diff_all_vs_one"] < 1e-13 and row["peer_access"] is True
+
+
+def test_host_timing_of_the_synchronous_entry_point():
+  """rmb_last_host_timing: host wall clock of the stages of the last rmb_matvec (bench.py's host_surface.breakdown_us)."""
+  from rigidmultiblobswall_amd import MobilityContext
+  r, f, t, eta, a, _ = _cloud(2000, 1)
+  ctx = MobilityContext(0)
+  try:
+    ctx.set_positions(r, a, None, True)
+    ctx.matvec("tt", f, eta)
+    ht = ctx.last_host_timing()
+    assert ht["c_call_us"] > 0 and ht["upload_us"] > 0 and ht["launch_us"] > 0 and ht["wait_and_download_us"] > 0
+    assert abs(ht["upload_us"] + ht["launch_us"] + ht["wait_and_download_us"] - ht["c_call_us"]) < 1e-6 * ht["c_call_us"] + 1e-3
+  finally:
+    ctx.close()

@@ -3,7 +3,7 @@
 single_wall_mobility_trans_times_force_hip(r_vectors, force, eta, a) on ONE device and on ALL visible devices through
 the single-process multi-device engine (mobility.set_devices), same inputs, results compared.  Prints one JSON line.
 
-  python tools/multi_surface_probe.py N_DEVICES [N_BLOBS ...]
+  python tools/multi_surface_probe.py N_DEVICES|d0,d1,... [N_BLOBS ...]
 """
 import json
 import os
@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 def main():
   from bench import d2_cloud
   from rigidmultiblobswall_amd import mobility as mob
-  n_dev = int(sys.argv[1])
+  # N_DEVICES, or an explicit list "0,0,0" (rehearsal on one GPU: the same device several times)
+  all_devs = [int(x) for x in sys.argv[1].split(",")] if "," in sys.argv[1] else list(range(int(sys.argv[1])))
   sizes = [int(x) for x in sys.argv[2:]] or [24576, 100000]
   mob.multi_min_blobs = 0
   rows = []
@@ -27,7 +28,7 @@ def main():
     r, f, eta, a = d2_cloud(n, seed=0)
     per = {}
     u_ref = None
-    for label, devs in (("one_device", [0]), ("all_devices", list(range(n_dev)))):
+    for label, devs in (("one_device", all_devs[:1]), ("all_devices", all_devs)):
       mob.set_devices(devs)
       for _ in range(3):
         u = mob.single_wall_mobility_trans_times_force_hip(r, f, eta, a)
