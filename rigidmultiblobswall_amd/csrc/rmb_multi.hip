@@ -40,22 +40,32 @@ struct ReduceArgs {
   long lo, hi;                      // this launch's slice of [0, len)
 };
 
+// Peer-mapped memory is read and written with system-scope accesses (sc0 sc1 on gfx950: served by the owning device's
+// memory, never by a line this device's L2 kept from the previous product).  Ordering between devices is by events at
+// kernel boundaries; the scope only keeps a stale cached copy out of the picture.
+__device__ __forceinline__ double peer_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void peer_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // out[v][i] = sum over shards, ascending shard index: a fixed order, so bit-reproducible partials give a
 // bit-reproducible product.  part[h] may live on a peer device (peer-mapped loads), out[v] too (peer-mapped stores).
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const ReduceArgs a) {
   const long i = a.lo + (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.hi) return;
   for (int v = 0; v < a.n_out; ++v) {
-    double s = a.part[0][v * a.len + i];
-    for (int h = 1; h < a.n_shards; ++h) s += a.part[h][v * a.len + i];
-    a.out[v][i] = s;
+    double s = peer_load(&a.part[0][v * a.len + i]);
+    for (int h = 1; h < a.n_shards; ++h) s += peer_load(&a.part[h][v * a.len + i]);
+    peer_store(&a.out[v][i], s);
   }
 }
 
 // dst (local) = src (possibly peer-mapped): how a shard pulls its inputs from devices[0]
 __global__ __launch_bounds__(256) void pull_kernel(double* dst, const double* src, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
+  if (i < n) dst[i] = peer_load(&src[i]);
 }
 
 struct Shard {
