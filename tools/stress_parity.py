@@ -138,3 +138,65 @@ for case in range(max(20, n_cases // 4)):
     print("SHARD CASE %d N=%d G=%d kind=%s wall=%s L=%s errs=%s" % (case, N, G, kind, wall, L, errs), flush=True)
 print("pair-shard cases %d, worst relative error %.3e" % (max(20, n_cases // 4), worst_shard))
 ctx.close()
+
+# --- round 4: workgroup-cooperative kernels, the multi-device engine (one GPU listed G times), sorted force culling ------
+from rigidmultiblobswall_amd.multi import MultiContext
+rng = np.random.RandomState(4321 + (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+worst4 = 0.0
+ctx = MobilityContext(0)
+engines = {}
+n4 = max(24, n_cases // 4)
+for case in range(n4):
+  N = int(rng.choice([3, 64, 65, 128, 129, 300, 777, 1500, 2049, 4097, 7000]))
+  G = int(rng.choice([2, 3, 5, 8]))
+  wall = bool(rng.rand() < 0.7)
+  a, eta = float(0.1 + rng.rand()), float(0.5 + rng.rand())
+  box = a * (N ** (1.0 / 3.0)) * float(rng.choice([6.0, 2.2]))
+  r = rng.rand(N, 3) * box
+  if wall:
+    r[:, 2] += (1.05 if rng.rand() < 0.5 else 0.6) * a
+  L = np.zeros(3)
+  if rng.rand() < 0.3:
+    L[int(rng.randint(2))] = box * (1.0 + rng.rand())
+  v, w = rng.randn(N, 3), rng.randn(N, 3)
+  pre = "single_wall" if wall else "no_wall"
+  errs = []
+  # (i) cooperative kernels forced, every kind + the fused row, against the oracle
+  ctx.set_positions(r, a, L, wall=wall)
+  ctx.set_option("sym_coop", 2)
+  for kind in ("tt", "tr", "rt", "rr"):
+    ref = getattr(oracle, "%s_mobility_%s_oracle" % (pre, names[kind]))(r, v, eta, a, periodic_length=L)
+    nrm = np.linalg.norm(ref)
+    if np.isfinite(nrm) and nrm > 1e-9 * np.linalg.norm(v) / (8.0 * np.pi * eta * a * a):
+      errs.append(np.linalg.norm(ctx.matvec(kind, v, eta) - ref) / nrm)
+  if wall:
+    ref = oracle.single_wall_mobility_trans_times_force_torque_oracle(r, v, w, eta, a, periodic_length=L)
+    errs.append(np.linalg.norm(ctx.matvec("tt_tr", v, eta, vec2=w) - ref) / np.linalg.norm(ref))
+  ctx.set_option("sym_coop", 1)
+  # (ii) the engine with the device listed G times: tt + rr + fused + forces against the oracle
+  if G not in engines:
+    engines[G] = MultiContext([0] * G)
+  m = engines[G]
+  m.set_option("deterministic", int(rng.choice([0, 2])))
+  m.set_positions(r, a, L, wall)
+  for kind in ("tt", "rr"):
+    ref = getattr(oracle, "%s_mobility_%s_oracle" % (pre, names[kind]))(r, v, eta, a, periodic_length=L)
+    errs.append(np.linalg.norm(m.matvec(kind, v, eta) - ref) / np.linalg.norm(ref))
+  if wall:
+    ref = oracle.single_wall_mobility_trans_times_force_torque_oracle(r, v, w, eta, a, periodic_length=L)
+    errs.append(np.linalg.norm(m.matvec("tt_tr", v, eta, vec2=w) - ref) / np.linalg.norm(ref))
+  # (iii) forces: sorted culling on a random permutation, single context and engine
+  eps, b = float(0.1 + rng.rand()), float(a * (0.02 + 0.3 * rng.rand()))
+  perm = rng.permutation(N)
+  F_ref = oracle.calc_blob_blob_forces_oracle(r, periodic_length=L, repulsion_strength=eps, debye_length=b, blob_radius=a)
+  ctx.set_positions(r[perm], a, L, wall=False)
+  errs.append(np.linalg.norm(ctx.blob_blob_force(eps, b, a) - F_ref[perm]) / max(np.linalg.norm(F_ref), 1e-300))
+  m.set_positions(r[perm], a, L, False)
+  errs.append(np.linalg.norm(m.blob_blob_force(eps, b, a) - F_ref[perm]) / max(np.linalg.norm(F_ref), 1e-300))
+  worst4 = max(worst4, max(errs))
+  if max(errs) > 1e-11:
+    print("R4 CASE %d N=%d G=%d wall=%s L=%s errs=%s" % (case, N, G, wall, L, ["%.1e" % e for e in errs]), flush=True)
+print("round-4 cases (cooperative kernels, multi-device engine, sorted force culling) %d, worst relative error %.3e" % (n4, worst4))
+for m in engines.values():
+  m.close()
+ctx.close()
