@@ -613,15 +613,23 @@ def rank_main(args):
     # multi-device engine (mobility.set_devices(all): pair shards on every GPU, fixed-order slice reduction over xGMI).
     # Run in a CHILD process with a timeout: it touches devices this process does not own, and a fault there must not
     # take the line down with it.
-    if n_dev < 2:
-      return None
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "multi_surface_probe.py"), str(n_dev)]
+    # With ONE device visible the same probe lists it twice: the engine's code path (two shard contexts, two streams,
+    # the slice reduction) on this box -- a rehearsal that shows its overhead, not a speed-up.
+    rehearsal = n_dev < 2
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "multi_surface_probe.py"), "0,0" if rehearsal else str(n_dev)] + \
+          (["24576"] if rehearsal else [])
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
     rows = [l for l in p.stdout.split("\n") if l.startswith("{")]
     if p.returncode != 0 or not rows:
       return {"error": "probe exited with %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])}
-    return json.loads(rows[-1])
-  stage("multi_device_surface", 160, multi_device_surface, single_rank_only=True)
+    out = json.loads(rows[-1])
+    out["rehearsal_on_one_gpu"] = rehearsal
+    if rehearsal:
+      out["note"] = ("one device visible: it is listed twice, so the two shards share the chip and `speedup` < 1 is the engine's "
+                     "hand-off overhead; on a node the list is every visible device")
+    return out
+  if not args.no_host_surface:
+    stage("multi_device_surface", 160, multi_device_surface, single_rank_only=True)
 
   def parity_and_cpu():
     from oracle import oracle
