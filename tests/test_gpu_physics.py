@@ -15,7 +15,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "experiments"))
 
 
 def test_roller_schemes_keep_the_equilibrium_height_distribution():

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))   # exp_equilibrium
 from rigidmultiblobswall_amd import structures as st
 from rigidmultiblobswall_amd.rollers import RollersIntegrator
 
