@@ -255,9 +255,11 @@ int rmb_default_ctx_set_device(int device);
  * 233-287 selects it, :445 / :599 call it; mobility/mobility.py:222-252 is the call shape): to give that call the
  * whole node the sharding has to sit behind it.  An engine owns one context per listed device, each with its own
  * stream.  Per product: inputs go to every device (host entry: one pinned staging copy + G uploads; device entry: every
- * shard pulls from devices[0] over xGMI), device g evaluates pair shard g of G (each unordered pair once, both blobs
- * updated) into a full-length partial, then device g sums slice g of the G partials in FIXED order through peer-mapped
- * reads and stores it where the result is wanted -- reduce-scatter + gather in one kernel per device.  With option
+ * shard pulls from devices[0] over xGMI with hipMemcpyPeerAsync), device g evaluates pair shard g of G (each unordered
+ * pair once, both blobs updated) into a full-length partial, then device g sums slice g of the G partials in FIXED order
+ * through peer-mapped reads of the other devices' partials and hands the slice over (peer copy to devices[0] / download).
+ * Caller-owned memory is only ever touched by runtime copies; peer-mapped loads are confined to buffers the engine
+ * allocated after it enabled peer access.  With option
  * "deterministic" = 2 the mobility products are bit-reproducible for a given device list (the forces' pair shards
  * flush with atomics whatever the option says).  No reference counterpart (single
  * device); the contract is "equal to the one-context result to rounding" (<= 1e-13).

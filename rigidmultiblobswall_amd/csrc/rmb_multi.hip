@@ -4,12 +4,12 @@
 // :445 / :599 call it; mobility/mobility.py:222-252 is the call shape), so "use the whole node" has to live behind the
 // same call.  One engine owns G shards; shard g = one rmb_ctx on devices[g] with its own stream.  A product is
 //   1. inputs -> every device (host: one pinned staging copy, then G async uploads; device: each shard pulls the vectors
-//      from devices[0] on its own stream -- a peer-read kernel, or hipMemcpyPeerAsync without peer access),
+//      from devices[0] on its own stream with hipMemcpyPeerAsync -- caller-owned memory is only touched by runtime copies),
 //   2. shard g sweeps pair shard g of G (rmb_matvec_pairshard_device & co.: each unordered pair once, both blobs updated)
 //      into a full-length partial on its device,
-//   3. device g adds slice g of the G partials IN FIXED ORDER (h = 0 .. G-1) through peer-mapped reads and writes the
-//      sum where the result is wanted (devices[0] for the *_device entry points, a pinned host buffer otherwise) --
-//      reduce-scatter and gather in one kernel per device, no intermediate copy.
+//   3. device g adds slice g of the G partials IN FIXED ORDER (h = 0 .. G-1) through peer-mapped reads of the other
+//      devices' partials (memory this engine allocated after enabling peer access) and hands the slice to where the
+//      result is wanted: a peer copy to devices[0] for the *_device entry points, a download to pinned memory otherwise.
 // With "deterministic" = 2 the partials are bit-reproducible and so is the sum.  Option "reduce" = 1 replaces step 3 by a
 // grouped RCCL all-reduce (ncclCommInitAll; librccl is dlopen()ed on first use so the library does not link it).
 // The same device may be listed several times (rehearsal of the G-device code path on one GPU: shards then share the
@@ -60,12 +60,6 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const ReduceArgs a) 
     for (int h = 1; h < a.n_shards; ++h) s += peer_load(&a.part[h][v * a.len + i]);
     peer_store(&a.out[v][i], s);
   }
-}
-
-// dst (local) = src (possibly peer-mapped): how a shard pulls its inputs from devices[0]
-__global__ __launch_bounds__(256) void pull_kernel(double* dst, const double* src, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = peer_load(&src[i]);
 }
 
 struct Shard {
@@ -125,6 +119,8 @@ struct rmb_multi {
   bool done_recorded = false;
   bool peer = true;                 // every pair of distinct devices has peer access enabled
   bool distinct = true;             // no device listed twice (RCCL needs that)
+  bool force_remote = false;        // RMB_MULTI_FORCE_REMOTE=1 (tests): treat every shard but the first as if it sat on another
+                                    // device than devices[0], so a one-GPU rehearsal runs the copies a node runs
   long opt_reduce = 0;              // 0 = fixed-order slice reduction (peer reads / staged copies), 1 = RCCL all-reduce
   long n = 0;
   bool have_positions = false;
@@ -158,6 +154,11 @@ int check_multi(rmb_multi* m, bool need_positions) {
   if (!m) return fail(RMB_ERR_ARG, "null multi-device engine");
   if (need_positions && !m->have_positions) return fail(RMB_ERR_STATE, "rmb_multi_set_positions has not been called");
   return 0;
+}
+
+// does shard g share the memory of devices[0] (the caller's vectors are then used in place)?
+bool local_to_primary(const rmb_multi* m, int g) {
+  return m->sh[g].device == m->sh[0].device && !(m->force_remote && g > 0);
 }
 
 void slice_of(long len, int g, int G, long* lo, long* hi) {
@@ -221,14 +222,14 @@ int shard_sweep(rmb_multi* m, int g, const Job& job) {
   const double* in_local[kMaxVec] = {nullptr, nullptr, nullptr, nullptr};
   if (!job.host) RMB_HIP(hipStreamWaitEvent(s.stream, m->ev_in, 0));
   for (int v = 0; v < p.n_in; ++v) {
-    if (!job.host && s.device == s0.device) { in_local[v] = job.in[v]; continue; }     // same memory: no copy
+    if (!job.host && local_to_primary(m, g)) { in_local[v] = job.in[v]; continue; }     // same memory: no copy
     if (int rc = s.in[v].reserve((size_t)len * sizeof(double))) return rc;
     if (job.host) {
       RMB_HIP(hipMemcpyAsync(s.in[v].p, job.in[v], (size_t)len * sizeof(double), hipMemcpyHostToDevice, s.stream));
-    } else if (m->peer) {
-      hipLaunchKernelGGL(pull_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s.stream, (double*)s.in[v].p, job.in[v], len);
-      RMB_HIP(hipGetLastError());
     } else {
+      // The caller's vectors were allocated by the caller (torch's allocator, say), possibly before this engine enabled
+      // peer access: only the runtime's own copy is safe on them.  Peer-mapped loads are kept for memory the engine
+      // allocated itself after enabling access (the partials, shard_reduce).
       RMB_HIP(hipMemcpyPeerAsync(s.in[v].p, s.device, job.in[v], s0.device, (size_t)len * sizeof(double), s.stream));
     }
     in_local[v] = (const double*)s.in[v].p;
@@ -255,7 +256,9 @@ int shard_reduce(rmb_multi* m, int g, const Job& job) {
   const long cnt = hi - lo;
   ReduceArgs ra;
   ra.n_shards = G; ra.n_out = p.n_out; ra.len = len; ra.lo = lo; ra.hi = hi;
-  const bool direct = !job.host && (m->peer || s.device == m->sh[0].device);   // may this device store into the result?
+  // Only devices[0] itself stores straight into the caller's result (caller-owned memory: see shard_sweep); the other
+  // devices reduce into a buffer of their own and hand the slice over with the runtime's peer copy.
+  const bool direct = !job.host && local_to_primary(m, g);
   for (int h = 0; h < G; ++h) ra.part[h] = (const double*)m->sh[h].part.p;
   if (!m->peer && cnt > 0) {
     // no peer access: bring slice g of every other device's partial here with copies the runtime routes itself
@@ -506,6 +509,8 @@ int rmb_multi_create(const int* devices, int n_dev, rmb_multi** out) {
     // through copies.  RMB_MULTI_NO_PEER=1 forces the staged path (rehearsal of that path on any box).
     const char* np = getenv("RMB_MULTI_NO_PEER");
     if (np && *np && *np != '0') m->peer = false;
+    const char* fr = getenv("RMB_MULTI_FORCE_REMOTE");
+    if (fr && *fr && *fr != '0') m->force_remote = true;
     for (int g = 0; g < n_dev && m->peer; ++g)
       for (int h = 0; h < n_dev && m->peer; ++h) {
         const int a = devices[g], b = devices[h];
@@ -656,14 +661,10 @@ int rmb_multi_set_positions_device(rmb_multi* m, const double* r_dev, long n, do
     // and its stream moves on: the copy below is ordered before that by ev_reduced -> primary)
     if (n > 0) {
       if (int rc = s.r_stage.reserve((size_t)len * sizeof(double))) return rc;
-      if (s.device == s0.device)
+      if (s.device == s0.device && !(m->force_remote && &s != &s0))
         RMB_HIP(hipMemcpyAsync(s.r_stage.p, r_dev, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
-      else if (m->peer) {
-        hipLaunchKernelGGL(pull_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s.stream, (double*)s.r_stage.p, r_dev, len);
-        RMB_HIP(hipGetLastError());
-      } else {
-        RMB_HIP(hipMemcpyPeerAsync(s.r_stage.p, s.device, r_dev, s0.device, (size_t)len * sizeof(double), s.stream));
-      }
+      else
+        RMB_HIP(hipMemcpyPeerAsync(s.r_stage.p, s.device, r_dev, s0.device, (size_t)len * sizeof(double), s.stream));   // caller-owned memory
     }
     if (int rc = rmb_set_positions_device(s.ctx, (const double*)s.r_stage.p, n, a, L, wall)) return rc;
     RMB_HIP(hipEventRecord(s.ev_reduced, s.stream));

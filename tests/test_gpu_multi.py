@@ -219,6 +219,39 @@ def test_staged_path_without_peer_access(monkeypatch, torch_mod):
     multi.close()
 
 
+@pytest.mark.parametrize("no_peer", ["0", "1"])
+def test_remote_shard_paths_on_one_gpu(monkeypatch, torch_mod, no_peer):
+  """RMB_MULTI_FORCE_REMOTE=1 makes every shard but the first behave as if it sat on another device than devices[0]:
+  inputs are pulled with hipMemcpyPeerAsync, slices are reduced into the shard's own buffer and handed to devices[0]
+  with a peer copy -- exactly the calls a node issues (caller-owned memory is never touched by peer-mapped loads)."""
+  torch = torch_mod
+  from rigidmultiblobswall_amd import MobilityContext
+  monkeypatch.setenv("RMB_MULTI_FORCE_REMOTE", "1")
+  monkeypatch.setenv("RMB_MULTI_NO_PEER", no_peer)
+  n = 1700
+  r, f, t, eta, a, _ = _cloud(n, 14)
+  rd, fd, td = (torch.as_tensor(x.reshape(-1), device="cuda:0") for x in (r, f, t))
+  single, multi = MobilityContext(0), _engine(4)
+  try:
+    single.set_positions(rd, a, None, True)
+    multi.set_positions(rd, a, None, True)
+    for kind, v2 in (("tt", None), ("tt_tr", td)):
+      assert rel_err(multi.matvec_device(kind, fd, eta, vec2=v2).cpu().numpy(),
+                     single.matvec_device(kind, fd, eta, vec2=v2).cpu().numpy()) < TOL_VS_SINGLE
+    o1 = single.matvec_op_device("grand", (fd, td), eta)
+    oG = multi.matvec_op_device("grand", (fd, td), eta)
+    for x, y in zip(oG, o1):
+      assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < TOL_VS_SINGLE
+    assert rel_err(multi.matvec("rr", t, eta), single.matvec("rr", t, eta)) < TOL_VS_SINGLE
+    single.set_positions(rd, a, None, False)
+    multi.set_positions(rd, a, None, False)
+    F1 = single.blob_blob_force_device(0.6, 0.2 * a, a).cpu().numpy()
+    assert rel_err(multi.blob_blob_force_device(0.6, 0.2 * a, a).cpu().numpy(), F1) < TOL_VS_SINGLE
+  finally:
+    single.close()
+    multi.close()
+
+
 def test_rccl_reduction_with_one_rank_and_its_argument_checks(torch_mod):
   """"reduce" = 1: librccl is resolved at run time and ncclCommInitAll / grouped ncclAllReduce run -- with the one
   device of this box that is a one-rank communicator; duplicates are refused (one rank per device)."""
