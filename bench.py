@@ -318,12 +318,12 @@ class Guard(object):
   def elapsed(self):
     return time.time() - self.t0
 
-  def publish_headline(self, line):
+  def publish_headline(self, line, full=False):
     self.line = line
     if self.rank == 0:
-      txt = json.dumps({k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline")
-                        if k in line})
-      sys.stderr.write("[bench headline] %s\n" % txt)
+      txt = json.dumps(line if full else {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                              "roofline") if k in line})
+      sys.stderr.write("[bench %s] %s\n" % ("line so far" if full else "headline", txt))
       sys.stderr.flush()
       for path in (os.path.join(self.run_dir, "headline.json"), os.path.join(ROOT, "gpurun_out", "bench_headline_last.json")):
         try:
@@ -628,8 +628,6 @@ def rank_main(args):
       out["note"] = ("one device visible: it is listed twice, so the two shards share the chip and `speedup` < 1 is the engine's "
                      "hand-off overhead; on a node the list is every visible device")
     return out
-  if not args.no_host_surface:
-    stage("multi_device_surface", 160, multi_device_surface, single_rank_only=True)
 
   def parity_and_cpu():
     from oracle import oracle
@@ -862,6 +860,11 @@ def rank_main(args):
   if not args.no_sweep:
     stage("config5_multiblob_brownian", 60, config5_multiblob)
 
+  if not args.no_host_surface and rank == 0 and world == 1:
+    # Last of all: first contact of the one-process engine with real peer devices happens in a child process, after
+    # every other number exists; the line as it stands goes to stderr and to the headline file first.
+    guard.publish_headline(line, full=True)
+    stage("multi_device_surface", 160, multi_device_surface, single_rank_only=True)
   line["wall_s"] = round(guard.elapsed(), 1)
   guard.finish()
   if rank == 0:
