@@ -11,24 +11,33 @@ import time
 
 def main(argv=None):
   ap = argparse.ArgumentParser(prog="python -m rigidmultiblobswall_amd",
-                               description="Run a RigidMultiblobsWall input deck on one MI355X")
+                               description="Run a RigidMultiblobsWall input deck on one MI355X, or on several from one process (--devices)")
   ap.add_argument("--input-file", dest="input_file", type=str, default="data.main", help="name of the input file")
   ap.add_argument("--print-residual", action="store_true", help="print gmres and lanczos residuals")
   ap.add_argument("--device", default="cuda:0")
+  ap.add_argument("--devices", default=None, metavar="0,1,...",
+                  help="run the O(N^2) pair sweeps of the deck on these GPUs from this ONE process (single-process "
+                       "multi-device engine, multi.MultiContext); the O(N) solver / stepper logic stays on the first")
   args = ap.parse_args(argv)
   from .read_input import ReadInput
   read = ReadInput(args.input_file)
   shutil.copyfile(args.input_file, read.output_name + ".inputfile")
   t0 = time.time()
+  ctx = None
+  if args.devices:
+    from .multi import MultiContext
+    devs = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+    ctx = MultiContext(devs)
+    args.device = "cuda:%d" % devs[0]
   if read.scheme in ("mobility", "resistance", "body_mobility"):
     from . import utilities
-    utilities.run(read, device=args.device)
+    utilities.run(read, device=args.device, ctx=ctx)
   else:
     if read.scheme.find("rollers") > -1:
       from . import rollers as engine
     else:
       from . import rigid_integrator as engine
-    integ = engine.integrator_from_input(read, device=args.device, rng=read.random_generator(save=True))
+    integ = engine.integrator_from_input(read, device=args.device, ctx=ctx, rng=read.random_generator(save=True))
     integ.print_residual = args.print_residual
     with open(read.output_name + ".bodies_info", "w") as fh:
       fh.write("num_of_body_types  %d\n" % len(integ.body_types))

@@ -116,9 +116,12 @@ def test_deterministic_step_equals_solve_plus_update():
   integ.close()
 
 
-def test_command_line_runs_a_reference_deck(tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_command_line_runs_a_reference_deck(tmp_path, devices):
   """`python -m rigidmultiblobswall_amd --input-file deck` = the reference's `python multi_bodies.py --input-file deck`:
-  same deck, same output files (.clones per step, .bodies_info, .info with the same iteration totals)."""
+  same deck, same output files (.clones per step, .bodies_info, .info with the same iteration totals).  With
+  `--devices` the pair sweeps run on the single-process multi-device engine (here: this box's GPU listed three times)
+  and the deck reproduces the same reference trajectory."""
   import subprocess
   import sys
   from conftest import ROOT
@@ -126,8 +129,8 @@ def test_command_line_runs_a_reference_deck(tmp_path):
   from rigidmultiblobswall_amd import structures
   g = load_golden([p for p in CASES if p.endswith("g9_rigid_stoch_slip_trapz.npz")][0])
   deck = write_case(g, str(tmp_path))
-  res = subprocess.run([sys.executable, "-m", "rigidmultiblobswall_amd", "--input-file", deck], cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
+  res = subprocess.run([sys.executable, "-m", "rigidmultiblobswall_amd", "--input-file", deck] +
+                       (["--devices", devices] if devices else []), cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
   for ID in [str(x) for x in g["IDs"]]:
     tl = g["trajectory_locations_" + ID]
