@@ -28,8 +28,10 @@ Objects on the line
                 the symmetric kernel evaluates each unordered pair once with 123 flops; it is never `frac`.
                 `issue` = VALU wave-instructions per launch from the same ISA count / kernel time against the fp64
                 issue ceiling measured live in this process (rmb_ubench_fp64_issue).
-                `traffic` (HBM bytes per launch) cannot be measured inside this process: it is the figure of the
-                committed rocprofv3 --pmc passes, tagged with its source, or null.
+                `traffic` (HBM bytes per launch) cannot be measured inside this process: the `traffic_live` stage runs
+                two child passes of this script under rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE) and puts the measured
+                figure on the line (`traffic_provenance.measured_in_this_run` true, the committed figure beside it);
+                without rocprofv3 it stays the figure of the committed passes, tagged with its source.
   value_unprimed  the same W + K steps run first thing, before the declared pre-warm (clock still ramping)
   host_surface  matvecs/s through single_wall_mobility_trans_times_force_hip with numpy in / out (the reference's
                 call shape, PCIe-inclusive) -- reported beside `value`, never `value`
@@ -607,6 +609,55 @@ def rank_main(args):
     return out
   if not args.no_host_surface:
     stage("host_surface", 10, host_surface, single_rank_only=True)
+
+  def traffic_live():
+    # HBM-side traffic of the dominant kernel measured NOW: two child passes of this same script under
+    # `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE, separately, the program directly after `--`, as
+    # MI355X_MICROARCH.md prescribes; gfx950: FETCH_SIZE counts half of the wide coalesced reads -> doubled; KB -> x1024).
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+      return {"error": "rocprofv3 not on PATH"}
+    fam = {3: "sym_coop_kernel<0, true, false>", 1: "sym_kernel<0, true, false>"}.get(res["path"], "sweep_kernel<0, true, false>")
+    out_dir = tempfile.mkdtemp(prefix="rmb_pmc_")
+    got = {}
+    try:
+      for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out_dir, counter)
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--blobs", str(N), "--steps", "20", "--warmup", "2", "--prewarm-ms", "0", "--no-sweep", "--no-cpu", "--no-host-surface"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RMB_BENCH_INJECT"):
+          env.pop(k, None)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd="/tmp", env=env)
+        vals = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+          with open(f) as fh:
+            for row in csv.DictReader(fh):
+              if row.get("Counter_Name") == counter and fam in row.get("Kernel_Name", ""):
+                vals.append(float(row["Counter_Value"]))
+        if p.returncode != 0 or not vals:
+          return {"error": "rocprofv3 --pmc %s pass gave no samples of %s (rc %d): %s" % (counter, fam, p.returncode, p.stderr[-300:])}
+        got[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+      shutil.rmtree(out_dir, ignore_errors=True)
+    live = (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
+    committed = line["roofline"].get("traffic")
+    line["roofline"]["traffic"] = int(round(live))
+    line["roofline"]["traffic_provenance"] = {
+        "measured_in_this_run": True, "kernel": "rmb::" + fam,
+        "method": "two child passes of this script under rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE separately, program directly "
+                  "after `--`): per-launch averages; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md)",
+        "FETCH_SIZE_kb": round(got["FETCH_SIZE"][0], 2), "WRITE_SIZE_kb": round(got["WRITE_SIZE"][0], 2),
+        "launches_sampled": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]],
+        "committed_figure_for_comparison": committed, "committed_source": traffic_src.get("source"),
+        "ratio_to_algorithmic_bytes": round(live / alg_bytes, 1)}
+    return None
+  if not args.no_sweep and not args.no_host_surface:
+    stage("traffic_live", 60, traffic_live, single_rank_only=True)
 
   def multi_device_surface():
     # More than one device visible to a one-rank run (a whole node): the same plugin call on the single-process
