@@ -620,7 +620,9 @@ def rank_main(args):
     import tempfile
     exe = shutil.which("rocprofv3")
     if exe is None:
-      return {"error": "rocprofv3 not on PATH"}
+      return {"skipped": "rocprofv3 not on PATH: roofline.traffic stays the committed figure"}
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+      return {"skipped": "this run is itself being profiled: no nested rocprofv3 passes"}
     fam = {3: "sym_coop_kernel<0, true, false>", 1: "sym_kernel<0, true, false>"}.get(res["path"], "sweep_kernel<0, true, false>")
     out_dir = tempfile.mkdtemp(prefix="rmb_pmc_")
     got = {}
