@@ -271,7 +271,7 @@ int rmb_default_ctx_set_device(int device);
  *     and "threads".
  *   - with several shards every shard has a worker thread that issues its HIP calls (~25 us per shard and product from
  *     one thread otherwise); RMB_MULTI_THREADS=0 keeps everything on the calling thread.  An engine is used from one
- *     thread at a time.
+ *     thread at a time and does not survive fork() (its worker threads do not exist in the child: create it there).
  *   - host entry points are synchronous.  *_device entry points take pointers on devices[0], are ordered after the work
  *     already queued on the engine's primary stream (rmb_multi_set_stream; NULL = default stream of devices[0]) and
  *     order that stream after their own completion; the primary stream must be alive when a call is made, and may be
