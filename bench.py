@@ -354,7 +354,8 @@ class Guard(object):
         fh.write("rank %d failed in stage %r: %s: %s" % (self.rank, stage, type(exc).__name__, exc))
     except OSError:
       os._exit(3)
-    time.sleep(3600)
+    time.sleep(15)      # the watchdogs (this rank's included) end the run within a second; if they are gone, leave anyway
+    os._exit(3)
 
   def _emit(self, reason):
     if self.rank == 0:
@@ -398,9 +399,11 @@ class Guard(object):
   def finish(self):
     """Main thread, normal end: True if it may print (the watchdog has not taken over)."""
     with self._lock:
-      if self._finished:
-        time.sleep(3600)
+      taken_over = self._finished
       self._finished = True
+    if taken_over:          # the watchdog is printing / leaving: do not print a second line
+      time.sleep(15)
+      os._exit(3)
     self._stop.set()
     return True
 
