@@ -2,7 +2,7 @@
 onto the symmetric skeleton against their one-sided sweeps.  Device-resident vectors, HIP-event kernel time summed
 per PRODUCT (a product made of several launches counts all of them), clocks primed first.
 
-  python tools/bench_ops.py [N ...]      -> gpurun_out/r2_ops_table.json
+  python tools/bench_ops.py [N ...]      -> gpurun_out/r2_ops_table.json (RMB_AB_OUT names another file: profiles/r4_ops_table.json)
   RMB_AB_LIB=<other build of librmb_mobility.so> RMB_AB_OUT=<json>   time that build instead (same-box A/B of two
   builds: boxes differ by a few per cent, so a change is only priced against a baseline built from the previous
   commit and timed in the same call)
