@@ -129,6 +129,15 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          staging and flushing its own): 0 = never, 1 = launches of at most four resident rounds of
  *                          workgroups (small suspensions, one rank's pair shard, products up to ~1e4 blobs: faster below
  *                          one round, same time with half the atomic flush traffic up to four), 2 = always
+ *   "sym_order"       [1]  symmetric kernels: order in which the tile pairs are visited: 1 = blocked (super-blocks of 32 x 32
+ *                          tiles, so that neighbouring step ranges re-use the same 64 tiles), 0 = row-major over the tile
+ *                          triangle.  The deterministic symmetric mode always runs row-major
+ *   "sym_xcd"         [1]  symmetric kernels: XCD-aware workgroup numbering -- every XCD (own L2) gets one contiguous eighth
+ *                          of the step range; with "sym_order" = 1 the tile loads of a launch mostly hit L2 (HBM fetch
+ *                          traffic / 10 at >= 1e5 blobs; the kernels are VALU-bound, so time moves little)
+ *   "sym_chunk_steps" [1024]  symmetric kernels: a wave's share of the rotation steps is cut into equal strided chunks of about
+ *                          this many steps (wave w takes chunks w, w + W, w + 2 W, ...), so that the waves running at the same
+ *                          time work on neighbouring tile pairs at any problem size; 0 = one contiguous range per wave
  *   "sym_wps"         [0]  symmetric kernels: cap on resident workgroups per CU (0 = occupancy limit)
  *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
  *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics

@@ -97,6 +97,9 @@ struct rmb_ctx {
   long opt_sym_fine_steps = 0;   // floor on steps per wave when less than one resident round is left (pair shards, small N); 0 = 16 or 32, chosen in plan_sym
   long opt_sym_coop = 1;       // workgroup-cooperative symmetric kernel (sym_coop_kernels.h): 0 = never, 1 = launches of at most
                                // kCoopMaxRounds resident rounds (small suspensions, pair shards, up to ~1e4 blobs), 2 = always
+  long opt_sym_chunk_steps = 1024;  // symmetric kernels: a wave's steps are cut into strided chunks of about this many (0 = one range)
+  long opt_sym_order = 1;      // unit order of the symmetric kernels: 1 = blocked (32 x 32 tile super-blocks), 0 = row-major
+  long opt_sym_xcd = 1;        // XCD-aware workgroup numbering (each XCD a contiguous eighth of the step range)
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;
                                // waves of one SIMD finish oldest-first, more rounds keep every SIMD at >= 3 active waves)
   // timing ring (events around the sweep kernel)
@@ -130,6 +133,9 @@ int plan_sym(rmb_ctx* c, const void* fn, int* occ_cache, size_t static_lds, long
 void shard_ranges(long n, long n_units, long shard, long nshards, long* step_begin, long* step_end, long* self_begin,
                   long* self_end);
 int sym_accumulators(rmb_ctx* c, long n_pad);
+// Steps per strided chunk: `spw` = steps per schedule unit (wave, or workgroup of the cooperative kernels) of a plan over
+// `n_sched` units; cut into R >= 1 equal chunks of about `target` steps (exactly balanced: every unit gets R chunks).
+long chunked_steps(const rmb_ctx* c, long total, long n_sched, long spw, long target);
 // whether the symmetric (each unordered pair once) path applies to the resident configuration
 bool sym_applies(const rmb_ctx* c);
 

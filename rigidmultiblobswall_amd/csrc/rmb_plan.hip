@@ -167,6 +167,13 @@ void shard_ranges(long n, long n_units, long shard, long nshards, long* step_beg
   *self_end = block * (shard + 1) < n ? block * (shard + 1) : n;
 }
 
+long chunked_steps(const rmb_ctx* c, long total, long n_sched, long spw, long target) {
+  if (c->opt_sym_chunk_steps <= 0 || target <= 0 || n_sched < 1) return spw;
+  const long rounds = (spw + target / 2) / target;       // chunks per schedule unit
+  if (rounds < 2) return spw;
+  return (total + n_sched * rounds - 1) / (n_sched * rounds);
+}
+
 // whether the symmetric (each unordered pair once) path applies to the resident configuration
 bool sym_applies(const rmb_ctx* c) {
   return c->opt_symmetric && c->opt_deterministic != 1 && c->tgt_begin == 0 && c->tgt_end == c->n && c->n >= 128;

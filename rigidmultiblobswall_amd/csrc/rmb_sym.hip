@@ -40,6 +40,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   a.n_pad = n_pad;
   a.n_tiles = (int)tiles;
   a.n_units = tiles * (tiles + 1) / 2;
+  a.order = (int)c->opt_sym_order; a.xcd = (int)c->opt_sym_xcd;
   shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
@@ -77,6 +78,8 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   const long blocks = plan.blocks;
   const long total_steps = a.step_end - a.step_begin;
   a.steps_per_wave = coop ? (total_steps + blocks - 1) / blocks : plan.steps_per_wave;    // coop: steps per WORKGROUP
+  a.steps_per_wave = chunked_steps(c, total_steps, coop ? blocks : blocks * rmb::kSymWaves, a.steps_per_wave,
+                                   c->opt_sym_chunk_steps * (coop ? rmb::kSymWaves : 1));
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   c->last_path = coop ? 3 : 1;
   a.skip_pairs = (int)c->opt_skip_pairs;
@@ -114,6 +117,7 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
   a.acc = (double*)c->symbuf.p;
   a.out_a = out_a; a.out_b = out_b;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  a.order = (int)c->opt_sym_order; a.xcd = (int)c->opt_sym_xcd;
   shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
@@ -130,7 +134,7 @@ int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, doub
                         rmb::kSymWavesPerEu))
     return rc;
   const long blocks = plan.blocks;
-  a.steps_per_wave = plan.steps_per_wave;
+  a.steps_per_wave = chunked_steps(c, a.step_end - a.step_begin, blocks * rmb::kSymWaves, plan.steps_per_wave, c->opt_sym_chunk_steps);
   c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
@@ -192,6 +196,7 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
   a.acc = (double*)c->symbuf.p;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  a.order = (int)c->opt_sym_order; a.xcd = (int)c->opt_sym_xcd;
   shard_ranges(n, a.n_units, shard, nshards, &a.step_begin, &a.step_end, &a.self_begin, &a.self_end);
   a.Lx = cf.L[0]; a.Ly = cf.L[1]; a.Lz = cf.L[2];
   a.iLx = cf.L[0] > 0 ? 1.0 / cf.L[0] : 0.0;
@@ -228,6 +233,8 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   }
   const long total_steps = a.step_end - a.step_begin;
   a.steps_per_wave = coop ? (total_steps + plan.blocks - 1) / plan.blocks : plan.steps_per_wave;     // coop: steps per WORKGROUP
+  a.steps_per_wave = chunked_steps(c, total_steps, coop ? plan.blocks : plan.blocks * rmb::kSymWaves, a.steps_per_wave,
+                                   c->opt_sym_chunk_steps * (coop ? rmb::kSymWaves : 1));
   c->last_path = coop ? 3 : 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
@@ -258,6 +265,7 @@ int symx_det_device(rmb_ctx* c, int op, const double* const* in, double* const* 
   for (int v = 0; v < 4; ++v) { a.in[v] = v < se.n_in ? in[v] : nullptr; a.out[v] = v < se.n_out ? out[v] : nullptr; }
   a.acc = (double*)c->symbuf.p;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  a.order = 0; a.xcd = 0;        // the ordered reduction enumerates the units row-major
   long sb_unused, se_unused;
   shard_ranges(n, a.n_units, shard, nshards, &sb_unused, &se_unused, &a.self_begin, &a.self_end);
   const long shard_ub = (long)((__int128)a.n_units * shard / nshards), shard_ue = (long)((__int128)a.n_units * (shard + 1) / nshards);
@@ -325,6 +333,7 @@ int sym_force_device(rmb_ctx* c, double eps, double b, double blob_radius, doubl
   a.acc = (double*)c->symbuf.p;
   a.out = out;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
+  a.order = (int)c->opt_sym_order; a.xcd = (int)c->opt_sym_xcd;
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
   a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
@@ -381,6 +390,12 @@ int sym_force_device(rmb_ctx* c, double eps, double b, double blob_radius, doubl
   if (need < 1) need = 1;
   if (blocks > need) blocks = need;
   c->last_path = 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
+  {
+    const long total_steps = a.step_end - a.step_begin, waves = blocks * rmb::kSymWaves;
+    const long spw = (total_steps + waves - 1) / waves;
+    const long ch = chunked_steps(c, total_steps, waves, spw, c->opt_sym_chunk_steps);
+    a.chunk_steps = ch < spw ? ch : 0;
+  }
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
   if (f32) k32.launch(&a, rmb::PairConsts{}, (unsigned)blocks, 0, c->stream);

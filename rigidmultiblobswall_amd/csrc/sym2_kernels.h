@@ -25,6 +25,7 @@ struct Sym2Args {
   long n, n_pad;
   int n_tiles;
   long n_units;
+  int order, xcd;       // as SymArgs
   long step_begin, step_end, steps_per_wave;
   long self_begin, self_end;
   double Lx, Ly, Lz, iLx, iLy, iLz;
@@ -69,12 +70,18 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
   double* acc_a = a.acc;
   double* acc_b = a.acc + 3 * a.n_pad;
 
-  const long w = (long)blockIdx.x * kSymWaves + wave;
-  long s = a.step_begin + w * a.steps_per_wave;
+  const long w = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x) * kSymWaves + wave;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = w;; chunk += (long)gridDim.x * kSymWaves) {
+  long s = a.step_begin + chunk * a.steps_per_wave;
+  if (s >= a.step_end) break;
   long s_end = s + a.steps_per_wave;
   if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
 
   int I_cur = -1;
   long i = 0;
@@ -188,10 +195,11 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
     }
     __builtin_amdgcn_wave_barrier();
     if (k1 == 64) {
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0 && vi_ok) flush_row();
+  }   // chunks
 }
 
 template <bool WALL>

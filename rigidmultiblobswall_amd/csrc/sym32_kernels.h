@@ -49,12 +49,18 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs 
   double* accj = accj_all[wave];
 
   // the static, exactly balanced schedule of sym_kernel
-  const long w = (long)blockIdx.x * kSymWaves + wave;
-  long s = a.step_begin + w * a.steps_per_wave;
+  const long w = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x) * kSymWaves + wave;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = w;; chunk += (long)gridDim.x * kSymWaves) {
+  long s = a.step_begin + chunk * a.steps_per_wave;
+  if (s >= a.step_end) break;
   long s_end = s + a.steps_per_wave;
   if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
 
   int I_cur = -1;
   long i = 0;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs 
     }
     __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
     if (k1 == 64) {
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0 && vi_ok) {
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym32_tt_kernel(const SymArgs 
     __hip_atomic_fetch_add(&a.acc[a.n_pad + i], (double)ui[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], (double)ui[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  }   // chunks
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -168,14 +175,20 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force32_kernel(const SymFo
   float4* tail = tail_all[wave];
   double* accj = accj_all[wave];
   const long n_waves = (long)gridDim.x * kSymWaves;
-  const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long w = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x) * kSymWaves + wave;
   const long s_total = a.step_end - a.step_begin;
-  const long spw = (s_total + n_waves - 1) / n_waves;
-  long s = a.step_begin + w * spw;
+  const long spw = a.chunk_steps > 0 ? a.chunk_steps : (s_total + n_waves - 1) / n_waves;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = w;; chunk += n_waves) {
+  long s = a.step_begin + chunk * spw;
+  if (s >= a.step_end) break;
   long s_end = s + spw;
   if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
   int I_cur = -1;
   long i = 0;
   bool vi_ok = false;
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force32_kernel(const SymFo
     if (a.bounds != nullptr && I != J && tile_gap2(a.bounds, I, J) > a.cull2) {
       // beyond the range of the float exponential (cull2 = (2a + 110 b)^2 here): the unit contributes exactly zero
       if (k1 == 64) {
-        if (++J == a.n_tiles) { ++I; J = I; }
+        unit_next(a.order, a.n_tiles, I, J);
       }
       continue;
     }
@@ -263,10 +276,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force32_kernel(const SymFo
     }
     __builtin_amdgcn_wave_barrier();
     if (k1 == 64) {
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0) flush_row();
+  }   // chunks
 }
 
 }  // namespace rmb

@@ -34,11 +34,17 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
   const char* rec_bytes = reinterpret_cast<const char*>(rec);
 
   // a.steps_per_wave carries the steps per WORKGROUP here (rmb_sym.hip)
-  long s = a.step_begin + (long)blockIdx.x * a.steps_per_wave;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x);; chunk += (long)gridDim.x) {
+  long s = a.step_begin + chunk * a.steps_per_wave;
+  if (s >= a.step_end) break;
   long s_end = s + a.steps_per_wave;
   if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
   if (wave == 1) { acci[lane] = 0.0; acci[64 + lane] = 0.0; acci[128 + lane] = 0.0; }
 
   int I_cur = -1;
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
       }
     }
     if (k1 == 64) {                    // next unit in row-major order
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0 && wave == 1 && i < a.n) {
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
     __hip_atomic_fetch_add(&a.acc[a.n_pad + i], acci[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], acci[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  }   // chunks
 }
 
 }  // namespace rmb

@@ -40,6 +40,8 @@ struct SymArgs {
   long n_pad;           // 64 * n_tiles
   int n_tiles;
   long n_units;         // n_tiles (n_tiles + 1) / 2
+  int order;            // unit order: 0 row-major, 1 blocked (unit_seek / unit_next); xcd != 0: XCD-aware workgroup numbering
+  int xcd;
   long step_begin, step_end;  // rotation steps [begin, end) of the n_units*64 this launch covers (pair shard)
   long steps_per_wave;        // ceil((step_end - step_begin) / waves): wave w takes [begin + w spw, +spw)
   long self_begin, self_end;  // targets whose self term this launch adds (exactly one shard per target)
@@ -137,6 +139,72 @@ __device__ __forceinline__ void unit_to_tiles(long u, int T, int& I, int& J) {
   J = (int)(u - (i * T - i * (i - 1) / 2) + i);
 }
 
+// ---- unit order and workgroup placement (round 4) ------------------------------------------------------------
+// order 0: row-major over the tile triangle (what the deterministic mode's ordered reduction assumes).
+// order 1: BLOCKED -- the triangle is cut into super-blocks of 32 x 32 tiles; super-blocks in row-major order, and
+//   inside a super-block the units in row-major order (the triangle I <= J inside a diagonal one).  Waves that work on
+//   neighbouring step ranges then touch the same 64 tiles for ~1000 units instead of sweeping a whole row of the
+//   triangle, and with the XCD-aware numbering below those waves sit behind ONE L2: the tile-J loads (3.6 KB per 4096
+//   pairs, all of them L2 misses at >= 1e5 blobs in row-major order) mostly hit.
+constexpr int kOrdShift = 5;
+constexpr int kOrdB = 1 << kOrdShift;
+
+__device__ __forceinline__ long blk_units_before_row(long P, long T) {   // super-rows before P are all kOrdB tall
+  const long B = kOrdB;
+  return P * (B * (B + 1) / 2) + B * (P * T - B * (P * (P + 1) / 2));
+}
+
+__device__ __forceinline__ void unit_seek(int order, long u, int T, int& I, int& J) {
+  if (order == 0) { unit_to_tiles(u, T, I, J); return; }
+  const int SB = (T + kOrdB - 1) >> kOrdShift;
+  int lo = 0, hi = SB - 1;
+  while (lo < hi) {                       // largest super-row whose first unit is <= u
+    const int mid = (lo + hi + 1) >> 1;
+    if (blk_units_before_row(mid, T) <= u) lo = mid; else hi = mid - 1;
+  }
+  const int P = lo;
+  long rem = u - blk_units_before_row(P, T);
+  const int sP = (T - (P << kOrdShift)) < kOrdB ? (T - (P << kOrdShift)) : kOrdB;
+  const long triP = (long)sP * (sP + 1) / 2;
+  if (rem < triP) {                       // diagonal super-block: row-major triangle of sP tiles
+    int li, lj;
+    unit_to_tiles(rem, sP, li, lj);
+    I = (P << kOrdShift) + li; J = (P << kOrdShift) + lj;
+    return;
+  }
+  rem -= triP;
+  const long per = (long)sP * kOrdB;      // every super-block right of the diagonal but the last is kOrdB wide
+  const int q = (int)(rem / per);
+  const int Q = P + 1 + q;
+  const int wQ = (T - (Q << kOrdShift)) < kOrdB ? (T - (Q << kOrdShift)) : kOrdB;
+  const long rem2 = rem - (long)q * per;
+  const int li = (int)(rem2 / wQ);
+  I = (P << kOrdShift) + li;
+  J = (Q << kOrdShift) + (int)(rem2 - (long)li * wQ);
+}
+
+__device__ __forceinline__ void unit_next(int order, int T, int& I, int& J) {
+  if (order == 0) {
+    if (++J == T) { ++I; J = I; }
+    return;
+  }
+  const int P = I >> kOrdShift, Q = J >> kOrdShift;
+  const int row_end = ((P + 1) << kOrdShift) < T ? ((P + 1) << kOrdShift) : T;
+  const int col_end = ((Q + 1) << kOrdShift) < T ? ((Q + 1) << kOrdShift) : T;
+  if (++J < col_end) return;                                     // same row of the same super-block
+  if (++I < row_end) { J = (P == Q) ? I : (Q << kOrdShift); return; }   // next row of the same super-block
+  if (((Q + 1) << kOrdShift) < T) { I = P << kOrdShift; J = (Q + 1) << kOrdShift; return; }   // next super-block of the super-row
+  I = (P + 1) << kOrdShift; J = I;                                // diagonal super-block of the next super-row
+}
+
+// XCD-aware numbering of the workgroups (cdna_hip_programming.md, T1): blocks are dealt round-robin over the 8 XCDs,
+// so blocks b and b + 8 share an L2; this bijection gives every XCD one CONTIGUOUS eighth of the numbering, i.e. of the
+// step range.  A speed choice only: any placement is correct.
+__device__ __forceinline__ long xcd_swizzle(long bid, long nwg) {
+  const long q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 template <int KIND, bool WALL, bool PERIODIC>
 __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(kSymWavesPerEu, kSymWavesPerEu))) void sym_kernel(const SymArgs a) {
   __shared__ double2 rec_all[kSymWaves][64 * 3];
@@ -149,14 +217,20 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
 
   // Static, exactly balanced schedule: the n_units * 64 rotation steps are cut into gridDim.x * 4 equal
   // contiguous ranges, one per wave; a range may begin and end inside a unit.
-  const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long w = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x) * kSymWaves + wave;
   const long long t_start = a.wave_clock ? wall_clock64() : 0;
-  long s = a.step_begin + w * a.steps_per_wave;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = w;; chunk += (long)gridDim.x * kSymWaves) {
+  long s = a.step_begin + chunk * a.steps_per_wave;
+  if (s >= a.step_end) break;
   long s_end = s + a.steps_per_wave;
   if (s_end > a.step_end) s_end = a.step_end;
   // decode the first unit once (row-major upper triangle); later units follow by increment
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
 
   int I_cur = -1;
   long i = 0;
@@ -271,7 +345,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
     }
     __builtin_amdgcn_wave_barrier();   // accj / rec are rewritten by the next unit
     if (k1 == 64) {                    // next unit in row-major order
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0 && vi_ok) {
@@ -279,6 +353,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
     __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ui.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], ui.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  }   // chunks
   if (a.wave_clock && lane == 0) {   // stamps go to a buffer nothing else reads
     // placement: HW_ID (reg 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID (reg 20) in the top 24 bits
     const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
@@ -320,6 +395,8 @@ struct SymForceArgs {
   long n, n_pad;
   int n_tiles;
   long n_units;
+  int order, xcd;       // as SymArgs
+  long chunk_steps;     // > 0: steps per strided chunk of a wave; 0: one contiguous range per wave
   double Lx, Ly, Lz, iLx, iLy, iLz;
   double eps_over_b, inv_b, two_a;
   ExpConsts ec;
@@ -416,14 +493,20 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
   double4* rec = rec_all[wave];
   double* accj = accj_all[wave];
   const long n_waves = (long)gridDim.x * kSymWaves;
-  const long w = (long)blockIdx.x * kSymWaves + wave;
+  const long w = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x) * kSymWaves + wave;
   const long s_total = a.step_end - a.step_begin;
-  const long spw = (s_total + n_waves - 1) / n_waves;
-  long s = a.step_begin + w * spw;
+  const long spw = a.chunk_steps > 0 ? a.chunk_steps : (s_total + n_waves - 1) / n_waves;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = w;; chunk += n_waves) {
+  long s = a.step_begin + chunk * spw;
+  if (s >= a.step_end) break;
   long s_end = s + spw;
   if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
   int I_cur = -1;
   long i = 0;
   bool vi_ok = false;
@@ -438,7 +521,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
         tile_gap2(a.bounds, I, J, PERIODIC ? a.Lx : 0.0, PERIODIC ? a.Ly : 0.0, PERIODIC ? a.Lz : 0.0) > a.cull2) {
       // every pair of this unit is beyond the range of the exponential: contributes exactly zero
       if (k1 == 64) {
-        if (++J == a.n_tiles) { ++I; J = I; }
+        unit_next(a.order, a.n_tiles, I, J);
       }
       continue;
     }
@@ -495,7 +578,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
     }
     __builtin_amdgcn_wave_barrier();
     if (k1 == 64) {
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0 && vi_ok) {
@@ -503,6 +586,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void sym_force_kernel(const SymForc
     __hip_atomic_fetch_add(&a.acc[a.n_pad + i], ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&a.acc[2 * a.n_pad + i], az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  }   // chunks
 }
 
 static __global__ __launch_bounds__(256) void sym_force_finalize_kernel(const SymForceArgs a) {

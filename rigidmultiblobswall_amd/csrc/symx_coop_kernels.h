@@ -29,11 +29,17 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_coop_kernel(const SymXArg
   const char* rec_bytes = reinterpret_cast<const char*>(rec);
 
   // a.steps_per_wave carries the steps per WORKGROUP here (rmb_sym.hip)
-  long s = a.step_begin + (long)blockIdx.x * a.steps_per_wave;
+  // strided chunks: wave / workgroup `id` takes the step ranges id, id + n, id + 2 n, ... of `spw` steps each (one range when
+  // the launch is planned that way: n spw >= the steps of the launch).  Waves that run at the same time then work on
+  // NEIGHBOURING ranges whatever the size of the problem -- with the blocked unit order and the XCD-aware numbering
+  // that keeps a launch's tile loads in one L2 (profiles/r4_unit_order.txt).
+  for (long chunk = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x);; chunk += (long)gridDim.x) {
+  long s = a.step_begin + chunk * a.steps_per_wave;
+  if (s >= a.step_end) break;
   long s_end = s + a.steps_per_wave;
   if (s_end > a.step_end) s_end = a.step_end;
   int I = 0, J = 0;
-  if (s < s_end) unit_to_tiles(s >> 6, a.n_tiles, I, J);
+  if (s < s_end) unit_seek(a.order, s >> 6, a.n_tiles, I, J);
   if (wave == 1) {
 #pragma unroll
     for (int c = 0; c < 3 * NO; ++c) acci[c * 64 + lane] = 0.0;
@@ -160,10 +166,11 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_coop_kernel(const SymXArg
       }
     }
     if (k1 == 64) {
-      if (++J == a.n_tiles) { ++I; J = I; }
+      unit_next(a.order, a.n_tiles, I, J);
     }
   }
   if (I_cur >= 0 && wave == 1) flush_row();
+  }   // chunks
 }
 
 }  // namespace rmb
