@@ -37,6 +37,8 @@ Objects on the line
                 call shape, PCIe-inclusive) -- reported beside `value`, never `value`
                 `devices` = what the call ran on (mobility.set_devices / RMB_DEVICES), `breakdown_us` = where one call's
                 time goes (position compare, upload, enqueue, sweep by HIP events, download + sync, Python)
+  rccl_one_rank  one-rank run: the N > 1 step's fp64 all-reduce through RCCL in a one-rank group, step timed with and
+                without it (child process, tools/rccl_one_rank_probe.py)
   multi_device_surface  one-rank run with several devices visible: the same call on the single-process multi-device
                 engine over all of them (child process with a timeout, tools/multi_surface_probe.py)
   cpu_baseline  the CPU oracle's -O3 -ffast-math OpenMP build timed on this host (rank 0, N = 1 only); `by_size`: every
@@ -685,6 +687,16 @@ def rank_main(args):
                      "hand-off overhead; on a node the list is every visible device")
     return out
 
+  def rccl_one_rank():
+    # RCCL cannot meet a second rank on a one-GPU box, but the N > 1 step's all-reduce can RUN there: a one-rank "nccl"
+    # group in a CHILD process (this one holds no process group at N = 1) times the step with and without it.
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank_probe.py"), str(N)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=110)
+    rows = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    if p.returncode != 0 or not rows:
+      return {"error": "probe exited with %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])}
+    return json.loads(rows[-1])
+
   def parity_and_cpu():
     from oracle import oracle
     r, f, eta, a = res["r"], res["f"], res["eta"], res["a"]
@@ -921,6 +933,7 @@ def rank_main(args):
     # every other number exists; the line as it stands goes to stderr and to the headline file first.
     guard.publish_headline(line, full=True)
     stage("multi_device_surface", 160, multi_device_surface, single_rank_only=True)
+    stage("rccl_one_rank", 120, rccl_one_rank, single_rank_only=True)
   line["wall_s"] = round(guard.elapsed(), 1)
   guard.finish()
   if rank == 0:

@@ -37,6 +37,8 @@ class MobilityContext(object):
     self._keepalive = None
     self._stream_handle = None  # hipStream_t the C context currently enqueues on
     self._user_stream = False   # True once set_stream() pinned a caller-owned stream
+    self._options_set = {}      # every option set through this wrapper (launch_signature)
+    self._geometry = None       # (n, a, L, wall) of the bound configuration
 
   def close(self):
     if getattr(self, "_h", None) is not None and self._h.value:
@@ -79,6 +81,14 @@ class MobilityContext(object):
 
   def set_option(self, key, value):
     _lib.check(self._lib.rmb_ctx_set_option(self._h, key.encode(), int(value)))
+    self._options_set[key] = int(value)
+
+  def launch_signature(self):
+    """Everything that decides WHICH launches a product of this context turns into, as far as this wrapper knows: the
+    number of blobs, radius, box and wall of the bound configuration and every option set through set_option().  A
+    captured hipGraph of device-path calls stays valid while this is unchanged (positions may move: the packed
+    coordinates are rewritten in place) -- rigid.py keys its captured Arnoldi iterations on it."""
+    return (self._geometry, tuple(self.target_range), tuple(sorted(self._options_set.items())))
 
   def get_option(self, key):
     v = ctypes.c_long()
@@ -102,6 +112,7 @@ class MobilityContext(object):
     self.n = n
     self.n_targets = n
     self.target_range = (0, n)
+    self._geometry = (int(n), float(a), tuple(float(x) for x in L), bool(wall))
 
   def set_target_range(self, begin, end):
     _lib.check(self._lib.rmb_set_target_range(self._h, int(begin), int(end)))

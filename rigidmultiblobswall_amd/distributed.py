@@ -78,11 +78,14 @@ class ShardedMobility(object):
   """M.v over the ranks of a process group: unordered pairs sharded + all-reduce (replicated API) or targets sharded +
   all-gather (block-distributed API); see the module docstring."""
 
-  def __init__(self, backend, group=None, device=None):
+  def __init__(self, backend, group=None, device=None, always_exchange=False):
+    """always_exchange: issue the collectives of the multi-rank path in a one-rank group too (they are skipped there by
+    default).  A one-GPU box can then run the all-reduce / all-gather / broadcast through RCCL exactly as a node does."""
     self.backend = backend
     self.group = group
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.exchange = self.world > 1 or (bool(always_exchange) and dist.is_initialized())
     self.device = torch.device(device) if device is not None else torch.device("cpu")
     self.n = 0
     self.begin = self.end = self.block = 0
@@ -94,7 +97,7 @@ class ShardedMobility(object):
   def _all_gather_blocks(self, local_flat, buf):
     """local_flat: (3*n_local,) -> view (3*n,) of the gathered, block-padded buffer."""
     width = 3 * self.block
-    if self.world == 1:  # nothing to exchange: the local block IS the full vector
+    if not self.exchange:  # nothing to exchange: the local block IS the full vector
       return local_flat, buf
     if buf is None or buf.numel() != width * self.world:
       buf = torch.empty(width * self.world, dtype=torch.float64, device=self.device)
@@ -164,14 +167,14 @@ class ShardedMobility(object):
     if (vec2_full is None and not in_plane and hasattr(self.backend, "supports_pairshard")
         and self.backend.supports_pairshard(kind, periodic)):
       part = self.backend.matvec_pairshard(kind, v, eta, self.rank, self.world, out=out)
-      if self.world > 1:
+      if self.exchange:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
     if (vec2_full is None and in_plane and kind in ("tt", "tr") and hasattr(self.backend, "matvec_op_pairshard")):
       # in-plane products are a row / column mask of the symmetric matrix: pair shard of the one-vector operation
       part = out if out is not None else torch.empty(3 * self.n, dtype=torch.float64, device=self.device)
       self.backend.matvec_op_pairshard(kind + "_multi", (v,), eta, self.rank, self.world, in_plane=True, outs=[part])
-      if self.world > 1:
+      if self.exchange:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
     v2 = self._to_dev(vec2_full) if vec2_full is not None else None
@@ -180,10 +183,10 @@ class ShardedMobility(object):
       part = out if out is not None else torch.empty(3 * self.n, dtype=torch.float64, device=self.device)
       self.backend.matvec_op_pairshard("velocity_from_force_torque", (v, v2), eta, self.rank, self.world, in_plane=in_plane,
                                        outs=[part])
-      if self.world > 1:
+      if self.exchange:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
-    if (kind == "tt_tr" and v2 is not None and not in_plane and self.world > 1
+    if (kind == "tt_tr" and v2 is not None and not in_plane and self.exchange
         and hasattr(self.backend, "supports_pairshard") and self.backend.supports_pairshard("tt", periodic)
         and self.backend.supports_pairshard("tr", periodic)):
       # fused M_tt f + M_tr tau: two pair-sharded symmetric passes, ONE all-reduce of the summed partials
@@ -193,7 +196,7 @@ class ShardedMobility(object):
       return part
     u_local = self.backend.matvec(kind, v, eta, vec2_full=v2, in_plane=in_plane)
     u_full, _ = self._all_gather_blocks(u_local.view(-1), None)
-    return u_full if self.world == 1 else u_full.clone()
+    return u_full if not self.exchange else u_full.clone()
 
   def blob_blob_force_local(self, eps, b, a):
     return self.backend.blob_blob_force(eps, b, a)
@@ -216,7 +219,7 @@ class ShardedMobility(object):
     if hasattr(self.backend, "matvec2_pairshard") and self.backend.supports_pairshard(kind, bool(self._periodic)):
       both = torch.empty((2, va.numel()), dtype=torch.float64, device=self.device)
       self.backend.matvec2_pairshard(kind, va, vb, eta, self.rank, self.world, out_a=both[0], out_b=both[1])
-      if self.world > 1:
+      if self.exchange:
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
       return both[0], both[1]
     return self.matvec_replicated(kind, va, eta), self.matvec_replicated(kind, vb, eta)
@@ -232,7 +235,7 @@ class ShardedMobility(object):
       stacked = torch.empty((n_out, 3 * self.n), dtype=torch.float64, device=self.device)
       self.backend.matvec_op_pairshard(op, vecs, eta, self.rank, self.world, in_plane=in_plane,
                                        outs=[stacked[c] for c in range(n_out)])
-      if self.world > 1:
+      if self.exchange:
         dist.all_reduce(stacked, op=dist.ReduceOp.SUM, group=self.group)
       return tuple(stacked[c] for c in range(n_out))
     mv = lambda kind, v, v2=None: self.matvec_replicated(kind, v, eta, vec2_full=v2, in_plane=in_plane)
@@ -256,12 +259,12 @@ class ShardedMobility(object):
     deterministic = bool(ctx.get_option("deterministic")) if ctx is not None and hasattr(ctx, "get_option") else False
     if hasattr(self.backend, "blob_blob_force_pairshard") and not deterministic:
       part = self.backend.blob_blob_force_pairshard(eps, b, a, self.rank, self.world)
-      if self.world > 1:
+      if self.exchange:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
       return part
     f_local = self.backend.blob_blob_force(eps, b, a)
     f_full, _ = self._all_gather_blocks(f_local.view(-1), None)
-    return f_full if self.world == 1 else f_full.clone()
+    return f_full if not self.exchange else f_full.clone()
 
 
 class ReplicatedContext(object):
@@ -299,7 +302,7 @@ class ReplicatedContext(object):
     on.  The replicated Krylov loops branch on such scalars; identical hardware and identical inputs already give
     identical values, this broadcast (a few bytes per iteration) turns that into a guarantee, so no rank can leave a
     loop one iteration early and strand the others in a collective."""
-    if self.sm.world > 1:
+    if self.sm.exchange:
       dist.broadcast(t, src=dist.get_global_rank(self.sm.group, 0) if self.sm.group is not None else 0, group=self.sm.group)
     return t
 

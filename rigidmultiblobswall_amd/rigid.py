@@ -19,6 +19,8 @@ with numpy + scipy on the host, here with every vector resident in HBM:
 
 PyTorch is used for device memory and batched small dense algebra only.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -170,12 +172,15 @@ class RigidSuspension(object):
     r, rels = self.blob_positions_device(self.location, self.orientation)
     for g, rel in zip(self.groups, rels):
       g.rel = rel
-      K = torch.zeros((rel.shape[0], g.n_b, 3, 6), dtype=torch.float64, device=self.device)
-      K[:, :, 0, 0] = 1.0; K[:, :, 1, 1] = 1.0; K[:, :, 2, 2] = 1.0
+      # K keeps its storage from one configuration to the next (captured Arnoldi iterations refer to it, _ArnoldiGraphs)
+      if g.K is None:
+        g.K = torch.zeros((rel.shape[0], 3 * g.n_b, 6), dtype=torch.float64, device=self.device)
+        K = g.K.view(rel.shape[0], g.n_b, 3, 6)
+        K[:, :, 0, 0] = 1.0; K[:, :, 1, 1] = 1.0; K[:, :, 2, 2] = 1.0
+      K = g.K.view(rel.shape[0], g.n_b, 3, 6)
       K[:, :, 0, 4] = rel[:, :, 2];  K[:, :, 0, 5] = -rel[:, :, 1]
       K[:, :, 1, 3] = -rel[:, :, 2]; K[:, :, 1, 5] = rel[:, :, 0]
       K[:, :, 2, 3] = rel[:, :, 1];  K[:, :, 2, 4] = -rel[:, :, 0]
-      g.K = K.reshape(rel.shape[0], 3 * g.n_b, 6)
     self.r_dev = r.reshape(-1)
     self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
 
@@ -334,23 +339,33 @@ class RigidSuspension(object):
       # the Krylov loop were observed to race on ROCm 7.0 torch; bmm does not.)
       g.Minv = torch.cholesky_inverse(g.Lchol)
       g.Minv = 0.5 * (g.Minv + g.Minv.transpose(1, 2))
-      g.K_pc = g.K
+      if g.K_pc is not None and g.K_pc.shape == g.K.shape:     # the K of the configuration the preconditioner was built at
+        g.K_pc.copy_(g.K)
+      else:
+        g.K_pc = g.K.clone()
       g.Linv = None
       g.Nbody = _body_mobility_from_resistance(torch.bmm(g.K.transpose(1, 2), torch.bmm(g.Minv, g.K)))
       # The preconditioner is linear in (slip, F): [lambda; U] = [[A11, A12], [A21, A22]] [slip; F] with
       #   A12 = -M^-1 K N,  A11 = M^-1 + A12 K^T M^-1,  A21 = A12^T,  A22 = -N      (multi_bodies.py:548-560 expanded),
       # so applying it is four batched GEMMs.  Prescribed bodies (:561-571): lambda = M^-1 slip, slot = K^T M^-1 slip.
       MinvK = torch.bmm(g.Minv, g.K)
-      g.A12 = -torch.bmm(MinvK, g.Nbody)
-      g.A11 = g.Minv + torch.bmm(g.A12, MinvK.transpose(1, 2))
-      g.A21 = g.A12.transpose(1, 2).contiguous()
-      g.A22 = -g.Nbody
+      A12 = -torch.bmm(MinvK, g.Nbody)
+      A11 = g.Minv + torch.bmm(A12, MinvK.transpose(1, 2))
+      A21 = A12.transpose(1, 2)
+      A22 = -g.Nbody
       if self.free is not None:
         fr = self._bodies_of(self.free, g).unsqueeze(-1)
-        g.A11 = fr * g.A11 + (1.0 - fr) * g.Minv
-        g.A12 = fr * g.A12
-        g.A21 = fr * g.A21 + (1.0 - fr) * MinvK.transpose(1, 2)
-        g.A22 = fr * g.A22
+        A11 = fr * A11 + (1.0 - fr) * g.Minv
+        A12 = fr * A12
+        A21 = fr * A21 + (1.0 - fr) * MinvK.transpose(1, 2)
+        A22 = fr * A22
+      # the four blocks keep their storage from one build to the next (captured Arnoldi iterations refer to them)
+      for name, new in (("A11", A11), ("A12", A12), ("A21", A21), ("A22", A22)):
+        old = getattr(g, name)
+        if old is not None and old.shape == new.shape:
+          old.copy_(new)
+        else:
+          setattr(g, name, new.contiguous())
     if self.device.type == "cuda":
       torch.cuda.synchronize(self.device)
     return self
@@ -390,11 +405,58 @@ class RigidSuspension(object):
     nrm = float(torch.linalg.norm(rhs))
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
-    sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
-                                           restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
-                                           sync=getattr(self.ctx, "sync_scalars", None), lag=getattr(self, "gmres_lag", None))
+    ws = self._arnoldi_graphs(restart)
+    if ws is None:
+      sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
+                                             restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
+                                             sync=getattr(self.ctx, "sync_scalars", None), lag=getattr(self, "gmres_lag", None))
+      info["rhs_norm"] = nrm
+      return sol * nrm, info
+    # Small systems: the device side of every Arnoldi iteration (preconditioner, operator, Gram-Schmidt, normalisation,
+    # column to page-locked memory: ~16 launches) is one captured hipGraph per iteration index, replayed from the third
+    # solve on.  The whole solve runs on the workspace's stream (a capture cannot happen on the default stream, and the
+    # context must already enqueue on the capturing stream when a capture begins).
+    cur = torch.cuda.current_stream(self.device)
+    ws.stream.wait_stream(cur)
+    with torch.cuda.stream(ws.stream):
+      self.ctx._follow_torch_stream()
+      ws.begin_solve()
+      sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
+                                             restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
+                                             ws=ws, on_replay=self._count_operator)
+      sol = sol * nrm
+    cur.wait_stream(ws.stream)
+    sol.record_stream(cur)
     info["rhs_norm"] = nrm
-    return sol * nrm, info
+    info["graph_replays"] = ws.replays_this_solve
+    return sol, info
+
+  def _count_operator(self):
+    self.matvec_count += 1
+    self.sweep_count += 1
+
+  # `gmres_graph`: None = automatic (on for a plain single-GPU context up to `gmres_graph_max_blobs` blobs, where the
+  # iteration is launch-bound: profiles/r4_gmres_graph.txt), True / False = forced.  RMB_GMRES_GRAPH=0 turns it off.
+  gmres_graph = None
+  gmres_graph_max_blobs = 6144
+
+  def _arnoldi_graphs(self, restart):
+    """The captured-iteration workspace for solve(), or None when the plain loop is to run."""
+    want = self.gmres_graph
+    if os.environ.get("RMB_GMRES_GRAPH", "") == "0":
+      want = False
+    if want is None:
+      want = self.n_blobs <= self.gmres_graph_max_blobs
+    if (not want or self.device.type != "cuda" or type(self.ctx) is not MobilityContext
+        or getattr(self, "gmres_lag", None) is False or self.ctx.get_option("timing") != 0):
+      return None
+    ws = getattr(self, "_arnoldi_ws", None)
+    if ws is None or ws.m != restart:
+      ws = self._arnoldi_ws = _ArnoldiGraphs(self.size, restart, self.device)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    ws.bind((self.ctx.launch_signature(), self.eta, ptr(self.free), ptr(self.prescribed_velocity),
+             tuple(tuple(ptr(t) for t in (g.K, g.A11, g.A12, g.A21, g.A22)) for g in self.groups)))
+    return ws
 
   def solve_mixed_precision(self, rhs, tol=1e-8, inner_tol=3e-5, restart=60, maxiter=1000, max_outer=8):
     """The same saddle-point solve by iterative refinement with a single-precision inner operator -- MI355X issues
@@ -615,6 +677,61 @@ class RigidSuspension(object):
 _pinned_pool = []
 
 
+class _ArnoldiGraphs(object):
+  """Static workspace of GMRES(restart) on one system size and, per iteration index j, a captured hipGraph of everything
+  the DEVICE does in that iteration.  On systems of a few thousand blobs an iteration is ~16 small launches whose
+  enqueueing costs more host time than they take to run (tools/experiments/exp_small_deck_gmres.py: ~200 us per
+  iteration around a 10-20 us blob product); replaying a graph is one call.
+
+  An index j runs eagerly the first time it is met, is captured once `capture_after` solves have been seen, and is
+  replayed from then on.  The graphs hold pointers: to this workspace, to the operator's K and preconditioner blocks
+  (rewritten in place by set_configuration / build_preconditioner), to the context's packed positions and accumulators.
+  bind() drops them whenever the signature the owner hands over changes."""
+  capture_after = 2
+
+  def __init__(self, n, restart, device):
+    self.n, self.m, self.device = int(n), int(restart), device
+    self.V = torch.zeros((self.m + 1, self.n), dtype=torch.float64, device=device)
+    self.cols = torch.zeros((self.m, self.m + 2), dtype=torch.float64, device=device)
+    self.host_cols = torch.zeros((self.m, self.m + 2), dtype=torch.float64).pin_memory()
+    self.stream = torch.cuda.Stream(device)
+    self.graphs, self.seen, self.signature = {}, set(), None
+    self.solves = self.captures = self.replays = self.replays_this_solve = 0
+
+  def bind(self, signature):
+    if signature != self.signature:
+      self.graphs.clear()
+      self.seen.clear()
+      self.signature = signature
+      self.solves = 0
+
+  def begin_solve(self):
+    self.solves += 1
+    self.replays_this_solve = 0
+
+  def run(self, j, body, on_replay=None):
+    g = self.graphs.get(j)
+    if g is None:
+      if j not in self.seen or self.solves <= self.capture_after:
+        body()                                   # eager: also warms every library call of this iteration's shapes
+        self.seen.add(j)
+        return
+      g = torch.cuda.CUDAGraph()
+      torch.cuda.synchronize(self.device)
+      g.capture_begin(capture_error_mode="thread_local")
+      try:
+        body()                                   # enqueues nothing: recorded into the graph (the owner counts it)
+      finally:
+        g.capture_end()
+      self.graphs[j] = g
+      self.captures += 1
+    elif on_replay is not None:
+      on_replay()
+    g.replay()
+    self.replays += 1
+    self.replays_this_solve += 1
+
+
 def _pinned_columns(rows, cols):
   for k, t in enumerate(_pinned_pool):
     if t.shape[0] >= rows and t.shape[1] >= cols:
@@ -622,7 +739,7 @@ def _pinned_columns(rows, cols):
   return torch.empty((max(rows, 62), max(cols, 63)), dtype=torch.float64).pin_memory()
 
 
-def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
+def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=None, on_replay=None):
   """GMRES(restart) on A.Minv written as a coroutine: it YIELDS every vector it needs the operator applied to and
   receives A(vector) back, so one driver can serve a single solve (gmres_right_preconditioned) or advance two solves
   in lockstep and hand both requests to a two-vector operator (gmres_pair_right_preconditioned).  Returns (x, info).
@@ -638,6 +755,9 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
   n = b.numel()
   if lag is None:
     lag = dev.type == "cuda"
+  if ws is not None:        # captured iterations (_ArnoldiGraphs): static buffers, the operator applied inside the step
+    assert A is not None and sync is None and dev.type == "cuda" and ws.n == n and ws.m == restart
+    lag = True
 
   def host_norm(v):
     t = torch.linalg.vector_norm(v).reshape(1)
@@ -657,13 +777,16 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
   res = beta / bnorm if bnorm > 0 else 0.0
   history = []
   wasted = 0
-  host_cols = _pinned_columns(restart + 1, restart + 2) if lag else None
+  host_cols = ws.host_cols if ws is not None else (_pinned_columns(restart + 1, restart + 2) if lag else None)
   events = [torch.cuda.Event(), torch.cuda.Event()] if lag else None
   try:
     while its < maxiter and res > tol:
       m = min(restart, maxiter - its)
-      V = torch.empty((m + 1, n), dtype=torch.float64, device=dev)
-      cols = torch.empty((m, m + 2), dtype=torch.float64, device=dev)      # row j = column j of H, then |w_j|
+      if ws is not None:
+        V, cols = ws.V, ws.cols
+      else:
+        V = torch.empty((m + 1, n), dtype=torch.float64, device=dev)
+        cols = torch.empty((m, m + 2), dtype=torch.float64, device=dev)    # row j = column j of H, then |w_j|
       V[0] = r / beta
       H = np.zeros((m + 1, m))
       cs, sn = np.zeros(m), np.zeros(m)
@@ -704,13 +827,8 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
         rate = min(1.0, res / prev_res) if prev_res else 1.0
         return res * rate > 20.0 * tol
 
-      pending, stop, last_norm = None, False, [0.0]
-      for j in range(m):
-        if pending is not None and not may_defer():
-          stop, pending = finish(pending), None
-          if stop:
-            break
-        w = yield Minv(V[j])
+      def orthogonalise(j, w):
+        """Two passes of classical Gram-Schmidt against V[0..j]; the new Hessenberg column and |w| go to cols[j]."""
         Vj = V[:j + 1]
         h = Vj @ w
         w = torch.addmv(w, Vj.t(), h, alpha=-1.0)
@@ -718,11 +836,28 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
         w = torch.addmv(w, Vj.t(), h2, alpha=-1.0)
         torch.add(h, h2, out=cols[j, :j + 1])
         torch.linalg.vector_norm(w, out=cols[j, j + 1])
-        if sync is not None:                                         # multi-rank: all ranks act on rank 0's numbers
-          sync(cols[j, :j + 2])
+        return w
+
+      pending, stop, last_norm = None, False, [0.0]
+      for j in range(m):
+        if pending is not None and not may_defer():
+          stop, pending = finish(pending), None
+          if stop:
+            break
+        if ws is not None:
+          def device_side(j=j):
+            w = orthogonalise(j, A(Minv(V[j])))
+            torch.div(w, cols[j, j + 1], out=V[j + 1])
+            host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
+          ws.run(j, device_side, on_replay)
+        else:
+          w = orthogonalise(j, (yield Minv(V[j])))
+          if sync is not None:                                       # multi-rank: all ranks act on rank 0's numbers
+            sync(cols[j, :j + 2])
         if lag:
-          torch.div(w, cols[j, j + 1], out=V[j + 1])                 # normalised on the device: no host value needed
-          host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
+          if ws is None:
+            torch.div(w, cols[j, j + 1], out=V[j + 1])               # normalised on the device: no host value needed
+            host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
           # fence on the stream the copy was enqueued on: the current stream of the VECTORS' device, which need not
           # be the process's current device (a suspension built on cuda:1 while cuda:0 is current)
           events[j & 1].record(torch.cuda.current_stream(dev))
@@ -747,7 +882,7 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
         beta = host_norm(r)
         res = beta / bnorm
   finally:
-    if host_cols is not None:
+    if host_cols is not None and ws is None:
       _pinned_pool.append(host_cols)
   x = Minv(y)
   if x0 is not None:
@@ -755,7 +890,8 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None):
   return x, dict(iterations=its, residual=res, converged=bool(res <= tol), history=history, discarded_sweeps=wasted)
 
 
-def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None, lag=None):
+def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None, lag=None, ws=None,
+                               on_replay=None):
   """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
   Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after `maxiter` INNER iterations in total -- not restart
   cycles: scipy (and the reference's call, maxiter=1000 with restart=60) counts cycles, i.e. up to 60 000 inner
@@ -765,7 +901,7 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
   iteration behind the device (`lag`, see _gmres_steps; None = on for CUDA tensors).
   x0: optional initial guess (the roller torque solve warm-starts from the previous step,
   quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
-  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag)
+  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag, ws=ws, A=A if ws is not None else None, on_replay=on_replay)
   try:
     request = next(steps)
     while True:

@@ -24,11 +24,18 @@ def rel(a, b):
 
 
 def main():
-  dist.init_process_group("gloo")
-  rank, world = dist.get_rank(), dist.get_world_size()
+  # RMB_DIST_BACKEND=nccl with ONE rank: the same collectives go through RCCL (always_exchange: a one-rank group skips
+  # them by default); several ranks on one device need gloo
+  backend = os.environ.get("RMB_DIST_BACKEND", "gloo")
   dev = torch.device("cuda:0")
   torch.cuda.set_device(dev)
-  sm = ShardedMobility(HipBackend(dev), device=dev)
+  if backend == "nccl":
+    dist.init_process_group("nccl", device_id=dev)
+  else:
+    dist.init_process_group(backend)
+  rank, world = dist.get_rank(), dist.get_world_size()
+  sm = ShardedMobility(HipBackend(dev), device=dev, always_exchange=backend == "nccl")
+  assert sm.exchange
   rc = ReplicatedContext(sm)
   single = MobilityContext(0)
   rng = np.random.RandomState(5)           # same numbers on every rank
@@ -101,7 +108,7 @@ def main():
   torch.cuda.synchronize()
   dist.barrier()
   if rank == 0:
-    print("gpu dist worker: %d checks on %d ranks ok" % (checked, world), flush=True)
+    print("gpu dist worker: %d checks on %d ranks ok (%s)" % (checked, world, dist.get_backend()), flush=True)
   single.close()
   dist.destroy_process_group()
 

@@ -44,6 +44,19 @@ def test_ranks_sharing_one_gpu_match_single_context(world):
   assert "checks on %d ranks ok" % world in outs[0]
 
 
+def test_one_rank_group_runs_every_collective_through_rccl():
+  """The box has one GPU and RCCL wants one device per rank, so the N > 1 collectives cannot meet a second rank here --
+  but they can RUN: a one-rank "nccl" group with always_exchange issues the fp64 all-reduce / all-gather / broadcast of
+  every product through RCCL (communicator set-up, the HIP stream hand-off between the library's stream and RCCL's,
+  fp64 SUM) and the results must still equal the single context."""
+  env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+             RMB_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_dist_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+  assert "checks on 1 ranks ok (nccl)" in res.stdout
+
+
 def test_bench_spawns_its_own_ranks():
   """`python bench.py --gpus 2` launched plainly must start 2 ranks itself and print n_gpus = 2 (gloo rehearsal on the
   one GPU of this box; on a multi-GPU node the same command uses RCCL)."""

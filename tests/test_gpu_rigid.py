@@ -290,3 +290,107 @@ def test_lagged_gmres_bookkeeping_equals_the_synchronous_loop():
   both(strict=False, tol=1e-10, restart=full["iterations"] - 1)   # one iteration into the next cycle
   both(tol=1e-1, restart=60)                                  # a handful of iterations
   both(tol=1e-10, restart=60, maxiter=9)                      # stops on the iteration cap, not converged
+
+
+def _shell_suspension(nb, seed=5, **kw):
+  import torch
+  from rigidmultiblobswall_amd import structures as st
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  R, eta = 1.0155, 0.957e-3
+  shell = st.icosahedron_shell(0.792079207921 * R)
+  a = st.min_blob_separation(shell) / 2
+  loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=seed)
+  return RigidSuspension([shell] * nb, loc, quat, a, eta, device=torch.device("cuda:0"), **kw), loc, quat
+
+
+def test_captured_arnoldi_iterations_equal_the_eager_loop():
+  """Small systems replay one captured hipGraph per Arnoldi iteration from the third solve on (rigid._ArnoldiGraphs).
+  The iterates are those of the eager loop -- same kernels, same order: iteration counts and residual histories equal,
+  solutions equal to rounding -- while bodies move, the preconditioner is rebuilt (K and the blocks are rewritten in
+  place under the graphs), the right-hand side changes, with restarts and with an initial guess; a context option that
+  changes the launches drops the graphs."""
+  import torch
+  nb = 40
+  eager, loc, quat = _shell_suspension(nb)
+  graphed, _, _ = _shell_suspension(nb)
+  eager.gmres_graph, graphed.gmres_graph = False, True
+  rng = np.random.RandomState(2)
+  n3 = 3 * eager.n_blobs
+  try:
+    replays = []
+    for step in range(7):
+      if step in (2, 4, 5):           # move the bodies; rebuild the preconditioner on some of the moves only
+        loc = loc + 0.02 * rng.randn(*loc.shape) * np.array([1.0, 1.0, 0.2])
+        for s in (eager, graphed):
+          s.set_configuration(loc, quat)
+          if step != 5:
+            s.build_preconditioner()
+      rhs = torch.as_tensor(rng.randn(eager.size), device="cuda:0")
+      kw = dict(tol=1e-9, restart=60)
+      if step == 3:
+        kw = dict(tol=1e-9, restart=60, x0=torch.as_tensor(1e-3 * rng.randn(eager.size), device="cuda:0"))
+      if step == 6:
+        kw = dict(tol=1e-9, restart=7)      # another restart length: a second workspace, eager again at first
+      m0 = (eager.matvec_count, graphed.matvec_count)
+      xe, ie = eager.solve(rhs, **kw)
+      xg, ig = graphed.solve(rhs, **kw)
+      torch.cuda.synchronize()
+      assert "graph_replays" in ig and "graph_replays" not in ie
+      replays.append(ig["graph_replays"])
+      assert ig["converged"] and ie["converged"]
+      if kw["restart"] == 60:
+        assert ig["iterations"] == ie["iterations"], (step, ie["iterations"], ig["iterations"])
+        assert np.allclose(ig["history"], ie["history"], rtol=1e-6, atol=0), step
+        assert eager.matvec_count - m0[0] == graphed.matvec_count - m0[1], step      # replays are counted as products
+      assert rel_err(xg.cpu().numpy(), xe.cpu().numpy()) < 1e-7, (step, rel_err(xg.cpu().numpy(), xe.cpu().numpy()))
+      # and it IS a solution: true residual of the graphed result by the eager operator
+      res = float(torch.linalg.norm(eager.apply_operator(xg) - rhs) / torch.linalg.norm(rhs))
+      assert res < 5e-9, (step, res)
+    assert replays[0] == 0 and replays[1] == 0 and all(r > 0 for r in replays[2:6]), replays
+    ws = graphed._arnoldi_ws
+    # a launch-changing option of the context: the signature differs, the graphs go, the next solves are eager again
+    graphed.ctx.set_option("deterministic", 2)
+    rhs = torch.as_tensor(rng.randn(eager.size), device="cuda:0")
+    xg, ig = graphed.solve(rhs, tol=1e-9)
+    xe, ie = eager.solve(rhs, tol=1e-9)
+    assert ig["graph_replays"] == 0 and rel_err(xg.cpu().numpy(), xe.cpu().numpy()) < 1e-7
+    graphed.ctx.set_option("deterministic", 0)
+  finally:
+    eager.close()
+    graphed.close()
+
+
+def test_captured_arnoldi_iterations_with_mixed_shapes_and_prescribed_bodies():
+  """The general operator path (two body shapes: gathers / scatters, torch.cat; an obstacle with prescribed kinematics)
+  under the captured iterations, against the eager loop; and the automatic switch: on below gmres_graph_max_blobs for a
+  plain context, off above it and with RMB_GMRES_GRAPH=0."""
+  import torch
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  g = np.load(os.path.join(GOLDEN, "g9_rigid_det_euler.npz"))
+  refs = [g["vertex_boomerang"]] * 2 + [g["vertex_shell"]] * 3
+  loc = np.concatenate([g["locations_boomerang"], g["locations_shell"]])
+  quat = np.concatenate([g["quaternions_boomerang"], g["quaternions_shell"]])
+  presc = np.array([False, False, True, False, False])
+  mk = lambda: RigidSuspension(refs, loc, quat, 0.25, 1.1, device=torch.device("cuda:0"), prescribed=presc)
+  eager, graphed = mk(), mk()
+  eager.gmres_graph = False
+  rng = np.random.RandomState(8)
+  try:
+    assert graphed.gmres_graph is None and graphed._arnoldi_graphs(60) is not None       # automatic: small system, plain context
+    graphed.gmres_graph_max_blobs = 3
+    assert graphed._arnoldi_graphs(60) is None
+    graphed.gmres_graph_max_blobs = 6144
+    os.environ["RMB_GMRES_GRAPH"] = "0"
+    try:
+      assert graphed._arnoldi_graphs(60) is None
+    finally:
+      del os.environ["RMB_GMRES_GRAPH"]
+    for step in range(5):
+      rhs = graphed.prescribe(torch.as_tensor(rng.randn(eager.size), device="cuda:0"))
+      xe, ie = eager.solve(rhs, tol=1e-10)
+      xg, ig = graphed.solve(rhs, tol=1e-10)
+      assert ig["iterations"] == ie["iterations"] and rel_err(xg.cpu().numpy(), xe.cpu().numpy()) < 1e-7
+      assert (ig["graph_replays"] > 0) == (step >= 2), (step, ig["graph_replays"])
+  finally:
+    eager.close()
+    graphed.close()
