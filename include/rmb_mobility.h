@@ -213,6 +213,31 @@ int rmb_matvec_op_pairshard_device(rmb_ctx* ctx, int op, int in_plane, int n_in,
 int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, long n_bodies, int n_b, double eta,
                                    double* out_dev);
 
+/* The O(N) pieces of the rigid-body saddle-point solve that sit between two sweeps (csrc/rmb_krylov.hip).  Device
+ * pointers, asynchronous on the context's stream, no positions needed, every reduction in a fixed order.
+ *
+ * rmb_block_apply_device: for every batch entry b (a rigid body)
+ *     y1_b = beta1 y1_b + alpha (A11_b x1_b + A12_b x2_b)       y1_b: r1 values at y1 + b r1,  x1_b: c1 values at x1 + b c1
+ *     y2_b = beta2 y2_b + alpha (A21_b x1_b + A22_b x2_b)       y2_b: r2 values at y2 + b r2,  x2_b: c2 values at x2 + b c2
+ * in ONE launch.  A block is addressed as p[b batch_stride + row row_stride + col col_stride] (a transposed block is
+ * the same memory with the two strides exchanged); a NULL rmb_block* or p == NULL is a zero block; beta == 0 does not
+ * read y.  x and y must not overlap.  c1 + c2 <= 8192.  Replaces the four batched products of the block-diagonal
+ * preconditioner (multi_bodies/multi_bodies.py:548-560: A = the blocks of [[M, -K], [-K^T, 0]]^-1 per body) and the
+ * K U / K^T lambda products of the operator (multi_bodies/multi_bodies.py:327-375 called from :424-471).
+ *
+ * rmb_krylov_orthogonalize_device: one Arnoldi step's orthogonalisation against the `rows` basis vectors V[0..rows)
+ * (row r at V + r ldv, n values), two passes of classical Gram-Schmidt:
+ *     h = V w;  w -= V^T h;  h2 = V w;  w -= V^T h2;   col[0..rows) = h + h2,  col[rows] = |w|,  v_next = w / |w|
+ * (w is overwritten with the orthogonalised, un-normalised vector; |w| == 0 leaves inf / nan in v_next, as the division
+ * would: test col[rows]).  rows <= 256.  Four launches; what scipy.sparse.linalg.gmres does internally for the
+ * reference (general_application_utils.py:608-627). */
+typedef struct rmb_block { const double* p; long batch_stride, row_stride, col_stride; } rmb_block;
+int rmb_block_apply_device(rmb_ctx* ctx, long n_batch, long r1, long c1, long r2, long c2, const rmb_block* a11,
+                           const rmb_block* a12, const rmb_block* a21, const rmb_block* a22, const double* x1_dev,
+                           const double* x2_dev, double alpha, double beta1, double* y1_dev, double beta2, double* y2_dev);
+int rmb_krylov_orthogonalize_device(rmb_ctx* ctx, long n, long rows, const double* V_dev, long ldv, double* w_dev,
+                                    double* col_dev, double* v_next_dev);
+
 /* Blob-blob soft repulsion on the resident positions (multi_bodies/forces_numba.py:12-55,
  * forces_pycuda.py:66-118): out (n_targets,3).  Uses the UNCLAMPED positions: call
  * rmb_set_positions with wall = 0 first (the reference passes raw r_vectors). */

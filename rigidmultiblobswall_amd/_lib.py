@@ -44,6 +44,9 @@ SYMBOLS = {
     "rmb_matvec_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_long,
                                                    ctypes.c_long]),
     "rmb_body_mobility_dense_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_double, _vp]),
+    "rmb_block_apply_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _vp, _vp,
+                                              _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, ctypes.c_double, _vp]),
+    "rmb_krylov_orthogonalize_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp]),
     "rmb_matvec_op_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,
                                             ctypes.c_double]),
     "rmb_matvec_op_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,
@@ -94,6 +97,13 @@ SYMBOLS = {
     "rmb_double_layer_device": (ctypes.c_int, [_vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, ctypes.c_int,
                                                ctypes.c_double, _vp]),
 }
+
+
+
+class Block(ctypes.Structure):
+  """rmb_block: p[b batch_stride + row row_stride + col col_stride] (strides in doubles)."""
+  _fields_ = [("p", ctypes.c_void_p), ("batch_stride", ctypes.c_long), ("row_stride", ctypes.c_long), ("col_stride", ctypes.c_long)]
+
 
 _lib = None
 

@@ -234,6 +234,41 @@ class MobilityContext(object):
                                                         float(eta), ctypes.c_void_p(out.data_ptr())))
     return out
 
+  # --- O(N) helpers of the rigid-body solve (csrc/rmb_krylov.hip) -------------------------------
+  @staticmethod
+  def _block(t, transpose=False):
+    """rmb_block of a (batch, rows, cols) CUDA float64 tensor (any strides), or of its transpose per batch entry."""
+    if t is None:
+      return None
+    assert t.dim() == 3 and t.dtype.itemsize == 8
+    bs, rs, cs = t.stride()
+    return _lib.Block(t.data_ptr(), bs, cs if transpose else rs, rs if transpose else cs)
+
+  def block_apply_device(self, a11, a12, a21, a22, x1, x2, y1, y2, alpha=1.0, beta1=0.0, beta2=0.0, transpose=(False,) * 4):
+    """y1_b = beta1 y1_b + alpha (A11_b x1_b + A12_b x2_b), y2_b likewise with A21, A22, for every batch entry b, in one
+    launch (rmb_block_apply_device).  a..: (batch, rows, cols) tensors or None (zero block); x1 (batch, c1), x2 (batch, c2),
+    y1 (batch, r1), y2 (batch, r2) contiguous views.  transpose[k]: use the k-th block transposed."""
+    nb, c1, c2, r1, r2 = x1.shape[0], x1.shape[1], x2.shape[1], y1.shape[1], y2.shape[1]
+    blocks = [self._block(t, tr) for t, tr in zip((a11, a12, a21, a22), transpose)]
+    refs = [ctypes.byref(b) if b is not None else None for b in blocks]
+    assert x1.is_contiguous() and x2.is_contiguous() and y1.is_contiguous() and y2.is_contiguous()
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_block_apply_device(self._h, nb, r1, c1, r2, c2, refs[0], refs[1], refs[2], refs[3],
+                                                ctypes.c_void_p(x1.data_ptr()), ctypes.c_void_p(x2.data_ptr()), float(alpha),
+                                                float(beta1), ctypes.c_void_p(y1.data_ptr()), float(beta2),
+                                                ctypes.c_void_p(y2.data_ptr())))
+
+  def krylov_orthogonalize_device(self, V, rows, w, col, v_next):
+    """Two classical Gram-Schmidt passes of w against V[:rows] (row-major (m, n) tensor), in place; col[:rows] = the
+    coefficients, col[rows] = |w|, v_next = w / |w| (rmb_krylov_orthogonalize_device)."""
+    n = w.numel()
+    assert V.stride(1) == 1 and V.shape[1] == n and w.is_contiguous() and col.is_contiguous() and v_next.is_contiguous()
+    assert col.numel() >= rows + 1 and v_next.numel() == n
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_krylov_orthogonalize_device(self._h, n, int(rows), ctypes.c_void_p(V.data_ptr()), V.stride(0),
+                                                         ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                                         ctypes.c_void_p(v_next.data_ptr())))
+
   def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
     out = np.empty(3 * self.n_targets)
     _lib.check(self._lib.rmb_blob_blob_force(self._h, float(repulsion_strength), float(debye_length),

@@ -122,7 +122,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->wave_clock.release(); c->tile_bounds.release(); c->fpos.release(); c->fperm.release(); c->fsort_keys.release(); c->fsort_vals.release(); c->fsort_tmp.release(); c->fsort_box.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release();
+  c->wave_clock.release(); c->tile_bounds.release(); c->fpos.release(); c->fperm.release(); c->fsort_keys.release(); c->fsort_vals.release(); c->fsort_tmp.release(); c->fsort_box.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release(); c->krylov.release();
   if (c->stream_switch) (void)hipEventDestroy(c->stream_switch);
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);

@@ -13,6 +13,7 @@
 //                    dense body blocks, position packing
 //   rmb_entry.hip    the extern "C" products: argument checks, routing between the two families, host staging
 //   rmb_multi.hip    the single-process multi-device engine (rmb_multi_*)
+//   rmb_krylov.hip   O(N) helpers of the rigid-body solve: batched 2 x 2 block product, fused Gram-Schmidt step
 #pragma once
 #include "../../include/rmb_mobility.h"
 
@@ -79,6 +80,7 @@ struct rmb_ctx {
   long wave_clock_n = 0;
   long opt_wave_clock = 0;
   long opt_skip_pairs = 0;
+  rmbi::DevBuf krylov;   // partial sums of rmb_krylov_orthogonalize_device
   rmbi::DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
   long symbuf_zeroed_for = -1;
   // options

@@ -1,0 +1,238 @@
+// rmb_krylov.hip -- the O(N) pieces of the rigid-body saddle-point solve that sit between two blob sweeps, as HIP
+// kernels on the context's stream (gfx950, fp64):
+//
+//   rmb_krylov_orthogonalize_device   one Arnoldi step's Gram-Schmidt: two classical passes against the Krylov basis,
+//                                     the new Hessenberg column, |w| and the normalised next basis vector -- 4 launches
+//                                     (what scipy's gmres does inside, general_application_utils.py:608-627 calls it;
+//                                     as torch ops: 2 gemv-T, 2 gemv-N, add, norm, div = 7 launches, the two gemv-T of
+//                                     a (j+1) x n basis alone 26 us at n = 4608 -- profiles/r4_gmres_graph.txt)
+//   rmb_block_apply_device            y1_b = beta1 y1_b + alpha (A11_b x1_b + A12_b x2_b),
+//                                     y2_b = beta2 y2_b + alpha (A21_b x1_b + A22_b x2_b)   for every body b,
+//                                     one launch: the block-diagonal preconditioner (multi_bodies.py:548-560, four
+//                                     batched GEMMs as torch ops) and the K / K^T products of the operator
+//                                     (multi_bodies.py:327-375, 424-471; two batched GEMMs) -- blocks are addressed
+//                                     with (batch, row, column) strides, so K^T is K with the strides exchanged.
+//
+// Both are HBM-latency-bound helpers of a few microseconds; they exist because up to a few thousand blobs the solver
+// loop AROUND the sweep costs several times the sweep (profiles/r4_gmres_graph.txt).  Every reduction runs in a fixed
+// order: results are bit-reproducible.
+#include "rmb_internal.h"
+
+#include <cmath>
+
+namespace rmbi {
+namespace {
+
+constexpr int kKrT = 256;            // threads per workgroup of the Gram-Schmidt kernels (4 waves)
+constexpr int kKrWaves = kKrT / 64;
+constexpr int kKrMaxRows = 256;      // basis vectors one call orthogonalises against (GMRES restart length + 1)
+constexpr long kKrMaxChunk = 4096;   // doubles of w a workgroup keeps in LDS (32 KB)
+
+struct OrthoArgs {
+  long n, rows, ldv, chunk, n_chunks;
+  const double* V;
+  double* w;
+  double* col;      // rows coefficients, then |w|
+  double* v_next;
+  double* part1;    // [rows][n_chunks] partial dots of pass 1
+  double* part2;    // [rows][n_chunks] partial dots of pass 2
+  double* part3;    // [n_chunks] partial |w|^2
+  double* h1;       // [rows] coefficients of pass 1
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;       // lane 0 holds the sum
+}
+
+// partial dots of this workgroup's chunk (in LDS) with every basis row: wave q takes rows q, q + 4, ...
+__device__ __forceinline__ void chunk_dots(const OrthoArgs& a, const double* wl, long base, long len, double* part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = wave; r < a.rows; r += kKrWaves) {
+    const double* row = a.V + r * a.ldv + base;
+    double s = 0.0;
+    for (long e = lane; e < len; e += 64) s += row[e] * wl[e];
+    s = wave_sum(s);
+    if (lane == 0) part[r * a.n_chunks + blockIdx.x] = s;
+  }
+}
+
+// coefficients = fixed-order sums of the partials over the chunks, into LDS; thread t takes row t, t + 256, ...
+__device__ __forceinline__ void reduce_partials(const OrthoArgs& a, const double* part, double* hl) {
+  for (long r = threadIdx.x; r < a.rows; r += kKrT) {
+    double s = 0.0;
+    for (long c = 0; c < a.n_chunks; ++c) s += part[r * a.n_chunks + c];
+    hl[r] = s;
+  }
+}
+
+// wl[e] -= sum_r hl[r] V[r][base + e]
+__device__ __forceinline__ void chunk_update(const OrthoArgs& a, double* wl, const double* hl, long base, long len) {
+  for (long e = threadIdx.x; e < len; e += kKrT) {
+    double s = wl[e];
+    for (long r = 0; r < a.rows; ++r) s -= hl[r] * a.V[r * a.ldv + base + e];
+    wl[e] = s;
+  }
+}
+
+__global__ __launch_bounds__(kKrT) void ortho_dots_kernel(const OrthoArgs a) {
+  extern __shared__ double lds[];
+  double* wl = lds;
+  const long base = blockIdx.x * a.chunk;
+  const long len = (a.n - base) < a.chunk ? (a.n - base) : a.chunk;
+  for (long e = threadIdx.x; e < len; e += kKrT) wl[e] = a.w[base + e];
+  __syncthreads();
+  chunk_dots(a, wl, base, len, a.part1);
+}
+
+// pass: 1 = subtract the pass-1 projection and take the pass-2 dots; 2 = subtract the pass-2 projection, |w|^2, column
+template <int PASS>
+__global__ __launch_bounds__(kKrT) void ortho_update_kernel(const OrthoArgs a) {
+  extern __shared__ double lds[];
+  double* wl = lds;
+  double* hl = lds + a.chunk;
+  const long base = blockIdx.x * a.chunk;
+  const long len = (a.n - base) < a.chunk ? (a.n - base) : a.chunk;
+  for (long e = threadIdx.x; e < len; e += kKrT) wl[e] = a.w[base + e];
+  reduce_partials(a, PASS == 1 ? a.part1 : a.part2, hl);
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (long r = threadIdx.x; r < a.rows; r += kKrT) {
+      if (PASS == 1) a.h1[r] = hl[r]; else a.col[r] = a.h1[r] + hl[r];
+    }
+  }
+  chunk_update(a, wl, hl, base, len);
+  __syncthreads();
+  for (long e = threadIdx.x; e < len; e += kKrT) a.w[base + e] = wl[e];
+  if (PASS == 1) {
+    chunk_dots(a, wl, base, len, a.part2);
+  } else {
+    __shared__ double wsum[kKrWaves];
+    double s = 0.0;
+    for (long e = threadIdx.x; e < len; e += kKrT) s += wl[e] * wl[e];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int q = 0; q < kKrWaves; ++q) t += wsum[q];
+      a.part3[blockIdx.x] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kKrT) void ortho_normalise_kernel(const OrthoArgs a) {
+  __shared__ double nrm;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (long c = 0; c < a.n_chunks; ++c) s += a.part3[c];
+    nrm = sqrt(s);
+    if (blockIdx.x == 0) a.col[a.rows] = nrm;
+  }
+  __syncthreads();
+  const double inv = 1.0 / nrm;      // |w| = 0 (exact breakdown): inf / nan in v_next, as w / |w| gives; the caller stops on col[rows] == 0
+  const long base = blockIdx.x * a.chunk;
+  const long len = (a.n - base) < a.chunk ? (a.n - base) : a.chunk;
+  for (long e = threadIdx.x; e < len; e += kKrT) a.v_next[base + e] = a.w[base + e] * inv;
+}
+
+// ---- batched two-by-two block matvec ---------------------------------------------------------------------------
+struct BlockRef { const double* p; long bs, rs, cs; };
+struct BlockApplyArgs {
+  long n_batch, r1, c1, r2, c2;
+  BlockRef a11, a12, a21, a22;
+  const double* x1; const double* x2;
+  double* y1; double* y2;
+  double alpha, beta1, beta2;
+};
+
+__global__ void block_apply_kernel(const BlockApplyArgs a) {
+  extern __shared__ double xl[];          // x1_b then x2_b
+  const long b = blockIdx.x;
+  for (long k = threadIdx.x; k < a.c1; k += blockDim.x) xl[k] = a.x1[b * a.c1 + k];
+  for (long k = threadIdx.x; k < a.c2; k += blockDim.x) xl[a.c1 + k] = a.x2[b * a.c2 + k];
+  __syncthreads();
+  for (long row = threadIdx.x; row < a.r1 + a.r2; row += blockDim.x) {
+    const bool top = row < a.r1;
+    const long r = top ? row : row - a.r1;
+    const BlockRef& left = top ? a.a11 : a.a21;
+    const BlockRef& right = top ? a.a12 : a.a22;
+    double s = 0.0;
+    if (left.p) {
+      const double* m = left.p + b * left.bs + r * left.rs;
+      for (long k = 0; k < a.c1; ++k) s += m[k * left.cs] * xl[k];
+    }
+    if (right.p) {
+      const double* m = right.p + b * right.bs + r * right.rs;
+      for (long k = 0; k < a.c2; ++k) s += m[k * right.cs] * xl[a.c1 + k];
+    }
+    double* y = top ? a.y1 + b * a.r1 + r : a.y2 + b * a.r2 + r;
+    const double beta = top ? a.beta1 : a.beta2;
+    *y = (beta == 0.0 ? 0.0 : beta * *y) + a.alpha * s;
+  }
+}
+
+}  // namespace
+}  // namespace rmbi
+
+using namespace rmbi;
+
+extern "C" {
+
+int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
+                                    double* v_next_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n < 1 || rows < 1 || rows > kKrMaxRows || ldv < n)
+    return fail(RMB_ERR_ARG, "rmb_krylov_orthogonalize_device: need n >= 1, 1 <= rows <= 256, ldv >= n");
+  if (!V_dev || !w_dev || !col_dev || !v_next_dev) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  OrthoArgs a;
+  a.n = n; a.rows = rows; a.ldv = ldv;
+  // chunks of 1024 doubles while that gives at most 256 workgroups, larger ones (up to what fits LDS) beyond: every
+  // workgroup re-sums the per-chunk partials, so their number stays bounded
+  long chunk = 1024;
+  while ((n + chunk - 1) / chunk > 256 && chunk < kKrMaxChunk) chunk *= 2;
+  a.chunk = chunk;
+  a.n_chunks = (n + chunk - 1) / chunk;
+  const size_t need = ((size_t)2 * rows * a.n_chunks + a.n_chunks + rows) * sizeof(double);
+  if (int rc = c->krylov.reserve(need)) return rc;
+  a.V = V_dev; a.w = w_dev; a.col = col_dev; a.v_next = v_next_dev;
+  a.part1 = (double*)c->krylov.p;
+  a.part2 = a.part1 + rows * a.n_chunks;
+  a.part3 = a.part2 + rows * a.n_chunks;
+  a.h1 = a.part3 + a.n_chunks;
+  const dim3 grid((unsigned)a.n_chunks), block(kKrT);
+  const size_t lds_w = (size_t)chunk * sizeof(double), lds_wh = lds_w + (size_t)rows * sizeof(double);
+  hipLaunchKernelGGL(ortho_dots_kernel, grid, block, lds_w, c->stream, a);
+  hipLaunchKernelGGL(ortho_update_kernel<1>, grid, block, lds_wh, c->stream, a);
+  hipLaunchKernelGGL(ortho_update_kernel<2>, grid, block, lds_wh, c->stream, a);
+  hipLaunchKernelGGL(ortho_normalise_kernel, grid, block, 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+int rmb_block_apply_device(rmb_ctx* c, long n_batch, long r1, long c1, long r2, long c2, const rmb_block* a11, const rmb_block* a12,
+                           const rmb_block* a21, const rmb_block* a22, const double* x1_dev, const double* x2_dev, double alpha,
+                           double beta1, double* y1_dev, double beta2, double* y2_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n_batch < 0 || r1 < 0 || c1 < 0 || r2 < 0 || c2 < 0) return fail(RMB_ERR_ARG, "rmb_block_apply_device: negative size");
+  if (n_batch == 0 || r1 + r2 == 0) return 0;
+  if ((size_t)(c1 + c2) * sizeof(double) > 64 * 1024)
+    return fail(RMB_ERR_ARG, "rmb_block_apply_device: c1 + c2 above 8192 (the operand of one batch entry is kept in LDS)");
+  if ((c1 > 0 && !x1_dev) || (c2 > 0 && !x2_dev) || (r1 > 0 && !y1_dev) || (r2 > 0 && !y2_dev)) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  BlockApplyArgs a;
+  a.n_batch = n_batch; a.r1 = r1; a.c1 = c1; a.r2 = r2; a.c2 = c2;
+  auto ref = [](const rmb_block* b) { return b && b->p ? BlockRef{b->p, b->batch_stride, b->row_stride, b->col_stride} : BlockRef{nullptr, 0, 0, 0}; };
+  a.a11 = ref(a11); a.a12 = ref(a12); a.a21 = ref(a21); a.a22 = ref(a22);
+  a.x1 = x1_dev; a.x2 = x2_dev; a.y1 = y1_dev; a.y2 = y2_dev;
+  a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2;
+  const long rows = r1 + r2;
+  const unsigned threads = rows <= 64 ? 64u : (rows <= 128 ? 128u : 256u);
+  hipLaunchKernelGGL(block_apply_kernel, dim3((unsigned)n_batch), dim3(threads), (size_t)(c1 + c2) * sizeof(double), c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ with numpy + scipy on the host, here with every vector resident in HBM:
 
 PyTorch is used for device memory and batched small dense algebra only.
 """
+import math
 import os
 
 import numpy as np
@@ -269,9 +270,16 @@ class RigidSuspension(object):
       top = res[:n3]
       self.matvec_count += 1
       self.sweep_count += 1
-      r = self.ctx.matvec_device("tt", lam.contiguous(), self.eta, out=top)
+      lam = lam.contiguous()
+      r = self.ctx.matvec_device("tt", lam, self.eta, out=top)
       if r.data_ptr() != top.data_ptr():       # contexts that do not write in place (test stand-ins)
         top.copy_(r)
+      if self._native_blocks():
+        # top -= K U and bottom = -K^T lambda in one launch (rmb_block_apply_device; K^T = K with exchanged strides)
+        self.ctx.block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.reshape(self.n_bodies, 6),
+                                    top.view(self.n_bodies, 3 * g.n_b), res[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
+                                    transpose=(False, False, True, False))
+        return res
       top.view(self.n_bodies, 3 * g.n_b, 1).baddbmm_(g.K, U.reshape(self.n_bodies, 6, 1), alpha=-1.0)
       bot = res[n3:].view(self.n_bodies, 6, 1)
       torch.baddbmm(bot, g.K.transpose(1, 2), lam.reshape(self.n_bodies, 3 * g.n_b, 1), beta=0.0, alpha=-1.0, out=bot)
@@ -382,6 +390,10 @@ class RigidSuspension(object):
       g = self.groups[0]
       slip = x[:n3].reshape(self.n_bodies, 3 * g.n_b, 1)
       lam = out[:n3].view(self.n_bodies, 3 * g.n_b, 1)
+      if self._native_blocks() and x.is_contiguous():
+        self.ctx.block_apply_device(g.A11, g.A12, g.A21, g.A22, x[:n3].view(self.n_bodies, 3 * g.n_b), F,
+                                    out[:n3].view(self.n_bodies, 3 * g.n_b), outU)      # the four blocks in one launch
+        return out
       U = outU.unsqueeze(-1)
       torch.bmm(g.A11, slip, out=lam)
       lam.baddbmm_(g.A12, F.unsqueeze(-1))
@@ -406,10 +418,12 @@ class RigidSuspension(object):
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
     ws = self._arnoldi_graphs(restart)
+    ortho = self.ctx.krylov_orthogonalize_device if self._native_blocks() and restart < 256 else None
     if ws is None:
       sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
                                              restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
-                                             sync=getattr(self.ctx, "sync_scalars", None), lag=getattr(self, "gmres_lag", None))
+                                             sync=getattr(self.ctx, "sync_scalars", None), lag=getattr(self, "gmres_lag", None),
+                                             ortho=ortho)
       info["rhs_norm"] = nrm
       return sol * nrm, info
     # Small systems: the device side of every Arnoldi iteration (preconditioner, operator, Gram-Schmidt, normalisation,
@@ -423,13 +437,24 @@ class RigidSuspension(object):
       ws.begin_solve()
       sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
                                              restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
-                                             ws=ws, on_replay=self._count_operator)
+                                             ws=ws, on_replay=self._count_operator, ortho=ortho)
       sol = sol * nrm
     cur.wait_stream(ws.stream)
     sol.record_stream(cur)
     info["rhs_norm"] = nrm
     info["graph_replays"] = ws.replays_this_solve
     return sol, info
+
+  # `native_helpers`: the O(N) pieces between two sweeps (K / K^T products, the preconditioner's four blocks, the
+  # Gram-Schmidt of an Arnoldi step) as the library's own kernels (csrc/rmb_krylov.hip) instead of batched-GEMM / GEMV
+  # launches: None = automatic (a plain single-GPU context), False = the torch operations.
+  native_helpers = None
+
+  def _native_blocks(self):
+    want = self.native_helpers
+    if want is None:
+      want = os.environ.get("RMB_NATIVE_HELPERS", "") != "0"
+    return bool(want) and self.device.type == "cuda" and type(self.ctx) is MobilityContext
 
   def _count_operator(self):
     self.matvec_count += 1
@@ -438,7 +463,7 @@ class RigidSuspension(object):
   # `gmres_graph`: None = automatic (on for a plain single-GPU context up to `gmres_graph_max_blobs` blobs, where the
   # iteration is launch-bound: profiles/r4_gmres_graph.txt), True / False = forced.  RMB_GMRES_GRAPH=0 turns it off.
   gmres_graph = None
-  gmres_graph_max_blobs = 6144
+  gmres_graph_max_blobs = 4096
 
   def _arnoldi_graphs(self, restart):
     """The captured-iteration workspace for solve(), or None when the plain loop is to run."""
@@ -454,7 +479,7 @@ class RigidSuspension(object):
     if ws is None or ws.m != restart:
       ws = self._arnoldi_ws = _ArnoldiGraphs(self.size, restart, self.device)
     ptr = lambda t: None if t is None else t.data_ptr()
-    ws.bind((self.ctx.launch_signature(), self.eta, ptr(self.free), ptr(self.prescribed_velocity),
+    ws.bind((self.ctx.launch_signature(), self.eta, self._native_blocks(), ptr(self.free), ptr(self.prescribed_velocity),
              tuple(tuple(ptr(t) for t in (g.K, g.A11, g.A12, g.A21, g.A22)) for g in self.groups)))
     return ws
 
@@ -739,7 +764,7 @@ def _pinned_columns(rows, cols):
   return torch.empty((max(rows, 62), max(cols, 63)), dtype=torch.float64).pin_memory()
 
 
-def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=None, on_replay=None):
+def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=None, on_replay=None, ortho=None):
   """GMRES(restart) on A.Minv written as a coroutine: it YIELDS every vector it needs the operator applied to and
   receives A(vector) back, so one driver can serve a single solve (gmres_right_preconditioned) or advance two solves
   in lockstep and hand both requests to a two-vector operator (gmres_pair_right_preconditioned).  Returns (x, info).
@@ -758,6 +783,8 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
   if ws is not None:        # captured iterations (_ArnoldiGraphs): static buffers, the operator applied inside the step
     assert A is not None and sync is None and dev.type == "cuda" and ws.n == n and ws.m == restart
     lag = True
+  if not lag or sync is not None:      # the fused Gram-Schmidt normalises on the device right away
+    ortho = None
 
   def host_norm(v):
     t = torch.linalg.vector_norm(v).reshape(1)
@@ -789,8 +816,8 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
         cols = torch.empty((m, m + 2), dtype=torch.float64, device=dev)    # row j = column j of H, then |w_j|
       V[0] = r / beta
       H = np.zeros((m + 1, m))
-      cs, sn = np.zeros(m), np.zeros(m)
-      g = np.zeros(m + 1)
+      cs, sn = [0.0] * m, [0.0] * m          # plain Python floats: the rotations below are a scalar recurrence, and numpy
+      g = [0.0] * (m + 1)                    # scalars cost ~10x a float operation (it is host time between two sweeps)
       g[0] = beta
       k_used = 0
       prev_res = None
@@ -800,26 +827,27 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
         nonlocal its, k_used, res, prev_res
         if lag:
           events[j & 1].synchronize()
-          col = host_cols[j, :j + 2].numpy()
+          col = host_cols[j, :j + 2].tolist()
         else:
-          col = cols[j, :j + 2].cpu().numpy()                         # the one host transfer of the iteration
-        H[:j + 2, j] = col
-        last_norm[0] = float(col[-1])
+          col = cols[j, :j + 2].tolist()                              # the one host transfer of the iteration
+        w_norm = col[-1]
+        last_norm[0] = w_norm
         for i in range(j):                                           # previous rotations
-          t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
-          H[i + 1, j] = -sn[i] * H[i, j] + cs[i] * H[i + 1, j]
-          H[i, j] = t
-        d = np.hypot(H[j, j], H[j + 1, j])
-        cs[j], sn[j] = (H[j, j] / d, H[j + 1, j] / d) if d > 0 else (1.0, 0.0)
-        H[j, j] = d
-        H[j + 1, j] = 0.0
+          t = cs[i] * col[i] + sn[i] * col[i + 1]
+          col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1]
+          col[i] = t
+        d = math.hypot(col[j], col[j + 1])
+        cs[j], sn[j] = (col[j] / d, col[j + 1] / d) if d > 0 else (1.0, 0.0)
+        col[j] = d
+        col[j + 1] = 0.0
+        H[:j + 2, j] = col
         g[j + 1] = -sn[j] * g[j]
         g[j] = cs[j] * g[j]
         its += 1
         k_used = j + 1
         prev_res, res = res, abs(g[j + 1]) / bnorm
         history.append(res)
-        return res <= tol or col[-1] == 0 or not np.isfinite(col[-1])
+        return res <= tol or w_norm == 0 or not math.isfinite(w_norm)
 
       def may_defer():
         """Whether the pending column can wait until the next iteration has been enqueued: not when the last
@@ -846,17 +874,25 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
             break
         if ws is not None:
           def device_side(j=j):
-            w = orthogonalise(j, A(Minv(V[j])))
-            torch.div(w, cols[j, j + 1], out=V[j + 1])
+            w = A(Minv(V[j]))
+            if ortho is not None:
+              ortho(V, j + 1, w, cols[j], V[j + 1])
+            else:
+              torch.div(orthogonalise(j, w), cols[j, j + 1], out=V[j + 1])
             host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
           ws.run(j, device_side, on_replay)
         else:
-          w = orthogonalise(j, (yield Minv(V[j])))
+          w = yield Minv(V[j])
+          if ortho is not None:                                      # both passes, column, |w| and V[j + 1] in four launches
+            ortho(V, j + 1, w if w.is_contiguous() else w.contiguous(), cols[j], V[j + 1])
+          else:
+            w = orthogonalise(j, w)
           if sync is not None:                                       # multi-rank: all ranks act on rank 0's numbers
             sync(cols[j, :j + 2])
         if lag:
           if ws is None:
-            torch.div(w, cols[j, j + 1], out=V[j + 1])               # normalised on the device: no host value needed
+            if ortho is None:
+              torch.div(w, cols[j, j + 1], out=V[j + 1])             # normalised on the device: no host value needed
             host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
           # fence on the stream the copy was enqueued on: the current stream of the VECTORS' device, which need not
           # be the process's current device (a suspension built on cuda:1 while cuda:0 is current)
@@ -875,7 +911,7 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
             break
       if pending is not None and not stop:
         finish(pending)
-      coef = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used]) if k_used > 0 else np.zeros(0)
+      coef = np.linalg.solve(np.triu(H[:k_used, :k_used]), np.array(g[:k_used])) if k_used > 0 else np.zeros(0)
       y = y + V[:k_used].t() @ torch.as_tensor(coef, device=dev)
       if res > tol and its < maxiter:                                # restart: true residual
         r = b - (yield Minv(y))
@@ -891,7 +927,7 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
 
 
 def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x0=None, sync=None, lag=None, ws=None,
-                               on_replay=None):
+                               on_replay=None, ortho=None):
   """Solve A x = b with x = x0 + Minv y, GMRES(restart) on A.Minv (general_application_utils.py:608-627).
   Stops when |b - A x| <= tol |b| (scipy `tol`, atol = 0) or after `maxiter` INNER iterations in total -- not restart
   cycles: scipy (and the reference's call, maxiter=1000 with restart=60) counts cycles, i.e. up to 60 000 inner
@@ -901,7 +937,8 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
   iteration behind the device (`lag`, see _gmres_steps; None = on for CUDA tensors).
   x0: optional initial guess (the roller torque solve warm-starts from the previous step,
   quaternion_integrator_rollers.py:961); the Krylov space is then built on the residual b - A x0."""
-  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag, ws=ws, A=A if ws is not None else None, on_replay=on_replay)
+  steps = _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag, ws=ws, A=A if ws is not None else None, on_replay=on_replay,
+                       ortho=ortho)
   try:
     request = next(steps)
     while True:

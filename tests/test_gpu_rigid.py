@@ -379,7 +379,7 @@ def test_captured_arnoldi_iterations_with_mixed_shapes_and_prescribed_bodies():
     assert graphed.gmres_graph is None and graphed._arnoldi_graphs(60) is not None       # automatic: small system, plain context
     graphed.gmres_graph_max_blobs = 3
     assert graphed._arnoldi_graphs(60) is None
-    graphed.gmres_graph_max_blobs = 6144
+    graphed.gmres_graph_max_blobs = 4096
     os.environ["RMB_GMRES_GRAPH"] = "0"
     try:
       assert graphed._arnoldi_graphs(60) is None

@@ -20,8 +20,14 @@ for nb in [int(x) for x in sys.argv[1:]] or [8, 64, 256, 1024]:
   cols = torch.zeros((m, m + 2), dtype=torch.float64, device=dev)
   host = torch.empty((m, m + 2), dtype=torch.float64).pin_memory()
 
+  native = os.environ.get("RMB_NATIVE_HELPERS", "") != "0"
+
   def body():
     w = rs.apply_operator(rs.apply_preconditioner(V[j]))
+    if native:
+      rs.ctx.krylov_orthogonalize_device(V, j + 1, w, cols[j], V[j + 1])
+      host[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
+      return
     Vj = V[:j + 1]
     h = Vj @ w
     w = torch.addmv(w, Vj.t(), h, alpha=-1.0)
