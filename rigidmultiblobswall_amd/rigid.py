@@ -310,6 +310,11 @@ class RigidSuspension(object):
       top = row[:n3]
       if r.data_ptr() != top.data_ptr():
         top.copy_(r)
+      if self._native_blocks() and x.is_contiguous():
+        self.ctx.block_apply_device(None, g.K, g.K, None, x[:n3].view(self.n_bodies, 3 * g.n_b), x[n3:].view(self.n_bodies, 6),
+                                    top.view(self.n_bodies, 3 * g.n_b), row[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
+                                    transpose=(False, False, True, False))
+        continue
       top.view(self.n_bodies, 3 * g.n_b, 1).baddbmm_(g.K, x[n3:].reshape(self.n_bodies, 6, 1), alpha=-1.0)
       bot = row[n3:].view(self.n_bodies, 6, 1)
       torch.baddbmm(bot, g.K.transpose(1, 2), x[:n3].reshape(self.n_bodies, 3 * g.n_b, 1), beta=0.0, alpha=-1.0, out=bot)
@@ -418,7 +423,7 @@ class RigidSuspension(object):
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
     ws = self._arnoldi_graphs(restart)
-    ortho = self.ctx.krylov_orthogonalize_device if self._native_blocks() and restart < 256 else None
+    ortho = self._ortho(restart)
     if ws is None:
       sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
                                              restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
@@ -455,6 +460,10 @@ class RigidSuspension(object):
     if want is None:
       want = os.environ.get("RMB_NATIVE_HELPERS", "") != "0"
     return bool(want) and self.device.type == "cuda" and type(self.ctx) is MobilityContext
+
+  def _ortho(self, restart):
+    """The fused Gram-Schmidt step for _gmres_steps, or None (torch operations)."""
+    return self.ctx.krylov_orthogonalize_device if self._native_blocks() and restart < 256 else None
 
   def _count_operator(self):
     self.matvec_count += 1
@@ -512,7 +521,7 @@ class RigidSuspension(object):
         self.ctx.set_option("precision", 32)
         dx, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, r / res,
                                               tol=max(inner_tol, 0.25 * tol / res), restart=restart, maxiter=maxiter - its,
-                                              sync=sync)
+                                              sync=sync, ortho=self._ortho(restart))
         self.ctx.set_option("precision", 64)
         its += info["iterations"]
         history.extend(h * res for h in info["history"])
@@ -539,7 +548,7 @@ class RigidSuspension(object):
       return self.solve(rhs_a, tol, restart, maxiter), self.solve(rhs_b, tol, restart, maxiter)
     (xa, ia), (xb, ib) = gmres_pair_right_preconditioned(self.apply_operator, self.apply_operator2, self.apply_preconditioner,
                                                          rhs_a / na, rhs_b / nb_, tol=tol, restart=restart, maxiter=maxiter,
-                                                         sync=getattr(self.ctx, "sync_scalars", None))
+                                                         sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho(restart))
     ia["rhs_norm"], ib["rhs_norm"] = na, nb_
     return (xa * na, ia), (xb * nb_, ib)
 
@@ -548,6 +557,14 @@ class RigidSuspension(object):
     """[M lambda - K U; -K^T lambda] given the blob product M lambda (the O(N) rest of apply_operator)."""
     n3 = 3 * self.n_blobs
     lam, U = x[:n3], x[n3:]
+    if self.free is None and len(self.groups) == 1 and self._native_blocks() and x.is_contiguous():
+      g = self.groups[0]
+      res = torch.empty_like(x)
+      res[:n3].copy_(Mlam)
+      self.ctx.block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.view(self.n_bodies, 6),
+                                  res[:n3].view(self.n_bodies, 3 * g.n_b), res[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
+                                  transpose=(False, False, True, False))
+      return res
     if self.free is None:
       return torch.cat([Mlam - self.K_times_U(U), -self.KT_times_lambda(lam)])
     U = U.view(self.n_bodies, 6)
@@ -565,7 +582,7 @@ class RigidSuspension(object):
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[], rhs_norm=0.0)
     n3 = 3 * self.n_blobs
     steps = _gmres_steps(self.apply_preconditioner, rhs / nrm, tol, restart, maxiter, None if x0 is None else x0 / nrm,
-                         getattr(self.ctx, "sync_scalars", None))
+                         getattr(self.ctx, "sync_scalars", None), ortho=self._ortho(restart))
     try:
       y = next(steps)
       while True:
@@ -947,12 +964,12 @@ def gmres_right_preconditioned(A, Minv, b, tol=1e-8, restart=60, maxiter=1000, x
     return done.value
 
 
-def gmres_pair_right_preconditioned(A, A2, Minv, b_a, b_b, tol=1e-8, restart=60, maxiter=1000, sync=None):
+def gmres_pair_right_preconditioned(A, A2, Minv, b_a, b_b, tol=1e-8, restart=60, maxiter=1000, sync=None, ortho=None):
   """Two independent solves A x_a = b_a, A x_b = b_b advanced in lockstep: while both are running, each iteration
   hands its two operator requests to A2(u, v) -> (A u, A v) -- one pass over the blob pairs with two vectors
   (rmb_matvec2_device) instead of two.  Every solve sees exactly the iterates it would see alone.
   Returns ((x_a, info_a), (x_b, info_b))."""
-  gens = [_gmres_steps(Minv, b, tol, restart, maxiter, None, sync) for b in (b_a, b_b)]
+  gens = [_gmres_steps(Minv, b, tol, restart, maxiter, None, sync, ortho=ortho) for b in (b_a, b_b)]
   requests, results = [None, None], [None, None]
   for k in (0, 1):
     try:
