@@ -231,6 +231,28 @@ int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, lon
  * (w is overwritten with the orthogonalised, un-normalised vector; |w| == 0 leaves inf / nan in v_next, as the division
  * would: test col[rows]).  rows <= 256.  Four launches; what scipy.sparse.linalg.gmres does internally for the
  * reference (general_application_utils.py:608-627). */
+/* Per-body geometry and the per-body factors of the block-diagonal preconditioner, one launch each (csrc/rmb_rigid.hip).
+ * Bodies of one call have n_b blobs each, stored body after body.
+ *
+ * rmb_rigid_configuration_device: r = R(q) ref + x for every blob (body/body.py:64-78; rotation matrix of the unit
+ * quaternion (s, p) as quaternion_integrator/quaternion.py:41-51), the body-frame offsets rel = R(q) ref and
+ * K = [I, -(rel x)] per blob (body/body.py:81-115).  ref (n_bodies, n_b, 3), loc (n_bodies, 3), quat (n_bodies, 4),
+ * r (n_bodies n_b, 3), rel (n_bodies, n_b, 3) or NULL, K (n_bodies, 3 n_b, 6) row-major or NULL.
+ *
+ * rmb_rigid_preconditioner_device: from each body's dense blob mobility Mb (n_bodies, 3 n_b, 3 n_b; symmetrised on
+ * load; rmb_body_mobility_dense_device builds it) and K: Lchol (Mb = L L^T, lower, zeros above), Linv = L^-1,
+ * Minv = Mb^-1, Nbody = (K^T Mb^-1 K)^-1 (6 x 6), and the blocks of [[Mb, -K], [-K^T, 0]]^-1:
+ *   A12 = -Mb^-1 K N (3 n_b x 6), A11 = Mb^-1 + A12 (Mb^-1 K)^T, A21 = A12^T (6 x 3 n_b), A22 = -N
+ * (multi_bodies/multi_bodies.py:516-531 builds L and N, :548-560 applies them).  *info_dev (one int, device) is set to
+ * 0 and then to 1 by any body whose Mb is not positive definite or whose 6 x 6 resistance K^T Mb^-1 K has no accurate
+ * inverse (single blobs, collinear rods: the reference takes the pseudo-inverse there, the caller must too).
+ * n_b <= 16 (one wavefront per body, the factors of a body live in LDS). */
+int rmb_rigid_configuration_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
+                                   const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev);
+int rmb_rigid_preconditioner_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Mb_dev, const double* K_dev,
+                                    double* Lchol_dev, double* Linv_dev, double* Minv_dev, double* Nbody_dev, double* A11_dev,
+                                    double* A12_dev, double* A21_dev, double* A22_dev, int* info_dev);
+
 typedef struct rmb_block { const double* p; long batch_stride, row_stride, col_stride; } rmb_block;
 int rmb_block_apply_device(rmb_ctx* ctx, long n_batch, long r1, long c1, long r2, long c2, const rmb_block* a11,
                            const rmb_block* a12, const rmb_block* a21, const rmb_block* a22, const double* x1_dev,

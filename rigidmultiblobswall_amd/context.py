@@ -258,6 +258,28 @@ class MobilityContext(object):
                                                 float(beta1), ctypes.c_void_p(y1.data_ptr()), float(beta2),
                                                 ctypes.c_void_p(y2.data_ptr())))
 
+  def rigid_configuration_device(self, ref, loc, quat, r, rel=None, K=None):
+    """Blob coordinates, body-frame offsets and K of every body in one launch (rmb_rigid_configuration_device).
+    ref (nb, n_b, 3), loc (nb, 3), quat (nb, 4); outputs r (nb n_b, 3), rel (nb, n_b, 3), K (nb, 3 n_b, 6), contiguous."""
+    nb, n_b = ref.shape[0], ref.shape[1]
+    for t in (ref, loc, quat, r, rel, K):
+      assert t is None or (t.is_contiguous() and t.dtype.itemsize == 8)
+    assert loc.numel() == 3 * nb and quat.numel() == 4 * nb and r.numel() == 3 * nb * n_b
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_configuration_device(self._h, nb, n_b, p(ref), p(loc), p(quat), p(r), p(rel), p(K)))
+
+  def rigid_preconditioner_device(self, Mb, K, Lchol, Linv, Minv, Nbody, A11, A12, A21, A22, info):
+    """Per-body Cholesky factor, inverses and the preconditioner's four blocks in one launch
+    (rmb_rigid_preconditioner_device).  Mb (nb, n, n), K (nb, n, 6), outputs contiguous; info: int32 tensor of one entry."""
+    nb, n = Mb.shape[0], Mb.shape[1]
+    outs = (Lchol, Linv, Minv, Nbody, A11, A12, A21, A22)
+    assert all(t.is_contiguous() for t in (Mb, K) + outs) and n % 3 == 0 and info.dtype.itemsize == 4
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_preconditioner_device(self._h, nb, n // 3, ctypes.c_void_p(Mb.data_ptr()),
+                                                         ctypes.c_void_p(K.data_ptr()), *[ctypes.c_void_p(t.data_ptr()) for t in outs],
+                                                         ctypes.c_void_p(info.data_ptr())))
+
   def krylov_orthogonalize_device(self, V, rows, w, col, v_next):
     """Two classical Gram-Schmidt passes of w against V[:rows] (row-major (m, n) tensor), in place; col[:rows] = the
     coefficients, col[rows] = |w|, v_next = w / |w| (rmb_krylov_orthogonalize_device)."""

@@ -13,6 +13,7 @@
 //                    dense body blocks, position packing
 //   rmb_entry.hip    the extern "C" products: argument checks, routing between the two families, host staging
 //   rmb_multi.hip    the single-process multi-device engine (rmb_multi_*)
+//   rmb_rigid.hip    per-body geometry (positions, K) and the per-body factors of the block-diagonal preconditioner
 //   rmb_krylov.hip   O(N) helpers of the rigid-body solve: batched 2 x 2 block product, fused Gram-Schmidt step
 #pragma once
 #include "../../include/rmb_mobility.h"

@@ -1,0 +1,246 @@
+// rmb_rigid.hip -- per-body geometry and the per-body factors of the block-diagonal preconditioner as ONE launch each
+// (gfx950, fp64).  Between two solves a time step moves the bodies and refactorises every body's own blob mobility; as
+// torch operations that is ~60 launches (quaternions -> rotations, batched GEMMs, strided fills of K, batched Cholesky /
+// triangular solves / 6 x 6 inverses) costing 0.4 + 0.8 ms whatever the size -- as much as the whole GMRES solve of a
+// 64-body deck, and 7 % of the step at 2048 bodies (tools/experiments/exp_step_breakdown.py, profiles/r4_gmres_graph.txt).
+//
+//   rmb_rigid_configuration_device    blob coordinates r = R(q) ref + x, body-frame offsets and K = [I, -(rel x)] of every
+//                                     body (body/body.py:64-115; quaternion convention of quaternion.py:41-51)
+//   rmb_rigid_preconditioner_device   per body: M_b = L L^T, L^-1, M_b^-1, N = (K^T M_b^-1 K)^-1 and the four blocks of
+//                                     [[M_b, -K], [-K^T, 0]]^-1 (multi_bodies.py:516-531 builds L and N once per step,
+//                                     :548-560 applies them); one wavefront per body, everything in LDS.
+#include "rmb_internal.h"
+
+#include <cmath>
+
+namespace rmbi {
+namespace {
+
+struct ConfigArgs {
+  long n_bodies, n_b;
+  const double* ref;    // (n_bodies, n_b, 3)
+  const double* loc;    // (n_bodies, 3)
+  const double* quat;   // (n_bodies, 4) as (s, p1, p2, p3)
+  double* r;            // (n_bodies n_b, 3)
+  double* rel;          // (n_bodies, n_b, 3) or null
+  double* K;            // (n_bodies, 3 n_b, 6) or null
+};
+
+__global__ __launch_bounds__(256) void rigid_config_kernel(const ConfigArgs a) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= a.n_bodies * a.n_b) return;
+  const long b = id / a.n_b;
+  const double s = a.quat[4 * b], p0 = a.quat[4 * b + 1], p1 = a.quat[4 * b + 2], p2 = a.quat[4 * b + 3];
+  const double d = s * s - 0.5;
+  const double x = a.ref[3 * id], y = a.ref[3 * id + 1], z = a.ref[3 * id + 2];
+  // R = 2 [[p0 p0 + d, p0 p1 - s p2, p0 p2 + s p1], [p1 p0 + s p2, p1 p1 + d, p1 p2 - s p0], [p2 p0 - s p1, p2 p1 + s p0, p2 p2 + d]]
+  const double rx = 2.0 * ((p0 * p0 + d) * x + (p0 * p1 - s * p2) * y + (p0 * p2 + s * p1) * z);
+  const double ry = 2.0 * ((p1 * p0 + s * p2) * x + (p1 * p1 + d) * y + (p1 * p2 - s * p0) * z);
+  const double rz = 2.0 * ((p2 * p0 - s * p1) * x + (p2 * p1 + s * p0) * y + (p2 * p2 + d) * z);
+  a.r[3 * id] = rx + a.loc[3 * b]; a.r[3 * id + 1] = ry + a.loc[3 * b + 1]; a.r[3 * id + 2] = rz + a.loc[3 * b + 2];
+  if (a.rel) { a.rel[3 * id] = rx; a.rel[3 * id + 1] = ry; a.rel[3 * id + 2] = rz; }
+  if (a.K) {
+    double* k = a.K + 18 * id;     // rows 3 l .. 3 l + 2 of body b: 18 consecutive doubles
+    k[0] = 1.0; k[1] = 0.0; k[2] = 0.0; k[3] = 0.0;  k[4] = rz;   k[5] = -ry;
+    k[6] = 0.0; k[7] = 1.0; k[8] = 0.0; k[9] = -rz;  k[10] = 0.0; k[11] = rx;
+    k[12] = 0.0; k[13] = 0.0; k[14] = 1.0; k[15] = ry; k[16] = -rx; k[17] = 0.0;
+  }
+}
+
+constexpr int kPcMaxN = 48;       // 3 n_b: two n x n LDS matrices + the n x 6 panels fit the default 64 KB of dynamic LDS
+
+struct PcArgs {
+  long n_bodies;
+  int n;                // 3 n_b
+  const double* Mb;     // (n_bodies, n, n)
+  const double* K;      // (n_bodies, n, 6)
+  double *Lchol, *Linv, *Minv, *Nbody, *A11, *A12, *A21, *A22;
+  int* info;
+};
+
+// One wavefront per body; thread t owns row t (n <= 48 < 64).
+__global__ __launch_bounds__(64) void rigid_pc_kernel(const PcArgs a) {
+  extern __shared__ double lds[];
+  const int n = a.n, t = threadIdx.x;
+  const long b = blockIdx.x;
+  double* A = lds;                 // M_b -> L (lower) -> M_b^-1
+  double* B = A + n * n;           // L^-1
+  double* Kl = B + n * n;          // n x 6
+  double* MK = Kl + n * 6;         // M_b^-1 K
+  double* A12l = MK + n * 6;       // -M_b^-1 K N
+  double* R = A12l + n * 6;        // 6 x 6: K^T M_b^-1 K
+  double* Nl = R + 36;             // 6 x 6: its inverse
+  __shared__ int bad;
+  if (t == 0) bad = 0;
+  const double* M = a.Mb + b * (long)n * n;
+  for (int idx = t; idx < n * n; idx += 64) {
+    const int i = idx / n, j = idx - i * n;
+    A[idx] = 0.5 * (M[idx] + M[j * n + i]);
+  }
+  for (int idx = t; idx < n * 6; idx += 64) Kl[idx] = a.K[b * (long)n * 6 + idx];
+  __syncthreads();
+  // ---- Cholesky, right-looking, lower ----
+  for (int k = 0; k < n; ++k) {
+    if (t == k) {
+      const double piv = A[k * n + k];
+      if (!(piv > 0.0)) bad = 1;
+      A[k * n + k] = sqrt(piv);
+    }
+    __syncthreads();
+    if (t > k && t < n) A[t * n + k] /= A[k * n + k];
+    __syncthreads();
+    if (t > k && t < n) {
+      const double lik = A[t * n + k];
+      for (int j = k + 1; j <= t; ++j) A[t * n + j] -= lik * A[j * n + k];
+    }
+    __syncthreads();
+  }
+  if (t < n) {
+    double* Lg = a.Lchol + b * (long)n * n + (long)t * n;
+    for (int j = 0; j < n; ++j) Lg[j] = j <= t ? A[t * n + j] : 0.0;
+  }
+  // ---- L^-1: thread c solves L x = e_c (forward substitution down its own column) ----
+  if (t < n) {
+    const int c = t;
+    for (int i = 0; i < c; ++i) B[i * n + c] = 0.0;
+    for (int i = c; i < n; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= A[i * n + k] * B[k * n + c];
+      B[i * n + c] = s / A[i * n + i];
+    }
+  }
+  __syncthreads();
+  if (t < n) {
+    double* Lig = a.Linv + b * (long)n * n + (long)t * n;
+    for (int j = 0; j < n; ++j) Lig[j] = B[t * n + j];
+  }
+  __syncthreads();     // every row of L has been written out and every column of L^-1 exists: A is free
+  // ---- M_b^-1 = L^-T L^-1 (symmetric term by term) ----
+  if (t < n) {
+    for (int j = 0; j < n; ++j) {
+      double s = 0.0;
+      for (int k = (t > j ? t : j); k < n; ++k) s += B[k * n + t] * B[k * n + j];
+      A[t * n + j] = s;
+    }
+    double* Mig = a.Minv + b * (long)n * n + (long)t * n;
+    for (int j = 0; j < n; ++j) Mig[j] = A[t * n + j];
+  }
+  __syncthreads();
+  if (t < n) {
+    for (int c = 0; c < 6; ++c) {
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += A[t * n + j] * Kl[j * 6 + c];
+      MK[t * 6 + c] = s;
+    }
+  }
+  __syncthreads();
+  if (t < 36) {
+    const int p = t / 6, q = t - 6 * p;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += Kl[i * 6 + p] * MK[i * 6 + q];
+    R[t] = s;
+  }
+  __syncthreads();
+  // ---- N = R^-1: Gauss-Jordan with partial pivoting on [R | I], one thread (216 multiply-adds) ----
+  if (t == 0) {
+    double w[6][12];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) { w[i][j] = R[i * 6 + j]; w[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; ++c) {
+      int piv = c;
+      for (int i = c + 1; i < 6; ++i) if (fabs(w[i][c]) > fabs(w[piv][c])) piv = i;
+      if (piv != c) for (int j = 0; j < 12; ++j) { const double tmp = w[c][j]; w[c][j] = w[piv][j]; w[piv][j] = tmp; }
+      const double dgl = w[c][c];
+      if (!(fabs(dgl) > 0.0)) { bad = 1; continue; }
+      const double inv = 1.0 / dgl;
+      for (int j = 0; j < 12; ++j) w[c][j] *= inv;
+      for (int i = 0; i < 6; ++i) {
+        if (i == c) continue;
+        const double f = w[i][c];
+        for (int j = 0; j < 12; ++j) w[i][j] -= f * w[c][j];
+      }
+    }
+    // residual of the inverse: a rank-deficient resistance (single blobs, collinear rods) must take the pseudo-inverse
+    // route of the caller (multi_bodies.py:531 uses pinv)
+    double worst = 0.0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 6; ++k) s += R[i * 6 + k] * w[k][6 + j];
+        const double e = fabs(s - (i == j ? 1.0 : 0.0));
+        if (!(e <= worst)) worst = e;       // NaN-propagating maximum
+      }
+    if (!(worst < 1e-8)) bad = 1;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) Nl[i * 6 + j] = 0.5 * (w[i][6 + j] + w[j][6 + i]);
+  }
+  __syncthreads();
+  if (t < 36) {
+    a.Nbody[b * 36 + t] = Nl[t];
+    a.A22[b * 36 + t] = -Nl[t];
+  }
+  // ---- A12 = -M_b^-1 K N,  A21 = A12^T,  A11 = M_b^-1 + A12 (M_b^-1 K)^T ----
+  if (t < n) {
+    for (int c = 0; c < 6; ++c) {
+      double s = 0.0;
+      for (int k = 0; k < 6; ++k) s += MK[t * 6 + k] * Nl[k * 6 + c];
+      A12l[t * 6 + c] = -s;
+      a.A12[b * (long)n * 6 + t * 6 + c] = -s;
+      a.A21[b * (long)n * 6 + (long)c * n + t] = -s;
+    }
+  }
+  __syncthreads();
+  if (t < n) {
+    double* A11g = a.A11 + b * (long)n * n + (long)t * n;
+    for (int j = 0; j < n; ++j) {
+      double s = A[t * n + j];
+      for (int c = 0; c < 6; ++c) s += A12l[t * 6 + c] * MK[j * 6 + c];
+      A11g[j] = s;
+    }
+  }
+  if (t == 0 && bad) atomicOr(a.info, 1);
+}
+
+}  // namespace
+}  // namespace rmbi
+
+using namespace rmbi;
+
+extern "C" {
+
+int rmb_rigid_configuration_device(rmb_ctx* c, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
+                                   const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n_bodies < 0 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_configuration_device: bad n_bodies / blobs per body");
+  if (n_bodies == 0) return 0;
+  if (!ref_dev || !loc_dev || !quat_dev || !r_dev) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  ConfigArgs a{n_bodies, n_b, ref_dev, loc_dev, quat_dev, r_dev, rel_dev, K_dev};
+  const long total = n_bodies * n_b;
+  hipLaunchKernelGGL(rigid_config_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+int rmb_rigid_preconditioner_device(rmb_ctx* c, long n_bodies, long n_b, const double* Mb_dev, const double* K_dev, double* Lchol_dev,
+                                    double* Linv_dev, double* Minv_dev, double* Nbody_dev, double* A11_dev, double* A12_dev,
+                                    double* A21_dev, double* A22_dev, int* info_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n_bodies < 0 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_preconditioner_device: bad n_bodies / blobs per body");
+  if (3 * n_b > kPcMaxN) return fail(RMB_ERR_ARG, "rmb_rigid_preconditioner_device: at most 16 blobs per body (the factors of one body are kept in LDS)");
+  if (n_bodies == 0) return 0;
+  if (!Mb_dev || !K_dev || !Lchol_dev || !Linv_dev || !Minv_dev || !Nbody_dev || !A11_dev || !A12_dev || !A21_dev || !A22_dev || !info_dev)
+    return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  PcArgs a;
+  a.n_bodies = n_bodies; a.n = (int)(3 * n_b);
+  a.Mb = Mb_dev; a.K = K_dev; a.Lchol = Lchol_dev; a.Linv = Linv_dev; a.Minv = Minv_dev; a.Nbody = Nbody_dev;
+  a.A11 = A11_dev; a.A12 = A12_dev; a.A21 = A21_dev; a.A22 = A22_dev; a.info = info_dev;
+  RMB_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
+  const size_t lds = ((size_t)2 * a.n * a.n + (size_t)18 * a.n + 72) * sizeof(double);
+  hipLaunchKernelGGL(rigid_pc_kernel, dim3((unsigned)n_bodies), dim3(64), lds, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ with numpy + scipy on the host, here with every vector resident in HBM:
 
 PyTorch is used for device memory and batched small dense algebra only.
 """
+import gc
 import math
 import os
 
@@ -157,6 +158,10 @@ class RigidSuspension(object):
     also returns the per-group body-frame offsets.  Does not touch the bound configuration."""
     loc, quat = self._as_dev(locations, 3), self._as_dev(quaternions, 4)
     r = torch.empty((self.n_blobs, 3), dtype=torch.float64, device=self.device)
+    if len(self.groups) == 1 and self._native_blocks():
+      rel = torch.empty((self.n_bodies, self.groups[0].n_b, 3), dtype=torch.float64, device=self.device)
+      self.ctx.rigid_configuration_device(self.groups[0].ref, loc.contiguous(), quat.contiguous(), r, rel)
+      return r, [rel]
     rels = []
     for g in self.groups:
       R = quaternion_rotation_matrix_torch(quat[g.body_idx])
@@ -170,6 +175,17 @@ class RigidSuspension(object):
     context's packed positions.  The preconditioner is NOT touched (the reference also keeps the one built at time
     level n for the other solves of a step); call build_preconditioner() to refresh it."""
     self.location, self.orientation = self._as_dev(locations, 3).clone(), self._as_dev(quaternions, 4).clone()
+    if len(self.groups) == 1 and self._native_blocks():
+      # one launch: blob coordinates, body-frame offsets and K (rmb_rigid_configuration_device), into storage that stays
+      g = self.groups[0]
+      if g.K is None or getattr(self, "_r_buf", None) is None:
+        self._r_buf = torch.empty((self.n_blobs, 3), dtype=torch.float64, device=self.device)
+        g.rel = torch.empty((self.n_bodies, g.n_b, 3), dtype=torch.float64, device=self.device)
+        g.K = torch.empty((self.n_bodies, 3 * g.n_b, 6), dtype=torch.float64, device=self.device)
+      self.ctx.rigid_configuration_device(g.ref, self.location, self.orientation, self._r_buf, g.rel, g.K)
+      self.r_dev = self._r_buf.view(-1)
+      self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
+      return
     r, rels = self.blob_positions_device(self.location, self.orientation)
     for g, rel in zip(self.groups, rels):
       g.rel = rel
@@ -190,6 +206,10 @@ class RigidSuspension(object):
     return self.r_dev.detach().cpu().numpy().reshape(-1, 3)
 
   def close(self):
+    ws = getattr(self, "_arnoldi_ws", None)
+    if ws is not None:
+      ws.release()
+      self._arnoldi_ws = None
     if self._own_ctx:
       self.ctx.close()
 
@@ -345,6 +365,8 @@ class RigidSuspension(object):
     """Per body: M_b (dense, device kernel), Cholesky, N_b = (K^T M_b^-1 K)^-1 (multi_bodies.py:516-531)."""
     for g in self.groups:
       Mb = self.ctx.body_mobility_dense_device(g.first_blob, g.n_b, self.eta)
+      if self._native_pc(g, Mb):
+        continue
       Mb = 0.5 * (Mb + Mb.transpose(1, 2))
       g.Lchol = torch.linalg.cholesky(Mb)
       # explicit inverse, as the reference stores it (mobility_inv_blobs, multi_bodies.py:524): applying
@@ -382,6 +404,37 @@ class RigidSuspension(object):
     if self.device.type == "cuda":
       torch.cuda.synchronize(self.device)
     return self
+
+  def _native_pc(self, g, Mb):
+    """The factors and blocks of group g in one launch (rmb_rigid_preconditioner_device, up to 16 blobs per body, all
+    bodies free).  False = not applicable, or a body's 6 x 6 resistance has no accurate inverse (single blobs, collinear
+    rods: the pseudo-inverse route of the torch path below, remembered for the group)."""
+    if (self.free is not None or 3 * g.n_b > 48 or not self._native_blocks()
+        or any(g is r for r in getattr(self, "_native_pc_rejected", ()))):
+      return False
+    nb, n = Mb.shape[0], 3 * g.n_b
+    shapes = dict(Lchol=(nb, n, n), Linv=(nb, n, n), Minv=(nb, n, n), Nbody=(nb, 6, 6), A11=(nb, n, n), A12=(nb, n, 6),
+                  A21=(nb, 6, n), A22=(nb, 6, 6))
+    fresh = {}
+    for name, shape in shapes.items():
+      cur = getattr(g, name)
+      fresh[name] = cur if (cur is not None and tuple(cur.shape) == shape and cur.is_contiguous()) else \
+          torch.empty(shape, dtype=torch.float64, device=self.device)
+    info = getattr(self, "_pc_info", None)
+    if info is None:
+      info = self._pc_info = torch.zeros(1, dtype=torch.int32, device=self.device)
+    self.ctx.rigid_preconditioner_device(Mb.contiguous(), g.K, *[fresh[k] for k in ("Lchol", "Linv", "Minv", "Nbody", "A11", "A12", "A21", "A22")],
+                                         info)
+    if int(info) != 0:
+      self._native_pc_rejected = tuple(getattr(self, "_native_pc_rejected", ())) + (g,)
+      return False
+    for name, t in fresh.items():
+      setattr(g, name, t)
+    if g.K_pc is not None and g.K_pc.shape == g.K.shape:
+      g.K_pc.copy_(g.K)
+    else:
+      g.K_pc = g.K.clone()
+    return True
 
   def apply_preconditioner(self, x):
     """Solve every body alone (multi_bodies.py:548-560):
@@ -742,10 +795,14 @@ class _ArnoldiGraphs(object):
 
   def bind(self, signature):
     if signature != self.signature:
-      self.graphs.clear()
-      self.seen.clear()
+      self.release()
       self.signature = signature
-      self.solves = 0
+
+  def release(self):
+    """Destroy the graphs now (a safe point: nothing is capturing) rather than whenever the collector finds them."""
+    self.graphs.clear()
+    self.seen.clear()
+    self.solves = 0
 
   def begin_solve(self):
     self.solves += 1
@@ -760,11 +817,19 @@ class _ArnoldiGraphs(object):
         return
       g = torch.cuda.CUDAGraph()
       torch.cuda.synchronize(self.device)
-      g.capture_begin(capture_error_mode="thread_local")
+      # No cyclic garbage collection while the stream is capturing: collecting a dead CUDAGraph (another suspension's,
+      # say) calls hipGraphDestroy, which HIP refuses during a capture -- and the refusal surfaces in a destructor.
+      gc_was_on = gc.isenabled()
+      gc.disable()
       try:
-        body()                                   # enqueues nothing: recorded into the graph (the owner counts it)
+        g.capture_begin(capture_error_mode="thread_local")
+        try:
+          body()                                 # enqueues nothing: recorded into the graph (the owner counts it)
+        finally:
+          g.capture_end()
       finally:
-        g.capture_end()
+        if gc_was_on:
+          gc.enable()
       self.graphs[j] = g
       self.captures += 1
     elif on_replay is not None:

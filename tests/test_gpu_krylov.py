@@ -105,3 +105,142 @@ def test_helper_argument_checks():
       ctx.block_apply_device(None, None, None, None, x1, x2, y, y.clone())   # operand of one entry does not fit LDS
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("nb,n_b", [(1, 1), (3, 2), (5, 12), (300, 12), (7, 16), (2048, 12), (4, 7)])
+def test_rigid_configuration_kernel_matches_the_body_formulas(nb, n_b):
+  """Blob coordinates, body-frame offsets and K of body/body.py:64-115 in one launch, against the numpy formulas
+  (rigid.blob_positions / quaternion_rotation_matrix, the rot matrix written out)."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  from rigidmultiblobswall_amd.rigid import blob_positions
+  rng = np.random.RandomState(nb + n_b)
+  ref = rng.randn(nb, n_b, 3)
+  loc = rng.randn(nb, 3) * 3
+  quat = rng.randn(nb, 4)
+  quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+  dev = lambda x: torch.as_tensor(x, device="cuda")
+  r = torch.empty((nb * n_b, 3), dtype=torch.float64, device="cuda")
+  rel = torch.empty((nb, n_b, 3), dtype=torch.float64, device="cuda")
+  K = torch.full((nb, 3 * n_b, 6), float("nan"), dtype=torch.float64, device="cuda")       # every entry must be written
+  ctx = MobilityContext(0)
+  try:
+    ctx.rigid_configuration_device(dev(ref), dev(loc), dev(quat), r, rel, K)
+    r_ref = np.concatenate([blob_positions(ref[b], loc[b], quat[b]) for b in range(nb)])
+    assert np.abs(r.cpu().numpy() - r_ref).max() < 1e-13
+    rel_ref = r_ref.reshape(nb, n_b, 3) - loc[:, None, :]
+    assert np.abs(rel.cpu().numpy() - rel_ref).max() < 1e-13
+    K_ref = np.zeros((nb, n_b, 3, 6))
+    K_ref[:, :, 0, 0] = K_ref[:, :, 1, 1] = K_ref[:, :, 2, 2] = 1.0
+    K_ref[:, :, 0, 4] = rel_ref[:, :, 2];  K_ref[:, :, 0, 5] = -rel_ref[:, :, 1]
+    K_ref[:, :, 1, 3] = -rel_ref[:, :, 2]; K_ref[:, :, 1, 5] = rel_ref[:, :, 0]
+    K_ref[:, :, 2, 3] = rel_ref[:, :, 1];  K_ref[:, :, 2, 4] = -rel_ref[:, :, 0]
+    assert np.abs(K.cpu().numpy() - K_ref.reshape(nb, 3 * n_b, 6)).max() < 1e-13
+    # outputs that are not wanted may be left out
+    r2 = torch.empty_like(r)
+    ctx.rigid_configuration_device(dev(ref), dev(loc), dev(quat), r2)
+    assert torch.equal(r2, r)
+  finally:
+    ctx.close()
+
+
+@pytest.mark.parametrize("nb,n_b", [(1, 3), (5, 12), (300, 12), (9, 16), (2048, 12), (6, 4)])
+def test_rigid_preconditioner_kernel_matches_dense_linear_algebra(nb, n_b):
+  """Per-body Cholesky factor, its inverse, M^-1, N = (K^T M^-1 K)^-1 and the four blocks of [[M, -K], [-K^T, 0]]^-1
+  (multi_bodies.py:516-560) against numpy on every body -- the blocks checked by what they must satisfy."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  rng = np.random.RandomState(nb * 7 + n_b)
+  n = 3 * n_b
+  G = rng.randn(nb, n, n)
+  Mb = G @ G.transpose(0, 2, 1) / n + 0.5 * np.eye(n)          # SPD, condition number O(10)
+  rel = rng.randn(nb, n_b, 3)
+  K = np.zeros((nb, n_b, 3, 6))
+  K[:, :, 0, 0] = K[:, :, 1, 1] = K[:, :, 2, 2] = 1.0
+  K[:, :, 0, 4] = rel[:, :, 2];  K[:, :, 0, 5] = -rel[:, :, 1]
+  K[:, :, 1, 3] = -rel[:, :, 2]; K[:, :, 1, 5] = rel[:, :, 0]
+  K[:, :, 2, 3] = rel[:, :, 1];  K[:, :, 2, 4] = -rel[:, :, 0]
+  K = K.reshape(nb, n, 6)
+  dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+  mk = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device="cuda")
+  out = dict(Lchol=mk(nb, n, n), Linv=mk(nb, n, n), Minv=mk(nb, n, n), Nbody=mk(nb, 6, 6), A11=mk(nb, n, n), A12=mk(nb, n, 6),
+             A21=mk(nb, 6, n), A22=mk(nb, 6, 6))
+  info = torch.ones(1, dtype=torch.int32, device="cuda")
+  ctx = MobilityContext(0)
+  try:
+    # a slightly unsymmetric input: the kernel symmetrises on load, like the torch path
+    skew = 1e-13 * rng.randn(nb, n, n)
+    ctx.rigid_preconditioner_device(dev(Mb + skew - skew.transpose(0, 2, 1)), dev(K), *out.values(), info)
+    assert int(info) == 0
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    L = np.linalg.cholesky(Mb)
+    assert np.abs(o["Lchol"] - L).max() < 1e-12 and np.abs(np.triu(o["Lchol"], 1)).max() == 0.0
+    eye = np.eye(n)
+    assert np.abs(o["Linv"] @ L - eye).max() < 1e-11
+    assert np.abs(o["Minv"] @ Mb - eye).max() < 1e-10 and np.abs(o["Minv"] - o["Minv"].transpose(0, 2, 1)).max() == 0.0
+    Rres = K.transpose(0, 2, 1) @ np.linalg.solve(Mb, K)
+    assert np.abs(o["Nbody"] @ Rres - np.eye(6)).max() < 1e-9 and np.abs(o["Nbody"] - o["Nbody"].transpose(0, 2, 1)).max() == 0.0
+    # the blocks ARE the inverse of the saddle-point matrix of one body
+    S = np.zeros((nb, n + 6, n + 6))
+    S[:, :n, :n] = Mb; S[:, :n, n:] = -K; S[:, n:, :n] = -K.transpose(0, 2, 1)
+    P = np.zeros_like(S)
+    P[:, :n, :n] = o["A11"]; P[:, :n, n:] = o["A12"]; P[:, n:, :n] = o["A21"]; P[:, n:, n:] = o["A22"]
+    assert np.abs(P @ S - np.eye(n + 6)).max() < 1e-8
+    assert np.abs(o["A21"] - o["A12"].transpose(0, 2, 1)).max() == 0.0
+    # a body whose resistance has no inverse (all blobs at the tracking point: K^T M^-1 K is rank 3): flagged
+    K_bad = K.copy(); K_bad[0, :, 3:] = 0.0
+    ctx.rigid_preconditioner_device(dev(Mb), dev(K_bad), *out.values(), info)
+    assert int(info) == 1
+    # and a matrix that is not positive definite
+    Mb_bad = Mb.copy(); Mb_bad[-1] = -Mb_bad[-1]
+    ctx.rigid_preconditioner_device(dev(Mb_bad), dev(K), *out.values(), info)
+    assert int(info) == 1
+    ctx.rigid_preconditioner_device(dev(Mb), dev(K), *out.values(), info)
+    assert int(info) == 0                                        # the flag is reset by every call
+  finally:
+    ctx.close()
+
+
+def test_native_preconditioner_equals_the_torch_build_and_single_blobs_take_the_pseudo_inverse():
+  """RigidSuspension.build_preconditioner through the kernel against native_helpers = False (batched torch.linalg): same
+  factors and blocks to rounding; a suspension of single-blob bodies (rank-3 resistance) is flagged by the kernel once
+  and keeps the reference's pseudo-inverse route."""
+  import torch
+  from rigidmultiblobswall_amd import structures as st
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  R, eta = 1.0155, 0.957e-3
+  shell = st.icosahedron_shell(0.792079207921 * R)
+  a = st.min_blob_separation(shell) / 2
+  nb = 50
+  loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=3)
+  nat = RigidSuspension([shell] * nb, loc, quat, a, eta, device="cuda:0")
+  ref = RigidSuspension([shell] * nb, loc, quat, a, eta, device="cuda:0")
+  ref.native_helpers = False
+  try:
+    ref.set_configuration(loc, quat)
+    assert rel_err(nat.r_vectors, ref.r_vectors) < 1e-14
+    assert rel_err(nat.groups[0].K.cpu().numpy(), ref.groups[0].K.cpu().numpy()) < 1e-14
+    nat.build_preconditioner(); ref.build_preconditioner()
+    assert nat.groups[0].Linv is not None and ref.groups[0].Linv is None
+    for name, tol in (("Lchol", 1e-12), ("Minv", 1e-10), ("Nbody", 1e-10), ("A11", 1e-10), ("A12", 1e-10), ("A21", 1e-10), ("A22", 1e-10)):
+      assert rel_err(getattr(nat.groups[0], name).cpu().numpy(), getattr(ref.groups[0], name).cpu().numpy()) < tol, name
+    ref._stochastic_factors()
+    assert rel_err(nat.groups[0].Linv.cpu().numpy(), ref.groups[0].Linv.cpu().numpy()) < 1e-11
+  finally:
+    nat.close(); ref.close()
+  one = np.zeros((1, 3))
+  loc1 = np.random.RandomState(0).rand(30, 3) * 8 + np.array([0, 0, 1.5])
+  quat1 = np.tile([1.0, 0, 0, 0], (30, 1))
+  s1 = RigidSuspension([one] * 30, loc1, quat1, 0.5, 1.0, device="cuda:0")
+  s2 = RigidSuspension([one] * 30, loc1, quat1, 0.5, 1.0, device="cuda:0")
+  s2.native_helpers = False
+  try:
+    s1.build_preconditioner(); s2.build_preconditioner()
+    assert len(s1._native_pc_rejected) == 1
+    assert rel_err(s1.groups[0].Nbody.cpu().numpy(), s2.groups[0].Nbody.cpu().numpy()) < 1e-12
+    FT = np.zeros((30, 6)); FT[:, 2] = -1.0
+    U1, _, i1 = s1.solve_mobility_problem(force_torque=FT, tol=1e-10)
+    U2, _, i2 = s2.solve_mobility_problem(force_torque=FT, tol=1e-10)
+    assert i1["converged"] and rel_err(U1[:, :3], U2[:, :3]) < 1e-8
+  finally:
+    s1.close(); s2.close()

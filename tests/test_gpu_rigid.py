@@ -394,3 +394,24 @@ def test_captured_arnoldi_iterations_with_mixed_shapes_and_prescribed_bodies():
   finally:
     eager.close()
     graphed.close()
+
+
+def test_capture_survives_garbage_from_an_earlier_suspension():
+  """A suspension that is dropped WITHOUT close() leaves its captured graphs to the cyclic collector; if that runs while
+  another suspension captures, hipGraphDestroy is refused mid-capture and the process aborts in a destructor (seen in
+  tools/experiments/exp_small_deck_step.py).  Captures therefore run with the collector paused."""
+  import gc
+  import torch
+  rng = np.random.RandomState(0)
+  for round_ in range(3):
+    s, _, _ = _shell_suspension(6, seed=round_)
+    s.gmres_graph = True
+    s._self_cycle = s                       # make it cyclic garbage on purpose, graphs alive, never closed
+    for k in range(4):
+      x, info = s.solve(torch.as_tensor(rng.randn(s.size), device="cuda:0"), tol=1e-9)
+    assert info["graph_replays"] > 0
+    del s
+    gc.set_threshold(1)                     # collect at every opportunity during the next round's captures
+  gc.set_threshold(700, 10, 10)
+  gc.collect()
+  torch.cuda.synchronize()
