@@ -246,9 +246,17 @@ int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, lon
  * (multi_bodies/multi_bodies.py:516-531 builds L and N, :548-560 applies them).  *info_dev (one int, device) is set to
  * 0 and then to 1 by any body whose Mb is not positive definite or whose 6 x 6 resistance K^T Mb^-1 K has no accurate
  * inverse (single blobs, collinear rods: the reference takes the pseudo-inverse there, the caller must too).
- * n_b <= 16 (one wavefront per body, the factors of a body live in LDS). */
+ * n_b <= 16 (one wavefront per body, the factors of a body live in LDS).
+ *
+ * rmb_rigid_advance_device: loc_out = loc + U[:, 0:3] dt, quat_out = quaternion(U[:, 3:6] dt) * quat for every body
+ * (quaternion_integrator/quaternion_integrator_multi_bodies.py:86-91; quaternion.py:17-39: the rotation quaternion is
+ * (cos |phi|/2, sin(|phi|/2) phi / |phi|), multiplied from the LEFT).  U (n_bodies, 6); dt_body_dev: NULL, or one step
+ * per body that replaces dt (the random finite difference scales the displacement by the body length).  Outputs may
+ * alias the inputs. */
 int rmb_rigid_configuration_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
                                    const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev);
+int rmb_rigid_advance_device(rmb_ctx* ctx, long n_bodies, const double* loc_dev, const double* quat_dev, const double* U_dev,
+                             double dt, const double* dt_body_dev, double* loc_out_dev, double* quat_out_dev);
 int rmb_rigid_preconditioner_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Mb_dev, const double* K_dev,
                                     double* Lchol_dev, double* Linv_dev, double* Minv_dev, double* Nbody_dev, double* A11_dev,
                                     double* A12_dev, double* A21_dev, double* A22_dev, int* info_dev);

@@ -45,6 +45,7 @@ SYMBOLS = {
                                                    ctypes.c_long]),
     "rmb_body_mobility_dense_device": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_double, _vp]),
     "rmb_rigid_configuration_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rmb_rigid_advance_device": (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _vp]),
     "rmb_rigid_preconditioner_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long] + [_vp] * 11),
     "rmb_block_apply_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _vp, _vp,
                                               _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, ctypes.c_double, _vp]),

@@ -269,6 +269,23 @@ class MobilityContext(object):
     self._follow_torch_stream()
     _lib.check(self._lib.rmb_rigid_configuration_device(self._h, nb, n_b, p(ref), p(loc), p(quat), p(r), p(rel), p(K)))
 
+  def rigid_advance_device(self, loc, quat, U, dt):
+    """(loc + U[:, :3] dt, quaternion(U[:, 3:] dt) * quat) as new tensors, one launch (rmb_rigid_advance_device).
+    dt: a float, or a per-body (nb,) / (nb, 1) tensor."""
+    import torch
+    nb = loc.shape[0]
+    U = U.reshape(nb, 6)
+    assert loc.is_contiguous() and quat.is_contiguous() and U.is_contiguous()
+    per_body = dt.reshape(-1).contiguous() if isinstance(dt, torch.Tensor) else None
+    assert per_body is None or per_body.numel() == nb
+    loc_out, quat_out = torch.empty_like(loc), torch.empty_like(quat)
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_advance_device(self._h, nb, ctypes.c_void_p(loc.data_ptr()), ctypes.c_void_p(quat.data_ptr()),
+                                                  ctypes.c_void_p(U.data_ptr()), 0.0 if per_body is not None else float(dt),
+                                                  ctypes.c_void_p(per_body.data_ptr()) if per_body is not None else None,
+                                                  ctypes.c_void_p(loc_out.data_ptr()), ctypes.c_void_p(quat_out.data_ptr())))
+    return loc_out, quat_out
+
   def rigid_preconditioner_device(self, Mb, K, Lchol, Linv, Minv, Nbody, A11, A12, A21, A22, info):
     """Per-body Cholesky factor, inverses and the preconditioner's four blocks in one launch
     (rmb_rigid_preconditioner_device).  Mb (nb, n, n), K (nb, n, 6), outputs contiguous; info: int32 tensor of one entry."""

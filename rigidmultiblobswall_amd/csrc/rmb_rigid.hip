@@ -6,6 +6,7 @@
 //
 //   rmb_rigid_configuration_device    blob coordinates r = R(q) ref + x, body-frame offsets and K = [I, -(rel x)] of every
 //                                     body (body/body.py:64-115; quaternion convention of quaternion.py:41-51)
+//   rmb_rigid_advance_device          x + v dt, quaternion(omega dt) * q for every body (quaternion_integrator_multi_bodies.py:86-91)
 //   rmb_rigid_preconditioner_device   per body: M_b = L L^T, L^-1, M_b^-1, N = (K^T M_b^-1 K)^-1 and the four blocks of
 //                                     [[M_b, -K], [-K^T, 0]]^-1 (multi_bodies.py:516-531 builds L and N once per step,
 //                                     :548-560 applies them); one wavefront per body, everything in LDS.
@@ -45,6 +46,34 @@ __global__ __launch_bounds__(256) void rigid_config_kernel(const ConfigArgs a) {
     k[6] = 0.0; k[7] = 1.0; k[8] = 0.0; k[9] = -rz;  k[10] = 0.0; k[11] = rx;
     k[12] = 0.0; k[13] = 0.0; k[14] = 1.0; k[15] = ry; k[16] = -rx; k[17] = 0.0;
   }
+}
+
+struct AdvanceArgs {
+  long n_bodies;
+  const double *loc, *quat, *U;
+  const double* dt_body;     // per-body step or null
+  double dt;
+  double *loc_out, *quat_out;
+};
+
+// x + v dt and quaternion(omega dt) * q (quaternion_integrator_multi_bodies.py:86-91; quaternion.py:17-39)
+__global__ __launch_bounds__(256) void rigid_advance_kernel(const AdvanceArgs a) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.n_bodies) return;
+  const double dt = a.dt_body ? a.dt_body[b] : a.dt;
+  const double* u = a.U + 6 * b;
+  a.loc_out[3 * b] = a.loc[3 * b] + u[0] * dt;
+  a.loc_out[3 * b + 1] = a.loc[3 * b + 1] + u[1] * dt;
+  a.loc_out[3 * b + 2] = a.loc[3 * b + 2] + u[2] * dt;
+  const double px = u[3] * dt, py = u[4] * dt, pz = u[5] * dt;
+  const double nrm = sqrt(px * px + py * py + pz * pz);
+  const double qs = cos(0.5 * nrm), f = nrm > 0.0 ? sin(0.5 * nrm) / nrm : 0.0;
+  const double qx = f * px, qy = f * py, qz = f * pz;
+  const double rs = a.quat[4 * b], rx = a.quat[4 * b + 1], ry = a.quat[4 * b + 2], rz = a.quat[4 * b + 3];
+  a.quat_out[4 * b] = qs * rs - (qx * rx + qy * ry + qz * rz);
+  a.quat_out[4 * b + 1] = qs * rx + rs * qx + (qy * rz - qz * ry);
+  a.quat_out[4 * b + 2] = qs * ry + rs * qy + (qz * rx - qx * rz);
+  a.quat_out[4 * b + 3] = qs * rz + rs * qz + (qx * ry - qy * rx);
 }
 
 constexpr int kPcMaxN = 48;       // 3 n_b: two n x n LDS matrices + the n x 6 panels fit the default 64 KB of dynamic LDS
@@ -218,6 +247,19 @@ int rmb_rigid_configuration_device(rmb_ctx* c, long n_bodies, long n_b, const do
   ConfigArgs a{n_bodies, n_b, ref_dev, loc_dev, quat_dev, r_dev, rel_dev, K_dev};
   const long total = n_bodies * n_b;
   hipLaunchKernelGGL(rigid_config_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+int rmb_rigid_advance_device(rmb_ctx* c, long n_bodies, const double* loc_dev, const double* quat_dev, const double* U_dev, double dt,
+                             const double* dt_body_dev, double* loc_out_dev, double* quat_out_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n_bodies < 0) return fail(RMB_ERR_ARG, "rmb_rigid_advance_device: negative n_bodies");
+  if (n_bodies == 0) return 0;
+  if (!loc_dev || !quat_dev || !U_dev || !loc_out_dev || !quat_out_dev) return fail(RMB_ERR_ARG, "null pointer");
+  RMB_HIP(hipSetDevice(c->device));
+  AdvanceArgs a{n_bodies, loc_dev, quat_dev, U_dev, dt_body_dev, dt, loc_out_dev, quat_out_dev};
+  hipLaunchKernelGGL(rigid_advance_kernel, dim3((unsigned)((n_bodies + 255) / 256)), dim3(256), 0, c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
 }

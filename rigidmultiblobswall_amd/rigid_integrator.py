@@ -180,11 +180,13 @@ class RigidIntegrator(object):
   def _move(self, location, orientation):
     self.susp.set_configuration(location, orientation)
 
-  @staticmethod
-  def _advance(location, orientation, velocities, dt):
+  def _advance(self, location, orientation, velocities, dt):
     """x + v dt and quaternion(omega dt) * q (quaternion_integrator_multi_bodies.py:86-91).  dt may be a per-body
     column for the translation (the RFD displacement is scaled by the body length)."""
     U = velocities.view(-1, 6)
+    per_body = isinstance(dt, torch.Tensor)
+    if self.susp._native_blocks() and (not per_body or dt.numel() == U.shape[0]):
+      return self.susp.ctx.rigid_advance_device(location.contiguous(), orientation.contiguous(), U.contiguous(), dt)   # one launch
     return location + U[:, 0:3] * dt, quaternion_multiply_torch(quaternion_from_rotation_torch(U[:, 3:6] * dt), orientation)
 
   def _valid(self, location, orientation):

@@ -244,3 +244,29 @@ def test_native_preconditioner_equals_the_torch_build_and_single_blobs_take_the_
     assert i1["converged"] and rel_err(U1[:, :3], U2[:, :3]) < 1e-8
   finally:
     s1.close(); s2.close()
+
+
+def test_rigid_advance_kernel_matches_the_quaternion_update():
+  """x + v dt and quaternion(omega dt) * q (quaternion_integrator_multi_bodies.py:86-91) in one launch against the torch
+  formulas of rigid.py, with a scalar step, a per-body step, and a body that does not rotate (|omega| = 0)."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  from rigidmultiblobswall_amd.rigid import quaternion_from_rotation_torch, quaternion_multiply_torch
+  g = torch.Generator().manual_seed(4)
+  nb = 777
+  loc = torch.randn(nb, 3, generator=g, dtype=torch.float64).cuda()
+  quat = torch.randn(nb, 4, generator=g, dtype=torch.float64)
+  quat = (quat / quat.norm(dim=1, keepdim=True)).cuda()
+  U = torch.randn(nb, 6, generator=g, dtype=torch.float64).cuda()
+  U[5, 3:] = 0.0
+  ctx = MobilityContext(0)
+  try:
+    for dt in (0.013, torch.rand(nb, 1, generator=g, dtype=torch.float64).cuda()):
+      l2, q2 = ctx.rigid_advance_device(loc, quat, U, dt)
+      l_ref = loc + U[:, :3] * dt
+      q_ref = quaternion_multiply_torch(quaternion_from_rotation_torch(U[:, 3:] * dt), quat)
+      assert float((l2 - l_ref).abs().max()) < 1e-14 and float((q2 - q_ref).abs().max()) < 1e-14
+      assert torch.equal(q2[5], quat[5])
+      assert float((q2.norm(dim=1) - 1).abs().max()) < 1e-14
+  finally:
+    ctx.close()
