@@ -653,7 +653,8 @@ class RigidSuspension(object):
       self.build_preconditioner()
     self._stochastic_factors()
     z, dim, _ = _prepare(z, None, self.device, None)
-    steps = _lanczos_steps(factor, tol, 1000, dim, z, print_residual, self.device, getattr(self.ctx, "sync_scalars", None))
+    steps = _lanczos_steps(factor, tol, 1000, dim, z, print_residual, self.device, getattr(self.ctx, "sync_scalars", None),
+                           ortho=self._ortho(0))
     try:
       w = next(steps)
       while True:
@@ -719,6 +720,13 @@ class RigidSuspension(object):
 
   def _blockdiag(self, x, which, transpose=False):
     out = torch.empty_like(x)
+    if len(self.groups) == 1 and self._native_blocks() and x.is_contiguous():
+      g = self.groups[0]
+      A = g.Linv if which == "Linv" else g.Lchol
+      none = x.new_empty((self.n_bodies, 0))
+      self.ctx.block_apply_device(A, None, None, None, x.view(self.n_bodies, 3 * g.n_b), none, out.view(self.n_bodies, 3 * g.n_b), none,
+                                  transpose=(bool(transpose), False, False, False))      # one launch, no gather / scatter
+      return out
     for g in self.groups:
       A = g.Linv if which == "Linv" else g.Lchol
       if transpose:
@@ -754,7 +762,7 @@ class RigidSuspension(object):
     one, _ = self._pc_mobility()
     return stochastic_forcing_lanczos(factor=factor, tolerance=tol, dim=3 * self.n_blobs, mobility_mult=one,
                                       L_mult=lambda x: self._blockdiag(x, "Lchol"), z=z, print_residual=print_residual,
-                                      device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
+                                      device=self.device, sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho(0))
 
   def stochastic_forcing_pair(self, z_a, factor_a, z_b, factor_b, tol=1e-8, print_residual=False):
     """Two forcings with the same mobility in lockstep (stochastic_forcing_lanczos_pair): one two-vector pair sweep per
@@ -766,7 +774,7 @@ class RigidSuspension(object):
     one, two = self._pc_mobility()
     return stochastic_forcing_lanczos_pair((factor_a, factor_b), (z_a, z_b), one, two, tolerance=tol,
                                            L_mult=lambda x: self._blockdiag(x, "Lchol"), print_residual=print_residual,
-                                           device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
+                                           device=self.device, sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho(0))
 
 # page-locked staging rows for the Hessenberg columns of running solves (allocated once, handed out per solve)
 _pinned_pool = []
