@@ -270,3 +270,34 @@ def test_rigid_advance_kernel_matches_the_quaternion_update():
       assert float((q2.norm(dim=1) - 1).abs().max()) < 1e-14
   finally:
     ctx.close()
+
+
+def test_lanczos_with_the_fused_step_equals_the_plain_recurrence():
+  """stochastic_forcing_lanczos with ortho = the fused orthogonalisation against the plain three-term recurrence + full
+  re-orthogonalisation: same iteration counts, the same M^{1/2} z to rounding, equal to the dense symmetric square root;
+  and an exact breakdown (z an eigenvector: |w| = 0 after one step) is survived."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  from rigidmultiblobswall_amd.stochastic import stochastic_forcing_lanczos, stochastic_forcing_eig_symm
+  rng = np.random.RandomState(3)
+  n = 900
+  Q, _ = np.linalg.qr(rng.randn(n, n))
+  lam = 10.0 ** rng.uniform(-1.5, 1.0, n)
+  M = torch.as_tensor((Q * lam) @ Q.T, device="cuda")
+  ctx = MobilityContext(0)
+  try:
+    for tol in (1e-3, 1e-8):
+      z = torch.as_tensor(rng.randn(n), device="cuda")
+      a, ia = stochastic_forcing_lanczos(factor=0.7, tolerance=tol, mobility_mult=lambda v: M @ v, z=z)
+      b, ib = stochastic_forcing_lanczos(factor=0.7, tolerance=tol, mobility_mult=lambda v: M @ v, z=z,
+                                         ortho=ctx.krylov_orthogonalize_device)
+      assert ia == ib, (tol, ia, ib)
+      assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-10
+      if tol < 1e-6:
+        ref = stochastic_forcing_eig_symm(M, factor=0.7, z=z)
+        assert rel_err(b.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    z = torch.as_tensor(Q[:, 5].copy(), device="cuda")        # eigenvector: the Krylov space is one-dimensional
+    b, ib = stochastic_forcing_lanczos(factor=1.0, tolerance=1e-8, mobility_mult=lambda v: M @ v, z=z, ortho=ctx.krylov_orthogonalize_device)
+    assert np.all(np.isfinite(b.cpu().numpy())) and rel_err(b.cpu().numpy(), np.sqrt(lam[5]) * Q[:, 5]) < 1e-7
+  finally:
+    ctx.close()
