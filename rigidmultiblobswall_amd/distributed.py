@@ -280,6 +280,12 @@ class ReplicatedContext(object):
     self.sm = sharded
     self.n = 0
 
+  @property
+  def helper_context(self):
+    """The rank's own MobilityContext, for the rank-local O(N) helper kernels of the callers (rigid.py: block products,
+    fused Gram-Schmidt, per-body geometry and factors); None for backends without one."""
+    return getattr(self.sm.backend, "ctx", None)
+
   def set_stream(self, stream_ptr):
     ctx = getattr(self.sm.backend, "ctx", None)
     if ctx is not None:

@@ -160,7 +160,7 @@ class RigidSuspension(object):
     r = torch.empty((self.n_blobs, 3), dtype=torch.float64, device=self.device)
     if len(self.groups) == 1 and self._native_blocks():
       rel = torch.empty((self.n_bodies, self.groups[0].n_b, 3), dtype=torch.float64, device=self.device)
-      self.ctx.rigid_configuration_device(self.groups[0].ref, loc.contiguous(), quat.contiguous(), r, rel)
+      self._native_blocks().rigid_configuration_device(self.groups[0].ref, loc.contiguous(), quat.contiguous(), r, rel)
       return r, [rel]
     rels = []
     for g in self.groups:
@@ -182,7 +182,7 @@ class RigidSuspension(object):
         self._r_buf = torch.empty((self.n_blobs, 3), dtype=torch.float64, device=self.device)
         g.rel = torch.empty((self.n_bodies, g.n_b, 3), dtype=torch.float64, device=self.device)
         g.K = torch.empty((self.n_bodies, 3 * g.n_b, 6), dtype=torch.float64, device=self.device)
-      self.ctx.rigid_configuration_device(g.ref, self.location, self.orientation, self._r_buf, g.rel, g.K)
+      self._native_blocks().rigid_configuration_device(g.ref, self.location, self.orientation, self._r_buf, g.rel, g.K)
       self.r_dev = self._r_buf.view(-1)
       self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
       return
@@ -296,7 +296,7 @@ class RigidSuspension(object):
         top.copy_(r)
       if self._native_blocks():
         # top -= K U and bottom = -K^T lambda in one launch (rmb_block_apply_device; K^T = K with exchanged strides)
-        self.ctx.block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.reshape(self.n_bodies, 6),
+        self._native_blocks().block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.reshape(self.n_bodies, 6),
                                     top.view(self.n_bodies, 3 * g.n_b), res[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
                                     transpose=(False, False, True, False))
         return res
@@ -331,7 +331,7 @@ class RigidSuspension(object):
       if r.data_ptr() != top.data_ptr():
         top.copy_(r)
       if self._native_blocks() and x.is_contiguous():
-        self.ctx.block_apply_device(None, g.K, g.K, None, x[:n3].view(self.n_bodies, 3 * g.n_b), x[n3:].view(self.n_bodies, 6),
+        self._native_blocks().block_apply_device(None, g.K, g.K, None, x[:n3].view(self.n_bodies, 3 * g.n_b), x[n3:].view(self.n_bodies, 6),
                                     top.view(self.n_bodies, 3 * g.n_b), row[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
                                     transpose=(False, False, True, False))
         continue
@@ -423,7 +423,7 @@ class RigidSuspension(object):
     info = getattr(self, "_pc_info", None)
     if info is None:
       info = self._pc_info = torch.zeros(1, dtype=torch.int32, device=self.device)
-    self.ctx.rigid_preconditioner_device(Mb.contiguous(), g.K, *[fresh[k] for k in ("Lchol", "Linv", "Minv", "Nbody", "A11", "A12", "A21", "A22")],
+    self._native_blocks().rigid_preconditioner_device(Mb.contiguous(), g.K, *[fresh[k] for k in ("Lchol", "Linv", "Minv", "Nbody", "A11", "A12", "A21", "A22")],
                                          info)
     if int(info) != 0:
       self._native_pc_rejected = tuple(getattr(self, "_native_pc_rejected", ())) + (g,)
@@ -449,7 +449,7 @@ class RigidSuspension(object):
       slip = x[:n3].reshape(self.n_bodies, 3 * g.n_b, 1)
       lam = out[:n3].view(self.n_bodies, 3 * g.n_b, 1)
       if self._native_blocks() and x.is_contiguous():
-        self.ctx.block_apply_device(g.A11, g.A12, g.A21, g.A22, x[:n3].view(self.n_bodies, 3 * g.n_b), F,
+        self._native_blocks().block_apply_device(g.A11, g.A12, g.A21, g.A22, x[:n3].view(self.n_bodies, 3 * g.n_b), F,
                                     out[:n3].view(self.n_bodies, 3 * g.n_b), outU)      # the four blocks in one launch
         return out
       U = outU.unsqueeze(-1)
@@ -509,14 +509,23 @@ class RigidSuspension(object):
   native_helpers = None
 
   def _native_blocks(self):
+    """The MobilityContext the helper kernels are launched through, or None (torch operations).  A plain context is its
+    own helper; a facade over several ranks (distributed.ReplicatedContext) hands out the rank's context: the helpers
+    are rank-local O(N) work on replicated vectors with fixed-order reductions, so every rank computes the same bits."""
     want = self.native_helpers
     if want is None:
       want = os.environ.get("RMB_NATIVE_HELPERS", "") != "0"
-    return bool(want) and self.device.type == "cuda" and type(self.ctx) is MobilityContext
+    if not want or self.device.type != "cuda":
+      return None
+    if type(self.ctx) is MobilityContext:
+      return self.ctx
+    h = getattr(self.ctx, "helper_context", None)
+    return h if type(h) is MobilityContext else None
 
   def _ortho(self, restart):
     """The fused Gram-Schmidt step for _gmres_steps, or None (torch operations)."""
-    return self.ctx.krylov_orthogonalize_device if self._native_blocks() and restart < 256 else None
+    h = self._native_blocks()
+    return h.krylov_orthogonalize_device if h is not None and restart < 256 else None
 
   def _count_operator(self):
     self.matvec_count += 1
@@ -541,7 +550,7 @@ class RigidSuspension(object):
     if ws is None or ws.m != restart:
       ws = self._arnoldi_ws = _ArnoldiGraphs(self.size, restart, self.device)
     ptr = lambda t: None if t is None else t.data_ptr()
-    ws.bind((self.ctx.launch_signature(), self.eta, self._native_blocks(), ptr(self.free), ptr(self.prescribed_velocity),
+    ws.bind((self.ctx.launch_signature(), self.eta, self._native_blocks() is not None, ptr(self.free), ptr(self.prescribed_velocity),
              tuple(tuple(ptr(t) for t in (g.K, g.A11, g.A12, g.A21, g.A22)) for g in self.groups)))
     return ws
 
@@ -614,7 +623,7 @@ class RigidSuspension(object):
       g = self.groups[0]
       res = torch.empty_like(x)
       res[:n3].copy_(Mlam)
-      self.ctx.block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.view(self.n_bodies, 6),
+      self._native_blocks().block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.view(self.n_bodies, 6),
                                   res[:n3].view(self.n_bodies, 3 * g.n_b), res[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
                                   transpose=(False, False, True, False))
       return res
@@ -724,7 +733,7 @@ class RigidSuspension(object):
       g = self.groups[0]
       A = g.Linv if which == "Linv" else g.Lchol
       none = x.new_empty((self.n_bodies, 0))
-      self.ctx.block_apply_device(A, None, None, None, x.view(self.n_bodies, 3 * g.n_b), none, out.view(self.n_bodies, 3 * g.n_b), none,
+      self._native_blocks().block_apply_device(A, None, None, None, x.view(self.n_bodies, 3 * g.n_b), none, out.view(self.n_bodies, 3 * g.n_b), none,
                                   transpose=(bool(transpose), False, False, False))      # one launch, no gather / scatter
       return out
     for g in self.groups:

@@ -185,8 +185,9 @@ class RigidIntegrator(object):
     column for the translation (the RFD displacement is scaled by the body length)."""
     U = velocities.view(-1, 6)
     per_body = isinstance(dt, torch.Tensor)
-    if self.susp._native_blocks() and (not per_body or dt.numel() == U.shape[0]):
-      return self.susp.ctx.rigid_advance_device(location.contiguous(), orientation.contiguous(), U.contiguous(), dt)   # one launch
+    helper = self.susp._native_blocks()
+    if helper is not None and (not per_body or dt.numel() == U.shape[0]):
+      return helper.rigid_advance_device(location.contiguous(), orientation.contiguous(), U.contiguous(), dt)   # one launch
     return location + U[:, 0:3] * dt, quaternion_multiply_torch(quaternion_from_rotation_torch(U[:, 3:6] * dt), orientation)
 
   def _valid(self, location, orientation):
