@@ -37,6 +37,8 @@ Objects on the line
                 call shape, PCIe-inclusive) -- reported beside `value`, never `value`
                 `devices` = what the call ran on (mobility.set_devices / RMB_DEVICES), `breakdown_us` = where one call's
                 time goes (position compare, upload, enqueue, sweep by HIP events, download + sync, Python)
+  small_deck_steps  one-rank run: whole time steps of the rigid-multiblob integrators on 64 / 256 shells (the reference's
+                usual sizes), where the solver loop around the sweep decides
   rccl_one_rank  one-rank run: the N > 1 step's fp64 all-reduce through RCCL in a one-rank group, step timed with and
                 without it (child process, tools/rccl_one_rank_probe.py)
   multi_device_surface  one-rank run with several devices visible: the same call on the single-process multi-device
@@ -822,6 +824,40 @@ def rank_main(args):
     return out
   if not args.no_sweep:
     stage("config3_gmres", 15, config3_gmres, single_rank_only=True)
+
+  def small_deck_steps():
+    # The reference's usual sizes (tens to hundreds of bodies): whole time steps of the rigid-multiblob integrators, where
+    # the loop AROUND the sweep decides (helper kernels + captured Arnoldi iterations, profiles/r4_gmres_graph.txt).
+    from rigidmultiblobswall_amd import structures as st
+    from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+    R, eta_s = 1.0155, 0.957e-3
+    shell = st.icosahedron_shell(0.792079207921 * R)
+    a_s = st.min_blob_separation(shell) / 2
+    rows = []
+    for nb, scheme, tol, n_steps in ((64, "deterministic_adams_bashforth", 1e-8, 30), (64, "stochastic_Slip_Trapz", 1e-6, 10),
+                                     (256, "deterministic_adams_bashforth", 1e-8, 30)):
+      loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
+      integ = RigidIntegrator([shell] * nb, loc, quat, scheme, a_s, eta_s, tolerance=tol, device=device, seed=9)
+      integ.kT, integ.g = 0.0041419464, 0.0024892 * 12
+      integ.repulsion_strength_wall, integ.debye_length_wall = 0.0165677856, 0.0656
+      integ.repulsion_strength, integ.debye_length = 0.0165677856, 0.0656
+      for step in range(4):
+        integ.advance_time_step(0.002, step=step)
+      torch.cuda.synchronize(device)
+      it0 = (integ.det_iterations_count, integ.stoch_iterations_count)
+      t0 = time.perf_counter()
+      for step in range(4, 4 + n_steps):
+        integ.advance_time_step(0.002, step=step)
+      torch.cuda.synchronize(device)
+      rows.append({"bodies": nb, "blobs": 12 * nb, "scheme": scheme, "solver_tolerance": tol, "steps": n_steps,
+                   "ms_per_step": round(1e3 * (time.perf_counter() - t0) / n_steps, 3),
+                   "gmres_iterations_per_step": round((integ.det_iterations_count - it0[0]) / n_steps, 1),
+                   "lanczos_iterations_per_step": round((integ.stoch_iterations_count - it0[1]) / n_steps, 1),
+                   "rejected_steps": integ.invalid_configuration_count})
+      integ.close()
+    return {"decks": rows, "note": "12-blob shells in a monolayer; helpers + captured Arnoldi iterations on (the defaults)"}
+  if not args.no_sweep:
+    stage("small_deck_steps", 8, small_deck_steps, single_rank_only=True)
 
   def sync_max(dt):
     if world > 1:
