@@ -294,7 +294,7 @@ class RigidSuspension(object):
       r = self.ctx.matvec_device("tt", lam, self.eta, out=top)
       if r.data_ptr() != top.data_ptr():       # contexts that do not write in place (test stand-ins)
         top.copy_(r)
-      if self._native_blocks():
+      if self._native_products():
         # top -= K U and bottom = -K^T lambda in one launch (rmb_block_apply_device; K^T = K with exchanged strides)
         self._native_blocks().block_apply_device(None, g.K, g.K, None, lam.view(self.n_bodies, 3 * g.n_b), U.reshape(self.n_bodies, 6),
                                     top.view(self.n_bodies, 3 * g.n_b), res[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
@@ -330,7 +330,7 @@ class RigidSuspension(object):
       top = row[:n3]
       if r.data_ptr() != top.data_ptr():
         top.copy_(r)
-      if self._native_blocks() and x.is_contiguous():
+      if self._native_products() and x.is_contiguous():
         self._native_blocks().block_apply_device(None, g.K, g.K, None, x[:n3].view(self.n_bodies, 3 * g.n_b), x[n3:].view(self.n_bodies, 6),
                                     top.view(self.n_bodies, 3 * g.n_b), row[n3:].view(self.n_bodies, 6), alpha=-1.0, beta1=1.0,
                                     transpose=(False, False, True, False))
@@ -448,7 +448,7 @@ class RigidSuspension(object):
       g = self.groups[0]
       slip = x[:n3].reshape(self.n_bodies, 3 * g.n_b, 1)
       lam = out[:n3].view(self.n_bodies, 3 * g.n_b, 1)
-      if self._native_blocks() and x.is_contiguous():
+      if self._native_products() and x.is_contiguous():
         self._native_blocks().block_apply_device(g.A11, g.A12, g.A21, g.A22, x[:n3].view(self.n_bodies, 3 * g.n_b), F,
                                     out[:n3].view(self.n_bodies, 3 * g.n_b), outU)      # the four blocks in one launch
         return out
@@ -521,6 +521,11 @@ class RigidSuspension(object):
       return self.ctx
     h = getattr(self.ctx, "helper_context", None)
     return h if type(h) is MobilityContext else None
+
+  def _native_products(self):
+    """_native_blocks() for the batched block products, which walk a block with one thread per row: fine while a body's
+    block stays cache-sized (up to 32 blobs per body), rocBLAS batched GEMM beyond."""
+    return self._native_blocks() if max(g.n_b for g in self.groups) <= 32 else None
 
   def _ortho(self, restart):
     """The fused Gram-Schmidt step for _gmres_steps, or None (torch operations)."""
@@ -619,7 +624,7 @@ class RigidSuspension(object):
     """[M lambda - K U; -K^T lambda] given the blob product M lambda (the O(N) rest of apply_operator)."""
     n3 = 3 * self.n_blobs
     lam, U = x[:n3], x[n3:]
-    if self.free is None and len(self.groups) == 1 and self._native_blocks() and x.is_contiguous():
+    if self.free is None and len(self.groups) == 1 and self._native_products() and x.is_contiguous():
       g = self.groups[0]
       res = torch.empty_like(x)
       res[:n3].copy_(Mlam)
@@ -729,7 +734,7 @@ class RigidSuspension(object):
 
   def _blockdiag(self, x, which, transpose=False):
     out = torch.empty_like(x)
-    if len(self.groups) == 1 and self._native_blocks() and x.is_contiguous():
+    if len(self.groups) == 1 and self._native_products() and x.is_contiguous():
       g = self.groups[0]
       A = g.Linv if which == "Linv" else g.Lchol
       none = x.new_empty((self.n_bodies, 0))
