@@ -122,6 +122,15 @@ class MultiContext(object):
     if (int(begin), int(end)) != (0, self.n):
       raise ValueError("the multi-device engine always produces all n targets (it shards pairs, not targets)")
 
+  @property
+  def helper_context(self):
+    """A plain context on devices[0] for the rank-local O(N) helper kernels of the callers (rigid.py: block products,
+    fused Gram-Schmidt, per-body geometry and factors).  They need no positions and run on torch's current stream of
+    devices[0], where the callers' vectors live and against which the engine orders every product."""
+    if self._aux is None:
+      self._aux = MobilityContext(self.device)
+    return self._aux
+
   def _auxiliary(self):
     """Plain context on devices[0] with the same configuration, for the O(n) / per-body work the engine does not shard."""
     if self._aux is None:

@@ -364,9 +364,13 @@ def test_rigid_solver_runs_on_the_engine(torch_mod):
     U1, _, info1 = ref.solve_mobility_problem(force_torque=FT, tol=1e-9)
     ref.close()
     sus = RigidSuspension([shell] * nb, loc, quat, a, 1.0, ctx=multi)
+    assert sus._native_blocks() is multi.helper_context        # the O(N) helper kernels run beside the engine's products
     UG, _, infoG = sus.solve_mobility_problem(force_torque=FT, tol=1e-9)
     assert abs(infoG["iterations"] - info1["iterations"]) <= 1
     assert rel_err(UG, U1) < 1e-8
+    sus.native_helpers = False                                 # and the torch operations give the same
+    UT, _, infoT = sus.solve_mobility_problem(force_torque=FT, tol=1e-9)
+    assert abs(infoT["iterations"] - info1["iterations"]) <= 1 and rel_err(UT, U1) < 1e-8
   finally:
     multi.close()
 
