@@ -189,9 +189,10 @@ int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double*
   RMB_HIP(hipSetDevice(c->device));
   OrthoArgs a;
   a.n = n; a.rows = rows; a.ldv = ldv;
-  // chunks of 1024 doubles while that gives at most 256 workgroups, larger ones (up to what fits LDS) beyond: every
-  // workgroup re-sums the per-chunk partials, so their number stays bounded
-  long chunk = 1024;
+  // chunks of 256 doubles (one per thread: small systems are latency-bound, 4608 unknowns are 18 workgroups instead of 5)
+  // while that gives at most 256 workgroups, larger ones (up to what fits LDS) beyond: every workgroup re-sums the
+  // per-chunk partials, so their number stays bounded
+  long chunk = 256;
   while ((n + chunk - 1) / chunk > 256 && chunk < kKrMaxChunk) chunk *= 2;
   a.chunk = chunk;
   a.n_chunks = (n + chunk - 1) / chunk;

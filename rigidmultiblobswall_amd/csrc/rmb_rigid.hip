@@ -9,7 +9,7 @@
 //   rmb_rigid_advance_device          x + v dt, quaternion(omega dt) * q for every body (quaternion_integrator_multi_bodies.py:86-91)
 //   rmb_rigid_preconditioner_device   per body: M_b = L L^T, L^-1, M_b^-1, N = (K^T M_b^-1 K)^-1 and the four blocks of
 //                                     [[M_b, -K], [-K^T, 0]]^-1 (multi_bodies.py:516-531 builds L and N once per step,
-//                                     :548-560 applies them); one wavefront per body, everything in LDS.
+//                                     :548-560 applies them); one workgroup per body, everything in LDS.
 #include "rmb_internal.h"
 
 #include <cmath>
@@ -87,8 +87,12 @@ struct PcArgs {
   int* info;
 };
 
-// One wavefront per body; thread t owns row t (n <= 48 < 64).
-__global__ __launch_bounds__(64) void rigid_pc_kernel(const PcArgs a) {
+constexpr int kPcT = 256;          // threads per body: four wavefronts
+
+// One workgroup per body, everything in LDS.  The O(n^3) pieces (trailing updates of the Cholesky factorisation, the
+// forward substitutions of L^-1, M_b^-1 = L^-T L^-1, A11) are spread over all 256 threads element by element; the
+// sequential dimension (n = 3 n_b <= 48 pivots / rows) costs one or two workgroup barriers per step.
+__global__ __launch_bounds__(kPcT) void rigid_pc_kernel(const PcArgs a) {
   extern __shared__ double lds[];
   const int n = a.n, t = threadIdx.x;
   const long b = blockIdx.x;
@@ -102,65 +106,65 @@ __global__ __launch_bounds__(64) void rigid_pc_kernel(const PcArgs a) {
   __shared__ int bad;
   if (t == 0) bad = 0;
   const double* M = a.Mb + b * (long)n * n;
-  for (int idx = t; idx < n * n; idx += 64) {
+  for (int idx = t; idx < n * n; idx += kPcT) {
     const int i = idx / n, j = idx - i * n;
     A[idx] = 0.5 * (M[idx] + M[j * n + i]);
   }
-  for (int idx = t; idx < n * 6; idx += 64) Kl[idx] = a.K[b * (long)n * 6 + idx];
+  for (int idx = t; idx < n * n; idx += kPcT) B[idx] = 0.0;
+  for (int idx = t; idx < n * 6; idx += kPcT) Kl[idx] = a.K[b * (long)n * 6 + idx];
   __syncthreads();
-  // ---- Cholesky, right-looking, lower ----
+  // ---- Cholesky, right-looking, lower: column k scaled by 1 / sqrt(pivot), then the trailing triangle updated ----
   for (int k = 0; k < n; ++k) {
-    if (t == k) {
-      const double piv = A[k * n + k];
-      if (!(piv > 0.0)) bad = 1;
-      A[k * n + k] = sqrt(piv);
-    }
+    const double piv = A[k * n + k];           // every thread reads the pivot before anyone overwrites it
     __syncthreads();
-    if (t > k && t < n) A[t * n + k] /= A[k * n + k];
+    if (t == 0 && !(piv > 0.0)) bad = 1;
+    const double root = sqrt(piv);
+    if (t == k) A[k * n + k] = root;
+    else if (t > k && t < n) A[t * n + k] /= root;
     __syncthreads();
-    if (t > k && t < n) {
-      const double lik = A[t * n + k];
-      for (int j = k + 1; j <= t; ++j) A[t * n + j] -= lik * A[j * n + k];
+    // elements (i, j), k < j <= i < n, of the trailing triangle: m = n - k - 1 rows, numbered row by row
+    const int m = n - k - 1;
+    for (int e = t; e < m * (m + 1) / 2; e += kPcT) {
+      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      while (i * (i + 1) / 2 > e) --i;
+      const int j = e - i * (i + 1) / 2;
+      const int gi = k + 1 + i, gj = k + 1 + j;
+      A[gi * n + gj] -= A[gi * n + k] * A[gj * n + k];
     }
     __syncthreads();
   }
-  if (t < n) {
-    double* Lg = a.Lchol + b * (long)n * n + (long)t * n;
-    for (int j = 0; j < n; ++j) Lg[j] = j <= t ? A[t * n + j] : 0.0;
+  for (int idx = t; idx < n * n; idx += kPcT) {
+    const int i = idx / n, j = idx - i * n;
+    a.Lchol[b * (long)n * n + idx] = j <= i ? A[idx] : 0.0;
   }
-  // ---- L^-1: thread c solves L x = e_c (forward substitution down its own column) ----
-  if (t < n) {
-    const int c = t;
-    for (int i = 0; i < c; ++i) B[i * n + c] = 0.0;
-    for (int i = c; i < n; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) s -= A[i * n + k] * B[k * n + c];
-      B[i * n + c] = s / A[i * n + i];
-    }
+  // ---- L^-1 row by row: (L^-1)[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] (L^-1)[k][c]) / L[i][i]; for a given i the
+  //      columns c <= i are independent.  Thread (c, part): four threads share one column's dot product. ----
+  for (int i = 0; i < n; ++i) {
+    const int c = t >> 2, part = t & 3;
+    double s = 0.0;
+    if (c < i) for (int k = c + part; k < i; k += 4) s += A[i * n + k] * B[k * n + c];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0 && c <= i) B[i * n + c] = ((c == i ? 1.0 : 0.0) - s) / A[i * n + i];
+    __syncthreads();
+  }
+  for (int idx = t; idx < n * n; idx += kPcT) a.Linv[b * (long)n * n + idx] = B[idx];
+  __syncthreads();     // L has been written out and L^-1 is complete: A is free
+  // ---- M_b^-1 = L^-T L^-1, element (i, j) = sum_{k >= max(i, j)} (L^-1)[k][i] (L^-1)[k][j]: symmetric term by term ----
+  for (int idx = t; idx < n * n; idx += kPcT) {
+    const int i = idx / n, j = idx - i * n;
+    double s = 0.0;
+    for (int k = (i > j ? i : j); k < n; ++k) s += B[k * n + i] * B[k * n + j];
+    A[idx] = s;
+    a.Minv[b * (long)n * n + idx] = s;
   }
   __syncthreads();
-  if (t < n) {
-    double* Lig = a.Linv + b * (long)n * n + (long)t * n;
-    for (int j = 0; j < n; ++j) Lig[j] = B[t * n + j];
-  }
-  __syncthreads();     // every row of L has been written out and every column of L^-1 exists: A is free
-  // ---- M_b^-1 = L^-T L^-1 (symmetric term by term) ----
-  if (t < n) {
-    for (int j = 0; j < n; ++j) {
-      double s = 0.0;
-      for (int k = (t > j ? t : j); k < n; ++k) s += B[k * n + t] * B[k * n + j];
-      A[t * n + j] = s;
-    }
-    double* Mig = a.Minv + b * (long)n * n + (long)t * n;
-    for (int j = 0; j < n; ++j) Mig[j] = A[t * n + j];
-  }
-  __syncthreads();
-  if (t < n) {
-    for (int c = 0; c < 6; ++c) {
-      double s = 0.0;
-      for (int j = 0; j < n; ++j) s += A[t * n + j] * Kl[j * 6 + c];
-      MK[t * 6 + c] = s;
-    }
+  for (int idx = t; idx < n * 6; idx += kPcT) {
+    const int i = idx / 6, c = idx - 6 * i;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += A[i * n + j] * Kl[j * 6 + c];
+    MK[idx] = s;
   }
   __syncthreads();
   if (t < 36) {
@@ -209,23 +213,20 @@ __global__ __launch_bounds__(64) void rigid_pc_kernel(const PcArgs a) {
     a.A22[b * 36 + t] = -Nl[t];
   }
   // ---- A12 = -M_b^-1 K N,  A21 = A12^T,  A11 = M_b^-1 + A12 (M_b^-1 K)^T ----
-  if (t < n) {
-    for (int c = 0; c < 6; ++c) {
-      double s = 0.0;
-      for (int k = 0; k < 6; ++k) s += MK[t * 6 + k] * Nl[k * 6 + c];
-      A12l[t * 6 + c] = -s;
-      a.A12[b * (long)n * 6 + t * 6 + c] = -s;
-      a.A21[b * (long)n * 6 + (long)c * n + t] = -s;
-    }
+  for (int idx = t; idx < n * 6; idx += kPcT) {
+    const int i = idx / 6, c = idx - 6 * i;
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += MK[i * 6 + k] * Nl[k * 6 + c];
+    A12l[idx] = -s;
+    a.A12[b * (long)n * 6 + idx] = -s;
+    a.A21[b * (long)n * 6 + (long)c * n + i] = -s;
   }
   __syncthreads();
-  if (t < n) {
-    double* A11g = a.A11 + b * (long)n * n + (long)t * n;
-    for (int j = 0; j < n; ++j) {
-      double s = A[t * n + j];
-      for (int c = 0; c < 6; ++c) s += A12l[t * 6 + c] * MK[j * 6 + c];
-      A11g[j] = s;
-    }
+  for (int idx = t; idx < n * n; idx += kPcT) {
+    const int i = idx / n, j = idx - i * n;
+    double s = A[idx];
+    for (int c = 0; c < 6; ++c) s += A12l[i * 6 + c] * MK[j * 6 + c];
+    a.A11[b * (long)n * n + idx] = s;
   }
   if (t == 0 && bad) atomicOr(a.info, 1);
 }
@@ -280,7 +281,7 @@ int rmb_rigid_preconditioner_device(rmb_ctx* c, long n_bodies, long n_b, const d
   a.A11 = A11_dev; a.A12 = A12_dev; a.A21 = A21_dev; a.A22 = A22_dev; a.info = info_dev;
   RMB_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
   const size_t lds = ((size_t)2 * a.n * a.n + (size_t)18 * a.n + 72) * sizeof(double);
-  hipLaunchKernelGGL(rigid_pc_kernel, dim3((unsigned)n_bodies), dim3(64), lds, c->stream, a);
+  hipLaunchKernelGGL(rigid_pc_kernel, dim3((unsigned)n_bodies), dim3(kPcT), lds, c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
 }
