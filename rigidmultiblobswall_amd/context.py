@@ -73,8 +73,7 @@ class MobilityContext(object):
   def _follow_torch_stream(self):
     if self._user_stream:
       return
-    import torch
-    h = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+    h = _current_raw_stream(self.device)
     if h != self._stream_handle:
       _lib.check(self._lib.rmb_ctx_set_stream(self._h, ctypes.c_void_p(h)))
       self._stream_handle = h
@@ -395,6 +394,24 @@ class MobilityContext(object):
 
   def synchronize(self):
     _lib.check(self._lib.rmb_ctx_synchronize(self._h))
+
+
+_raw_stream = None
+
+
+def _current_raw_stream(device_index):
+  """hipStream_t of torch's current stream on `device_index`, as an int.  Every *_device call asks for it, so the cheap
+  accessor is used when this torch has it (0.3 us; torch.cuda.current_stream() builds a Stream object: 3.5 us, a third
+  of a small product's launch cost)."""
+  global _raw_stream
+  if _raw_stream is None:
+    import torch
+    fast = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if fast is not None:
+      _raw_stream = fast
+    else:
+      _raw_stream = lambda idx: torch.cuda.current_stream(torch.device("cuda", idx)).cuda_stream   # noqa: E731
+  return _raw_stream(device_index)
 
 
 def _is_torch_cuda(x):

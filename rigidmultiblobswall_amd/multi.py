@@ -74,8 +74,8 @@ class MultiContext(object):
   def _follow_torch_stream(self):
     if self._user_stream:
       return
-    import torch
-    h = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+    from .context import _current_raw_stream
+    h = _current_raw_stream(self.device)
     if h != self._stream_handle:
       _lib.check(self._lib.rmb_multi_set_stream(self._h, ctypes.c_void_p(h)))
       self._stream_handle = h
