@@ -288,6 +288,18 @@ def no_wall_mobility_trans_times_force_source_target_hip(source, target, force, 
   return _source_target(source, target, force, radius_source, radius_target, eta, False, kwargs)
 
 
+def mobility_vector_product_source_target_one_wall_hip(source, target, force, radius_source, radius_target, eta, *args, **kwargs):
+  '''The reference's pure-Python twin of the same product (mobility/mobility.py:830-902,
+  `mobility_vector_product_source_target_one_wall`; equal to its numba sibling to rounding, checked when the goldens were
+  generated): served by the same kernel.'''
+  return _source_target(source, target, force, radius_source, radius_target, eta, True, kwargs)
+
+
+def mobility_vector_product_source_target_unbounded_hip(source, target, force, radius_source, radius_target, eta, *args, **kwargs):
+  '''mobility/mobility.py:905-960 (`mobility_vector_product_source_target_unbounded`, Zuk et al. 2014): unbounded twin.'''
+  return _source_target(source, target, force, radius_source, radius_target, eta, False, kwargs)
+
+
 def free_surface_mobility_trans_times_force_source_target_hip(source, target, force, radius_source, radius_target, eta,
                                                               *args, **kwargs):
   '''Same below a stress-free surface at z = 0 (mobility/mobility.py:1409-1429, kernel mobility_numba.py:1941-2091):

@@ -607,6 +607,12 @@ def test_source_target_golden(mob):
   u = mob.mobility_radii_trans_times_force(g["mixed_source"], g["mixed_force"], float(g["mixed_eta"]), 0.3, g["mixed_radius_source"],
                                            mob.single_wall_mobility_trans_times_force_source_target_hip)
   assert rel_err(u, g["mixed_radii_self_wall1"]) < TOL_D1
+  # the reference's pure-Python twins of the two products (mobility.py:830-960) under their own names; they take no
+  # periodic_length (the reference: "pseudo-PBC are not implemented for this function"), so the open-boundary cases
+  for name in ("small", "mixed"):
+    args = [g[name + "_" + k] for k in ("source", "target", "force", "radius_source", "radius_target")]
+    for wall, fn in ((1, mob.mobility_vector_product_source_target_one_wall_hip), (0, mob.mobility_vector_product_source_target_unbounded_hip)):
+      assert rel_err(fn(*args, float(g[name + "_eta"])), g["%s_wall%d" % (name, wall)]) < TOL_D1
 
 
 @pytest.mark.parametrize("ns,nt", [(1, 1), (3, 700), (5000, 64), (4000, 3000)])
