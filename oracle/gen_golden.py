@@ -140,8 +140,12 @@ def main():
   for nm, L in (("g5_forces_N100", np.zeros(3)), ("g5_forces_periodic_N100", np.array([2.5, 3.0, 0.0]))):
     F = forces_numba.calc_blob_blob_forces_numba(r, periodic_length=L, repulsion_strength=eps,
                                                  debye_length=b, blob_radius=af)
+    # the k-d tree variant (forces_numba.py:142-271, `blob_blob_force_implementation tree_numba`): pairs beyond
+    # 2 a + 30 b are dropped, so it differs from the full sum by e^-30 of a contact force at most
+    F_tree = forces_numba.calc_blob_blob_forces_tree_numba(r, periodic_length=L, repulsion_strength=eps,
+                                                           debye_length=b, blob_radius=af)
     np.savez_compressed(os.path.join(out_dir, nm + ".npz"), r_vectors=r, periodic_length=L,
-                        repulsion_strength=eps, debye_length=b, blob_radius=af, force=F)
+                        repulsion_strength=eps, debye_length=b, blob_radius=af, force=F, force_tree=F_tree)
     print("  %s" % nm, flush=True)
   # one radius per blob (forces_numba.py:125-137)
   radii = af * (0.5 + rng.rand(N))

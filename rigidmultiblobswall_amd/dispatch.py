@@ -55,7 +55,7 @@ def _zero_forces(r_vectors, *args, **kwargs):
 
 
 def set_blob_blob_forces(implementation, accept_reference_gpu_names=False, *args, **kwargs):
-  table = {"None": _zero_forces, "hip": _forces.calc_blob_blob_forces_hip}
+  table = {"None": _zero_forces, "hip": _forces.calc_blob_blob_forces_hip, "tree_hip": _forces.calc_blob_blob_forces_tree_hip}
   if accept_reference_gpu_names:
     table["pycuda"] = table["hip"]
   if implementation == "radii_hip":

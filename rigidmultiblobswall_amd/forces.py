@@ -57,6 +57,15 @@ def calc_blob_blob_forces_hip(r_vectors, *args, **kwargs):
   return ctx.blob_blob_force(eps, b, a)
 
 
+def calc_blob_blob_forces_tree_hip(r_vectors, *args, **kwargs):
+  """`tree_numba` twin (multi_bodies/forces_numba.py:142-271): the reference builds a k-d tree and keeps the pairs within
+  2 a + 30 b.  The force kernel here skips whole tile pairs whose bounding boxes are further apart than the exponential
+  reaches in double precision (after a device Morton sort of the blobs), which changes no bit of the full sum -- so this
+  is `calc_blob_blob_forces_hip`, and it differs from the reference's truncated sum by e^-30 of a contact force per
+  dropped pair (4e-14 relative on the goldens)."""
+  return calc_blob_blob_forces_hip(r_vectors, *args, **kwargs)
+
+
 def calc_blob_blob_forces_radii_hip(r_vectors, radius_blobs, *args, **kwargs):
   """`radii_numba` twin (multi_bodies/forces_numba.py:125-137): every blob has its own radius and two blobs touch at
   r = a_i + a_j.  Same keyword arguments as above (`blob_radius` is ignored, as in the reference kernel)."""

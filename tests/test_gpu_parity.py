@@ -81,6 +81,13 @@ def test_golden_forces(path):
     F = calc_blob_blob_forces_hip(g["r_vectors"], **kw)
   assert F.shape == g["force"].shape
   assert rel_err(F, g["force"]) < TOL_D2
+  if "force_tree" in g:
+    # the reference's k-d tree variant drops pairs beyond 2 a + 30 b: e^-30 of a contact force each
+    from rigidmultiblobswall_amd.forces import calc_blob_blob_forces_tree_hip
+    from rigidmultiblobswall_amd import dispatch
+    assert dispatch.set_blob_blob_forces("tree_hip") is calc_blob_blob_forces_tree_hip
+    Ft = calc_blob_blob_forces_tree_hip(g["r_vectors"], **kw)
+    assert np.array_equal(Ft, F) and rel_err(Ft, g["force_tree"]) < 1e-12
 
 
 # ---------------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ def test_blob_blob_forces_match_reference(oracle, path):
     F = oracle.calc_blob_blob_forces_oracle(g["r_vectors"], **kw)
   assert F.shape == g["force"].shape
   assert rel_err(F, g["force"]) < TOL
+  if "force_tree" in g:         # forces_numba.py:142-271: the full sum minus pairs beyond 2 a + 30 b
+    assert rel_err(F, g["force_tree"]) < 1e-12
 
 
 def test_fast_flavour_agrees(oracle):
