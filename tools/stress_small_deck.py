@@ -1,0 +1,36 @@
+"""Soak of the small-deck path (helper kernels + captured Arnoldi iterations, preconditioner rebuilt every step): thousands
+of integrator steps, the state checked for finiteness / unit quaternions, the solver for convergence, and the captured
+graphs for being used.  python tools/stress_small_deck.py [det_steps] [stoch_steps]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rigidmultiblobswall_amd import structures as st
+from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+R, eta = 1.0155, 0.957e-3
+shell = st.icosahedron_shell(0.792079207921 * R)
+a = st.min_blob_separation(shell) / 2
+n_det = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+n_sto = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+for nb, scheme, tol, steps, dt in ((64, "deterministic_adams_bashforth", 1e-8, n_det, 0.002), (30, "deterministic_midpoint", 1e-9, n_det // 3, 0.004),
+                                   (64, "stochastic_Slip_Trapz", 1e-6, n_sto, 0.002), (100, "stochastic_first_order_RFD", 1e-6, n_sto, 0.002)):
+  loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=nb)
+  integ = RigidIntegrator([shell] * nb, loc, quat, scheme, a, eta, tolerance=tol, device="cuda:0", seed=3)
+  integ.kT, integ.g = 0.0041419464, 0.0024892 * 12
+  integ.repulsion_strength_wall, integ.debye_length_wall = 0.0165677856, 0.0656
+  integ.repulsion_strength, integ.debye_length = 0.0165677856, 0.0656
+  t0 = time.perf_counter()
+  for step in range(steps):
+    integ.advance_time_step(dt, step=step)
+    if step % 250 == 249:
+      q = integ.orientation
+      assert bool(torch.isfinite(integ.location).all()) and float((torch.linalg.norm(q, dim=1) - 1).abs().max()) < 1e-10
+      print("  %s step %d: %.2f ms/step, z in [%.2f, %.2f], gmres its %d, rejected %d" % (
+          scheme, step + 1, 1e3 * (time.perf_counter() - t0) / (step + 1), float(integ.location[:, 2].min()), float(integ.location[:, 2].max()),
+          integ.det_iterations_count, integ.invalid_configuration_count), flush=True)
+  torch.cuda.synchronize()
+  ws = getattr(integ.susp, "_arnoldi_ws", None)
+  print("%s, %d bodies: %d steps ok, %.2f ms/step; graphs captured %s, replays %s" % (
+      scheme, nb, steps, 1e3 * (time.perf_counter() - t0) / steps, None if ws is None else ws.captures, None if ws is None else ws.replays), flush=True)
+  assert bool(torch.isfinite(integ.location).all())
+  integ.close()
+print("SOAK OK")
