@@ -253,7 +253,7 @@ def load_isa():
 
 def isa_key(path):
   """librmb_mobility.isa.json entry of the kernel family a product ran on (context option "last_path")."""
-  return {0: "sweep_tt_wall", 1: "sym_tt_wall", 2: "symx_single_tt_wall", 3: "sym_coop_tt_wall"}.get(path, "sym_tt_wall")
+  return {0: "sweep_tt_wall", 1: "sym_tt_wall", 2: "symx_single_tt_wall", 3: "sym_coop_tt_wall", 4: "sym2t_tt_wall"}.get(path, "sym_tt_wall")
 
 
 def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None, key=None):
@@ -262,15 +262,26 @@ def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None, key=Non
   st = isa["kernels"].get(key or ("sym_tt_wall" if sym else "sweep_tt_wall")) if isa else None
   if st is None:
     return None, None
+  pps = st.get("pairs_per_step", 1)
+  valu_launch = None
   if sym:
     tiles = (N + 63) // 64
     wave_steps = (tiles * (tiles + 1) // 2 * 64 - tiles) / world       # rotation steps (diagonal units skip k = 0)
     pair_evals = float(N) * (N - 1) / 2 / world                         # real (unpadded) unordered pairs
+    if pps == 2:
+      # two target blobs per lane (sym2t_kernel): a step of a unit (row pair p, tile J >= 2p + 2) evaluates two pairs; the
+      # two columns at the diagonal of every row pair run through one-target loops (priced with sym_kernel's count)
+      pairs_rows = (tiles + 1) // 2
+      fused_steps = 64 * sum(max(tiles - 2 * p - 2, 0) for p in range(pairs_rows))
+      single_steps = wave_steps * world - 2 * fused_steps
+      one = isa["kernels"].get("sym_tt_wall", st)
+      valu_launch = (st["valu_per_step"] * fused_steps + one["valu_per_step"] * single_steps) / world
   else:
     wave_steps = float(-(-n_local // 64)) * N
     pair_evals = float(n_local) * N
-  ex_tf = st["flops_per_lane_step"] * pair_evals / kern_s / 1e12
-  executed = {"flops_per_pair_evaluation": st["flops_per_lane_step"], "pair_evaluations_per_launch": pair_evals,
+  flops_pair = st["flops_per_lane_step"] / float(pps)
+  ex_tf = flops_pair * pair_evals / kern_s / 1e12
+  executed = {"flops_per_pair_evaluation": flops_pair, "pair_evaluations_per_launch": pair_evals,
               "achieved": round(ex_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": round(ex_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
               "source": "FMA = 2, mul/add/rsq = 1 flop, counted over the pair loop of this build's ISA "
@@ -278,13 +289,13 @@ def executed_views(isa, sym, N, world, n_local, kern_s, issue_peak=None, key=Non
               "instruction_mix_per_step": st["classes"]}
   issue = None
   if issue_peak:
-    valu = st["valu_per_step"] * wave_steps
+    valu = valu_launch if valu_launch is not None else st["valu_per_step"] * wave_steps
     issue = {"valu_wave_instr_per_launch": valu, "achieved": round(valu / kern_s / 1e9, 1), "peak": round(issue_peak, 1),
              "unit": "G wave-instr/s", "frac": round(valu / kern_s / 1e9 / issue_peak, 4),
              "peak_source": "rmb_ubench_fp64_issue: independent v_fma_f64, 4 waves per SIMD on every CU, 40 launches, "
                             "measured in this process right after the timed loop",
-             "note": "two of the %d VALU instructions per step are v_rsq_f64, which issue at ~0.3x the FMA rate "
-                     "(profiles/r1_ubench_fp64_issue_rates.txt)" % st["valu_per_step"]}
+             "note": "%d of the %d VALU instructions per step are v_rsq_f64, which issue at ~0.3x the FMA rate "
+                     "(profiles/r1_ubench_fp64_issue_rates.txt)" % (2 * pps, st["valu_per_step"])}
   return executed, issue
 
 
@@ -492,6 +503,8 @@ def rank_main(args):
       "bound": "valu_fp64",
       "kernel": {3: "rmb::sym_coop_kernel<TT,wall> (each unordered pair once, both blobs updated; the four waves of a workgroup "
                     "share one staged tile and one flush per tile)",
+                 4: "rmb::sym2t_kernel<TT,wall> (each unordered pair once, both blobs updated; two target blobs per lane share one "
+                    "record read and one set of LDS adds per rotation step)",
                  1: "rmb::sym_kernel<TT,wall> (each unordered pair once, both blobs updated)"}.get(res["path"], "rmb::sweep_kernel<TT,wall>"),
       # utilisation, <= 1 by construction: fp64 flops this kernel EXECUTES per launch / kernel time / fp64 vector peak
       "achieved": executed["achieved"], "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed["frac"],
@@ -630,7 +643,7 @@ def rank_main(args):
       return {"skipped": "rocprofv3 not on PATH: roofline.traffic stays the committed figure"}
     if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
       return {"skipped": "this run is itself being profiled: no nested rocprofv3 passes"}
-    fam = {3: "sym_coop_kernel<0, true, false>", 1: "sym_kernel<0, true, false>"}.get(res["path"], "sweep_kernel<0, true, false>")
+    fam = {3: "sym_coop_kernel<0, true, false>", 1: "sym_kernel<0, true, false>", 4: "sym2t_kernel<0, true>"}.get(res["path"], "sweep_kernel<0, true, false>")
     out_dir = tempfile.mkdtemp(prefix="rmb_pmc_")
     got = {}
     try:
@@ -764,7 +777,8 @@ def rank_main(args):
           "kernel_ms_avg": round(rs["kern_ms"], 4), "allreduce_bytes": 0 if world == 1 else 24 * nb,
           "algorithmic_tflops_all_ranks": round(211.0 * float(nb) * nb / (rs["dt"] / st_) / 1e12, 2),
           "executed_frac": _exec_frac(isa, rs["launch"]["chunks"] == 0, nb, world, rs["n_local"], rs["kern_ms"] * 1e-3, isa_key(rs["path"])),
-          "kernel_family": {0: "one-sided sweep", 1: "symmetric, per wave", 3: "symmetric, workgroup-cooperative"}.get(rs["path"]),
+          "kernel_family": {0: "one-sided sweep", 1: "symmetric, per wave", 3: "symmetric, workgroup-cooperative",
+                            4: "symmetric, two target blobs per lane"}.get(rs["path"]),
           "hbm_algorithmic_gbps": round(72.0 * nb / (rs["kern_ms"] * 1e-3) / 1e9, 4), "launch": rs["launch"]}
       if tb is not None:
         # HBM-side traffic of one launch from the committed rocprofv3 --pmc passes (not measured in this run) over

@@ -129,6 +129,10 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          staging and flushing its own): 0 = never, 1 = launches of at most four resident rounds of
  *                          workgroups (small suspensions, one rank's pair shard, products up to ~1e4 blobs: faster below
  *                          one round, same time with half the atomic flush traffic up to four), 2 = always
+ *   "sym_two_targets" [1]  tt / tr / rt / rr with open boundaries: two target blobs per lane (sym2t_kernels.h: a lane keeps
+ *                          blob `lane` of two tile rows, so one record read and one set of LDS adds serve two pairs; +3-4.5 %
+ *                          from 1e4 to 1e6 blobs, half the atomic flush traffic): 0 = never, 1 = launches of at least one
+ *                          resident round of workgroups (smaller ones stay with the cooperative kernel), 2 = always
  *   "sym_order"       [1]  symmetric kernels: order in which the tile pairs are visited: 1 = blocked (super-blocks of 32 x 32
  *                          tiles, so that neighbouring step ranges re-use the same 64 tiles), 0 = row-major over the tile
  *                          triangle.  The deterministic symmetric mode always runs row-major
@@ -146,7 +150,7 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
 int rmb_ctx_set_option(rmb_ctx* ctx, const char* key, long value);
 /* Current value of an option (same keys); lets a caller switch one temporarily and restore what was there.  Read-only
  * key "last_path": the kernel family of the last product (0 one-sided sweep, 1 symmetric per wave, 2 deterministic
- * symmetric, 3 symmetric workgroup-cooperative). */
+ * symmetric, 3 symmetric workgroup-cooperative, 4 symmetric with two target blobs per lane). */
 int rmb_ctx_get_option(rmb_ctx* ctx, const char* key, long* value);
 
 /* Upload / pack positions: fuses shift_heights + damping_matrix_B (mobility.py:52-84).

@@ -101,6 +101,7 @@ struct rmb_ctx {
   long opt_sym_coop = 1;       // workgroup-cooperative symmetric kernel (sym_coop_kernels.h): 0 = never, 1 = launches of at most
                                // kCoopMaxRounds resident rounds (small suspensions, pair shards, up to ~1e4 blobs), 2 = always
   long opt_sym_chunk_steps = 1024;  // symmetric kernels: a wave's steps are cut into strided chunks of about this many (0 = one range)
+  long opt_sym_two_targets = 1;   // sym2t_kernel (two target blobs per lane) for tt / tr / rt / rr, open boundaries: 0 off, 1 from one resident round on, 2 always
   long opt_sym_order = 1;      // unit order of the symmetric kernels: 1 = blocked (32 x 32 tile super-blocks), 0 = row-major
   long opt_sym_xcd = 1;        // XCD-aware workgroup numbering (each XCD a contiguous eighth of the step range)
   long opt_sym_oversub = 8;    // launch this many times the resident workgroup count (measured: -4..8 % kernel time;

@@ -7,6 +7,7 @@
 
 #include "sym_kernels.h"
 #include "sym_coop_kernels.h"
+#include "sym2t_kernels.h"
 #include "sym2_kernels.h"
 #include "symx_kernels.h"
 
@@ -14,9 +15,11 @@ namespace rmbi {
 
 namespace {
 typedef void (*sym_fn)(const rmb::SymArgs);
-struct SymEntry { sym_fn sweep; sym_fn fin; int occ; sym_fn coop; int coop_occ; };
+struct SymEntry { sym_fn sweep; sym_fn fin; int occ; sym_fn coop; int coop_occ; sym_fn two; int two_occ; };
 template <int KIND, bool WALL, bool PER> SymEntry make_sym_entry() {
-  return SymEntry{rmb::sym_kernel<KIND, WALL, PER>, rmb::sym_finalize_kernel<KIND, WALL>, 0, rmb::sym_coop_kernel<KIND, WALL, PER>, 0};
+  sym_fn two = nullptr;
+  if constexpr (!PER) two = rmb::sym2t_kernel<KIND, WALL>;      // two target blobs per lane: open boundaries only
+  return SymEntry{rmb::sym_kernel<KIND, WALL, PER>, rmb::sym_finalize_kernel<KIND, WALL>, 0, rmb::sym_coop_kernel<KIND, WALL, PER>, 0, two, 0};
 }
 // [kind tt,tr,rt,rr][wall][periodic]
 #define RMB_SYM_ROW(K) {{make_sym_entry<K, false, false>(), make_sym_entry<K, false, true>()}, {make_sym_entry<K, true, false>(), make_sym_entry<K, true, true>()}}
@@ -65,7 +68,23 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   // WRITE_SIZE 54.4 -> 27.4 MB per launch, 146.7 vs 147.8 us), 0.5-1 % slower at >= 8 rounds
   // (profiles/r4_coop_kernel_ab.txt): by default up to kCoopMaxRounds.
   constexpr long kCoopMaxRounds = 4;
-  const bool coop = !f32 && !c->opt_wave_clock &&
+  // Two target blobs per lane (sym2t_kernels.h): units are (row pair, tile) -- half as many steps, two pairs per step.
+  // From one resident round on (smaller launches stay with the cooperative kernel, whose four waves share a unit).
+  bool two = false;
+  if (se.two && !f32 && !c->opt_wave_clock && c->opt_sym_two_targets && c->opt_sym_coop != 2 && tiles >= 4) {
+    rmb::SymArgs t = a;
+    t.n_units = rmb::units2_total(tiles);
+    shard_ranges(n, t.n_units, shard, nshards, &t.step_begin, &t.step_end, &t.self_begin, &t.self_end);
+    SymPlan plan2;
+    if (int rc = plan_sym(c, (const void*)se.two, &se.two_occ, stat, t.step_end - t.step_begin, true, &plan2, rmb::kSymWavesPerEu))
+      return rc;
+    if (!plan2.sub_round || c->opt_sym_two_targets == 2) {
+      two = true;
+      a = t;
+      plan = plan2;
+    }
+  }
+  const bool coop = !two && !f32 && !c->opt_wave_clock &&
                     (c->opt_sym_coop == 2 || (c->opt_sym_coop == 1 && (plan.sub_round || plan.blocks <= kCoopMaxRounds * plan.round)));
   if (coop) {
     const size_t coop_lds = sizeof(double2) * 64 * 3 + sizeof(double) * 2 * 3 * 64;
@@ -81,7 +100,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   a.steps_per_wave = chunked_steps(c, total_steps, coop ? blocks : blocks * rmb::kSymWaves, a.steps_per_wave,
                                    c->opt_sym_chunk_steps * (coop ? rmb::kSymWaves : 1));
   c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = blocks;
-  c->last_path = coop ? 3 : 1;
+  c->last_path = coop ? 3 : (two ? 4 : 1);
   a.skip_pairs = (int)c->opt_skip_pairs;
   a.accumulate = accumulate ? 1 : 0;
   a.wave_clock = nullptr;
@@ -95,7 +114,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   if (f32) {
     k32.launch(&a, a.k, (unsigned)blocks, plan.dyn_lds, c->stream);
   } else {
-    hipLaunchKernelGGL(coop ? se.coop : se.sweep, dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
+    hipLaunchKernelGGL(coop ? se.coop : (two ? se.two : se.sweep), dim3((unsigned)blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
   }
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;

@@ -963,3 +963,53 @@ def test_cooperative_generic_skeleton_matches_the_per_wave_one(n):
         assert rel_err(ctx.matvec_device("tt_free", vs[0], eta).cpu().numpy(), ref) < 1e-13
   finally:
     ctx.close()
+
+
+@pytest.mark.parametrize("N", [200, 256, 257, 449, 1000, 4097, 10000])
+def test_two_target_blobs_per_lane_equal_the_one_target_kernels(N):
+  """sym2t_kernel (context option "sym_two_targets"; a lane keeps blob `lane` of two tile rows, units are (row pair, tile))
+  against the one-target symmetric kernels and the oracle: every kind, wall and no wall, odd and even tile counts, a
+  partial last tile, whole products and pair shards (step ranges of the row-pair units), forced from the smallest launch."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  from oracle import oracle
+  rng = np.random.RandomState(N)
+  a, eta = 0.4, 1.7
+  r = rng.rand(N, 3) * (N / 0.05) ** (1.0 / 3.0) * a
+  r[:, 2] += 0.2 * a                       # some blobs below z = a: clamp + B path
+  f = rng.randn(N, 3)
+  rd = torch.as_tensor(r.reshape(-1), device="cuda"); fd = torch.as_tensor(f.reshape(-1), device="cuda")
+  ctx = MobilityContext(0)
+  try:
+    for wall in (True, False):
+      ctx.set_positions(rd, a, None, wall)
+      for kind in ("tt", "tr", "rt", "rr"):
+        ctx.set_option("sym_two_targets", 0)
+        ref = ctx.matvec_device(kind, fd, eta).clone()
+        assert ctx.get_option("last_path") in (1, 3)
+        ctx.set_option("sym_two_targets", 2)
+        got = ctx.matvec_device(kind, fd, eta).clone()
+        assert ctx.get_option("last_path") == 4
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 1e-13, (N, wall, kind)
+        for G in (2, 5):
+          tot = torch.zeros_like(ref)
+          for g in range(G):
+            tot += ctx.matvec_pairshard_device(kind, fd, eta, g, G)
+          assert rel_err(tot.cpu().numpy(), ref.cpu().numpy()) < 1e-13, (N, wall, kind, G)
+      if N <= 1000:
+        ctx.set_option("sym_two_targets", 2)
+        u = ctx.matvec_device("tt", fd, eta).cpu().numpy()
+        fn = oracle.single_wall_mobility_trans_times_force_oracle if wall else oracle.no_wall_mobility_trans_times_force_oracle
+        assert rel_err(u, fn(r, f, eta, a).reshape(-1)) < 1e-12, (N, wall)
+    # the default: two targets from one resident round of workgroups on, the cooperative kernel below
+    ctx.set_option("sym_two_targets", 1)
+    ctx.set_positions(rd, a, None, True)
+    ctx.matvec_device("tt", fd, eta)
+    assert ctx.get_option("last_path") == (4 if N >= 10000 else 3)
+    # periodic products keep the one-target kernels
+    ctx.set_positions(rd, a, np.array([0.0, 9.0 * a * N ** (1 / 3.0), 0.0]), True)
+    ctx.set_option("sym_two_targets", 2)
+    ctx.matvec_device("tt", fd, eta)
+    assert ctx.get_option("last_path") in (1, 3)
+  finally:
+    ctx.close()

@@ -64,3 +64,63 @@ def test_unit_order_and_xcd_numbering(tmp_path):
   subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, cpp])
   res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
   assert res.returncode == 0 and "problems 0" in res.stdout, res.stdout + res.stderr
+
+
+HARNESS2 = r'''
+int main() {
+  long bad = 0;
+  std::vector<int> Ts;
+  for (int T = 1; T <= 140; ++T) Ts.push_back(T);
+  Ts.push_back(157); Ts.push_back(384); Ts.push_back(1563); Ts.push_back(2049);
+  for (int T : Ts) {
+    const long n_units = units2_total(T);
+    long expect = 0;
+    for (int p = 0; 2 * p < T; ++p) expect += T - 2 * p;
+    if (expect != n_units) ++bad;
+    for (int order = 0; order <= 1; ++order) {
+      std::set<std::pair<int, int>> seen;
+      int p = -1, J = -1;
+      for (long u = 0; u < n_units; ++u) {
+        int ps, Js;
+        unit2_seek(order, u, T, ps, Js);
+        if (u == 0) { p = ps; J = Js; }
+        if (ps != p || Js != J) { ++bad; p = ps; J = Js; }
+        if (p < 0 || 2 * p >= T || J < 2 * p || J >= T) ++bad;
+        if (!seen.insert({p, J}).second) ++bad;
+        unit2_next(order, T, p, J);
+      }
+      if ((long)seen.size() != n_units) ++bad;
+    }
+  }
+  {   // 1e6 blobs = 15 625 tiles: seek agrees with a run of nexts at a few places
+    const int T = 15625; const long n_units = units2_total(T);
+    for (int order = 0; order <= 1; ++order)
+      for (long u0 : {0L, 23456789L, n_units / 2, n_units - 6000}) {
+        int p, J; unit2_seek(order, u0, T, p, J);
+        for (long u = u0; u < u0 + 5000 && u < n_units; ++u) {
+          int ps, Js; unit2_seek(order, u, T, ps, Js);
+          if (ps != p || Js != J) { ++bad; p = ps; J = Js; }
+          unit2_next(order, T, p, J);
+        }
+      }
+  }
+  printf("problems %ld\n", bad);
+  return bad != 0;
+}
+'''
+
+
+def test_row_pair_unit_order(tmp_path):
+  """The unit grid of the two-targets-per-lane kernel (csrc/sym2t_kernels.h: unit2_seek / unit2_next, plain and blocked):
+  every (row pair p, tile J >= 2p) exactly once, seek and next agree."""
+  src = open(os.path.join(ROOT, "rigidmultiblobswall_amd", "csrc", "sym2t_kernels.h")).read()
+  begin = src.index("// ---- unit order ----")
+  end = src.index("template <int KIND, bool WALL>\n__global__", begin)
+  code = ("#include <cmath>\n#include <cstdio>\n#include <set>\n#include <utility>\n#include <vector>\n"
+          "#define __device__\n#define __host__\n#define __forceinline__ inline\nconstexpr int kOrdShift = 5;\n" + src[begin:end] + HARNESS2)
+  cpp, exe = str(tmp_path / "unit2_order.cpp"), str(tmp_path / "unit2_order")
+  with open(cpp, "w") as fh:
+    fh.write(code)
+  subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, cpp])
+  res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0 and "problems 0" in res.stdout, res.stdout + res.stderr

@@ -23,9 +23,9 @@ shutil.copy(os.path.join(src, "bench_line_under_trace.json"), base + "_line_unde
 
 with open(os.path.join(src, "summary.json")) as fh:
   summ = json.load(fh)
-kern = [v for k, v in summ.items() if "sym_kernel<0, true, false>" in k or "sym_coop_kernel<0, true, false>" in k]
+kern = [v for k, v in summ.items() if "sym_kernel<0, true, false>" in k or "sym_coop_kernel<0, true, false>" in k or "sym2t_kernel<0, true>" in k]
 if not kern:
-  raise SystemExit("no rmb::sym_kernel / sym_coop_kernel<0, true, false> in %s/summary.json" % src)
+  raise SystemExit("no rmb::sym_kernel / sym_coop_kernel / sym2t_kernel <TT, wall> in %s/summary.json" % src)
 kern.sort(key=lambda v: -v.get("trace_n", 0))     # the one the timed steps ran
 k = kern[0]
 ub = [v for kk, v in summ.items() if "ubench_fma64_kernel" in kk]

@@ -29,6 +29,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 KERNELS = {
     "sym_tt_wall": "_ZN3rmb10sym_kernelILi0ELb1ELb0EEE",
     "sym_coop_tt_wall": "_ZN3rmb15sym_coop_kernelILi0ELb1ELb0EEE",
+    "sym2t_tt_wall": "_ZN3rmb12sym2t_kernelILi0ELb1EEE",      # two target blobs per lane: a step evaluates TWO pairs
     "sym_tt_nowall": "_ZN3rmb10sym_kernelILi0ELb0ELb0EEE",
     "sym_tr_wall": "_ZN3rmb10sym_kernelILi1ELb1ELb0EEE",
     "sym_rt_wall": "_ZN3rmb10sym_kernelILi2ELb1ELb0EEE",
@@ -171,6 +172,7 @@ def generate(path=OUT):
     st = kernel_loop_stats(asm, pref)
     if st is not None:
       st.pop("_self_test", None)
+      st["pairs_per_step"] = 2 if name.startswith("sym2t_") else 1
       res["kernels"][name] = st
   with open(path, "w") as fh:
     json.dump(res, fh, indent=1)

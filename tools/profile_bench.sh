@@ -24,4 +24,4 @@ python3 tools/summarize_profile.py ${OUT} ${STEPS} > ${OUT}/summary.txt 2>&1
 grep "^{" ${OUT}/trace.log | tail -1 > ${OUT}/bench_line_under_trace.json
 # keep the merge-back small: the raw per-dispatch CSVs of the large passes are not needed once summarised
 find ${OUT} -name "*.csv" -size +2M -delete
-grep -E "sym_kernel|sym_coop_kernel|ubench|sym_finalize" ${OUT}/summary.txt | head -40
+grep -E "sym_kernel|sym_coop_kernel|sym2t_kernel|ubench|sym_finalize" ${OUT}/summary.txt | head -40
