@@ -37,6 +37,8 @@ Objects on the line
                 call shape, PCIe-inclusive) -- reported beside `value`, never `value`
                 `devices` = what the call ran on (mobility.set_devices / RMB_DEVICES), `breakdown_us` = where one call's
                 time goes (position compare, upload, enqueue, sweep by HIP events, download + sync, Python)
+  two_targets_ab  one-rank run: the headline product on the one-target kernels and with two target blobs per lane, alternating
+                in this process (a same-box A/B of the round's kernel change)
   small_deck_steps  one-rank run: whole time steps of the rigid-multiblob integrators on 64 / 256 shells (the reference's
                 usual sizes), where the solver loop around the sweep decides
   rccl_one_rank  one-rank run: the N > 1 step's fp64 all-reduce through RCCL in a one-rank group, step timed with and
@@ -838,6 +840,40 @@ def rank_main(args):
     return out
   if not args.no_sweep:
     stage("config3_gmres", 15, config3_gmres, single_rank_only=True)
+
+  def two_targets_ab():
+    # Same box, same process, alternating: the headline product on the one-target symmetric kernels (round 3 / early
+    # round 4: cooperative up to four resident rounds, per wave above) and with two target blobs per lane (the default).
+    # Boxes of the pool differ by several per cent, so a kernel change is only visible in a same-run comparison.
+    ctx = backend.ctx
+    r_, f_, eta_, a_ = d2_cloud(N, seed=0)
+    ctx.set_positions(torch.as_tensor(r_.reshape(-1), device=device), a_, None, wall=True)
+    fd_ = torch.as_tensor(f_.reshape(-1), device=device)
+    out_ = torch.empty(3 * N, dtype=torch.float64, device=device)
+    keep_timing = ctx.get_option("timing")
+    ctx.set_option("timing", 1)
+    res_ab = {0: [], 1: []}
+    try:
+      for _ in range(3):
+        for mode in (0, 1):
+          ctx.set_option("sym_two_targets", mode)
+          for _ in range(5):
+            ctx.matvec_device("tt", fd_, eta_, out=out_)
+          torch.cuda.synchronize(device)
+          ctx.timing_reset()
+          for _ in range(100):
+            ctx.matvec_device("tt", fd_, eta_, out=out_)
+          torch.cuda.synchronize(device)
+          res_ab[mode].append(float(np.mean(ctx.timing_collect(100))) * 1e3)
+    finally:
+      ctx.set_option("sym_two_targets", 1)
+      ctx.set_option("timing", keep_timing)
+    one, two = float(np.mean(res_ab[0])), float(np.mean(res_ab[1]))
+    return {"n_blobs": N, "kernel_us_one_target_per_lane": round(one, 2), "kernel_us_two_targets_per_lane": round(two, 2),
+            "speedup": round(one / two, 4), "rounds": 3, "launches_per_round": 100,
+            "note": "HIP events around every launch, clocks primed by the timed loop; option sym_two_targets 0 / 1"}
+  if world == 1 and not args.no_sweep and not any(kv.startswith("sym_two_targets=") for kv in args.ctx_option):
+    stage("two_targets_ab", 3, two_targets_ab, single_rank_only=True)
 
   def small_deck_steps():
     # The reference's usual sizes (tens to hundreds of bodies): whole time steps of the rigid-multiblob integrators, where
