@@ -69,7 +69,7 @@ for N in SIZES:
   t = {}
   for kind in ("tt", "tr", "rt", "rr"):
     t[kind] = timed(ctx, lambda: ctx.matvec_device(kind, fd, eta), reps, 1)
-    row(N, "wall " + kind, "sym_kernel", t[kind])
+    row(N, "wall " + kind, "sym2t_kernel (two target blobs per lane; sym_kernel / sym_coop_kernel with sym_two_targets = 0)", t[kind])
   ctx.set_option("precision", 32)
   row(N, "wall tt, single precision", "sym32_tt_kernel", timed(ctx, lambda: ctx.matvec_device("tt", fd, eta), reps, 1), t["tt"])
   ctx.set_option("precision", 64)
