@@ -352,7 +352,11 @@ int sym_force_device(rmb_ctx* c, double eps, double b, double blob_radius, doubl
   a.acc = (double*)c->symbuf.p;
   a.out = out;
   a.n = n; a.n_pad = n_pad; a.n_tiles = (int)tiles; a.n_units = tiles * (tiles + 1) / 2;
-  a.order = (int)c->opt_sym_order; a.xcd = (int)c->opt_sym_xcd;
+  // Row-major units and plain workgroup numbering, whatever "sym_order" / "sym_xcd" say: with tile culling most units cost
+  // nothing and the ones that do sit next to the diagonal (after the Morton sort), so the blocked order hands neighbouring
+  // waves equally heavy runs of super-block rows; measured 3.37 vs 5.01 ms on a 3D cloud of 1e5 blobs, 2.39 vs 2.64 ms on
+  // the 262 144-roller monolayer (tools/experiments/exp_force_ab.py).  The strided chunks stay.
+  a.order = 0; a.xcd = 0;
   a.Lx = c->L[0]; a.Ly = c->L[1]; a.Lz = c->L[2];
   a.iLx = c->L[0] > 0 ? 1.0 / c->L[0] : 0.0;
   a.iLy = c->L[1] > 0 ? 1.0 / c->L[1] : 0.0;
@@ -412,7 +416,9 @@ int sym_force_device(rmb_ctx* c, double eps, double b, double blob_radius, doubl
   {
     const long total_steps = a.step_end - a.step_begin, waves = blocks * rmb::kSymWaves;
     const long spw = (total_steps + waves - 1) / waves;
-    const long ch = chunked_steps(c, total_steps, waves, spw, c->opt_sym_chunk_steps);
+    // a quarter of the mobility kernels' chunk: the surviving units are few and uneven, shorter chunks balance them
+    // (3D cloud of 1e5 blobs 3.36 -> 3.05 ms, monolayer unchanged; tools/experiments/exp_force_ab.py)
+    const long ch = chunked_steps(c, total_steps, waves, spw, c->opt_sym_chunk_steps / 4);
     a.chunk_steps = ch < spw ? ch : 0;
   }
   int slot;
