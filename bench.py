@@ -854,8 +854,15 @@ def rank_main(args):
     ctx.set_option("timing", 1)
     res_ab = {0: [], 1: []}
     try:
-      for _ in range(3):
-        for mode in (0, 1):
+      # the stages before this one leave the GPU idle for seconds (CPU baseline, child processes): prime the clocks as the
+      # headline does, or whichever mode is measured first pays the ramp
+      t_prime = time.perf_counter()
+      while time.perf_counter() - t_prime < 0.3:
+        for _ in range(20):
+          ctx.matvec_device("tt", fd_, eta_, out=out_)
+        torch.cuda.synchronize(device)
+      for rnd in range(4):
+        for mode in ((0, 1) if rnd % 2 == 0 else (1, 0)):
           ctx.set_option("sym_two_targets", mode)
           for _ in range(5):
             ctx.matvec_device("tt", fd_, eta_, out=out_)
@@ -864,14 +871,16 @@ def rank_main(args):
           for _ in range(100):
             ctx.matvec_device("tt", fd_, eta_, out=out_)
           torch.cuda.synchronize(device)
-          res_ab[mode].append(float(np.mean(ctx.timing_collect(100))) * 1e3)
+          res_ab[mode].append(float(np.median(ctx.timing_collect(100))) * 1e3)
     finally:
       ctx.set_option("sym_two_targets", 1)
       ctx.set_option("timing", keep_timing)
-    one, two = float(np.mean(res_ab[0])), float(np.mean(res_ab[1]))
+    one, two = float(np.median(res_ab[0])), float(np.median(res_ab[1]))
     return {"n_blobs": N, "kernel_us_one_target_per_lane": round(one, 2), "kernel_us_two_targets_per_lane": round(two, 2),
-            "speedup": round(one / two, 4), "rounds": 3, "launches_per_round": 100,
-            "note": "HIP events around every launch, clocks primed by the timed loop; option sym_two_targets 0 / 1"}
+            "speedup": round(one / two, 4), "rounds": 4, "launches_per_round": 100,
+            "per_round_us": {"one_target": [round(x, 2) for x in res_ab[0]], "two_targets": [round(x, 2) for x in res_ab[1]]},
+            "note": "median of the per-round medians; HIP events around every launch (adds ~8 us to both); clocks primed for "
+                    "0.3 s first, the order of the two modes alternates from round to round; option sym_two_targets 0 / 1"}
   if world == 1 and not args.no_sweep and not any(kv.startswith("sym_two_targets=") for kv in args.ctx_option):
     stage("two_targets_ab", 3, two_targets_ab, single_rank_only=True)
 
