@@ -131,8 +131,8 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          one round, same time with half the atomic flush traffic up to four), 2 = always
  *   "sym_two_targets" [1]  tt / tr / rt / rr with open boundaries: two target blobs per lane (sym2t_kernels.h: a lane keeps
  *                          blob `lane` of two tile rows, so one record read and one set of LDS adds serve two pairs; +3-4.5 %
- *                          from 1e4 to 1e6 blobs, half the atomic flush traffic): 0 = never, 1 = launches of at least one
- *                          resident round of workgroups (smaller ones stay with the cooperative kernel), 2 = always
+ *                          from 1e4 to 1e6 blobs, half the atomic flush traffic): 0 = never, 1 = launches of at least half a
+ *                          resident round of workgroups (~6000 blobs; smaller ones stay with the cooperative kernel), 2 = always
  *   "sym_order"       [1]  symmetric kernels: order in which the tile pairs are visited: 1 = blocked (super-blocks of 32 x 32
  *                          tiles, so that neighbouring step ranges re-use the same 64 tiles), 0 = row-major over the tile
  *                          triangle.  The deterministic symmetric mode always runs row-major

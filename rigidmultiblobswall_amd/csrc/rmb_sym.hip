@@ -69,7 +69,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   // (profiles/r4_coop_kernel_ab.txt): by default up to kCoopMaxRounds.
   constexpr long kCoopMaxRounds = 4;
   // Two target blobs per lane (sym2t_kernels.h): units are (row pair, tile) -- half as many steps, two pairs per step.
-  // From one resident round on (smaller launches stay with the cooperative kernel, whose four waves share a unit).
+  // From half a resident round on (smaller launches stay with the cooperative kernel, whose four waves share a unit).
   bool two = false;
   if (se.two && !f32 && !c->opt_wave_clock && c->opt_sym_two_targets && c->opt_sym_coop != 2 && tiles >= 4) {
     rmb::SymArgs t = a;
@@ -78,7 +78,9 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
     SymPlan plan2;
     if (int rc = plan_sym(c, (const void*)se.two, &se.two_occ, stat, t.step_end - t.step_begin, true, &plan2, rmb::kSymWavesPerEu))
       return rc;
-    if (!plan2.sub_round || c->opt_sym_two_targets == 2) {
+    // from half a unit (32 steps) per resident wave on: 6000 blobs on a whole MI355X (59.4 vs 60.3 us; 76.4 vs 80.4 at 7000,
+    // 97.2 vs 101.8 at 8000; below, the cooperative kernel wins: 50.7 vs 44.5 us at 5000 -- tools/experiments/exp_sym2t_threshold.py)
+    if (!plan2.sub_round || (t.step_end - t.step_begin) >= 32 * plan2.round * rmb::kSymWaves || c->opt_sym_two_targets == 2) {
       two = true;
       a = t;
       plan = plan2;
