@@ -197,6 +197,43 @@ for case in range(n4):
   if max(errs) > 1e-11:
     print("R4 CASE %d N=%d G=%d wall=%s L=%s errs=%s" % (case, N, G, wall, L, ["%.1e" % e for e in errs]), flush=True)
 print("round-4 cases (cooperative kernels, multi-device engine, sorted force culling) %d, worst relative error %.3e" % (n4, worst4))
+
+# --- end of round 4: two target blobs per lane (sym2t_kernel) forced at random sizes, kinds, clouds, pair shards -------------
+rng = np.random.RandomState(987 + (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+worst2t, n2t = 0.0, max(40, n_cases // 3)
+ctx2 = MobilityContext(0)
+ctx2.set_option("sym_two_targets", 2)
+for case in range(n2t):
+  N = int(rng.choice([193, 256, 257, 320, 449, 777, 1025, 1500, 2049, 3000, 4097]))
+  kind = str(rng.choice(["tt", "tr", "rt", "rr"]))
+  wall = bool(rng.rand() < 0.7)
+  a, eta = float(0.1 + rng.rand()), float(0.5 + rng.rand())
+  style = int(rng.randint(3))
+  box = a * (N ** (1.0 / 3.0)) * [6.0, 2.2, 3.0][style]
+  r = rng.rand(N, 3) * box
+  if style == 2:
+    r[:, 2] -= 0.15 * box
+  elif wall:
+    r[:, 2] += 1.05 * a
+  v = rng.randn(N, 3)
+  ref = getattr(oracle, "%s_mobility_%s_oracle" % ("single_wall" if wall else "no_wall", names[kind]))(r, v, eta, a)
+  nrm = np.linalg.norm(ref)
+  if not (np.isfinite(nrm) and nrm > 0):
+    continue
+  ctx2.set_positions(r, a, None, wall=wall)
+  got = ctx2.matvec(kind, v, eta)
+  assert ctx2.get_option("last_path") == 4
+  errs = [np.linalg.norm(got - ref) / nrm]
+  import torch
+  G = int(rng.choice([2, 3, 7]))
+  vd = torch.as_tensor(v.reshape(-1), device="cuda")
+  tot = sum(ctx2.matvec_pairshard_device(kind, vd, eta, g, G) for g in range(G)).cpu().numpy()
+  errs.append(np.linalg.norm(tot - ref) / nrm)
+  worst2t = max(worst2t, max(errs))
+  if max(errs) > 1e-11:
+    print("2T CASE %d N=%d kind=%s wall=%s style=%d G=%d errs=%s" % (case, N, kind, wall, style, G, ["%.1e" % e for e in errs]), flush=True)
+ctx2.close()
+print("two-targets-per-lane cases %d (whole products + pair shards against the oracle), worst relative error %.3e" % (n2t, worst2t))
 for m in engines.values():
   m.close()
 ctx.close()
