@@ -52,7 +52,8 @@ Objects on the line
 The run cannot hang and cannot lose its headline (class Guard): the headline goes to stderr and to a file the moment
 it exists; every later stage is started only if all ranks agree that it fits the wall-clock budget (--budget-s, 420 s);
 a rank whose stage raises drops a marker file and every rank's watchdog thread ends the run within a second -- rank 0
-prints the line with what exists plus `extras_aborted`; the same watchdog cuts a stage that never returns at the budget.
+prints the line with what exists plus `extras_aborted`; the same watchdog cuts a stage that never returns, at the stage's
+own limit (--stage-limit-s, counted from the stage's start) or at the budget.  All clocks are time.monotonic().
 """
 import argparse
 import json
@@ -99,6 +100,9 @@ def parse_args():
   ap.add_argument("--budget-s", type=float, default=420.0,
                   help="wall-clock budget of the whole run: stages that would not fit are skipped on all ranks, and at the "
                        "budget the watchdog prints the line with what exists and ends the run (the driver's limit is 600 s)")
+  ap.add_argument("--stage-limit-s", type=float, default=240.0,
+                  help="no single extra after the headline may run longer than this, counted from the moment the stage starts "
+                       "(the watchdog then prints the line with what exists and ends the run); 0 disables")
   ap.add_argument("--no-host-surface", action="store_true",
                   help="skip the host_surface extra (profiling runs: the last K dispatches of the trace are then the timed ones)")
   return ap.parse_args()
@@ -322,11 +326,13 @@ class Guard(object):
       the line with what it has (plus `extras_aborted`) and every rank leaves with os._exit -- whatever collective
       the main thread is stuck in."""
 
-  def __init__(self, rank, world, budget_s, run_dir, t0):
+  def __init__(self, rank, world, budget_s, run_dir, t0, stage_limit_s=None):
     import threading
     self.rank, self.world, self.budget, self.run_dir, self.t0 = rank, world, float(budget_s), run_dir, t0
+    self.stage_limit = float(stage_limit_s) if stage_limit_s else None
     self.line = None
     self.stage = "headline"
+    self.stage_t0 = None            # monotonic clock at the last begin() that let a stage start
     self._lock = threading.Lock()
     self._finished = False
     self._stop = threading.Event()
@@ -335,7 +341,9 @@ class Guard(object):
     self._thread.start()
 
   def elapsed(self):
-    return time.time() - self.t0
+    """Seconds since the rank started, on the MONOTONIC clock (a wall-clock step on a freshly leased box must not
+    trip the budget)."""
+    return time.monotonic() - self.t0
 
   def publish_headline(self, line, full=False):
     self.line = line
@@ -362,7 +370,12 @@ class Guard(object):
     ok = el + expect_s < self.budget
     if ok:
       self.stage = stage
+      self.stage_t0 = time.monotonic()
     return ok
+
+  def end(self):
+    """The stage begin() admitted has returned: its own time limit no longer applies."""
+    self.stage_t0 = None
 
   def fail(self, stage, exc):
     """A stage raised on this rank of a multi-rank run: tell every rank's watchdog, then wait to be taken down."""
@@ -396,8 +409,13 @@ class Guard(object):
     import glob
     while not self._stop.wait(0.25):
       reason = None
+      st0 = self.stage_t0
       if self.elapsed() > self.budget:
         reason = "wall-clock budget exhausted"
+      elif self.stage_limit is not None and st0 is not None and time.monotonic() - st0 > self.stage_limit:
+        # counted from the stage's own begin(), not from interpreter start: independent of how long import torch,
+        # the rendezvous and the headline took on this box
+        reason = "stage exceeded its time limit (%.0f s)" % self.stage_limit
       else:
         marks = sorted(glob.glob(os.path.join(self.run_dir, "abort_rank*")))
         if marks:
@@ -440,7 +458,7 @@ def _inject(stage, rank):
 
 
 def rank_main(args):
-  t_start = time.time()
+  t_start = time.monotonic()
   import torch
   import torch.distributed as dist
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -459,7 +477,7 @@ def rank_main(args):
   torch.cuda.set_device(device)
   run_dir = os.environ.get("RMB_BENCH_RUN_DIR") or os.path.join(
       "/tmp", "rmb_bench_%d_%s" % (os.getppid() if world > 1 else os.getpid(), os.environ.get("MASTER_PORT", "0")))
-  guard = Guard(rank, world, args.budget_s, run_dir, t_start)
+  guard = Guard(rank, world, args.budget_s, run_dir, t_start, stage_limit_s=args.stage_limit_s)
   if world > 1:
     if backend_name == "nccl":
       dist.init_process_group("nccl", device_id=device)
@@ -477,6 +495,7 @@ def rank_main(args):
   sm = ShardedMobility(backend, device=device)
 
   N = args.blobs
+  _inject("headline", rank)       # test hook: a rank that never produces its headline (cut by the whole-run budget)
   res = run_config(torch, dist, sm, backend, N, args.steps, args.warmup, world, rank, device, "pair", args.prewarm_ms,
                    unprimed=True)
   ms_per_step = 1e3 * res["dt"] / args.steps
@@ -579,6 +598,8 @@ def rank_main(args):
       line[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
       if world > 1:
         guard.fail(key, exc)
+    finally:
+      guard.end()
 
   # ---- extras ---------------------------------------------------------------------------------------------------
   def host_surface():

@@ -8,7 +8,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librmb_mobility.so")
+# RMB_DIAGNOSTICS=1 (tools/ only): the diagnostics build, whose option table knows "wave_clock" and "skip_pairs" -- the
+# release library refuses them (they change which kernel runs / make results wrong by design).
+DIAGNOSTICS = os.environ.get("RMB_DIAGNOSTICS", "0") not in ("", "0")
+LIB_PATH = os.path.join(_HERE, "librmb_mobility_diag.so" if DIAGNOSTICS else "librmb_mobility.so")
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p

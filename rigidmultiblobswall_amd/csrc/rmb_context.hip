@@ -2,6 +2,7 @@
 // diagnostics and the library's default context (include/rmb_mobility.h: "library / device", "persistent context").
 #include "rmb_internal.h"
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -172,8 +173,16 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "deterministic")) { c->opt_deterministic = value; return 0; }
   if (!strcmp(key, "det_workspace_mb")) { c->opt_det_workspace_mb = value < 1 ? 1 : value; return 0; }
   if (!strcmp(key, "sym_wps")) { c->opt_sym_wps = value; return 0; }
+#ifdef RMB_DIAGNOSTICS
+  // Diagnostics that make results WRONG ("skip_pairs") or change which kernel runs ("wave_clock") exist only in the
+  // diagnostics build of the library (librmb_mobility_diag.so, tools/ only): the release library's option table does
+  // not know them, so the boundary cannot be talked into a silent wrong answer.
   if (!strcmp(key, "wave_clock")) { c->opt_wave_clock = value; return 0; }
   if (!strcmp(key, "skip_pairs")) { c->opt_skip_pairs = value; return 0; }
+#else
+  if (!strcmp(key, "wave_clock") || !strcmp(key, "skip_pairs"))
+    return fail(RMB_ERR_ARG, std::string("option \"") + key + "\" exists only in the diagnostics build (librmb_mobility_diag.so, RMB_DIAGNOSTICS=1)");
+#endif
   if (!strcmp(key, "sym_pin")) { c->opt_sym_pin = value; return 0; }
   if (!strcmp(key, "precision")) {
     if (value != 32 && value != 64) return fail(RMB_ERR_ARG, "precision must be 32 or 64");
@@ -214,6 +223,27 @@ int rmb_ctx_get_option(rmb_ctx* c, const char* key, long* value) {
   // read-only: which kernel family the last product ran on (0 one-sided sweep, 1 symmetric per-wave, 2 deterministic
   // symmetric, 3 symmetric workgroup-cooperative)
   if (!strcmp(key, "last_path")) { *value = c->last_path; return 0; }
+  if (!strcmp(key, "diagnostics_build")) {
+#ifdef RMB_DIAGNOSTICS
+    *value = 1;
+#else
+    *value = 0;
+#endif
+    return 0;
+  }
+  // read-only: a hash of the addresses of every device buffer the library owns for this context.  A captured hipGraph
+  // of device-path calls holds those addresses by value; it stays valid exactly while this number is unchanged (a
+  // buffer that grows is freed and reallocated, DevBuf::reserve).
+  if (!strcmp(key, "buffers_signature")) {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&h](const rmbi::DevBuf& b) { h = (h ^ (unsigned long long)(uintptr_t)b.p) * 1099511628211ull; };
+    mix(c->pos); mix(c->r_stage); mix(c->vec); mix(c->vec2); mix(c->out); mix(c->partial); mix(c->tmp3n); mix(c->tile_bounds);
+    mix(c->fpos); mix(c->fperm); mix(c->fsort_keys); mix(c->fsort_vals); mix(c->fsort_tmp); mix(c->fsort_box); mix(c->det_ws);
+    for (const auto& b : c->st) mix(b);
+    mix(c->wave_clock); mix(c->krylov); mix(c->symbuf);
+    *value = (long)(h >> 1);
+    return 0;
+  }
   for (const auto& e : table)
     if (!strcmp(key, e.name)) { *value = *e.v; return 0; }
   return fail(RMB_ERR_ARG, std::string("unknown option: ") + key);

@@ -74,6 +74,32 @@ int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, doub
 
 // Multi-block operations (include/rmb_mobility.h, enum rmb_op).  One symmetric pass when that path applies (or for a
 // pair shard); otherwise composed from the one-sided sweeps (target sub-ranges, "deterministic", n < 128).
+// One pair shard of a single-vector product.  `in_plane` (the reference's in_plane_* wrappers: z row / column masked) is
+// honoured for the free-surface block only -- the one kind the multi-device engine routes here with it (the wall / open
+// kinds with in_plane go through matvec_op_impl's *_MULTI operations); the public rmb_matvec_pairshard_device passes 0.
+int matvec_pairshard_impl(rmb_ctx* c, int kind, int in_plane, const double* v, double eta, double* out, long shard, long nshards) {
+  if (int rc = check_ready(c)) return rc;
+  if ((kind < 0 || kind > rmb::KIND_RR) && kind != rmb::KIND_TT_FREE)
+    return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT / TR / RT / RR / TT_FREE_SURFACE (RMB_TT_TR: rmb_matvec_op_pairshard_device)");
+  if (kind == rmb::KIND_TT_FREE && c->wall)
+    return fail(RMB_ERR_STATE, "RMB_TT_FREE_SURFACE uses raw heights: call rmb_set_positions with wall = 0");
+  if (in_plane && kind != rmb::KIND_TT_FREE)
+    return fail(RMB_ERR_ARG, "pair shards with in_plane: use rmb_matvec_op_pairshard_device (RMB_OP_*_MULTI) for RMB_TT / TR / RT / RR");
+  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
+  if (c->n == 0) return 0;
+  if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  c->last_path = 1;
+  const int sx = kind == rmb::KIND_TT_FREE ? SX_FREE : SX_TT + kind;
+  const double* in[2] = {v, nullptr};
+  double* outs[1] = {out};
+  if (c->opt_deterministic == 2)        // bit-reproducible shard: whole units, ordered reduction (symx_det_device)
+    return symx_det_device(c, sx, in, outs, eta, in_plane ? 1 : 0, shard, nshards);
+  if (kind == rmb::KIND_TT_FREE) return symx_device(c, SX_FREE, in, outs, eta, in_plane ? 1 : 0, shard, nshards);
+  return sym_device(c, kind, v, eta, out, shard, nshards);
+}
+
 int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* const* in, int n_out, double* const* out,
                    double eta, long shard, long nshards) {
   if (int rc = check_ready(c)) return rc;
@@ -213,24 +239,7 @@ int rmb_matvec2_device(rmb_ctx* c, int kind, const double* vec_a, const double* 
 }
 
 int rmb_matvec_pairshard_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards) {
-  if (int rc = check_ready(c)) return rc;
-  if ((kind < 0 || kind > rmb::KIND_RR) && kind != rmb::KIND_TT_FREE)
-    return fail(RMB_ERR_ARG, "pair sharding is implemented for RMB_TT / TR / RT / RR / TT_FREE_SURFACE (RMB_TT_TR: rmb_matvec_op_pairshard_device)");
-  if (kind == rmb::KIND_TT_FREE && c->wall)
-    return fail(RMB_ERR_STATE, "RMB_TT_FREE_SURFACE uses raw heights: call rmb_set_positions with wall = 0");
-  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(RMB_ERR_ARG, "bad shard / nshards");
-  if (c->n == 0) return 0;
-  if (!v || !out) return fail(RMB_ERR_ARG, "null vector / output pointer");
-  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
-  RMB_HIP(hipSetDevice(c->device));
-  c->last_path = 1;
-  const int sx = kind == rmb::KIND_TT_FREE ? SX_FREE : SX_TT + kind;
-  const double* in[2] = {v, nullptr};
-  double* outs[1] = {out};
-  if (c->opt_deterministic == 2)        // bit-reproducible shard: whole units, ordered reduction (symx_det_device)
-    return symx_det_device(c, sx, in, outs, eta, 0, shard, nshards);
-  if (kind == rmb::KIND_TT_FREE) return symx_device(c, SX_FREE, in, outs, eta, 0, shard, nshards);
-  return sym_device(c, kind, v, eta, out, shard, nshards);
+  return matvec_pairshard_impl(c, kind, 0, v, eta, out, shard, nshards);
 }
 
 int rmb_matvec_op_device(rmb_ctx* c, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,

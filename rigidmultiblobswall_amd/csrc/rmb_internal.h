@@ -195,6 +195,7 @@ int ubench_fp64_issue(rmb_ctx* c, int launches, double* g_wave_instr_per_s);
 
 // ---- rmb_entry.hip (used by the multi-device engine too) ------------------------------------------------------
 int matvec_device_impl(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out);
+int matvec_pairshard_impl(rmb_ctx* c, int kind, int in_plane, const double* v, double eta, double* out, long shard, long nshards);
 int matvec_op_impl(rmb_ctx* c, int op, int in_plane, int n_in, const double* const* in, int n_out, double* const* out,
                    double eta, long shard, long nshards);
 int force_device_impl(rmb_ctx* c, double eps, double b, double blob_radius, double* out, const double* radii = nullptr,

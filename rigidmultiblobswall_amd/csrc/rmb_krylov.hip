@@ -196,7 +196,11 @@ int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double*
   while ((n + chunk - 1) / chunk > 256 && chunk < kKrMaxChunk) chunk *= 2;
   a.chunk = chunk;
   a.n_chunks = (n + chunk - 1) / chunk;
-  const size_t need = ((size_t)2 * rows * a.n_chunks + a.n_chunks + rows) * sizeof(double);
+  // Sized for the LARGEST basis (kKrMaxRows) whatever `rows` is: the scratch then depends on n only and never moves
+  // while a solve walks up its iteration indices.  rigid.py captures one hipGraph per iteration index with these
+  // addresses baked in; a buffer that grew with `rows` was freed and reallocated every 2-3 indices, and the graphs
+  // captured for lower indices replayed into freed memory.  ~1 MB for up to 65 536 unknowns.
+  const size_t need = ((size_t)2 * kKrMaxRows * a.n_chunks + a.n_chunks + kKrMaxRows) * sizeof(double);
   if (int rc = c->krylov.reserve(need)) return rc;
   a.V = V_dev; a.w = w_dev; a.col = col_dev; a.v_next = v_next_dev;
   a.part1 = (double*)c->krylov.p;

@@ -150,6 +150,37 @@ int pinned_reserve(rmb_multi* m, size_t bytes) {
   return 0;
 }
 
+// Every shard's partial for the largest product (kMaxVec outputs of 3n doubles).  Called from rmb_multi_set_positions*:
+// if a buffer has to grow, everything the previous calls left in flight on ANY device is drained first, because peers
+// read these buffers.
+int reserve_partials(rmb_multi* m, long n) {
+  const size_t need = (size_t)kMaxVec * 3 * (size_t)n * sizeof(double);
+  bool grow = false;
+  for (const Shard& s : m->sh) grow = grow || need > s.part.cap;
+  if (!grow) return 0;
+  for (Shard& s : m->sh) {
+    RMB_HIP(hipSetDevice(s.device));
+    RMB_HIP(hipStreamSynchronize(s.stream));
+  }
+  if (m->done_recorded) { RMB_HIP(hipEventSynchronize(m->ev_done)); }
+  for (Shard& s : m->sh) {
+    RMB_HIP(hipSetDevice(s.device));
+    if (int rc = s.part.reserve(need)) return rc;
+  }
+  return 0;
+}
+
+// The engine sets the calling thread's current device as it goes (devices[g] for every shard); every rmb_multi_* entry
+// point puts back what was current on entry, on every return path -- an in-process torch caller would otherwise find its
+// implicit-device allocations and current stream on another GPU.
+struct DeviceGuard {
+  int saved = -1;
+  DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) { saved = -1; (void)hipGetLastError(); } }
+  ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int check_multi(rmb_multi* m, bool need_positions) {
   if (!m) return fail(RMB_ERR_ARG, "null multi-device engine");
   if (need_positions && !m->have_positions) return fail(RMB_ERR_STATE, "rmb_multi_set_positions has not been called");
@@ -202,7 +233,7 @@ int rccl_comms(rmb_multi* m) {
 }
 
 int launch_kind(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long g, long G) {
-  return rmb_matvec_pairshard_device(c, p.kind, in[0], p.eta, out[0], g, G);
+  return rmbi::matvec_pairshard_impl(c, p.kind, p.in_plane, in[0], p.eta, out[0], g, G);   // in_plane: free surface only (product_of_kind)
 }
 int launch_op(rmb_ctx* c, const Product& p, const double* const* in, double* const* out, long g, long G) {
   return rmbi::matvec_op_impl(c, p.op, p.in_plane, p.n_in, in, p.n_out, out, p.eta, g, G);
@@ -234,7 +265,10 @@ int shard_sweep(rmb_multi* m, int g, const Job& job) {
     }
     in_local[v] = (const double*)s.in[v].p;
   }
-  if (int rc = s.part.reserve((size_t)p.n_out * len * sizeof(double))) return rc;
+  // `part` is the one buffer OTHER devices read (peer-mapped loads of reduce_slices_kernel): it is sized for kMaxVec
+  // outputs when the positions are set (reserve_partials, after the previous job has drained everywhere) and never
+  // reallocated by a product -- a hipFree here could pull it from under a peer's reduction of the previous product.
+  if ((size_t)p.n_out * len * sizeof(double) > s.part.cap) return fail(RMB_ERR_STATE, "engine partial buffer smaller than the product (internal)");
   double* outs[kMaxVec];
   for (int v = 0; v < p.n_out; ++v) outs[v] = (double*)s.part.p + v * len;
   if (int rc = p.launch(s.ctx, p, in_local, outs, g, G)) return rc;
@@ -459,7 +493,7 @@ int product_of_kind(rmb_multi* m, int kind, int in_plane, bool have_vec2, double
   p->n_out = 1;
   if (kind == rmb::KIND_TT_TR) { p->op = RMB_OP_VELOCITY_FROM_FORCE_TORQUE; p->launch = launch_op; }
   else if (in_plane && kind <= rmb::KIND_RR) { p->op = RMB_OP_TT_MULTI + kind; p->launch = launch_op; }   // row / column mask of the symmetric block
-  else p->launch = launch_kind;
+  else p->launch = launch_kind;      // RMB_TT_FREE_SURFACE keeps its in_plane mask (matvec_pairshard_impl), like the single context
   (void)m;
   return 0;
 }
@@ -476,6 +510,7 @@ int product_of_op(int op, int in_plane, int n_in, int n_out, double eta, Product
 extern "C" {
 
 int rmb_multi_create(const int* devices, int n_dev, rmb_multi** out) {
+  DeviceGuard restore_device_;
   if (!out) return fail(RMB_ERR_ARG, "null engine out pointer");
   if (!devices || n_dev < 1 || n_dev > kMaxShards) return fail(RMB_ERR_ARG, "device list must hold 1..16 entries");
   int n_vis = 0;
@@ -539,6 +574,7 @@ int rmb_multi_create(const int* devices, int n_dev, rmb_multi** out) {
 }
 
 int rmb_multi_destroy(rmb_multi* m) {
+  DeviceGuard restore_device_;
   if (!m) return 0;
   if (!m->workers.empty()) {
     {
@@ -580,6 +616,7 @@ int rmb_multi_shard_ctx(rmb_multi* m, int shard, rmb_ctx** ctx) {
 }
 
 int rmb_multi_set_stream(rmb_multi* m, void* hip_stream) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, false)) return rc;
   const hipStream_t next = (hipStream_t)hip_stream;
   if (next != m->primary) {
@@ -595,6 +632,7 @@ int rmb_multi_set_stream(rmb_multi* m, void* hip_stream) {
 }
 
 int rmb_multi_set_option(rmb_multi* m, const char* key, long value) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, false)) return rc;
   if (!key) return fail(RMB_ERR_ARG, "null key");
   if (!strcmp(key, "reduce")) {
@@ -618,12 +656,14 @@ int rmb_multi_get_option(rmb_multi* m, const char* key, long* value) {
 }
 
 int rmb_multi_set_positions(rmb_multi* m, const double* r_host, long n, double a, const double* L, int wall) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, false)) return rc;
   if (n < 0) return fail(RMB_ERR_ARG, "negative n");
   if (n > 0 && !r_host) return fail(RMB_ERR_ARG, "null positions");
   if (!(a > 0.0)) return fail(RMB_ERR_ARG, "blob radius must be positive");
   const size_t rb = (size_t)3 * n * sizeof(double);
   if (m->done_recorded) { RMB_HIP(hipEventSynchronize(m->ev_done)); }
+  if (int rc = reserve_partials(m, n)) return rc;
   if (n > 0) {
     if (int rc = pinned_reserve(m, rb)) return rc;
     memcpy(m->pinned, r_host, rb);
@@ -646,12 +686,14 @@ int rmb_multi_set_positions(rmb_multi* m, const double* r_host, long n, double a
 }
 
 int rmb_multi_set_positions_device(rmb_multi* m, const double* r_dev, long n, double a, const double* L, int wall) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, false)) return rc;
   if (n < 0) return fail(RMB_ERR_ARG, "negative n");
   if (n > 0 && !r_dev) return fail(RMB_ERR_ARG, "null positions");
   if (!(a > 0.0)) return fail(RMB_ERR_ARG, "blob radius must be positive");
   const long len = 3 * n;
   Shard& s0 = m->sh[0];
+  if (int rc = reserve_partials(m, n)) return rc;
   RMB_HIP(hipSetDevice(s0.device));
   RMB_HIP(hipEventRecord(m->ev_in, m->primary));
   for (Shard& s : m->sh) {
@@ -680,6 +722,7 @@ int rmb_multi_set_positions_device(rmb_multi* m, const double* r_dev, long n, do
 
 int rmb_multi_matvec(rmb_multi* m, int kind, int in_plane, const double* vec_host, const double* vec2_host, double eta,
                      double* out_host) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, true)) return rc;
   if (m->n == 0) return 0;
   if (!vec_host || !out_host) return fail(RMB_ERR_ARG, "null vector / output pointer");
@@ -692,6 +735,7 @@ int rmb_multi_matvec(rmb_multi* m, int kind, int in_plane, const double* vec_hos
 
 int rmb_multi_matvec_device(rmb_multi* m, int kind, int in_plane, const double* vec_dev, const double* vec2_dev, double eta,
                             double* out_dev) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, true)) return rc;
   if (m->n == 0) return 0;
   if (!vec_dev || !out_dev) return fail(RMB_ERR_ARG, "null vector / output pointer");
@@ -704,6 +748,7 @@ int rmb_multi_matvec_device(rmb_multi* m, int kind, int in_plane, const double* 
 
 int rmb_multi_matvec_op_device(rmb_multi* m, int op, int in_plane, int n_in, const double* const* in_dev, int n_out,
                                double* const* out_dev, double eta) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, true)) return rc;
   if (!in_dev || !out_dev) return fail(RMB_ERR_ARG, "null vector / output list");
   Product p;
@@ -715,6 +760,7 @@ int rmb_multi_matvec_op_device(rmb_multi* m, int op, int in_plane, int n_in, con
 }
 
 int rmb_multi_blob_blob_force(rmb_multi* m, double repulsion_strength, double debye_length, double blob_radius, double* out_host) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, true)) return rc;
   if (m->n == 0) return 0;
   if (!out_host) return fail(RMB_ERR_ARG, "null output pointer");
@@ -726,6 +772,7 @@ int rmb_multi_blob_blob_force(rmb_multi* m, double repulsion_strength, double de
 
 int rmb_multi_blob_blob_force_device(rmb_multi* m, double repulsion_strength, double debye_length, double blob_radius,
                                      double* out_dev) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, true)) return rc;
   if (m->n == 0) return 0;
   if (!out_dev) return fail(RMB_ERR_ARG, "null output pointer");
@@ -736,6 +783,7 @@ int rmb_multi_blob_blob_force_device(rmb_multi* m, double repulsion_strength, do
 }
 
 int rmb_multi_synchronize(rmb_multi* m) {
+  DeviceGuard restore_device_;
   if (int rc = check_multi(m, false)) return rc;
   for (Shard& s : m->sh) {
     RMB_HIP(hipSetDevice(s.device));

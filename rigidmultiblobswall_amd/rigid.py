@@ -554,6 +554,7 @@ class RigidSuspension(object):
     ws = getattr(self, "_arnoldi_ws", None)
     if ws is None or ws.m != restart:
       ws = self._arnoldi_ws = _ArnoldiGraphs(self.size, restart, self.device)
+    ws.buffers = getattr(self.ctx, "buffers_signature", None)
     ptr = lambda t: None if t is None else t.data_ptr()
     ws.bind((self.ctx.launch_signature(), self.eta, self._native_blocks() is not None, ptr(self.free), ptr(self.prescribed_velocity),
              tuple(tuple(ptr(t) for t in (g.K, g.A11, g.A12, g.A21, g.A22)) for g in self.groups)))
@@ -814,6 +815,9 @@ class _ArnoldiGraphs(object):
     self.stream = torch.cuda.Stream(device)
     self.graphs, self.seen, self.signature = {}, set(), None
     self.solves = self.captures = self.replays = self.replays_this_solve = 0
+    self.buffers = None               # callable: the context's buffers_signature() (set by the owner), checked before a replay
+    self.buffers_at_capture = None
+    self.stale_drops = 0
 
   def bind(self, signature):
     if signature != self.signature:
@@ -832,6 +836,16 @@ class _ArnoldiGraphs(object):
 
   def run(self, j, body, on_replay=None):
     g = self.graphs.get(j)
+    if g is not None and self.buffers is not None:
+      # The graph holds the addresses of the context's internal buffers by value.  An eager iteration of THIS solve (a
+      # higher index met for the first time, another product on the shared context) may have grown one of them since
+      # bind(): then every graph captured before is stale -- drop them all and go on eagerly.
+      now = self.buffers()
+      if now != self.buffers_at_capture:
+        self.graphs.clear()
+        self.stale_drops += 1
+        self.buffers_at_capture = now
+        g = None
     if g is None:
       if j not in self.seen or self.solves <= self.capture_after:
         body()                                   # eager: also warms every library call of this iteration's shapes
@@ -852,6 +866,12 @@ class _ArnoldiGraphs(object):
       finally:
         if gc_was_on:
           gc.enable()
+      if self.buffers is not None:
+        now = self.buffers()
+        if self.graphs and now != self.buffers_at_capture:    # the eager warm-ups must have sized everything: never expected
+          self.graphs.clear()
+          self.stale_drops += 1
+        self.buffers_at_capture = now
       self.graphs[j] = g
       self.captures += 1
     elif on_replay is not None:

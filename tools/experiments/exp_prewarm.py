@@ -7,6 +7,7 @@
    Results with skip_pairs != 0 are WRONG by construction; only the time is used.
 """
 import os
+os.environ.setdefault("RMB_DIAGNOSTICS", "1")   # skip_pairs / wave_clock exist in the diagnostics build only (librmb_mobility_diag.so)
 import sys
 import time
 

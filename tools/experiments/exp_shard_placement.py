@@ -1,6 +1,7 @@
 """Why do the waves of a one-round pair-shard launch start over ~20 us when the chip starts 5120 empty waves in 3 us
 (tools/ubench_dispatch.hip)?  Per-wave start / end stamps + placement (XCC, SE, CU, SIMD) of one G = 8 shard at 1e4."""
 import os, sys, time
+os.environ.setdefault("RMB_DIAGNOSTICS", "1")   # skip_pairs / wave_clock exist in the diagnostics build only (librmb_mobility_diag.so)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext

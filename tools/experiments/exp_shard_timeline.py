@@ -4,6 +4,7 @@ For G in (1, 2, 4, 8): sweep time by HIP events (clocks primed), per-wave start 
 the same with skip_pairs = 1 (prologue + epilogue only, no pair arithmetic), and the end-to-end time of
 sweep + finalize per call without events (what a rank really spends before its all-reduce)."""
 import os, sys, time
+os.environ.setdefault("RMB_DIAGNOSTICS", "1")   # skip_pairs / wave_clock exist in the diagnostics build only (librmb_mobility_diag.so)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rigidmultiblobswall_amd import MobilityContext
