@@ -87,7 +87,7 @@ class MobilityContext(object):
     number of blobs, radius, box and wall of the bound configuration and every option set through set_option().  A
     captured hipGraph of device-path calls stays valid while this is unchanged (positions may move: the packed
     coordinates are rewritten in place) -- rigid.py keys its captured Arnoldi iterations on it."""
-    return (self._geometry, tuple(self.target_range), tuple(sorted(self._options_set.items())), self.buffers_signature())
+    return (self._geometry, tuple(self.target_range), tuple(sorted(self._options_set.items())))
 
   def buffers_signature(self):
     """Hash of the addresses of every device buffer the library owns for this context (read-only option

@@ -93,12 +93,16 @@ int resident_blocks(const void* fn, int* cache) {
 // zeroed once; every finalize kernel re-zeroes what its sweep touched.
 constexpr int kSymMaxOut = 4;
 int sym_accumulators(rmb_ctx* c, long n_pad) {
+  // The accumulators are zero between products whatever layout the last product used: the kernels only add into entries
+  // the finalize kernel of the same product reads and re-zeroes.  So the buffer is cleared ONCE, in full, when it is
+  // (re)allocated -- never because n_pad changed: a context shared by two suspensions would otherwise put a memset into
+  // whichever captured hipGraph happens to run first after the switch (rigid.py, _ArnoldiGraphs).
   const size_t acc_bytes = (size_t)3 * kSymMaxOut * n_pad * sizeof(double);
-  if (acc_bytes > c->symbuf.cap || c->symbuf_zeroed_for != n_pad) {
+  if (acc_bytes > c->symbuf.cap) {
     if (int rc = c->symbuf.reserve(acc_bytes)) return rc;
-    RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, acc_bytes, c->stream));
-    c->symbuf_zeroed_for = n_pad;
+    RMB_HIP(hipMemsetAsync(c->symbuf.p, 0, c->symbuf.cap, c->stream));
   }
+  c->symbuf_zeroed_for = n_pad;
   return 0;
 }
 

@@ -836,16 +836,15 @@ class _ArnoldiGraphs(object):
 
   def run(self, j, body, on_replay=None):
     g = self.graphs.get(j)
-    if g is not None and self.buffers is not None:
-      # The graph holds the addresses of the context's internal buffers by value.  An eager iteration of THIS solve (a
-      # higher index met for the first time, another product on the shared context) may have grown one of them since
-      # bind(): then every graph captured before is stale -- drop them all and go on eagerly.
-      now = self.buffers()
-      if now != self.buffers_at_capture:
-        self.graphs.clear()
-        self.stale_drops += 1
-        self.buffers_at_capture = now
-        g = None
+    if g is not None and self.buffers is not None and self.buffers() != self.buffers_at_capture:
+      # The graph holds the addresses of the context's internal buffers by value, and one of them has moved since the
+      # capture (another, larger suspension used the shared context; a product grew a scratch buffer): every graph is
+      # stale.  Same treatment as a changed signature in bind(): drop them, run eagerly again, capture afresh after
+      # `capture_after` further solves.
+      self.release()
+      self.solves = 1            # this solve is the first of the new series
+      self.stale_drops += 1
+      g = None
     if g is None:
       if j not in self.seen or self.solves <= self.capture_after:
         body()                                   # eager: also warms every library call of this iteration's shapes
@@ -868,7 +867,7 @@ class _ArnoldiGraphs(object):
           gc.enable()
       if self.buffers is not None:
         now = self.buffers()
-        if self.graphs and now != self.buffers_at_capture:    # the eager warm-ups must have sized everything: never expected
+        if self.graphs and now != self.buffers_at_capture:    # the eager warm-ups have sized everything: never expected
           self.graphs.clear()
           self.stale_drops += 1
         self.buffers_at_capture = now

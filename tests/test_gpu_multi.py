@@ -72,6 +72,11 @@ def test_host_products_equal_single_context_and_oracle(oracle, G, n):
       else:
         u1 = single.matvec("tt_free", f, eta)
         assert rel_err(multi.matvec("tt_free", f, eta), u1) < TOL_VS_SINGLE
+        # the engine used to drop in_plane for the free-surface block (the single context honours it)
+        u1 = single.matvec("tt_free", f, eta, in_plane=True)
+        uG = multi.matvec("tt_free", f, eta, in_plane=True)
+        assert rel_err(uG, u1) < TOL_VS_SINGLE and np.all(uG.reshape(-1, 3)[:, 2] == 0.0)
+        assert rel_err(u1, single.matvec("tt_free", f, eta)) > 1e-3          # the mask does something
   finally:
     single.close()
     multi.close()
@@ -403,3 +408,44 @@ def test_host_timing_of_the_synchronous_entry_point():
     assert abs(ht["upload_us"] + ht["launch_us"] + ht["wait_and_download_us"] - ht["c_call_us"]) < 1e-6 * ht["c_call_us"] + 1e-3
   finally:
     ctx.close()
+
+
+def test_engine_restores_the_callers_device_and_never_moves_its_partials(torch_mod):
+  """(i) every rmb_multi_* entry point leaves the calling thread's current HIP device as it found it (on a node
+  the engine walks over devices[g]; here: still cuda:0 and torch's current stream untouched); (ii) the partial buffers
+  peers read are sized for the largest product (4 outputs) when the positions are set and never reallocated by a
+  product: a one-output product followed by GRAND (two outputs) and a four-vector pass, all asynchronous, equal the
+  single context."""
+  torch = torch_mod
+  from rigidmultiblobswall_amd import MobilityContext
+  n = 3000
+  r, f, t, eta, a, _ = _cloud(n, 33)
+  dev = torch.device("cuda:0")
+  rd, fd, td = (torch.as_tensor(x.reshape(-1), device=dev) for x in (r, f, t))
+  single, multi = MobilityContext(0), _engine(3)
+  try:
+    single.set_positions(rd, a, None, True)
+    multi.set_positions(rd, a, None, True)
+    assert torch.cuda.current_device() == 0
+    outs = [multi.matvec_device("tt", fd, eta)]                          # n_out = 1 ...
+    outs += list(multi.matvec_op_device("grand", (fd, td), eta))         # ... then 2, enqueued behind it
+    outs += list(multi.matvec_op_device("rr_multi", (fd, td, fd - td, fd + td), eta))     # ... then 4
+    outs += [multi.matvec_device("tt", td, eta)]
+    assert torch.cuda.current_device() == 0
+    torch.cuda.synchronize()
+    refs = [single.matvec_device("tt", fd, eta)] + list(single.matvec_op_device("grand", (fd, td), eta)) + \
+           list(single.matvec_op_device("rr_multi", (fd, td, fd - td, fd + td), eta)) + [single.matvec_device("tt", td, eta)]
+    for k, (x, y) in enumerate(zip(outs, refs)):
+      assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < TOL_VS_SINGLE, k
+    # a larger configuration on the same engine: the partials grow at set_positions (after a drain), not inside a product
+    n2 = 5000
+    r2, f2, t2, _, _, _ = _cloud(n2, 34)
+    multi.set_positions(r2, a, None, True)
+    single.set_positions(r2, a, None, True)
+    assert rel_err(multi.matvec("tt", f2, eta), single.matvec("tt", f2, eta)) < TOL_VS_SINGLE
+    o1, o2 = multi.matvec_op_device("grand", tuple(torch.as_tensor(x.reshape(-1), device=dev) for x in (f2, t2)), eta)
+    s1, s2 = single.matvec_op_device("grand", tuple(torch.as_tensor(x.reshape(-1), device=dev) for x in (f2, t2)), eta)
+    assert rel_err(o1.cpu().numpy(), s1.cpu().numpy()) < TOL_VS_SINGLE and rel_err(o2.cpu().numpy(), s2.cpu().numpy()) < TOL_VS_SINGLE
+  finally:
+    single.close()
+    multi.close()

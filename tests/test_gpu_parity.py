@@ -112,6 +112,87 @@ def test_vs_oracle_d1_dense_overlapping(mob, oracle, stem):
   assert rel_err(u, ref) < TOL_D1, rel_err(u, ref)
 
 
+# ---------------------------------------------------------------------------------------------
+# 2b. sym2t_kernel (two target blobs per lane) DIRECTLY against the oracle / the reference's fixtures, at the sizes where
+#     it is the default: every kind x wall / no wall, whole products and pair shards.  Reference
+#     arithmetic: mobility_numba.py:124-287 (tt), :548-686 (tr), :938-1073 (rt), :1189-1328 (rr) and their no-wall twins.
+# ---------------------------------------------------------------------------------------------
+def _edge_sample(n, k=96, seed=1):
+  """Targets incl. the edges of the 64-blob tiles, both rows of the first / last row pair and the partial last tile."""
+  tg = np.random.RandomState(seed).choice(n, k, replace=False)
+  edges = [0, 63, 64, 127, 128, 191, n - 1, n - 64, n - 65, n - 128, (n // 2) // 64 * 64, (n // 2) // 64 * 64 + 63]
+  tg[:len(edges)] = [e for e in edges]
+  return np.unique(tg[(tg >= 0) & (tg < n)])
+
+
+def _oracle_on_targets(oracle, kind, wall, r, v, eta, a, tg):
+  """The reference wrapper's result (shift_heights + B on both sides, mobility/mobility.py:1132-1163) on `tg` only."""
+  if not wall:
+    return oracle.raw_matvec_targets(kind, 0, r, v, eta, a, tg)
+  r_eff, bdiag, _ = oracle.wall_regularisation(r, a)
+  ref = oracle.raw_matvec_targets(kind, 1, r_eff, np.asarray(v).reshape(-1, 3) * bdiag[:, None], eta, a, tg)
+  return (ref.reshape(-1, 3) * bdiag[tg][:, None]).reshape(-1)
+
+
+@pytest.mark.parametrize("N", [10000, 24576, 24577])
+@pytest.mark.parametrize("wall", [True, False], ids=["wall", "no_wall"])
+def test_two_targets_kernel_vs_oracle_where_it_is_the_default(Ctx, oracle, N, wall):
+  """1e4 (configs[1]), 24 576 (configs[2]) and 24 577 blobs (odd tile count + a one-blob last tile); D2 cloud lowered so
+  that ~2 % of the blobs sit below z = a (height clamp + B-damping path); default options -- last_path must say sym2t."""
+  import torch
+  r, v, eta, a = d2_cloud(N, seed=N % 1000)
+  r = r.copy(); r[:, 2] -= 0.45 * a          # z in [0.65 a, ...): some blobs below z = a
+  assert not wall or np.sum(r[:, 2] < a) > 20
+  tg = _edge_sample(N)
+  vd = torch.as_tensor(v.reshape(-1), device="cuda")
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(torch.as_tensor(r.reshape(-1), device="cuda"), a, None, wall)
+    for kind in ("tt", "tr", "rt", "rr"):
+      ref = _oracle_on_targets(oracle, kind, wall, r, v, eta, a, tg)
+      u = ctx.matvec_device(kind, vd, eta).cpu().numpy()
+      assert ctx.get_option("last_path") == 4, (kind, ctx.get_option("last_path"))      # rmb::sym2t_kernel<kind, wall>
+      assert np.all(np.isfinite(u))
+      e = rel_err(u.reshape(-1, 3)[tg].reshape(-1), ref)
+      assert e < TOL_D2, (N, wall, kind, e)
+      for G in (2, 8):        # pair shards of an N-GPU run, summed as the all-reduce would
+        tot = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
+        for g in range(G):
+          tot += ctx.matvec_pairshard_device(kind, vd, eta, g, G)
+        e = rel_err(tot.cpu().numpy().reshape(-1, 3)[tg].reshape(-1), ref)
+        assert e < TOL_D2, (N, wall, kind, G, e)
+  finally:
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["g1_test_blobs_N1000", "g1_test_blobs_N300", "g3_wall_cloud_N200"])
+def test_two_targets_kernel_forced_on_the_reference_fixtures(Ctx, name):
+  """The reference's own outputs (tests/golden, generated from the imported reference) with sym_two_targets = 2 forced, so
+  the fixtures that normally run on the cooperative kernel meet every sym2t instantiation too."""
+  import os
+  import torch
+  from conftest import GOLDEN
+  g = load_golden(os.path.join(GOLDEN, name + ".npz"))
+  r, v, eta, a = g["r_vectors"], g["vector"], float(g["eta"]), float(g["a"])
+  assert not np.any(g["periodic_length"])
+  vd = torch.as_tensor(np.ascontiguousarray(v).reshape(-1), device="cuda")
+  ctx = Ctx(0)
+  try:
+    ctx.set_option("sym_two_targets", 2)
+    for wall in (True, False):
+      ctx.set_positions(torch.as_tensor(np.ascontiguousarray(r).reshape(-1), device="cuda"), a, None, wall)
+      for kind in ("tt", "tr", "rt", "rr"):
+        key = ("wall_" if wall else "no_wall_") + kind
+        if key not in g:            # the N = 1000 fixture holds tt only (the reference's pure-Python kernels take minutes there)
+          continue
+        u = ctx.matvec_device(kind, vd, eta).cpu().numpy()
+        assert ctx.get_option("last_path") == 4, (key, ctx.get_option("last_path"))
+        tol = TOL_D2 if "wall_cloud" in name else TOL_D1
+        assert rel_err(u, g[key]) < tol, (name, key, rel_err(u, g[key]))
+  finally:
+    ctx.close()
+
+
 def test_config2_size_1e4_wall_tt(mob, oracle):
   """BASELINE.json configs[1]: 1e4 random blobs above a wall, single_wall_mobility_trans_times_force."""
   r, f, eta, a = d2_cloud(10000, seed=0)

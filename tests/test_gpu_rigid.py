@@ -360,6 +360,84 @@ def test_captured_arnoldi_iterations_equal_the_eager_loop():
     graphed.close()
 
 
+def test_captured_iterations_survive_longer_solves_and_a_shared_context():
+  """the captured graphs hold the addresses of the library's internal buffers by value.  (i) The
+  Gram-Schmidt scratch used to grow with the iteration index, so a solve that reached a higher index than the captured
+  ones freed the buffer under them: capture with short solves, run a longer one, replay a short one -- the scratch must
+  not have moved (buffers_signature constant) and the results must equal the eager loop.  (ii) A context shared by two
+  suspensions of different sizes (n -> n' -> n) moves the packed positions / accumulators: the stale graphs are dropped
+  before a replay (stale_drops) instead of being replayed into freed memory."""
+  import torch
+  from rigidmultiblobswall_amd import MobilityContext
+  nb = 40
+  eager, loc, quat = _shell_suspension(nb)
+  graphed, _, _ = _shell_suspension(nb)
+  eager.gmres_graph, graphed.gmres_graph = False, True
+  rng = np.random.RandomState(4)
+
+  def both(tol, label, sus=(None, None)):
+    e, g = sus if sus[0] is not None else (eager, graphed)
+    rhs = torch.as_tensor(rng.randn(e.size), device="cuda:0")
+    xe, ie = e.solve(rhs, tol=tol, restart=60)
+    xg, ig = g.solve(rhs, tol=tol, restart=60)
+    torch.cuda.synchronize()
+    assert ig["iterations"] == ie["iterations"], (label, ie["iterations"], ig["iterations"])
+    assert rel_err(xg.cpu().numpy(), xe.cpu().numpy()) < 1e-7, (label, rel_err(xg.cpu().numpy(), xe.cpu().numpy()))
+    res = float(torch.linalg.norm(e.apply_operator(xg) - rhs) / torch.linalg.norm(rhs))
+    assert res < 5 * tol, (label, res)
+    return ig
+
+  try:
+    short = [both(1e-2, "short %d" % k) for k in range(4)]          # captures the first few iteration indices
+    assert short[-1]["graph_replays"] > 0
+    sig = graphed.ctx.buffers_signature()
+    k_short = short[-1]["iterations"]
+    long_ = both(1e-10, "long")                                     # reaches indices never seen before: eager there
+    assert long_["iterations"] >= k_short + 5, (k_short, long_["iterations"])
+    assert graphed.ctx.buffers_signature() == sig                   # nothing the graphs point at has moved
+    again = both(1e-2, "short again")                               # replays the graphs captured BEFORE the long solve
+    assert again["graph_replays"] > 0 and graphed._arnoldi_ws.stale_drops == 0
+    both(1e-10, "long again")
+    both(1e-10, "long, captured now")
+    assert graphed.ctx.buffers_signature() == sig
+  finally:
+    eager.close()
+    graphed.close()
+
+  # (ii) one context, two suspensions: 20 shells, then 60 shells (every per-blob buffer grows), then the 20 again
+  ctx = MobilityContext(0)
+  small_e, _, _ = _shell_suspension(20, seed=3)
+  big_e, _, _ = _shell_suspension(60, seed=4)
+  small_g, loc_s, quat_s = _shell_suspension(20, seed=3, ctx=ctx)
+  big_g, loc_b, quat_b = _shell_suspension(60, seed=4, ctx=ctx)
+  small_e.gmres_graph = big_e.gmres_graph = False
+  small_g.gmres_graph = big_g.gmres_graph = True
+  try:
+    small_g.set_configuration(loc_s, quat_s)          # the shared context holds the LAST configuration bound: rebind
+    for k in range(4):
+      ig = both(1e-8, "small %d" % k, (small_e, small_g))
+    assert ig["graph_replays"] > 0
+    sig_small = ctx.buffers_signature()
+    big_g.set_configuration(loc_b, quat_b)
+    for k in range(4):
+      ig = both(1e-8, "big %d" % k, (big_e, big_g))
+    assert ig["graph_replays"] > 0 and ctx.buffers_signature() != sig_small
+    small_g.set_configuration(loc_s, quat_s)
+    ig = both(1e-8, "small after big", (small_e, small_g))
+    assert small_g._arnoldi_ws.stale_drops == 1 and ig["graph_replays"] == 0      # noticed BEFORE the first replay
+    for k in range(3):                                                            # eager, eager, captured afresh
+      ig = both(1e-8, "small after big, %d" % k, (small_e, small_g))
+    assert ig["graph_replays"] > 0 and small_g._arnoldi_ws.stale_drops == 1
+    # and the big one again: nothing moved since its captures (buffers only grow), its graphs are still good
+    big_g.set_configuration(loc_b, quat_b)
+    ig = both(1e-8, "big after small", (big_e, big_g))
+    assert ig["graph_replays"] > 0 and big_g._arnoldi_ws.stale_drops == 0
+  finally:
+    for s_ in (small_e, big_e, small_g, big_g):
+      s_.close()
+    ctx.close()
+
+
 def test_captured_arnoldi_iterations_with_mixed_shapes_and_prescribed_bodies():
   """The general operator path (two body shapes: gathers / scatters, torch.cat; an obstacle with prescribed kinematics)
   under the captured iterations, against the eager loop; and the automatic switch: on below gmres_graph_max_blobs for a
