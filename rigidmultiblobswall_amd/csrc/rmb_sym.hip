@@ -71,7 +71,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   // Two target blobs per lane (sym2t_kernels.h): units are (row pair, tile) -- half as many steps, two pairs per step.
   // From half a resident round on (smaller launches stay with the cooperative kernel, whose four waves share a unit).
   bool two = false;
-  if (se.two && !f32 && !c->opt_wave_clock && c->opt_sym_two_targets && c->opt_sym_coop != 2 && tiles >= 4) {
+  if (se.two && !f32 && c->opt_sym_two_targets && c->opt_sym_coop != 2 && tiles >= 4) {
     rmb::SymArgs t = a;
     t.n_units = rmb::units2_total(tiles);
     shard_ranges(n, t.n_units, shard, nshards, &t.step_begin, &t.step_end, &t.self_begin, &t.self_end);
@@ -107,7 +107,9 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   a.accumulate = accumulate ? 1 : 0;
   a.wave_clock = nullptr;
   if (c->opt_wave_clock) {
-    c->wave_clock_n = blocks * rmb::kSymWaves;
+    // [waves][2] stamps (start, end | placement); sym2t_kernel adds a second region [waves][2] of per-wave phase totals in
+    // shader-clock cycles (staging incl. its wait, everything) -- rmb_wave_clock_collect hands out both as 2 x waves rows
+    c->wave_clock_n = blocks * rmb::kSymWaves * (two ? 2 : 1);
     if (int rc = c->wave_clock.reserve((size_t)2 * c->wave_clock_n * sizeof(long long))) return rc;
     a.wave_clock = (long long*)c->wave_clock.p;
   }

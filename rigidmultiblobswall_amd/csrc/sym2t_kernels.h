@@ -107,6 +107,11 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
   const char* rec_bytes = reinterpret_cast<const char*>(rec);
 
   const long w = (a.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (long)blockIdx.x) * kSymWaves + wave;
+  // diagnostics build only (option "wave_clock"): wall-clock start / end of the wave and the shader-clock cycles it spends
+  // staging tiles (loads issued -> records visible in LDS); a.wave_clock is null otherwise (wave-uniform branches)
+  const long long t_start = a.wave_clock ? wall_clock64() : 0;
+  const long long c_start = a.wave_clock ? (long long)__builtin_readcyclecounter() : 0;
+  long long c_stage = 0;
   for (long chunk = w;; chunk += (long)gridDim.x * kSymWaves) {
   long s = a.step_begin + chunk * a.steps_per_wave;
   if (s >= a.step_end) break;
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
     const int k1 = (left < 64 - k0) ? (int)(k0 + left) : 64;
     s += k1 - k0;
 
+    const long long c_s0 = a.wave_clock ? (long long)__builtin_readcyclecounter() : 0;
     if (p != p_cur) {
       if (p_cur >= 0) flush_rows();
       p_cur = p;
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (a.wave_clock) c_stage += (long long)__builtin_readcyclecounter() - c_s0;
 
     const int kb = (a.skip_pairs & 1) ? k1 : k0;
     if (J >= 2 * p + 2) {
@@ -239,6 +246,15 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
   }
   if (p_cur >= 0) flush_rows();
   }   // chunks
+  if (a.wave_clock && lane == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+    const long n_waves = (long)gridDim.x * kSymWaves;
+    a.wave_clock[2 * w] = t_start;
+    a.wave_clock[2 * w + 1] = (wall_clock64() & 0xffffffffffLL) | ((long long)(hw & 0xffff) << 40) | ((long long)(xcc & 0xf) << 56);
+    a.wave_clock[2 * (n_waves + w)] = c_stage;
+    a.wave_clock[2 * (n_waves + w) + 1] = (long long)__builtin_readcyclecounter() - c_start;
+  }
 }
 
 }  // namespace rmb
