@@ -8,6 +8,7 @@
 //                    the symmetric force kernel
 //   rmb_sym32.hip    their single-precision twins (handed over as launch thunks)
 //   rmb_symx_coop.hip  workgroup-cooperative instances of the generic symmetric skeleton (launch thunks too)
+//   rmb_symx2t.hip, rmb_symx2t_per.hip  two-targets-per-lane instances of the generic skeleton, open / pseudo-periodic
 //   rmb_sort.hip     Morton ordering of the blobs for the force kernel's tile culling (rocPRIM radix sort)
 //   rmb_sweep.hip    launchers of the one-sided kernels: sweep, force sweep, source->target, pressure / double layer,
 //                    dense body blocks, position packing
@@ -177,6 +178,10 @@ Kernel32 symx32(int sx, bool wall);
 Kernel32 sym_force32(bool radii);
 // ---- rmb_symx_coop.hip: workgroup-cooperative instances of the generic skeleton, same thunk shape (fp64) ---------
 Kernel32 symx_coop(int sx, bool wall, bool periodic);
+// ---- rmb_symx2t.hip / rmb_symx2t_per.hip: two-targets-per-lane instances of the generic skeleton (symx2t_kernels.h) ------
+// fn == nullptr when the operation has none; *waves_per_eu = what the instance was compiled for (plan_sym's residency cap)
+Kernel32 symx_two_open(int sx, bool wall, int* waves_per_eu);
+Kernel32 symx_two_periodic(int sx, bool wall, int* waves_per_eu);
 
 // ---- rmb_sweep.hip -----------------------------------------------------------------------------------------
 int pack_positions(rmb_ctx* c, const double* r_dev, long n, double a, const double* L, int wall);

@@ -51,6 +51,24 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   a.iLz = c->L[2] > 0 ? 1.0 / c->L[2] : 0.0;
   a.prefactor = 1.0 / (8.0 * M_PI * eta);
   a.k = make_pair_consts(c->a);
+  // Pseudo-periodic single-vector products: the two-targets-per-lane instance of the generic skeleton (symx2t_kernels.h:
+  // one record read and one set of LDS adds for the 2 x 3^d image pairs of a step) from half a unit per resident wave on,
+  // the same rule as below; smaller launches stay here (cooperative kernel).  The wave_clock diagnostic lives in sym_kernel.
+  if (periodic && c->opt_sym_two_targets && c->opt_sym_coop != 2 && tiles >= 4 && !c->opt_wave_clock) {
+    int wpe = 0;
+    const Kernel32 cand = symx_two_periodic(SX_TT + kind, c->wall != 0, &wpe);
+    if (cand.fn) {
+      long sb, se_, qb, qe;
+      shard_ranges(n, rmb::units2_total(tiles), shard, nshards, &sb, &se_, &qb, &qe);
+      SymPlan plan2;
+      if (int rc = plan_sym(c, cand.fn, cand.occ, cand.static_lds, se_ - sb, true, &plan2, wpe)) return rc;
+      if (!plan2.sub_round || (se_ - sb) >= 32 * plan2.round * rmb::kSymWaves || c->opt_sym_two_targets == 2) {
+        const double* in[2] = {v, nullptr};
+        double* outs[1] = {out};
+        return symx_device(c, SX_TT + kind, in, outs, eta, 0, shard, nshards, accumulate ? 1 : 0);
+      }
+    }
+  }
   SymPlan plan;
   // single-precision mode (mobility_pycuda.py:7-19 `precision = 'single'`): tt with open boundaries only
   const bool f32 = c->opt_precision == 32 && kind == RMB_TT && !periodic;
@@ -201,6 +219,8 @@ SymXEntry g_symx[SX_COUNT][2][2] = {
 #undef RMB_SX_KIND
 #undef RMB_SX_ROW
 
+bool coop_forced(const rmb_ctx* c) { return c->opt_sym_coop == 2; }
+
 SymConf conf_of(const rmb_ctx* c) {
   return SymConf{(const double4*)c->pos.p, c->n, {c->L[0], c->L[1], c->L[2]}, c->wall, nullptr};
 }
@@ -249,7 +269,29 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   Kernel32 kc{nullptr, 0, nullptr, nullptr};
   if (!f32 && (c->opt_sym_coop == 2 || (c->opt_sym_coop == 1 && (plan.sub_round || three_vectors))))
     kc = symx_coop(op, cf.wall != 0, periodic);
-  const bool coop = kc.fn != nullptr;
+  // Two target blobs per lane (symx2t_kernels.h; option "sym_two_targets"): fused row, grand, force column, one block on
+  // two vectors, and every pseudo-periodic single-vector product.  Same rule as sym_device: from half a unit per resident
+  // wave on (smaller launches stay with the cooperative instances), units = (row pair, tile).
+  Kernel32 k2{nullptr, 0, nullptr, nullptr};
+  if (!f32 && !coop_forced(c) && c->opt_sym_two_targets && tiles >= 4) {
+    int wpe = 0;
+    const Kernel32 cand = periodic ? symx_two_periodic(op, cf.wall != 0, &wpe) : symx_two_open(op, cf.wall != 0, &wpe);
+    if (cand.fn) {
+      rmb::SymXArgs t = a;
+      t.n_units = rmb::units2_total(tiles);
+      shard_ranges(n, t.n_units, shard, nshards, &t.step_begin, &t.step_end, &t.self_begin, &t.self_end);
+      SymPlan plan2;
+      if (int rc = plan_sym(c, cand.fn, cand.occ, cand.static_lds, t.step_end - t.step_begin, true, &plan2, wpe)) return rc;
+      if (!plan2.sub_round || (t.step_end - t.step_begin) >= 32 * plan2.round * rmb::kSymWaves || c->opt_sym_two_targets == 2) {
+        k2 = cand;
+        a = t;
+        plan = plan2;
+        kc = Kernel32{nullptr, 0, nullptr, nullptr};
+      }
+    }
+  }
+  const bool two = k2.fn != nullptr;
+  const bool coop = !two && kc.fn != nullptr;
   if (coop) {
     const long fine = (a.step_end - a.step_begin) <= 12288 ? 4 : 8;     // as sym_device
     if (int rc = plan_sym(c, kc.fn, kc.occ, kc.static_lds, a.step_end - a.step_begin, true, &plan, 0, fine)) return rc;
@@ -258,10 +300,11 @@ int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out,
   a.steps_per_wave = coop ? (total_steps + plan.blocks - 1) / plan.blocks : plan.steps_per_wave;     // coop: steps per WORKGROUP
   a.steps_per_wave = chunked_steps(c, total_steps, coop ? plan.blocks : plan.blocks * rmb::kSymWaves, a.steps_per_wave,
                                    c->opt_sym_chunk_steps * (coop ? rmb::kSymWaves : 1));
-  c->last_path = coop ? 3 : 1; c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
+  c->last_path = coop ? 3 : (two ? 4 : 1); c->last_tiles = tiles; c->last_chunks = 0; c->last_wgs = plan.blocks;
   int slot;
   if (int rc = timing_begin(c, &slot)) return rc;
   if (f32) k32.launch(&a, a.k, (unsigned)plan.blocks, plan.dyn_lds, c->stream);
+  else if (two) k2.launch(&a, a.k, (unsigned)plan.blocks, plan.dyn_lds, c->stream);
   else if (coop) kc.launch(&a, a.k, (unsigned)plan.blocks, plan.dyn_lds, c->stream);
   else     hipLaunchKernelGGL(se.sweep, dim3((unsigned)plan.blocks), dim3(64 * rmb::kSymWaves), plan.dyn_lds, c->stream, a);
   RMB_HIP(hipGetLastError());

@@ -1003,10 +1003,121 @@ def test_two_target_blobs_per_lane_equal_the_one_target_kernels(N):
     ctx.set_positions(rd, a, None, True)
     ctx.matvec_device("tt", fd, eta)
     assert ctx.get_option("last_path") == (4 if N >= 10000 else 3)
-    # periodic products keep the one-target kernels
+    # periodic products: the two-target instance of the generic skeleton (round 5, symx2t_kernels.h) when forced, the
+    # one-target kernels with the option off
     ctx.set_positions(rd, a, np.array([0.0, 9.0 * a * N ** (1 / 3.0), 0.0]), True)
     ctx.set_option("sym_two_targets", 2)
-    ctx.matvec_device("tt", fd, eta)
+    u2 = ctx.matvec_device("tt", fd, eta).clone()
+    assert ctx.get_option("last_path") == 4
+    ctx.set_option("sym_two_targets", 0)
+    u1 = ctx.matvec_device("tt", fd, eta)
     assert ctx.get_option("last_path") in (1, 3)
+    assert rel_err(u2.cpu().numpy(), u1.cpu().numpy()) < 1e-13
+  finally:
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: two target blobs per lane for the multi-block / multi-vector operations and the pseudo-periodic products
+# (csrc/symx2t_kernels.h).  Reference semantics: fused row mobility_pycuda.py:1266-1391, grand product
+# quaternion_integrator_rollers.py:1114-1121, image convention mobility_numba.py:170-197.
+# ---------------------------------------------------------------------------------------------
+TWO_T_CASES = [
+    # (N, wall, L)       odd / even tile counts, a partial last tile, open and pseudo-periodic in one and two directions
+    (257, True, None), (1000, True, None), (4097, True, None), (1000, False, None),
+    (700, True, (14.0, 16.0, 0.0)), (449, True, (0.0, 13.0, 0.0)), (700, False, (9.0, 0.0, 11.0)),
+]
+
+
+@pytest.mark.parametrize("N,wall,L", TWO_T_CASES)
+def test_two_targets_generic_operations_vs_oracle(Ctx, oracle, torch_mod, N, wall, L):
+  """Every operation that has a two-targets-per-lane instance, forced from the smallest launch (sym_two_targets = 2),
+  against the oracle's blocks: whole products, three pair shards summed, the in-plane masks."""
+  torch = torch_mod
+  r, f, eta, a = d2_cloud(N, seed=N + 7)
+  r = r.copy(); r[:, 2] -= 0.3 * a                      # some blobs below z = a: clamp + B-damping with a wall
+  t = np.random.RandomState(N + 8).randn(N, 3)
+  ref = _oracle_blocks(oracle, wall, r, f, t, eta, a, L)
+  ctx = Ctx(0)
+  try:
+    ctx.set_option("sym_two_targets", 2)
+    ctx.set_positions(_dev(torch, r), a, L, wall=wall)
+    fd, td = _dev(torch, f), _dev(torch, t)
+
+    def check(op, vecs, want, in_plane=False, tol=TOL_D2):
+      outs = ctx.matvec_op_device(op, vecs, eta, in_plane=in_plane)
+      assert ctx.get_option("last_path") == 4, (op, ctx.get_option("last_path"))      # rmb::symx2t_kernel
+      for o, w in zip(outs, want):
+        assert rel_err(o.cpu().numpy(), w) < tol, (op, N, wall, L, in_plane, rel_err(o.cpu().numpy(), w))
+      parts = [ctx.matvec_op_device(op, vecs, eta, in_plane=in_plane, shard=g, nshards=3) for g in range(3)]
+      for c, w in enumerate(want):
+        assert rel_err(sum(p_[c] for p_ in parts).cpu().numpy(), w) < tol, (op, "shards")
+
+    check("velocity_from_force_torque", (fd, td), [ref["tt_f"] + ref["tr_t"]])
+    check("grand", (fd, td), [ref["tt_f"] + ref["tr_t"], ref["rt_f"] + ref["rr_t"]])
+    check("force_column", (fd,), [ref["tt_f"], ref["rt_f"]])
+    kw = dict(periodic_length=np.zeros(3) if L is None else np.asarray(L, dtype=np.float64))
+    for kind in ("tt", "tr", "rt", "rr"):
+      check(kind + "_multi", (fd, td), [oracle._wrapped(kind, int(wall), r, v, eta, a, **kw) for v in (f, t)])
+    if wall:
+      refp = _oracle_blocks(oracle, wall, r, f, t, eta, a, L, in_plane=True)
+      check("velocity_from_force_torque", (fd, td), [refp["tt_f"] + refp["tr_t"]], in_plane=True)
+      check("tt_multi", (fd, td), [oracle._wrapped("tt", 1, r, v, eta, a, in_plane=True, **kw) for v in (f, t)], in_plane=True)
+    if L is not None:
+      # the pseudo-periodic single-vector products go to the same instances (sym_device hands them over)
+      for kind in ("tt", "tr", "rt", "rr"):
+        u = ctx.matvec_device(kind, fd, eta).cpu().numpy()
+        assert ctx.get_option("last_path") == 4
+        assert rel_err(u, oracle._wrapped(kind, int(wall), r, f, eta, a, **kw)) < TOL_D2, (kind, N, wall, L)
+        tot = sum(ctx.matvec_pairshard_device(kind, fd, eta, g, 4) for g in range(4)).cpu().numpy()
+        assert rel_err(tot, u) < TOL_SHARD, (kind, "shards")
+    # and they equal the one-target kernels to rounding
+    ctx.set_option("sym_two_targets", 0)
+    one = [o.cpu().numpy() for o in ctx.matvec_op_device("grand", (fd, td), eta)]
+    assert ctx.get_option("last_path") in (1, 3)
+    ctx.set_option("sym_two_targets", 2)
+    two = [o.cpu().numpy() for o in ctx.matvec_op_device("grand", (fd, td), eta)]
+    for x, y in zip(two, one):
+      assert rel_err(x, y) < 1e-13
+  finally:
+    ctx.close()
+
+
+@pytest.mark.parametrize("periodic", [False, True], ids=["open", "periodic_xy"])
+def test_two_targets_generic_operations_are_the_default_at_24576_blobs(Ctx, oracle, torch_mod, periodic):
+  """configs[2] size, default options: fused row, grand, two-vector and (periodic) single-vector products run on the
+  two-target instances (last_path 4) and match the oracle on a sample of targets incl. tile edges."""
+  torch = torch_mod
+  from test_gpu_parity import _edge_sample
+  N = 24576
+  r, f, eta, a = d2_cloud(N, seed=3)
+  r = r.copy(); r[:, 2] -= 0.45 * a
+  t = np.random.RandomState(4).randn(N, 3)
+  box = (N * (4.0 / 3.0) * np.pi * a ** 3 / 0.05) ** (1.0 / 3.0)
+  L = np.array([box, box, 0.0]) if periodic else None
+  tg = _edge_sample(N, k=64)
+  r_eff, bdiag, _ = oracle.wall_regularisation(r, a)
+
+  def ref(kind, v):
+    x = oracle.raw_matvec_targets(kind, 1, r_eff, v * bdiag[:, None], eta, a, tg, L=L)
+    return (x.reshape(-1, 3) * bdiag[tg][:, None]).reshape(-1)
+
+  pick = lambda o: o.cpu().numpy().reshape(-1, 3)[tg].reshape(-1)
+  ctx = Ctx(0)
+  try:
+    ctx.set_positions(_dev(torch, r), a, L, wall=True)
+    fd, td = _dev(torch, f), _dev(torch, t)
+    u, w = ctx.matvec_op_device("grand", (fd, td), eta)
+    assert ctx.get_option("last_path") == 4
+    assert rel_err(pick(u), ref("tt", f) + ref("tr", t)) < TOL_D2 and rel_err(pick(w), ref("rt", f) + ref("rr", t)) < TOL_D2
+    (u,) = ctx.matvec_op_device("velocity_from_force_torque", (fd, td), eta)
+    assert ctx.get_option("last_path") == 4 and rel_err(pick(u), ref("tt", f) + ref("tr", t)) < TOL_D2
+    ua, ub = ctx.matvec_op_device("tt_multi", (fd, td), eta)
+    assert ctx.get_option("last_path") == 4
+    assert rel_err(pick(ua), ref("tt", f)) < TOL_D2 and rel_err(pick(ub), ref("tt", t)) < TOL_D2
+    if periodic:
+      for kind in ("tt", "rr"):
+        u = ctx.matvec_device(kind, fd, eta)
+        assert ctx.get_option("last_path") == 4 and rel_err(pick(u), ref(kind, f)) < TOL_D2, kind
   finally:
     ctx.close()
