@@ -39,6 +39,8 @@ Objects on the line
                 time goes (position compare, upload, enqueue, sweep by HIP events, download + sync, Python)
   two_targets_ab  one-rank run: the headline product on the one-target kernels and with two target blobs per lane, alternating
                 in this process (a same-box A/B of the round's kernel change)
+  two_targets_ops_ab  one-rank run: the fused row / grand product at 1e4 and 1e5 blobs and the pseudo-periodic tt / fused row at
+                24 576 blobs, one target per lane against two (the default), alternating in this process
   small_deck_steps  one-rank run: whole time steps of the rigid-multiblob integrators on 64 / 256 shells (the reference's
                 usual sizes), where the solver loop around the sweep decides
   rccl_one_rank  one-rank run: the N > 1 step's fp64 all-reduce through RCCL in a one-rank group, step timed with and
@@ -904,6 +906,54 @@ def rank_main(args):
                     "0.3 s first, the order of the two modes alternates from round to round; option sym_two_targets 0 / 1"}
   if world == 1 and not args.no_sweep and not any(kv.startswith("sym_two_targets=") for kv in args.ctx_option):
     stage("two_targets_ab", 3, two_targets_ab, single_rank_only=True)
+
+  def two_targets_ops_ab():
+    # Round 5: the multi-block / multi-vector operations and the pseudo-periodic products with two target blobs per lane
+    # (csrc/symx2t_kernels.h, the default) against the one-target kernels, same box, same process, alternating rounds.
+    # These are what the configs[4] steps are made of (rollers: fused row + grand; mobility_pycuda.py:1266-1391,
+    # quaternion_integrator_rollers.py:1114-1121; periodic images mobility_numba.py:170-197).
+    ctx = backend.ctx
+    keep_timing = ctx.get_option("timing")
+    ctx.set_option("timing", 1)
+    rows = []
+    try:
+      for nb, periodic, reps in ((10000, False, 40), (100000, False, 4), (24576, True, 6)):
+        r_, f_, eta_, a_ = d2_cloud(nb, seed=0)
+        box = (nb * (4.0 / 3.0) * np.pi * a_ ** 3 / 0.05) ** (1.0 / 3.0)
+        L_ = np.array([box, box, 0.0]) if periodic else None
+        ctx.set_positions(torch.as_tensor(r_.reshape(-1), device=device), a_, L_, wall=True)
+        vs = [torch.as_tensor(x.reshape(-1), device=device) for x in (f_, np.random.RandomState(1).randn(nb, 3))]
+        outs = [torch.empty(3 * nb, dtype=torch.float64, device=device) for _ in range(2)]
+        calls = [("fused row: u = M_tt f + M_tr tau", lambda: ctx.matvec_op_device("velocity_from_force_torque", vs, eta_, outs=outs[:1])),
+                 ("grand: [u; w] = M [f; tau]", lambda: ctx.matvec_op_device("grand", vs, eta_, outs=outs))]
+        if periodic:
+          calls = [("tt (9 images per pair)", lambda: ctx.matvec_device("tt", vs[0], eta_, out=outs[0]))] + calls[:1]
+        t_prime = time.perf_counter()
+        while time.perf_counter() - t_prime < 0.2:
+          calls[0][1](); torch.cuda.synchronize(device)
+        for label, call in calls:
+          res_ab, path = {0: [], 1: []}, {}
+          for rnd in range(2):
+            for mode in ((0, 1) if rnd % 2 == 0 else (1, 0)):
+              ctx.set_option("sym_two_targets", mode)
+              for _ in range(2):
+                call()
+              torch.cuda.synchronize(device); ctx.timing_reset()
+              for _ in range(reps):
+                call()
+              torch.cuda.synchronize(device)
+              res_ab[mode].append(float(np.median(ctx.timing_collect(reps))) * 1e3)
+              path[mode] = ctx.get_option("last_path")
+          one, two = float(np.median(res_ab[0])), float(np.median(res_ab[1]))
+          rows.append({"n_blobs": nb, "periodic_xy": periodic, "operation": label, "kernel_us_one_target_per_lane": round(one, 2),
+                       "kernel_us_two_targets_per_lane": round(two, 2), "speedup": round(one / two, 4),
+                       "kernel_family": {1: "per wave", 3: "cooperative", 4: "two targets per lane"}.get(path[1])})
+    finally:
+      ctx.set_option("sym_two_targets", 1)
+      ctx.set_option("timing", keep_timing)
+    return {"rows": rows, "note": "median of 2 alternating rounds, HIP events around every sweep launch; option sym_two_targets 0 / 1"}
+  if world == 1 and not args.no_sweep and not any(kv.startswith("sym_two_targets=") for kv in args.ctx_option):
+    stage("two_targets_ops_ab", 8, two_targets_ops_ab, single_rank_only=True)
 
   def small_deck_steps():
     # The reference's usual sizes (tens to hundreds of bodies): whole time steps of the rigid-multiblob integrators, where
