@@ -250,7 +250,9 @@ int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, lon
  * (multi_bodies/multi_bodies.py:516-531 builds L and N, :548-560 applies them).  *info_dev (one int, device) is set to
  * 0 and then to 1 by any body whose Mb is not positive definite or whose 6 x 6 resistance K^T Mb^-1 K has no accurate
  * inverse (single blobs, collinear rods: the reference takes the pseudo-inverse there, the caller must too).
- * n_b <= 16 (one workgroup per body, the factors of a body live in LDS).
+ * n_b <= 42, i.e. the reference's 12- and 42-blob shells (one workgroup per body, the factors of a body live in LDS: two
+ * n x n matrices up to 16 blobs, ONE matrix worked on in place -- Cholesky, triangular inverse, M^-1 formed on the way out --
+ * from 17 to 42 blobs: 126 x 126 doubles = 127 KB of the 160 KB).
  *
  * rmb_rigid_advance_device: loc_out = loc + U[:, 0:3] dt, quat_out = quaternion(U[:, 3:6] dt) * quat for every body
  * (quaternion_integrator/quaternion_integrator_multi_bodies.py:86-91; quaternion.py:17-39: the rotation quaternion is

@@ -214,6 +214,21 @@ def main():
     if args.only and args.only != name:
       continue
     case(args.ref, out_dir, name, scheme, bodies, n_steps, a=a, **kw)
+  # Round 5: the reference's 42-blob shell (Structures/shell_N_42_Rg_0_8913_Rh_1.vertex; its timing harness uses the 12 /
+  # 42 / 162 family, examples/Mobility_Prod_Timing/Multiblob.inputfile:52-55) -- bodies of more than 16 blobs, whose
+  # per-body preconditioner factors (multi_bodies.py:752-903) the build keeps in LDS one matrix at a time.  Blob radius =
+  # half the smallest blob separation (Mobility_Prod_Timing/main.py:121-126).
+  shell42 = read_vertex_file.read_vertex_file(os.path.join(S, "shell_N_42_Rg_0_8913_Rh_1.vertex"))[:, :3]
+  d = np.linalg.norm(shell42[:, None, :] - shell42[None, :, :], axis=2)
+  a42 = float(np.min(d[d > 0]) / 2)
+  rng42 = np.random.RandomState(4242)
+  loc42 = np.array([[2.6 * (k % 3) + 0.2 * rng42.rand(), 2.6 * (k // 3) + 0.2 * rng42.rand(), 1.3 + 0.5 * rng42.rand()] for k in range(6)])
+  bodies42 = [("shell42", shell42, loc42, random_quaternions(rng42, 6))]
+  for name, scheme, n_steps, kw in (("g9_rigid_det_euler_42blob_shells", "deterministic_forward_euler", 2, {}),
+                                    ("g9_rigid_stoch_slip_trapz_42blob_shells", "stochastic_Slip_Trapz", 1, dict(kT=kT, seed=13))):
+    if args.only and args.only != name:
+      continue
+    case(args.ref, out_dir, name, scheme, bodies42, n_steps, a=a42, **kw)
 
 
 if __name__ == "__main__":

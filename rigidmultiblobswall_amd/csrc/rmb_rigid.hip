@@ -89,6 +89,43 @@ struct PcArgs {
 
 constexpr int kPcT = 256;          // threads per body: four wavefronts
 
+// N = R^-1 for the 6 x 6 resistance R = K^T M_b^-1 K of one body: Gauss-Jordan with partial pivoting on [R | I], run by ONE
+// thread; the result is symmetrised.  Returns false when R has no accurate inverse (residual of R N - I above 1e-8): a
+// rank-deficient resistance (single blobs, collinear rods) must take the pseudo-inverse route of the caller
+// (multi_bodies.py:531 uses pinv).
+__device__ bool invert_resistance(const double* R, double* Nl) {
+  bool ok = true;
+  double w[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { w[i][j] = R[i * 6 + j]; w[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int i = c + 1; i < 6; ++i) if (fabs(w[i][c]) > fabs(w[piv][c])) piv = i;
+    if (piv != c) for (int j = 0; j < 12; ++j) { const double tmp = w[c][j]; w[c][j] = w[piv][j]; w[piv][j] = tmp; }
+    const double dgl = w[c][c];
+    if (!(fabs(dgl) > 0.0)) { ok = false; continue; }
+    const double inv = 1.0 / dgl;
+    for (int j = 0; j < 12; ++j) w[c][j] *= inv;
+    for (int i = 0; i < 6; ++i) {
+      if (i == c) continue;
+      const double f = w[i][c];
+      for (int j = 0; j < 12; ++j) w[i][j] -= f * w[c][j];
+    }
+  }
+  double worst = 0.0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 6; ++k) s += R[i * 6 + k] * w[k][6 + j];
+      const double e = fabs(s - (i == j ? 1.0 : 0.0));
+      if (!(e <= worst)) worst = e;       // NaN-propagating maximum
+    }
+  if (!(worst < 1e-8)) ok = false;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) Nl[i * 6 + j] = 0.5 * (w[i][6 + j] + w[j][6 + i]);
+  return ok;
+}
+
 // One workgroup per body, everything in LDS.  The O(n^3) pieces (trailing updates of the Cholesky factorisation, the
 // forward substitutions of L^-1, M_b^-1 = L^-T L^-1, A11) are spread over all 256 threads element by element; the
 // sequential dimension (n = 3 n_b <= 48 pivots / rows) costs one or two workgroup barriers per step.
@@ -175,38 +212,7 @@ __global__ __launch_bounds__(kPcT) void rigid_pc_kernel(const PcArgs a) {
   }
   __syncthreads();
   // ---- N = R^-1: Gauss-Jordan with partial pivoting on [R | I], one thread (216 multiply-adds) ----
-  if (t == 0) {
-    double w[6][12];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) { w[i][j] = R[i * 6 + j]; w[i][6 + j] = (i == j) ? 1.0 : 0.0; }
-    for (int c = 0; c < 6; ++c) {
-      int piv = c;
-      for (int i = c + 1; i < 6; ++i) if (fabs(w[i][c]) > fabs(w[piv][c])) piv = i;
-      if (piv != c) for (int j = 0; j < 12; ++j) { const double tmp = w[c][j]; w[c][j] = w[piv][j]; w[piv][j] = tmp; }
-      const double dgl = w[c][c];
-      if (!(fabs(dgl) > 0.0)) { bad = 1; continue; }
-      const double inv = 1.0 / dgl;
-      for (int j = 0; j < 12; ++j) w[c][j] *= inv;
-      for (int i = 0; i < 6; ++i) {
-        if (i == c) continue;
-        const double f = w[i][c];
-        for (int j = 0; j < 12; ++j) w[i][j] -= f * w[c][j];
-      }
-    }
-    // residual of the inverse: a rank-deficient resistance (single blobs, collinear rods) must take the pseudo-inverse
-    // route of the caller (multi_bodies.py:531 uses pinv)
-    double worst = 0.0;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        double s = 0.0;
-        for (int k = 0; k < 6; ++k) s += R[i * 6 + k] * w[k][6 + j];
-        const double e = fabs(s - (i == j ? 1.0 : 0.0));
-        if (!(e <= worst)) worst = e;       // NaN-propagating maximum
-      }
-    if (!(worst < 1e-8)) bad = 1;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) Nl[i * 6 + j] = 0.5 * (w[i][6 + j] + w[j][6 + i]);
-  }
+  if (t == 0 && !invert_resistance(R, Nl)) bad = 1;
   __syncthreads();
   if (t < 36) {
     a.Nbody[b * 36 + t] = Nl[t];
@@ -227,6 +233,134 @@ __global__ __launch_bounds__(kPcT) void rigid_pc_kernel(const PcArgs a) {
     double s = A[idx];
     for (int c = 0; c < 6; ++c) s += A12l[i * 6 + c] * MK[j * 6 + c];
     a.A11[b * (long)n * n + idx] = s;
+  }
+  if (t == 0 && bad) atomicOr(a.info, 1);
+}
+
+
+// ---- bodies of 17 .. 42 blobs (n = 3 n_b <= 128): ONE n x n matrix in LDS (126^2 doubles = 127 KB of the 160 KB) ----------
+// The reference's own shells have 12 / 42 / 162 blobs (multi_bodies/Structures/shell_N_42_Rg_0_225.vertex; its timing
+// harness multi_bodies/examples/Mobility_Prod_Timing uses them); two matrices as above do not fit for 42.  So everything
+// runs IN PLACE on one matrix: Cholesky (lower) -> L written out -> L^-1 in place (column by column from the last one,
+// LAPACK dtrti2's order; the column being replaced is first copied to a vector) -> L^-1 written out; M_b^-1 = L^-T L^-1 is
+// never stored in LDS: K-panels go through Y = L^-1 K (M_b^-1 K = L^-T Y, R = Y^T Y) and the last pass forms every element
+// of M_b^-1 from two columns of L^-1, stores it and adds the rank-6 term of A11.  1024 threads (16 waves) per body; the
+// trailing update of the factorisation runs wave = row, lane = column (conflict-free LDS reads through a copy of the
+// pivot column).
+constexpr int kPcLargeT = 1024;
+constexpr int kPcLargeMaxN = 128;
+
+__global__ __launch_bounds__(kPcLargeT) void rigid_pc_large_kernel(const PcArgs a) {
+  extern __shared__ double lds[];
+  const int n = a.n, t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  constexpr int kWaves = kPcLargeT / 64;
+  const long b = blockIdx.x;
+  double* A = lds;                 // M_b -> L (lower) -> L^-1 (lower); the strict upper triangle is never read after the load
+  double* col = A + n * n;         // n: the pivot column (factorisation) / the column being inverted
+  double* Kl = col + n;            // n x 6
+  double* Y = Kl + n * 6;          // L^-1 K
+  double* MK = Y + n * 6;          // M_b^-1 K
+  double* A12l = MK + n * 6;       // -M_b^-1 K N
+  double* R = A12l + n * 6;        // 6 x 6
+  double* Nl = R + 36;             // 6 x 6
+  __shared__ int bad;
+  if (t == 0) bad = 0;
+  const double* M = a.Mb + b * (long)n * n;
+  for (int idx = t; idx < n * n; idx += kPcLargeT) {
+    const int i = idx / n, j = idx - i * n;
+    A[idx] = 0.5 * (M[idx] + M[j * n + i]);
+  }
+  for (int idx = t; idx < n * 6; idx += kPcLargeT) Kl[idx] = a.K[b * (long)n * 6 + idx];
+  __syncthreads();
+  // ---- Cholesky, right-looking, lower: two barriers per pivot ----
+  for (int k = 0; k < n; ++k) {
+    __syncthreads();                               // the trailing update of the previous pivot is complete
+    const double piv = A[k * n + k];               // nobody writes A[k][k] before the next barrier
+    if (t == 0 && !(piv > 0.0)) bad = 1;
+    const double root = sqrt(piv);
+    if (t > k && t < n) { const double v = A[t * n + k] / root; A[t * n + k] = v; col[t] = v; }
+    __syncthreads();
+    if (t == k) A[k * n + k] = root;               // nobody reads A[k][k] any more: the update touches rows / columns > k
+    for (int gi = k + 1 + wave; gi < n; gi += kWaves) {
+      const double ci = col[gi];
+      for (int gj = k + 1 + lane; gj <= gi; gj += 64) A[gi * n + gj] -= ci * col[gj];
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * n; idx += kPcLargeT) {
+    const int i = idx / n, j = idx - i * n;
+    a.Lchol[b * (long)n * n + idx] = j <= i ? A[idx] : 0.0;
+  }
+  __syncthreads();
+  // ---- L^-1 in place, columns from the last to the first: X = L^-1 satisfies X[j][j] = 1 / L[j][j] and
+  //      X[j+1:, j] = -X[j][j] * (X[j+1:, j+1:] L[j+1:, j]); the trailing block X[j+1:, j+1:] is already in place ----
+  for (int j = n - 1; j >= 0; --j) {
+    const double dj = 1.0 / A[j * n + j];
+    if (t > j && t < n) col[t] = A[t * n + j];
+    __syncthreads();
+    if (t == 0) A[j * n + j] = dj;
+    {
+      // row i = j + 1 + (t / 8): eight threads share its dot product over k = j + 1 .. i
+      const int i = j + 1 + (t >> 3), part = t & 7;
+      double s = 0.0;
+      if (i < n) for (int k = j + 1 + part; k <= i; k += 8) s += A[i * n + k] * col[k];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (i < n && part == 0) A[i * n + j] = -dj * s;
+    }
+    __syncthreads();
+  }
+  for (int idx = t; idx < n * n; idx += kPcLargeT) {
+    const int i = idx / n, j = idx - i * n;
+    a.Linv[b * (long)n * n + idx] = j <= i ? A[idx] : 0.0;
+  }
+  // ---- Y = L^-1 K,  M_b^-1 K = L^-T Y,  R = K^T M_b^-1 K = Y^T Y ----
+  for (int idx = t; idx < n * 6; idx += kPcLargeT) {
+    const int i = idx / 6, c = idx - 6 * i;
+    double s = 0.0;
+    for (int k = 0; k <= i; ++k) s += A[i * n + k] * Kl[k * 6 + c];
+    Y[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * 6; idx += kPcLargeT) {
+    const int i = idx / 6, c = idx - 6 * i;
+    double s = 0.0;
+    for (int k = i; k < n; ++k) s += A[k * n + i] * Y[k * 6 + c];
+    MK[idx] = s;
+  }
+  if (t < 36) {
+    const int p = t / 6, q = t - 6 * p;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += Y[i * 6 + p] * Y[i * 6 + q];
+    R[t] = s;
+  }
+  __syncthreads();
+  if (t == 0 && !invert_resistance(R, Nl)) bad = 1;
+  __syncthreads();
+  if (t < 36) {
+    a.Nbody[b * 36 + t] = Nl[t];
+    a.A22[b * 36 + t] = -Nl[t];
+  }
+  for (int idx = t; idx < n * 6; idx += kPcLargeT) {
+    const int i = idx / 6, c = idx - 6 * i;
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += MK[i * 6 + k] * Nl[k * 6 + c];
+    A12l[idx] = -s;
+    a.A12[b * (long)n * 6 + idx] = -s;
+    a.A21[b * (long)n * 6 + (long)c * n + i] = -s;
+  }
+  __syncthreads();
+  // ---- M_b^-1[i][j] = sum_{k >= max(i, j)} (L^-1)[k][i] (L^-1)[k][j] (symmetric term by term),  A11 = M_b^-1 + A12 (M_b^-1 K)^T ----
+  for (int idx = t; idx < n * n; idx += kPcLargeT) {
+    const int i = idx / n, j = idx - i * n;
+    double s = 0.0;
+    for (int k = (i > j ? i : j); k < n; ++k) s += A[k * n + i] * A[k * n + j];
+    a.Minv[b * (long)n * n + idx] = s;
+    double s11 = s;
+    for (int c = 0; c < 6; ++c) s11 += A12l[i * 6 + c] * MK[j * 6 + c];
+    a.A11[b * (long)n * n + idx] = s11;
   }
   if (t == 0 && bad) atomicOr(a.info, 1);
 }
@@ -270,7 +404,8 @@ int rmb_rigid_preconditioner_device(rmb_ctx* c, long n_bodies, long n_b, const d
                                     double* A21_dev, double* A22_dev, int* info_dev) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
   if (n_bodies < 0 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_preconditioner_device: bad n_bodies / blobs per body");
-  if (3 * n_b > kPcMaxN) return fail(RMB_ERR_ARG, "rmb_rigid_preconditioner_device: at most 16 blobs per body (the factors of one body are kept in LDS)");
+  if (3 * n_b > kPcLargeMaxN)
+    return fail(RMB_ERR_ARG, "rmb_rigid_preconditioner_device: at most 42 blobs per body (the factors of one body are kept in LDS)");
   if (n_bodies == 0) return 0;
   if (!Mb_dev || !K_dev || !Lchol_dev || !Linv_dev || !Minv_dev || !Nbody_dev || !A11_dev || !A12_dev || !A21_dev || !A22_dev || !info_dev)
     return fail(RMB_ERR_ARG, "null pointer");
@@ -280,8 +415,16 @@ int rmb_rigid_preconditioner_device(rmb_ctx* c, long n_bodies, long n_b, const d
   a.Mb = Mb_dev; a.K = K_dev; a.Lchol = Lchol_dev; a.Linv = Linv_dev; a.Minv = Minv_dev; a.Nbody = Nbody_dev;
   a.A11 = A11_dev; a.A12 = A12_dev; a.A21 = A21_dev; a.A22 = A22_dev; a.info = info_dev;
   RMB_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
-  const size_t lds = ((size_t)2 * a.n * a.n + (size_t)18 * a.n + 72) * sizeof(double);
-  hipLaunchKernelGGL(rigid_pc_kernel, dim3((unsigned)n_bodies), dim3(kPcT), lds, c->stream, a);
+  if (a.n <= kPcMaxN) {
+    const size_t lds = ((size_t)2 * a.n * a.n + (size_t)18 * a.n + 72) * sizeof(double);
+    hipLaunchKernelGGL(rigid_pc_kernel, dim3((unsigned)n_bodies), dim3(kPcT), lds, c->stream, a);
+  } else {
+    // one matrix + the pivot column + four n x 6 panels + two 6 x 6: 146.7 KB at n = 126 (one workgroup per CU)
+    const size_t lds = ((size_t)a.n * a.n + (size_t)25 * a.n + 72) * sizeof(double);
+    if (lds + 1024 > c->lds_per_cu) return fail(RMB_ERR_STATE, "rmb_rigid_preconditioner_device: the device's LDS is too small for this body size");
+    RMB_HIP(hipFuncSetAttribute((const void*)rigid_pc_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rigid_pc_large_kernel, dim3((unsigned)n_bodies), dim3(kPcLargeT), lds, c->stream, a);
+  }
   RMB_HIP(hipGetLastError());
   return 0;
 }

@@ -406,10 +406,10 @@ class RigidSuspension(object):
     return self
 
   def _native_pc(self, g, Mb):
-    """The factors and blocks of group g in one launch (rmb_rigid_preconditioner_device, up to 16 blobs per body, all
-    bodies free).  False = not applicable, or a body's 6 x 6 resistance has no accurate inverse (single blobs, collinear
+    """The factors and blocks of group g in one launch (rmb_rigid_preconditioner_device, up to 42 blobs per body -- the
+    reference's 12- and 42-blob shells -- all bodies free).  False = not applicable, or a body's 6 x 6 resistance has no accurate inverse (single blobs, collinear
     rods: the pseudo-inverse route of the torch path below, remembered for the group)."""
-    if (self.free is not None or 3 * g.n_b > 48 or not self._native_blocks()
+    if (self.free is not None or 3 * g.n_b > 128 or not self._native_blocks()
         or any(g is r for r in getattr(self, "_native_pc_rejected", ()))):
       return False
     nb, n = Mb.shape[0], 3 * g.n_b

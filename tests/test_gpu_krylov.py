@@ -144,7 +144,9 @@ def test_rigid_configuration_kernel_matches_the_body_formulas(nb, n_b):
     ctx.close()
 
 
-@pytest.mark.parametrize("nb,n_b", [(1, 3), (5, 12), (300, 12), (9, 16), (2048, 12), (6, 4)])
+@pytest.mark.parametrize("nb,n_b", [(1, 3), (5, 12), (300, 12), (9, 16), (2048, 12), (6, 4),
+                                    # round 5: 17 .. 42 blobs per body, ONE n x n matrix in LDS, everything in place
+                                    (3, 17), (7, 30), (2, 42), (300, 42)])
 def test_rigid_preconditioner_kernel_matches_dense_linear_algebra(nb, n_b):
   """Per-body Cholesky factor, its inverse, M^-1, N = (K^T M^-1 K)^-1 and the four blocks of [[M, -K], [-K^T, 0]]^-1
   (multi_bodies.py:516-560) against numpy on every body -- the blocks checked by what they must satisfy."""
@@ -244,6 +246,41 @@ def test_native_preconditioner_equals_the_torch_build_and_single_blobs_take_the_
     assert i1["converged"] and rel_err(U1[:, :3], U2[:, :3]) < 1e-8
   finally:
     s1.close(); s2.close()
+
+
+def test_native_preconditioner_for_the_references_42_blob_shells():
+  """Bodies of 42 blobs (multi_bodies/Structures/shell_N_42_Rg_0_8913_Rh_1.vertex through the g9 fixture): the per-body
+  factors come from the in-place LDS kernel (Linv is only set by the native path), equal the batched torch.linalg build, and
+  the preconditioned solve takes the same iterations either way."""
+  import os
+  import torch
+  from conftest import GOLDEN, load_golden
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  g = load_golden(os.path.join(GOLDEN, "g9_rigid_det_euler_42blob_shells.npz"))
+  shell, loc, quat = g["vertex_shell42"], g["locations_shell42"], g["quaternions_shell42"]
+  assert len(shell) == 42
+  d = np.linalg.norm(shell[:, None] - shell[None], axis=2)
+  a, eta = float(np.min(d[d > 0]) / 2), 1.1
+  # 6 bodies as the fixture, and 60 of them on a lattice (more workgroups than one per CU is not needed for the check)
+  loc60 = np.array([[2.6 * (k % 8), 2.6 * (k // 8), 1.4] for k in range(60)])
+  quat60 = np.tile(quat, (10, 1))
+  for L_, Q_ in ((loc, quat), (loc60, quat60)):
+    nb = len(L_)
+    nat = RigidSuspension([shell] * nb, L_, Q_, a, eta, device="cuda:0")
+    ref = RigidSuspension([shell] * nb, L_, Q_, a, eta, device="cuda:0")
+    ref.native_helpers = False
+    try:
+      nat.build_preconditioner(); ref.build_preconditioner()
+      assert nat.groups[0].Linv is not None and ref.groups[0].Linv is None          # the kernel ran, not torch.linalg
+      assert not getattr(nat, "_native_pc_rejected", ())
+      for name, tol in (("Lchol", 1e-12), ("Minv", 1e-9), ("Nbody", 1e-9), ("A11", 1e-9), ("A12", 1e-9), ("A21", 1e-9), ("A22", 1e-9)):
+        assert rel_err(getattr(nat.groups[0], name).cpu().numpy(), getattr(ref.groups[0], name).cpu().numpy()) < tol, name
+      FT = np.zeros((nb, 6)); FT[:, 2] = -1.0; FT[:, 4] = 0.3
+      U1, _, i1 = nat.solve_mobility_problem(force_torque=FT, tol=1e-9)
+      U2, _, i2 = ref.solve_mobility_problem(force_torque=FT, tol=1e-9)
+      assert i1["converged"] and abs(i1["iterations"] - i2["iterations"]) <= 1 and rel_err(U1, U2) < 1e-7
+    finally:
+      nat.close(); ref.close()
 
 
 def test_rigid_advance_kernel_matches_the_quaternion_update():
