@@ -285,11 +285,30 @@ int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double
     RMB_HIP(hipMemcpyAsync(c->vec2.p, v2, vb, hipMemcpyHostToDevice, c->stream));
     v2d = (const double*)c->vec2.p;
   }
+  // Result hand-off.  Small results (<= "host_zero_copy" bytes, 768 KB): the finalize kernel stores straight into page-locked,
+  // device-mapped host memory (coalesced 2 KB store instructions, store_aos_coalesced) and the call ends with ONE stream
+  // wait + a host memcpy into the caller's array -- no device-to-host copy command, whose hand-over between the compute and
+  // the copy queue costs more than 240 KB over PCIe do (tools/ubench_hostwrite.hip: -11 us per call at 1e3 and 1e4 blobs).
+  // Larger results take the copy command (mapped stores lose from ~1e5 blobs on); so does the one-sided sweep
+  // ("deterministic" = 1), whose final stores are 8 bytes at a stride of 24.
+  const bool zero_copy = c->opt_host_zero_copy > 0 && ob <= (size_t)c->opt_host_zero_copy && c->opt_deterministic != 1 && n >= 128;
+  if (zero_copy && ob > c->host_out_cap) {
+    if (c->host_out) { (void)hipHostFree(c->host_out); c->host_out = nullptr; c->host_out_cap = 0; }
+    const size_t want = ob + ob / 8 + 4096;
+    RMB_HIP(hipHostMalloc(&c->host_out, want, hipHostMallocMapped));
+    RMB_HIP(hipHostGetDevicePointer((void**)&c->host_out_dev, c->host_out, 0));
+    c->host_out_cap = want;
+  }
   const auto t1 = std::chrono::steady_clock::now();
-  if (int rc = matvec_device_impl(c, kind, in_plane, (const double*)c->vec.p, v2d, eta, (double*)c->out.p)) return rc;
+  if (int rc = matvec_device_impl(c, kind, in_plane, (const double*)c->vec.p, v2d, eta, zero_copy ? c->host_out_dev : (double*)c->out.p)) return rc;
   const auto t2 = std::chrono::steady_clock::now();
-  RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
-  RMB_HIP(hipStreamSynchronize(c->stream));
+  if (zero_copy) {
+    RMB_HIP(hipStreamSynchronize(c->stream));
+    memcpy(out, c->host_out, ob);
+  } else {
+    RMB_HIP(hipMemcpyAsync(out, c->out.p, ob, hipMemcpyDeviceToHost, c->stream));
+    RMB_HIP(hipStreamSynchronize(c->stream));
+  }
   const auto t3 = std::chrono::steady_clock::now();
   const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::micro>(b - a).count();

@@ -84,6 +84,12 @@ struct rmb_ctx {
   long opt_skip_pairs = 0;
   rmbi::DevBuf krylov;   // partial sums of rmb_krylov_orthogonalize_device
   rmbi::DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
+  // result hand-off of the synchronous host entry point (rmb_matvec): page-locked, device-mapped host memory the finalize
+  // kernel stores into directly (coalesced), for results up to opt_host_zero_copy bytes
+  void* host_out = nullptr;
+  double* host_out_dev = nullptr;
+  size_t host_out_cap = 0;
+  long opt_host_zero_copy = 768 << 10;   // bytes (32 768 blobs: level at 43 000, +1 % at 1e5); 0 = always a device-to-host copy command
   long symbuf_zeroed_for = -1;
   // options
   long opt_chunks = 0;

@@ -363,22 +363,43 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+// AoS result of a workgroup's 256 blobs through LDS, so that every store instruction writes 2 KB of CONSECUTIVE addresses
+// (thread t writes doubles t, t + 256, t + 512 of the workgroup's 768) instead of 8 bytes at a stride of 24: the same
+// bytes with a third of the write transactions, and the only way the result can go straight into page-locked host memory
+// at a useful rate (rmb_matvec's zero-copy hand-off: partial-line writes over PCIe are 2x slower than a copy from ~4000
+// blobs on, profiles/r4_exp_host_staging_rejected.txt).  `tile` = 768 doubles of LDS; base = first blob of the workgroup.
+__device__ __forceinline__ void store_aos_coalesced(double* tile, double* out, long base, long n, double x, double y, double z,
+                                                    bool valid, bool accumulate) {
+  const int t = threadIdx.x;
+  if (valid) { tile[3 * t] = x; tile[3 * t + 1] = y; tile[3 * t + 2] = z; }
+  __syncthreads();
+  const long lim = 3 * n;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const long g = 3 * base + c * 256 + t;
+    if (g < lim) out[g] = accumulate ? out[g] + tile[c * 256 + t] : tile[c * 256 + t];
+  }
+  __syncthreads();          // the tile is reused by the caller's next output
+}
+
 template <int KIND, bool WALL>
 __global__ __launch_bounds__(256) void sym_finalize_kernel(const SymArgs a) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
-  a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;   // ready for the next product
-  const double4 p = a.pos[i];
-  const double b = p.w;
-  if (i >= a.self_begin && i < a.self_end)
-    self_term<KIND, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
-  const double sc = a.prefactor * b;
-  if (a.accumulate) {
-    a.out[3 * i] += acc.x * sc; a.out[3 * i + 1] += acc.y * sc; a.out[3 * i + 2] += acc.z * sc;
-  } else {
-    a.out[3 * i] = acc.x * sc; a.out[3 * i + 1] = acc.y * sc; a.out[3 * i + 2] = acc.z * sc;
+  __shared__ double tile[768];
+  const long base = (long)blockIdx.x * blockDim.x;
+  const long i = base + threadIdx.x;
+  const bool valid = i < a.n;
+  Vec3 acc = {0.0, 0.0, 0.0};
+  double sc = 0.0;
+  if (valid) {
+    acc.x = a.acc[i]; acc.y = a.acc[a.n_pad + i]; acc.z = a.acc[2 * a.n_pad + i];
+    a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;   // ready for the next product
+    const double4 p = a.pos[i];
+    const double b = p.w;
+    if (i >= a.self_begin && i < a.self_end)
+      self_term<KIND, WALL>(a.k, p.z, a.vec[3 * i] * b, a.vec[3 * i + 1] * b, a.vec[3 * i + 2] * b, 0, 0, 0, acc);
+    sc = a.prefactor * b;
   }
+  store_aos_coalesced(tile, a.out, base, a.n, acc.x * sc, acc.y * sc, acc.z * sc, valid, a.accumulate != 0);
 }
 
 

@@ -560,31 +560,36 @@ __global__ __launch_bounds__(256) void symx_det_combine_kernel(const SymXArgs a,
 template <class OP, bool WALL>
 __global__ __launch_bounds__(256) void symx_finalize_kernel(const SymXArgs a) {
   constexpr int NI = OP::NIN, NO = OP::NOUT, NX = SymXExtra<OP>::value;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const double4 p = a.pos[i];
-  const double b = p.w;
-  double vi[3 * NI + NX], u[3 * NO];
-  if constexpr (NX > 0) vi[3 * NI] = a.extra[i];
+  __shared__ double tile[768];
+  const long base = (long)blockIdx.x * blockDim.x;
+  const long i = base + threadIdx.x;
+  const bool valid = i < a.n;
+  double u[3 * NO];
 #pragma unroll
-  for (int v = 0; v < NI; ++v) {
-    vi[3 * v] = a.in[v][3 * i] * b; vi[3 * v + 1] = a.in[v][3 * i + 1] * b;
-    vi[3 * v + 2] = a.in_plane ? 0.0 : a.in[v][3 * i + 2] * b;
+  for (int c = 0; c < 3 * NO; ++c) u[c] = 0.0;
+  double sc = 0.0;
+  if (valid) {
+    const double4 p = a.pos[i];
+    const double b = p.w;
+    double vi[3 * NI + NX];
+    if constexpr (NX > 0) vi[3 * NI] = a.extra[i];
+#pragma unroll
+    for (int v = 0; v < NI; ++v) {
+      vi[3 * v] = a.in[v][3 * i] * b; vi[3 * v + 1] = a.in[v][3 * i + 1] * b;
+      vi[3 * v + 2] = a.in_plane ? 0.0 : a.in[v][3 * i + 2] * b;
+    }
+#pragma unroll
+    for (int c = 0; c < 3 * NO; ++c) {
+      u[c] = a.acc[(long)c * a.n_pad + i];
+      a.acc[(long)c * a.n_pad + i] = 0.0;   // ready for the next product
+    }
+    if (i >= a.self_begin && i < a.self_end) OP::template self<WALL>(a.k, p.z, vi, u);
+    sc = a.prefactor * b;
   }
 #pragma unroll
-  for (int c = 0; c < 3 * NO; ++c) {
-    u[c] = a.acc[(long)c * a.n_pad + i];
-    a.acc[(long)c * a.n_pad + i] = 0.0;   // ready for the next product
-  }
-  if (i >= a.self_begin && i < a.self_end) OP::template self<WALL>(a.k, p.z, vi, u);
-  const double sc = a.prefactor * b;
-#pragma unroll
-  for (int o = 0; o < NO; ++o) {
-    double* out = a.out[o];
-    const double x = u[3 * o] * sc, y = u[3 * o + 1] * sc, z = a.in_plane ? 0.0 : u[3 * o + 2] * sc;
-    if (a.accumulate & (1 << o)) { out[3 * i] += x; out[3 * i + 1] += y; out[3 * i + 2] += z; }
-    else { out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z; }
-  }
+  for (int o = 0; o < NO; ++o)      // coalesced AoS stores through LDS (store_aos_coalesced, sym_kernels.h)
+    store_aos_coalesced(tile, a.out[o], base, a.n, u[3 * o] * sc, u[3 * o + 1] * sc, a.in_plane ? 0.0 : u[3 * o + 2] * sc, valid,
+                        (a.accumulate & (1 << o)) != 0);
 }
 
 }  // namespace rmb
