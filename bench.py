@@ -643,13 +643,16 @@ def rank_main(args):
       total_us = 1e3 * out["ms_per_call"]
       out["breakdown_us"] = {
           "position_compare_and_options": round(bind_us, 1),
-          "upload_24N_bytes": round(acc[0], 1), "kernel_enqueue": round(acc[1], 1),
+          "upload_24N_bytes_host_memcpy_and_pull_kernel_enqueue": round(acc[0], 1), "kernel_enqueue": round(acc[1], 1),
           "sweep_kernel_hip_events": round(k_us, 1),
-          "finalize_download_24N_bytes_and_sync": round(max(acc[2] - k_us, 0.0), 1),
+          "finalize_into_mapped_memory_stream_wait_and_memcpy_24N_bytes": round(max(acc[2] - k_us, 0.0), 1),
           "python_ctypes_numpy_alloc": round(max(total_us - bind_us - acc[3], 0.0), 1),
           "c_call_total": round(acc[3], 1), "call_total": round(total_us, 1),
           "note": "upload / enqueue / wait+download: host wall clock inside rmb_matvec (rmb_last_host_timing), measured with "
-                  "per-launch HIP events on (adds ~5 us); the pageable upload is staged, so the call returns when it is done"}
+                  "per-launch HIP events on (adds ~5 us to enqueue and ~15 us to the call, so c_call_total exceeds call_total, which "
+                  "is timed without them).  Up to 768 KB per vector the input goes through page-locked mapped memory + a pull kernel on "
+                  "the product's queue and the finalize kernel stores the result straight into mapped memory: one stream wait and a "
+                  "host memcpy, no copy-queue command either way (options host_zero_copy / host_zero_copy_in)"}
     mob.reset()
     return out
   if not args.no_host_surface:

@@ -123,7 +123,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->wave_clock.release(); c->tile_bounds.release(); c->fpos.release(); c->fperm.release(); c->fsort_keys.release(); c->fsort_vals.release(); c->fsort_tmp.release(); c->fsort_box.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); if (c->host_out) { (void)hipHostFree(c->host_out); c->host_out = nullptr; c->host_out_cap = 0; } c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release(); c->krylov.release();
+  c->wave_clock.release(); c->tile_bounds.release(); c->fpos.release(); c->fperm.release(); c->fsort_keys.release(); c->fsort_vals.release(); c->fsort_tmp.release(); c->fsort_box.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); if (c->host_out) { (void)hipHostFree(c->host_out); c->host_out = nullptr; c->host_out_cap = 0; } if (c->host_in) { (void)hipHostFree(c->host_in); c->host_in = nullptr; c->host_in_cap = 0; } c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release(); c->krylov.release();
   if (c->stream_switch) (void)hipEventDestroy(c->stream_switch);
   for (auto e : c->ev0) (void)hipEventDestroy(e);
   for (auto e : c->ev1) (void)hipEventDestroy(e);
@@ -204,6 +204,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   }
   if (!strcmp(key, "sym_chunk_steps")) { c->opt_sym_chunk_steps = value < 0 ? 0 : value; return 0; }
   if (!strcmp(key, "sym_two_targets")) { c->opt_sym_two_targets = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+  if (!strcmp(key, "host_zero_copy_in")) { c->opt_host_zero_copy_in = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_zero_copy")) { c->opt_host_zero_copy = value < 0 ? 0 : value; return 0; }
   if (!strcmp(key, "sym_order")) { c->opt_sym_order = value ? 1 : 0; return 0; }
   if (!strcmp(key, "sym_xcd")) { c->opt_sym_xcd = value ? 1 : 0; return 0; }
@@ -219,7 +220,7 @@ int rmb_ctx_get_option(rmb_ctx* c, const char* key, long* value) {
       {"fused_symmetric", &c->opt_fused_symmetric}, {"symx_single", &c->opt_symx_single},
       {"deterministic", &c->opt_deterministic}, {"det_workspace_mb", &c->opt_det_workspace_mb}, {"sym_wps", &c->opt_sym_wps},
       {"wave_clock", &c->opt_wave_clock}, {"skip_pairs", &c->opt_skip_pairs}, {"sym_pin", &c->opt_sym_pin},
-      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"force_cull", &c->opt_force_cull}, {"force_sort", &c->opt_force_sort}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps}, {"sym_coop", &c->opt_sym_coop}, {"sym_order", &c->opt_sym_order}, {"host_zero_copy", &c->opt_host_zero_copy}, {"sym_two_targets", &c->opt_sym_two_targets}, {"sym_chunk_steps", &c->opt_sym_chunk_steps}, {"sym_xcd", &c->opt_sym_xcd},
+      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"force_cull", &c->opt_force_cull}, {"force_sort", &c->opt_force_sort}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps}, {"sym_coop", &c->opt_sym_coop}, {"sym_order", &c->opt_sym_order}, {"host_zero_copy", &c->opt_host_zero_copy}, {"host_zero_copy_in", &c->opt_host_zero_copy_in}, {"sym_two_targets", &c->opt_sym_two_targets}, {"sym_chunk_steps", &c->opt_sym_chunk_steps}, {"sym_xcd", &c->opt_sym_xcd},
       {"sym_min_steps", &c->opt_sym_min_steps}};
   // read-only: which kernel family the last product ran on (0 one-sided sweep, 1 symmetric per-wave, 2 deterministic
   // symmetric, 3 symmetric workgroup-cooperative)

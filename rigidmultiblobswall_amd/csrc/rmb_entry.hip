@@ -278,11 +278,32 @@ int rmb_matvec(rmb_ctx* c, int kind, int in_plane, const double* v, const double
   const size_t vb = (size_t)3 * n * sizeof(double), ob = (size_t)3 * n_tgt * sizeof(double);
   if (int rc = c->vec.reserve(vb)) return rc;
   if (int rc = c->out.reserve(ob)) return rc;
-  RMB_HIP(hipMemcpyAsync(c->vec.p, v, vb, hipMemcpyHostToDevice, c->stream));
+  // Inputs.  Small vectors (as the result below): host memcpy into page-locked, device-mapped memory + a pull kernel on
+  // the product's own queue, instead of a host-to-device copy command on the copy queue.
+  const bool pull_in = c->opt_host_zero_copy_in && c->opt_host_zero_copy > 0 && vb <= (size_t)c->opt_host_zero_copy && n >= 128;
+  const int n_vec = kind == rmb::KIND_TT_TR ? 2 : 1;
+  if (pull_in && (size_t)n_vec * vb > c->host_in_cap) {
+    if (c->host_in) { (void)hipHostFree(c->host_in); c->host_in = nullptr; c->host_in_cap = 0; }
+    const size_t want = 2 * (vb + vb / 8) + 4096;
+    RMB_HIP(hipHostMalloc(&c->host_in, want, hipHostMallocMapped));
+    RMB_HIP(hipHostGetDevicePointer((void**)&c->host_in_dev, c->host_in, 0));
+    c->host_in_cap = want;
+  }
+  if (pull_in) {
+    memcpy(c->host_in, v, vb);
+    if (int rc = pull_mapped(c, (double*)c->vec.p, c->host_in_dev, 3 * n)) return rc;
+  } else {
+    RMB_HIP(hipMemcpyAsync(c->vec.p, v, vb, hipMemcpyHostToDevice, c->stream));
+  }
   const double* v2d = nullptr;
   if (kind == rmb::KIND_TT_TR) {
     if (int rc = c->vec2.reserve(vb)) return rc;
-    RMB_HIP(hipMemcpyAsync(c->vec2.p, v2, vb, hipMemcpyHostToDevice, c->stream));
+    if (pull_in) {
+      memcpy((char*)c->host_in + vb, v2, vb);
+      if (int rc = pull_mapped(c, (double*)c->vec2.p, c->host_in_dev + 3 * n, 3 * n)) return rc;
+    } else {
+      RMB_HIP(hipMemcpyAsync(c->vec2.p, v2, vb, hipMemcpyHostToDevice, c->stream));
+    }
     v2d = (const double*)c->vec2.p;
   }
   // Result hand-off.  Small results (<= "host_zero_copy" bytes, 768 KB): the finalize kernel stores straight into page-locked,

@@ -89,6 +89,10 @@ struct rmb_ctx {
   void* host_out = nullptr;
   double* host_out_dev = nullptr;
   size_t host_out_cap = 0;
+  void* host_in = nullptr;       // ... and the same for its input vectors (two of them: RMB_TT_TR)
+  double* host_in_dev = nullptr;
+  size_t host_in_cap = 0;
+  long opt_host_zero_copy_in = 1;   // inputs of rmb_matvec through mapped memory + a pull kernel (sizes as host_zero_copy)
   long opt_host_zero_copy = 768 << 10;   // bytes (32 768 blobs: level at 43 000, +1 % at 1e5); 0 = always a device-to-host copy command
   long symbuf_zeroed_for = -1;
   // options
@@ -195,6 +199,7 @@ int pack_positions_radii(rmb_ctx* c, const double* r_dev, const double* rad_dev,
 int sweep_device(rmb_ctx* c, int kind, int in_plane, const double* v, const double* v2, double eta, double* out);
 int force_sweep_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out, const double* radii);
 int add_inplace(rmb_ctx* c, double* y, const double* x, long n);
+int pull_mapped(rmb_ctx* c, double* dst_dev, const double* src_mapped_dev, long n);
 int body_dense_device(rmb_ctx* c, const long* first_blob_dev, long n_bodies, int n_b, double eta, double* out_dev);
 int st_sweep_device(rmb_ctx* c, long ns, const double4* src_packed, const double* rad_s, const double* force, long nt,
                     const double4* tgt_packed, const double* rad_t, double eta, const double* L, int wall, double* out);

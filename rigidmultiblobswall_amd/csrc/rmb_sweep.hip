@@ -169,6 +169,22 @@ __global__ void add_inplace_kernel(double* y, const double* x, long n) {
 }
 }  // namespace
 
+namespace {
+// dst (device memory) = src (page-locked host memory mapped into the device's address space): 16 bytes per lane,
+// consecutive lanes consecutive addresses -- the upload of rmb_matvec's input vectors as a kernel of the SAME queue
+__global__ __launch_bounds__(256) void pull_mapped_kernel(double* dst, const double* src, long n) {
+  const long i = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i + 1 < n) *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
+  else if (i < n) dst[i] = src[i];
+}
+}  // namespace
+
+int pull_mapped(rmb_ctx* c, double* dst_dev, const double* src_mapped_dev, long n) {
+  hipLaunchKernelGGL(pull_mapped_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, c->stream, dst_dev, src_mapped_dev, n);
+  RMB_HIP(hipGetLastError());
+  return 0;
+}
+
 int add_inplace(rmb_ctx* c, double* y, const double* x, long n) {
   hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, y, x, n);
   RMB_HIP(hipGetLastError());

@@ -15,8 +15,8 @@ for N, reps in ((200, 1000), (1000, 1000), (4000, 500), (10000, 400), (24576, 10
   for _ in range(100 if N <= 10000 else 10): ctx.matvec("tt", f, eta)
   fd = torch.as_tensor(f.reshape(-1), device="cuda"); od = torch.empty(3 * N, dtype=torch.float64, device="cuda")
   reps = min(reps, 150)
-  for zc in (0, 1 << 22, 0, 1 << 22, 0, 1 << 22):
-    ctx.set_option("host_zero_copy", zc)
+  for zc, zin in ((0, 0), (1 << 22, 0), (1 << 22, 1), (0, 0), (1 << 22, 0), (1 << 22, 1)):
+    ctx.set_option("host_zero_copy", zc); ctx.set_option("host_zero_copy_in", zin)
     # The synchronous host path keeps the GPU ~70 % busy at best and the fp64 clock sags within tens of milliseconds of such a
     # duty cycle (a first version of this script, like round 4's, read that sag as an after-effect of mapped memory): prime
     # the clocks with back-to-back device products before EVERY measurement and keep the measurement short.
@@ -33,6 +33,6 @@ for N, reps in ((200, 1000), (1000, 1000), (4000, 500), (10000, 400), (24576, 10
       ht = ctx.last_host_timing(); acc += [ht["upload_us"], ht["launch_us"], ht["wait_and_download_us"], ht["c_call_us"]]
     dt = (time.perf_counter() - t0) / reps * 1e6
     acc /= reps
-    print("N=%6d zero_copy %d: %8.1f us per call   (upload %.1f, enqueue %.1f, wait + download %.1f, C call %.1f)   diff %.1e"
-          % (N, int(zc > 0), dt, *acc, np.linalg.norm(u - ref) / np.linalg.norm(ref)), flush=True)
+    print("N=%6d zero_copy out %d in %d: %8.1f us per call   (upload %.1f, enqueue %.1f, wait + download %.1f, C call %.1f)   diff %.1e"
+          % (N, int(zc > 0), zin, dt, *acc, np.linalg.norm(u - ref) / np.linalg.norm(ref)), flush=True)
 ctx.close()
