@@ -207,6 +207,16 @@ def main():
       ("g9_rigid_obstacle_slip_trapz", "stochastic_Slip_Trapz", with_obstacle(3), 2, dict(kT=kT, seed=10)),
       ("g9_rigid_stoch_slip_trapz_16shells", "stochastic_Slip_Trapz", mixed(0, 16), 2, dict(kT=kT, seed=6)),
   ]
+  # Round 5: the dense-algebra schemes (quaternion_integrator_multi_bodies.py:110, :552, :738, :1346).  Fixman and the RFD
+  # scheme take N^{1/2} W as V S^{1/2} W from numpy's eigendecomposition (stochastic_forcing_eig), which depends on the
+  # eigenvector basis: only boomerangs at generic positions there (distinct eigenvalues of the body mobility; a shell's
+  # near-degenerate pairs would make the trajectory depend on round-off).  Slip_Mid_DLA uses the symmetric square root.
+  cases += [
+      ("g9_rigid_dense_det_euler", "deterministic_forward_euler_dense_algebra", mixed(2, 3), 3, {}),
+      ("g9_rigid_dense_stoch_RFD", "stochastic_first_order_RFD_dense_algebra", mixed(3, 0), 2, dict(kT=kT, seed=21)),
+      ("g9_rigid_dense_Fixman", "Fixman", mixed(3, 0), 2, dict(kT=kT, seed=22)),
+      ("g9_rigid_dense_slip_mid_DLA", "stochastic_Slip_Mid_DLA", mixed(2, 3), 2, dict(kT=kT, seed=23)),
+  ]
   # a larger deterministic case (480 blobs: several tiles of the symmetric kernel, chunked sweeps), one step
   cases.append(("g9_rigid_det_euler_40shells", "deterministic_forward_euler", mixed(0, 40), 1, {}))
   cases.append(("g9_rigid_stoch_slip_trapz_40shells", "stochastic_Slip_Trapz", mixed(0, 40), 1, dict(kT=kT, seed=12)))

@@ -201,6 +201,22 @@ class RigidSuspension(object):
     self.r_dev = r.reshape(-1)
     self.ctx.set_positions(self.r_dev, self.a, self.L, self.wall)
 
+  # ---- dense operators of the whole suspension (the reference's "dense algebra" schemes and one-shot utilities) ----
+  def dense_blob_mobility(self):
+    """(3N, 3N) blob mobility at the bound configuration: body_dense_tt_kernel with the whole suspension as one "body"
+    (the reference calls self.mobility_blobs(r_vectors, eta, a), multi_bodies.py:207-230), symmetrised."""
+    first = torch.zeros(1, dtype=torch.int64, device=self.device)
+    M = self.ctx.body_mobility_dense_device(first, self.n_blobs, self.eta)[0]
+    return 0.5 * (M + M.t())
+
+  def dense_K(self):
+    """(3N, 6 n_bodies) block-diagonal geometric matrix (multi_bodies.py:300-324)."""
+    K = torch.zeros((3 * self.n_blobs, 6 * self.n_bodies), dtype=torch.float64, device=self.device)
+    for g in self.groups:
+      for k, body in enumerate(g.body_idx.tolist()):
+        K[g.blob_idx3[k], 6 * body:6 * body + 6] = g.K[k]
+    return K
+
   @property
   def r_vectors(self):
     return self.r_dev.detach().cpu().numpy().reshape(-1, 3)

@@ -612,6 +612,149 @@ class RigidIntegrator(object):
 
 
 # ---- driver: reference input deck -> integrator -> time loop ------------------------------------------
+  # ---- dense-algebra schemes --------------------------------------------------------------------------------------
+  # quaternion_integrator_multi_bodies.py:110-139 (deterministic_forward_euler_dense_algebra), :552-623
+  # (stochastic_first_order_RFD_dense_algebra), :738-800 (Fixman), :1346-1438 (stochastic_Slip_Mid_DLA), on the dense
+  # solves :1550-1635.  O(N^3) by definition, meant for a few bodies: the blob mobility is built densely on the device
+  # (body_dense_tt_kernel, the whole suspension as one "body") and factorised there with torch.linalg.  The reference takes
+  # N^{1/2} W from numpy's eigendecomposition as V S^{1/2} W (stochastic_forcing_eig, stochastic_forcing.py:7-41) -- NOT
+  # the symmetric square root, so the result depends on LAPACK's eigenvector signs; the 6 n_bodies x 6 n_bodies matrix
+  # goes to the host and through the same numpy routine so that a run with the reference's seed follows its trajectory.
+  # The draws come in the reference's order.
+  def _pinv(self, A):
+    return torch.linalg.pinv(A, rtol=1e-14, hermitian=False)
+
+  def _dense_solve(self):
+    """(U, N, M, R, K) of solve_mobility_problem_DLA (:1592-1635): N = pinv(K^T M^-1 K), U = N (F + K^T M^-1 slip)...
+    with the sign convention of the callers below: dense_algebra (:1550-1589) SUBTRACTS the slip term, DLA adds it."""
+    rs = self.susp
+    M = rs.dense_blob_mobility()
+    R = torch.linalg.inv(M)
+    K = rs.dense_K()
+    N = self._pinv(K.t() @ R @ K)
+    FT = self.force_torque_calculator().reshape(-1)
+    force_slip = K.t() @ (R @ self._slip())
+    return FT, force_slip, N, M, R, K
+
+  def solve_mobility_problem_dense_algebra(self):
+    """(velocities, body mobility) as :1550-1589: U = N (F - K^T M^-1 slip)."""
+    FT, force_slip, N, M, R, K = self._dense_solve()
+    return N @ (FT - force_slip), N
+
+  def solve_mobility_problem_DLA(self):
+    """(velocities, N, M, M^-1, K) as :1592-1635: U = N (F + K^T M^-1 slip)."""
+    FT, force_slip, N, M, R, K = self._dense_solve()
+    return N @ (FT + force_slip), N, M, R, K
+
+  def _eig_forcing(self, mobility, factor, z=None):
+    """factor V S^{1/2} z with numpy.linalg.eigh on the host, non-positive eigenvalues dropped (stochastic_forcing.py:7-41);
+    z = None draws it HERE, after whatever the caller drew before (the reference's order)."""
+    vals, vecs = np.linalg.eigh(mobility.cpu().numpy())
+    root = np.sqrt(np.where(vals > 0, vals, 0.0))
+    zz = self._normal(len(vals)) if z is None else z
+    return torch.as_tensor(factor * (vecs @ (root * zz.cpu().numpy())), device=self.device)
+
+  def _eig_symm_forcing(self, mobility, z):
+    """V S^{1/2} V^T z (stochastic_forcing_eig_symm, stochastic_forcing.py:44-81): independent of the eigenvector basis, so
+    it stays on the device."""
+    vals, vecs = torch.linalg.eigh(mobility)
+    return vecs @ (torch.sqrt(torch.clamp(vals, min=0.0)) * (vecs.t() @ z))
+
+  def deterministic_forward_euler_dense_algebra(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      self._move(self.location, self.orientation)
+      U, _ = self.solve_mobility_problem_dense_algebra()
+      new = self._advance(self.location, self.orientation, U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+
+  def stochastic_first_order_RFD_dense_algebra(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      self._move(*old)
+      U, N = self.solve_mobility_problem_dense_algebra()
+      rfd_noise = self._normal(6 * self.Nbodies)
+      U = U + self._eig_forcing(N, math.sqrt(2 * self.kT / dt))
+      W = rfd_noise.view(-1, 6)
+      Lb = self.body_length.unsqueeze(1)
+      force_rfd = W.clone()
+      force_rfd[:, 0:3] /= Lb
+      moved = (old[0] + W[:, 0:3] * (self.rf_delta * Lb),
+               quaternion_multiply_torch(quaternion_from_rotation_torch(W[:, 3:6] * self.rf_delta), old[1]))
+      self._move(*moved)
+      rs = self.susp
+      K = rs.dense_K()
+      N_new = self._pinv(K.t() @ torch.linalg.inv(rs.dense_blob_mobility()) @ K)
+      U = U + (self.kT / self.rf_delta) * ((N_new - N) @ force_rfd.reshape(-1))
+      new = self._advance(old[0], old[1], U, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
+
+  def Fixman(self, dt, *args, **kwargs):
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      self._move(*old)
+      U_mid, N = self.solve_mobility_problem_dense_algebra()
+      W1 = self._normal(6 * self.Nbodies)
+      W_cor = W1 + self._normal(6 * self.Nbodies)
+      Nhalf_W1 = self._eig_forcing(N, math.sqrt(4 * self.kT / dt), z=W1)
+      Nhalf_Wcor = self._eig_forcing(N, math.sqrt(self.kT / dt), z=W_cor)
+      Ninvhalf_cor = self._pinv(N) @ Nhalf_Wcor
+      mid = self._advance(old[0], old[1], U_mid + Nhalf_W1, 0.5 * dt)
+      if not self._valid(*mid):
+        continue
+      self._move(*mid)
+      U_new, N_mid = self.solve_mobility_problem_dense_algebra()
+      U_new = U_new + N_mid @ Ninvhalf_cor
+      new = self._advance(old[0], old[1], U_new, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
+
+  def stochastic_Slip_Mid_DLA(self, dt, *args, **kwargs):
+    n3 = 3 * self.Nblobs
+    while True:
+      self.preprocess(self)
+      old = (self.location, self.orientation)
+      self._move(*old)
+      U_mid, N_mid, M_mid, R_mid, K_mid = self.solve_mobility_problem_DLA()
+      W1 = self._normal(n3)
+      W_slip = self._normal(n3)
+      Wcor = W1 + self._normal(n3)
+      W_RFD = (N_mid @ (K_mid.t() @ (R_mid @ W_slip))).view(-1, 6)
+      MxW_slip = M_mid @ W_slip
+      KTxW_slip = K_mid.t() @ W_slip
+      Mhalf_W1 = self._eig_symm_forcing(M_mid, W1)
+      Mhalf_Wcor = self._eig_symm_forcing(M_mid, Wcor)
+      U_mid = U_mid + math.sqrt(4 * self.kT / dt) * (N_mid @ (K_mid.t() @ (R_mid @ Mhalf_W1)))
+      # random finite difference: bodies displaced by rf_delta W_RFD (no body-length scaling in this scheme, :1390-1393)
+      rfd = (old[0] + W_RFD[:, 0:3] * self.rf_delta,
+             quaternion_multiply_torch(quaternion_from_rotation_torch(W_RFD[:, 3:6] * self.rf_delta), old[1]))
+      self._move(*rfd)
+      DxM = self.susp.dense_blob_mobility() @ W_slip - MxW_slip
+      DxKT = self.susp.dense_K().t() @ W_slip - KTxW_slip
+      mid = self._advance(old[0], old[1], U_mid, 0.5 * dt)
+      if not self._valid(*mid):
+        continue
+      self._move(*mid)
+      U_new, N_new, M_new, R_new, K_new = self.solve_mobility_problem_DLA()
+      RHS_cor = -(self.kT / self.rf_delta) * DxKT + K_new.t() @ (R_new @ (math.sqrt(self.kT / dt) * Mhalf_Wcor +
+                                                                        (self.kT / self.rf_delta) * DxM))
+      U_new = U_new + N_new @ RHS_cor
+      new = self._advance(old[0], old[1], U_new, dt)
+      self.postprocess(self)
+      if self._valid(*new):
+        return self._accept(*new)
+      self._move(*old)
+
+
 def bodies_from_input(read):
   """Bodies of a deck as multi_bodies/multi_bodies.py:1160-1212 creates them: every `structure` line = vertex file +
   clones file (+ optional .slip file with one body-frame slip per blob).  Returns a dict with one reference

@@ -21,17 +21,11 @@ from .rigid_integrator import bodies_from_input, lab_frame_slip, RigidIntegrator
 
 
 def _dense_blob_mobility(rs):
-  first = torch.zeros(1, dtype=torch.int64, device=rs.device)
-  M = rs.ctx.body_mobility_dense_device(first, rs.n_blobs, rs.eta)[0]
-  return 0.5 * (M + M.t())
+  return rs.dense_blob_mobility()
 
 
 def _dense_K(rs):
-  K = torch.zeros((3 * rs.n_blobs, 6 * rs.n_bodies), dtype=torch.float64, device=rs.device)
-  for g in rs.groups:
-    for k, body in enumerate(g.body_idx.tolist()):
-      K[g.blob_idx3[k], 6 * body:6 * body + 6] = g.K[k]
-  return K
+  return rs.dense_K()
 
 
 def run(read, device="cuda:0", ctx=None, write=True):
