@@ -28,6 +28,8 @@
 #ifndef RMB_MOBILITY_H
 #define RMB_MOBILITY_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -259,6 +261,27 @@ int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, lon
  * (cos |phi|/2, sin(|phi|/2) phi / |phi|), multiplied from the LEFT).  U (n_bodies, 6); dt_body_dev: NULL, or one step
  * per body that replaces dt (the random finite difference scales the displacement by the body length).  Outputs may
  * alias the inputs. */
+/* The rigid-body saddle-point operator in one call (multi_bodies/multi_bodies.py:424-471, all bodies free, one body shape):
+ *   out[0 .. 3N)        = M_tt lambda - K U          (N = n_bodies n_b blobs, lambda = x[0 .. 3N), U = x[3N .. 3N + 6 n_bodies))
+ *   out[3N .. 3N + 6nb) = -K^T lambda
+ * on the context's resident configuration (n = n_bodies n_b).  K (n_bodies, 3 n_b, 6) row-major as
+ * rmb_rigid_configuration_device writes it.  With the symmetric kernels (open boundaries, double precision, default
+ * modes) this is the pair sweep + ONE finishing launch (workgroup = body: self term, scaling, - K U, and -K^T lambda by
+ * a reduction over the body's blobs); otherwise the product and the two K products as separate launches, same result. */
+int rmb_rigid_operator_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* K_dev, const double* x_dev, double eta,
+                              double* out_dev);
+/* One Arnoldi step of the right-preconditioned GMRES of the rigid-body problem (quaternion_integrator_multi_bodies.py:
+ * 1441-1547 -> general_application_utils.py:608-627; all bodies free, one body shape), enqueued by ONE call:
+ *   z = P^-1 v_j   (the four blocks of rmb_rigid_preconditioner_device, one launch),
+ *   w = [M z_lambda - K z_U; -K^T z_lambda]   (rmb_rigid_operator_device: pair sweep + one finishing launch),
+ *   two classical Gram-Schmidt passes of w against v_0 .. v_j, column j of the Hessenberg matrix to col_dev[0 .. j + 1]
+ *   (and to col_mapped_dev when not NULL), |w| to col_dev[j + 1], v_{j+1} = w / |w|   (rmb_krylov_orthogonalize2_device).
+ * V_dev: (restart + 1) rows of ldv doubles, n = 3 n_bodies n_b + 6 n_bodies unknowns each; z_dev, w_dev: n doubles of
+ * scratch.  Seven launches from one host call, no copy command -- what a small deck's iteration costs is the number of
+ * launches (~4.5 us each however little they do) and of host calls, not their work (profiles/r5_gmres_step.txt). */
+int rmb_rigid_arnoldi_step_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev,
+                                  const double* A21_dev, const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j,
+                                  double eta, double* z_dev, double* w_dev, double* col_dev, double* col_mapped_dev);
 int rmb_rigid_configuration_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
                                    const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev);
 int rmb_rigid_advance_device(rmb_ctx* ctx, long n_bodies, const double* loc_dev, const double* quat_dev, const double* U_dev,
@@ -273,6 +296,15 @@ int rmb_block_apply_device(rmb_ctx* ctx, long n_batch, long r1, long c1, long r2
                            const double* x2_dev, double alpha, double beta1, double* y1_dev, double beta2, double* y2_dev);
 int rmb_krylov_orthogonalize_device(rmb_ctx* ctx, long n, long rows, const double* V_dev, long ldv, double* w_dev,
                                     double* col_dev, double* v_next_dev);
+/* The same step with the new column written once more to col_mapped_dev (rows + 1 doubles of page-locked, device-mapped
+ * host memory from rmb_host_mapped_alloc; NULL = rmb_krylov_orthogonalize_device): the host reads it after one event wait,
+ * no copy command. */
+int rmb_krylov_orthogonalize2_device(rmb_ctx* ctx, long n, long rows, const double* V_dev, long ldv, double* w_dev,
+                                     double* col_dev, double* v_next_dev, double* col_mapped_dev);
+/* Page-locked host memory mapped into the device's address space (hipHostMallocMapped), zero-filled: *host = the address
+ * the host reads / writes, *dev = the address kernels use.  Freed with rmb_host_mapped_free(host). */
+int rmb_host_mapped_alloc(size_t bytes, void** host, void** dev);
+int rmb_host_mapped_free(void* host);
 
 /* Blob-blob soft repulsion on the resident positions (multi_bodies/forces_numba.py:12-55,
  * forces_pycuda.py:66-118): out (n_targets,3).  Uses the UNCLAMPED positions: call

@@ -53,6 +53,12 @@ SYMBOLS = {
     "rmb_block_apply_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _vp, _vp,
                                               _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, ctypes.c_double, _vp]),
     "rmb_krylov_orthogonalize_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp]),
+    "rmb_krylov_orthogonalize2_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp, _vp, _vp]),
+    "rmb_host_mapped_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "rmb_host_mapped_free": (ctypes.c_int, [_vp]),
+    "rmb_rigid_operator_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_rigid_arnoldi_step_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long,
+                                                    ctypes.c_long, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "rmb_matvec_op_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,
                                             ctypes.c_double]),
     "rmb_matvec_op_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp,

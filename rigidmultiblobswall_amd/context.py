@@ -302,16 +302,40 @@ class MobilityContext(object):
                                                          ctypes.c_void_p(K.data_ptr()), *[ctypes.c_void_p(t.data_ptr()) for t in outs],
                                                          ctypes.c_void_p(info.data_ptr())))
 
-  def krylov_orthogonalize_device(self, V, rows, w, col, v_next):
+  def krylov_orthogonalize_device(self, V, rows, w, col, v_next, col_mapped=0):
     """Two classical Gram-Schmidt passes of w against V[:rows] (row-major (m, n) tensor), in place; col[:rows] = the
-    coefficients, col[rows] = |w|, v_next = w / |w| (rmb_krylov_orthogonalize_device)."""
+    coefficients, col[rows] = |w|, v_next = w / |w| (rmb_krylov_orthogonalize2_device).  col_mapped: device address of
+    rows + 1 doubles of mapped host memory (MappedHostArray.dev_ptr + offset) that receive the column too, or 0."""
     n = w.numel()
     assert V.stride(1) == 1 and V.shape[1] == n and w.is_contiguous() and col.is_contiguous() and v_next.is_contiguous()
     assert col.numel() >= rows + 1 and v_next.numel() == n
     self._follow_torch_stream()
-    _lib.check(self._lib.rmb_krylov_orthogonalize_device(self._h, n, int(rows), ctypes.c_void_p(V.data_ptr()), V.stride(0),
-                                                         ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(col.data_ptr()),
-                                                         ctypes.c_void_p(v_next.data_ptr())))
+    _lib.check(self._lib.rmb_krylov_orthogonalize2_device(self._h, n, int(rows), ctypes.c_void_p(V.data_ptr()), V.stride(0),
+                                                          ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                                          ctypes.c_void_p(v_next.data_ptr()),
+                                                          ctypes.c_void_p(col_mapped) if col_mapped else None))
+
+  def rigid_arnoldi_step_device(self, A11, A12, A21, A22, K, V, j, eta, z, w, col, col_mapped=0):
+    """One Arnoldi step of the rigid-body GMRES enqueued by one call (rmb_rigid_arnoldi_step_device): z = P^-1 V[j],
+    w = A z, Gram-Schmidt against V[:j + 1], column -> col (and the mapped host address), V[j + 1] = w / |w|."""
+    nb, n_b = K.shape[0], K.shape[1] // 3
+    for t in (A11, A12, A21, A22, K, z, w, col):
+      assert t.is_contiguous()
+    assert V.stride(1) == 1 and V.shape[1] == z.numel() == w.numel() == 3 * nb * n_b + 6 * nb and col.numel() >= j + 2
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_arnoldi_step_device(self._h, nb, n_b, p(A11), p(A12), p(A21), p(A22), p(K), p(V), V.stride(0), int(j),
+                                                       float(eta), p(z), p(w), p(col), ctypes.c_void_p(col_mapped) if col_mapped else None))
+
+  def rigid_operator_device(self, K, x, eta, out):
+    """out = [M_tt lambda - K U; -K^T lambda] for x = [lambda; U] on the resident configuration (all bodies free, one body
+    shape; rmb_rigid_operator_device): the pair sweep + one finishing launch.  K (n_bodies, 3 n_b, 6) contiguous."""
+    nb, n_b = K.shape[0], K.shape[1] // 3
+    assert K.is_contiguous() and x.is_contiguous() and out.is_contiguous() and x.numel() == 3 * nb * n_b + 6 * nb == out.numel()
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_operator_device(self._h, nb, n_b, ctypes.c_void_p(K.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                                   float(eta), ctypes.c_void_p(out.data_ptr())))
+    return out
 
   def blob_blob_force(self, repulsion_strength, debye_length, blob_radius):
     out = np.empty(3 * self.n_targets)
@@ -426,3 +450,30 @@ def _is_torch_cuda(x):
   except ImportError:
     return False
   return isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64
+
+
+class MappedHostArray(object):
+  """A float64 numpy array in page-locked host memory that is mapped into the device's address space
+  (rmb_host_mapped_alloc): kernels store into `dev_ptr`, the host reads `array` after one event / stream wait -- no copy
+  command.  Freed with close() or when collected."""
+
+  def __init__(self, shape):
+    self._lib = _lib.load()
+    n = int(np.prod(shape))
+    h, d = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(self._lib.rmb_host_mapped_alloc(ctypes.c_size_t(8 * n), ctypes.byref(h), ctypes.byref(d)))
+    self._host = h
+    self.dev_ptr = int(d.value)
+    self.array = np.ctypeslib.as_array((ctypes.c_double * n).from_address(h.value)).reshape(shape)
+
+  def close(self):
+    if self._host is not None:
+      self.array = None
+      self._lib.rmb_host_mapped_free(self._host)
+      self._host = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

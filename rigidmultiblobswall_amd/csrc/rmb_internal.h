@@ -159,8 +159,10 @@ bool sym_applies(const rmb_ctx* c);
 enum SymXOp { SX_TT = 0, SX_TR, SX_RT, SX_RR, SX_FUSED, SX_GRAND, SX_COLF, SX_FREE, SX_RADII, SX_K2, SX_COUNT = SX_K2 + 12 };
 // Configuration a symmetric pass runs on: the context's resident one, or a caller-packed one (per-blob radii)
 struct SymConf { const double4* pos; long n; double L[3]; int wall; const double* extra; };
+// no_finalize: leave the raw sums in the accumulators (c->symbuf: [3][n_pad], unscaled, no self term) -- the caller
+// launches its own finishing kernel (rmb_rigid_operator_device); not for the pseudo-periodic / fp32 routes
 int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard = 0, long nshards = 1,
-               bool accumulate = false);
+               bool accumulate = false, bool no_finalize = false);
 int sym2_device(rmb_ctx* c, const double* va, const double* vb, double eta, double* out_a, double* out_b, long shard = 0,
                 long nshards = 1);
 int symx_device(rmb_ctx* c, int op, const double* const* in, double* const* out, double eta, int in_plane, long shard,

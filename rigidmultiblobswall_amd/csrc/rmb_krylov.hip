@@ -19,6 +19,7 @@
 #include "rmb_internal.h"
 
 #include <cmath>
+#include <cstring>
 
 namespace rmbi {
 namespace {
@@ -33,6 +34,7 @@ struct OrthoArgs {
   const double* V;
   double* w;
   double* col;      // rows coefficients, then |w|
+  double* col_host; // the same column once more, in page-locked device-mapped host memory, or nullptr
   double* v_next;
   double* part1;    // [rows][n_chunks] partial dots of pass 1
   double* part2;    // [rows][n_chunks] partial dots of pass 2
@@ -128,14 +130,25 @@ __global__ __launch_bounds__(kKrT) void ortho_normalise_kernel(const OrthoArgs a
     double s = 0.0;
     for (long c = 0; c < a.n_chunks; ++c) s += a.part3[c];
     nrm = sqrt(s);
-    if (blockIdx.x == 0) a.col[a.rows] = nrm;
+    if (blockIdx.x == 0) {
+      a.col[a.rows] = nrm;
+      if (a.col_host) a.col_host[a.rows] = nrm;
+    }
   }
+  if (a.col_host && blockIdx.x == 0)      // col[0..rows) was written by the launch before this one
+    for (long r = threadIdx.x; r < a.rows; r += kKrT) a.col_host[r] = a.col[r];
   __syncthreads();
   const double inv = 1.0 / nrm;      // |w| = 0 (exact breakdown): inf / nan in v_next, as w / |w| gives; the caller stops on col[rows] == 0
   const long base = blockIdx.x * a.chunk;
   const long len = (a.n - base) < a.chunk ? (a.n - base) : a.chunk;
   for (long e = threadIdx.x; e < len; e += kKrT) a.v_next[base + e] = a.w[base + e] * inv;
 }
+
+// (Round 5 measured the whole step in ONE workgroup for systems of up to 6144 unknowns -- workgroup barriers instead of
+//  kernel boundaries -- and dropped it: one CU pulls the (rows x n) basis four times through its own L2 port, 17-24 us per
+//  step at 17 basis rows growing to 40 us at 60 (wave = row), 23-40 us with thread = unknown, against 4 x 4.5 us for the
+//  four launches below, whose workgroups spread over the chip; and dependent launches of one stream start back to back
+//  once they are queued -- what a tiny kernel costs is its ~4.5 us floor, not a gap.  profiles/r5_gmres_step.txt.)
 
 // ---- batched two-by-two block matvec ---------------------------------------------------------------------------
 struct BlockRef { const double* p; long bs, rs, cs; };
@@ -182,6 +195,11 @@ extern "C" {
 
 int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
                                     double* v_next_dev) {
+  return rmb_krylov_orthogonalize2_device(c, n, rows, V_dev, ldv, w_dev, col_dev, v_next_dev, nullptr);
+}
+
+int rmb_krylov_orthogonalize2_device(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
+                                     double* v_next_dev, double* col_mapped_dev) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
   if (n < 1 || rows < 1 || rows > kKrMaxRows || ldv < n)
     return fail(RMB_ERR_ARG, "rmb_krylov_orthogonalize_device: need n >= 1, 1 <= rows <= 256, ldv >= n");
@@ -189,6 +207,7 @@ int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double*
   RMB_HIP(hipSetDevice(c->device));
   OrthoArgs a;
   a.n = n; a.rows = rows; a.ldv = ldv;
+  a.V = V_dev; a.w = w_dev; a.col = col_dev; a.v_next = v_next_dev; a.col_host = col_mapped_dev;
   // chunks of 256 doubles (one per thread: small systems are latency-bound, 4608 unknowns are 18 workgroups instead of 5)
   // while that gives at most 256 workgroups, larger ones (up to what fits LDS) beyond: every workgroup re-sums the
   // per-chunk partials, so their number stays bounded
@@ -202,7 +221,6 @@ int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double*
   // captured for lower indices replayed into freed memory.  ~1 MB for up to 65 536 unknowns.
   const size_t need = ((size_t)2 * kKrMaxRows * a.n_chunks + a.n_chunks + kKrMaxRows) * sizeof(double);
   if (int rc = c->krylov.reserve(need)) return rc;
-  a.V = V_dev; a.w = w_dev; a.col = col_dev; a.v_next = v_next_dev;
   a.part1 = (double*)c->krylov.p;
   a.part2 = a.part1 + rows * a.n_chunks;
   a.part3 = a.part2 + rows * a.n_chunks;
@@ -214,6 +232,27 @@ int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double*
   hipLaunchKernelGGL(ortho_update_kernel<2>, grid, block, lds_wh, c->stream, a);
   hipLaunchKernelGGL(ortho_normalise_kernel, grid, block, 0, c->stream, a);
   RMB_HIP(hipGetLastError());
+  return 0;
+}
+
+// Page-locked host memory mapped into the device's address space: what a kernel may store into so that the host reads a
+// result after one event / stream wait, without a copy command (the Hessenberg column of an Arnoldi step; rmb_matvec does
+// the same internally).  *host_out = the address the host reads, *dev_out = the address kernels use.
+int rmb_host_mapped_alloc(size_t bytes, void** host_out, void** dev_out) {
+  if (!host_out || !dev_out || bytes == 0) return fail(RMB_ERR_ARG, "rmb_host_mapped_alloc: null pointer / zero size");
+  void* h = nullptr;
+  RMB_HIP(hipHostMalloc(&h, bytes, hipHostMallocMapped));
+  void* d = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+  if (e != hipSuccess) { (void)hipHostFree(h); return fail(RMB_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e)); }
+  memset(h, 0, bytes);
+  *host_out = h; *dev_out = d;
+  return 0;
+}
+
+int rmb_host_mapped_free(void* host) {
+  if (!host) return 0;
+  RMB_HIP(hipHostFree(host));
   return 0;
 }
 

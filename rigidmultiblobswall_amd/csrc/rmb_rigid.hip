@@ -365,6 +365,69 @@ __global__ __launch_bounds__(kPcLargeT) void rigid_pc_large_kernel(const PcArgs 
   if (t == 0 && bad) atomicOr(a.info, 1);
 }
 
+
+// ---- the saddle-point operator's finishing launch: workgroup = body ------------------------------------------------
+struct OpFinArgs {
+  const double4* pos;
+  const double* x;        // [lambda (3N); U (6 n_bodies)]
+  const double* K;        // (n_bodies, 3 n_b, 6)
+  double* acc;            // [3][n_pad] raw sums of the symmetric tt sweep; re-zeroed here
+  double* out;            // [M lambda - K U (3N); -K^T lambda (6 n_bodies)]
+  long n, n_pad, n_bodies;
+  int n_b;
+  double prefactor;
+  rmb::PairConsts k;
+};
+
+// Thread l < n_b finishes blob i = body n_b + l exactly as sym_finalize_kernel does (self term of the B-damped lambda,
+// scaling by b_i / (8 pi eta)), subtracts row i of K U, and contributes its three rows of K^T lambda to a fixed-order
+// reduction over the body.
+template <bool WALL>
+__global__ __launch_bounds__(256) void rigid_operator_finish_kernel(const OpFinArgs a) {
+  __shared__ double part[4][6];
+  const long body = blockIdx.x;
+  const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+  const long n3 = 3 * a.n;
+  double kt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (l < a.n_b) {
+    const long i = body * a.n_b + l;
+    rmb::Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
+    a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;     // ready for the next product
+    const double4 p = a.pos[i];
+    const double b = p.w;
+    const double lx = a.x[3 * i], ly = a.x[3 * i + 1], lz = a.x[3 * i + 2];
+    rmb::self_term<rmb::KIND_TT, WALL>(a.k, p.z, lx * b, ly * b, lz * b, 0, 0, 0, acc);
+    const double sc = a.prefactor * b;
+    const double* U = a.x + n3 + 6 * body;
+    const double* Kr = a.K + (body * 3 * a.n_b + 3 * l) * 6;
+    double u[3] = {acc.x * sc, acc.y * sc, acc.z * sc};
+    const double lam[3] = {lx, ly, lz};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        s += Kr[6 * c + q] * U[q];
+        kt[q] += Kr[6 * c + q] * lam[c];
+      }
+      a.out[3 * i + c] = u[c] - s;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    double v = kt[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) part[wave][q] = v;
+  }
+  __syncthreads();
+  if (l < 6) {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w][l];
+    a.out[n3 + 6 * body + l] = -s;
+  }
+}
+
 }  // namespace
 }  // namespace rmbi
 
@@ -427,6 +490,58 @@ int rmb_rigid_preconditioner_device(rmb_ctx* c, long n_bodies, long n_b, const d
   }
   RMB_HIP(hipGetLastError());
   return 0;
+}
+
+int rmb_rigid_operator_device(rmb_ctx* c, long n_bodies, long n_b, const double* K_dev, const double* x_dev, double eta,
+                              double* out_dev) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1 || n_b > 256) return fail(RMB_ERR_ARG, "rmb_rigid_operator_device: need n_bodies >= 1 and 1 <= n_b <= 256");
+  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_operator_device: the resident configuration does not hold n_bodies x n_b blobs");
+  if (c->tgt_begin != 0 || c->tgt_end != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_operator_device: needs the full target range");
+  if (!K_dev || !x_dev || !out_dev) return fail(RMB_ERR_ARG, "null pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  const long n = c->n, n3 = 3 * n;
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  if (sym_applies(c) && !periodic && c->opt_deterministic == 0 && c->opt_precision == 64) {
+    // pair sweep with the raw sums left in the accumulators, then ONE finishing launch
+    if (int rc = sym_device(c, rmb::KIND_TT, x_dev, eta, out_dev, 0, 1, false, true)) return rc;
+    OpFinArgs a;
+    a.pos = (const double4*)c->pos.p; a.x = x_dev; a.K = K_dev; a.acc = (double*)c->symbuf.p; a.out = out_dev;
+    a.n = n; a.n_pad = 64 * ((n + 63) / 64); a.n_bodies = n_bodies; a.n_b = (int)n_b;
+    a.prefactor = 1.0 / (8.0 * M_PI * eta);
+    a.k = make_pair_consts(c->a);
+    const unsigned threads = (unsigned)(64 * ((n_b + 63) / 64));
+    if (c->wall) hipLaunchKernelGGL(rigid_operator_finish_kernel<true>, dim3((unsigned)n_bodies), dim3(threads), 0, c->stream, a);
+    else         hipLaunchKernelGGL(rigid_operator_finish_kernel<false>, dim3((unsigned)n_bodies), dim3(threads), 0, c->stream, a);
+    RMB_HIP(hipGetLastError());
+    return 0;
+  }
+  // any other mode (one-sided sweep below 128 blobs, periodic images, deterministic / single-precision options): the
+  // product, then top -= K U and bottom = -K^T lambda through the block kernel -- the same result in three launches
+  if (int rc = matvec_device_impl(c, rmb::KIND_TT, 0, x_dev, nullptr, eta, out_dev)) return rc;
+  rmb_block kb{K_dev, 3 * n_b * 6, 6, 1};            // K as (batch, row, col)
+  rmb_block kt{K_dev, 3 * n_b * 6, 1, 6};            // K^T: strides exchanged
+  return rmb_block_apply_device(c, n_bodies, 3 * n_b, 3 * n_b, 6, 6, nullptr, &kb, &kt, nullptr, x_dev, x_dev + n3, -1.0, 1.0, out_dev, 0.0,
+                                out_dev + n3);
+}
+
+int rmb_rigid_arnoldi_step_device(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev,
+                                  const double* A21_dev, const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j,
+                                  double eta, double* z_dev, double* w_dev, double* col_dev, double* col_mapped_dev) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1 || j < 0) return fail(RMB_ERR_ARG, "rmb_rigid_arnoldi_step_device: bad n_bodies / n_b / j");
+  if (!A11_dev || !A12_dev || !A21_dev || !A22_dev || !K_dev || !V_dev || !z_dev || !w_dev || !col_dev) return fail(RMB_ERR_ARG, "null pointer");
+  const long nn = 3 * n_b, n3 = 3 * n_bodies * n_b, n = n3 + 6 * n_bodies;
+  if (ldv < n) return fail(RMB_ERR_ARG, "rmb_rigid_arnoldi_step_device: ldv < 3 N + 6 n_bodies");
+  const double* v = V_dev + j * ldv;
+  // z = P^-1 v_j: the four blocks of every body's [[M_b, -K], [-K^T, 0]]^-1 in one launch
+  const rmb_block b11{A11_dev, nn * nn, nn, 1}, b12{A12_dev, nn * 6, 6, 1}, b21{A21_dev, 6 * nn, nn, 1}, b22{A22_dev, 36, 6, 1};
+  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 6, 6, &b11, &b12, &b21, &b22, v, v + n3, 1.0, 0.0, z_dev, 0.0, z_dev + n3)) return rc;
+  // w = A z: pair sweep + one finishing launch
+  if (int rc = rmb_rigid_operator_device(c, n_bodies, n_b, K_dev, z_dev, eta, w_dev)) return rc;
+  // two Gram-Schmidt passes against v_0 .. v_j, Hessenberg column, |w|, v_{j+1}
+  return rmb_krylov_orthogonalize2_device(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev);
 }
 
 }  // extern "C"

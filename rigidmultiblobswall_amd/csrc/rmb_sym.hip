@@ -27,7 +27,8 @@ SymEntry g_sym[4][2][2] = {RMB_SYM_ROW(rmb::KIND_TT), RMB_SYM_ROW(rmb::KIND_TR),
 #undef RMB_SYM_ROW
 }  // namespace
 
-int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards, bool accumulate) {
+int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, long shard, long nshards, bool accumulate,
+               bool no_finalize) {
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   SymEntry& se = g_sym[kind][c->wall ? 1 : 0][periodic ? 1 : 0];
   const long n = c->n;
@@ -54,6 +55,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   // Pseudo-periodic single-vector products: the two-targets-per-lane instance of the generic skeleton (symx2t_kernels.h:
   // one record read and one set of LDS adds for the 2 x 3^d image pairs of a step) from half a unit per resident wave on,
   // the same rule as below; smaller launches stay here (cooperative kernel).  The wave_clock diagnostic lives in sym_kernel.
+  if (periodic && no_finalize) return fail(RMB_ERR_STATE, "sym_device: no_finalize is for open boundaries (internal)");
   if (periodic && c->opt_sym_two_targets && c->opt_sym_coop != 2 && tiles >= 4 && !c->opt_wave_clock) {
     int wpe = 0;
     const Kernel32 cand = symx_two_periodic(SX_TT + kind, c->wall != 0, &wpe);
@@ -140,6 +142,7 @@ int sym_device(rmb_ctx* c, int kind, const double* v, double eta, double* out, l
   }
   RMB_HIP(hipGetLastError());
   if (int rc = timing_end(c, slot)) return rc;
+  if (no_finalize) return 0;          // the caller finishes the accumulators itself
   const dim3 fgrid((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(se.fin, fgrid, dim3(256), 0, c->stream, a);
   RMB_HIP(hipGetLastError());

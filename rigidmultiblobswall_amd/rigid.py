@@ -226,6 +226,10 @@ class RigidSuspension(object):
     if ws is not None:
       ws.release()
       self._arnoldi_ws = None
+    ns = getattr(self, "_arnoldi_native", None)
+    if ns is not None:
+      ns.close()
+      self._arnoldi_native = None
     if self._own_ctx:
       self.ctx.close()
 
@@ -306,6 +310,10 @@ class RigidSuspension(object):
       top = res[:n3]
       self.matvec_count += 1
       self.sweep_count += 1
+      helper = self._native_blocks()
+      if helper is not None and helper is self.ctx and x.is_contiguous() and g.n_b <= 256 and self.fused_operator:
+        # sweep + ONE finishing launch (self term, scaling, - K U, -K^T lambda): rmb_rigid_operator_device
+        return helper.rigid_operator_device(g.K, x, self.eta, res)
       lam = lam.contiguous()
       r = self.ctx.matvec_device("tt", lam, self.eta, out=top)
       if r.data_ptr() != top.data_ptr():       # contexts that do not write in place (test stand-ins)
@@ -491,8 +499,20 @@ class RigidSuspension(object):
     nrm = float(torch.linalg.norm(rhs))
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
-    ws = self._arnoldi_graphs(restart)
     ortho = self._ortho(restart)
+    ns = self._native_arnoldi(restart)
+    if ns is not None:
+      # One C call per Arnoldi iteration enqueues all of its launches (rmb_rigid_arnoldi_step_device: preconditioner blocks,
+      # pair sweep, finishing launch with the K products, fused Gram-Schmidt that also stores the Hessenberg column into
+      # mapped host memory): 7 launches from one host call, no graph, no copy command.
+      ns.bind(self)
+      sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
+                                             restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
+                                             ws=ns, on_replay=self._count_operator, ortho=ortho)
+      info["rhs_norm"] = nrm
+      info["native_steps"] = ns.steps_this_solve
+      return sol * nrm, info
+    ws = self._arnoldi_graphs(restart)
     if ws is None:
       sol, info = gmres_right_preconditioned(self.apply_operator, self.apply_preconditioner, rhs / nrm, tol=tol,
                                              restart=restart, maxiter=maxiter, x0=None if x0 is None else x0 / nrm,
@@ -518,6 +538,27 @@ class RigidSuspension(object):
     info["rhs_norm"] = nrm
     info["graph_replays"] = ws.replays_this_solve
     return sol, info
+
+  fused_operator = True       # False: the product and the K products as separate launches (A/B, tests)
+  native_step = None          # None = automatic, False = never: one C call per Arnoldi iteration (_ArnoldiNative)
+
+  def _native_arnoldi(self, restart):
+    """The one-call-per-iteration workspace for solve(), or None.  Applies to what rmb_rigid_arnoldi_step_device covers: one
+    body shape of at most 32 blobs, all bodies free, a plain single-GPU context, the host bookkeeping one iteration late.
+    `gmres_graph = True` (forced captured iterations) and `native_step = False` / RMB_NATIVE_STEP=0 turn it off."""
+    want = self.native_step
+    if os.environ.get("RMB_NATIVE_STEP", "") == "0":
+      want = False
+    if (want is False or self.gmres_graph is True or self.free is not None or len(self.groups) != 1 or self.device.type != "cuda"
+        or type(self.ctx) is not MobilityContext or self._native_products() is not self.ctx or not self.fused_operator
+        or getattr(self, "gmres_lag", None) is False or not (0 < restart < 256)):
+      return None
+    ns = getattr(self, "_arnoldi_native", None)
+    if ns is None or ns.m != restart or ns.n != self.size:
+      if ns is not None:
+        ns.close()
+      ns = self._arnoldi_native = _ArnoldiNative(self.size, restart, self.device)
+    return ns
 
   # `native_helpers`: the O(N) pieces between two sweeps (K / K^T products, the preconditioner's four blocks, the
   # Gram-Schmidt of an Arnoldi step) as the library's own kernels (csrc/rmb_krylov.hip) instead of batched-GEMM / GEMV
@@ -571,6 +612,8 @@ class RigidSuspension(object):
     if ws is None or ws.m != restart:
       ws = self._arnoldi_ws = _ArnoldiGraphs(self.size, restart, self.device)
     ws.buffers = getattr(self.ctx, "buffers_signature", None)
+    if self._ortho(restart) is not None and os.environ.get("RMB_MAPPED_COLUMNS", "") != "0":
+      ws.use_mapped_columns()
     ptr = lambda t: None if t is None else t.data_ptr()
     ws.bind((self.ctx.launch_signature(), self.eta, self._native_blocks() is not None, ptr(self.free), ptr(self.prescribed_velocity),
              tuple(tuple(ptr(t) for t in (g.K, g.A11, g.A12, g.A21, g.A22)) for g in self.groups)))
@@ -811,6 +854,57 @@ class RigidSuspension(object):
 _pinned_pool = []
 
 
+class _ArnoldiNative(object):
+  """Static workspace of GMRES(restart) whose device side of an iteration is ONE call into the library
+  (MobilityContext.rigid_arnoldi_step_device).  Same interface as _ArnoldiGraphs towards _gmres_steps: V, cols, host_cols
+  (here page-locked memory mapped into the device's address space: the Gram-Schmidt kernel stores the column there
+  itself) and run(j, ...)."""
+
+  def __init__(self, n, restart, device):
+    from .context import MappedHostArray
+    self.n, self.m, self.device = int(n), int(restart), device
+    self.V = torch.zeros((self.m + 1, self.n), dtype=torch.float64, device=device)
+    self.cols = torch.zeros((self.m, self.m + 2), dtype=torch.float64, device=device)
+    self.z = torch.empty(self.n, dtype=torch.float64, device=device)
+    self.w = torch.empty(self.n, dtype=torch.float64, device=device)
+    self.mapped = MappedHostArray((self.m, self.m + 2))
+    self.host_cols = self.mapped.array
+    self.owner = None
+    self.steps = self.steps_this_solve = 0
+
+  def bind(self, owner):
+    """Once per solve: everything of the step call that does not change from one iteration to the next, as plain integers
+    (building sixteen ctypes objects per iteration costs more host time than the GPU needs for the iteration)."""
+    self.owner = owner
+    self.steps_this_solve = 0
+    ctx, g = owner.ctx, owner.groups[0]
+    for t in (g.A11, g.A12, g.A21, g.A22, g.K):
+      assert t.is_contiguous()
+    ctx._follow_torch_stream()                   # the solve stays on the stream that is current now
+    self._fn = ctx._lib.rmb_rigid_arnoldi_step_device
+    self._head = (ctx._h, g.K.shape[0], g.K.shape[1] // 3, g.A11.data_ptr(), g.A12.data_ptr(), g.A21.data_ptr(), g.A22.data_ptr(),
+                  g.K.data_ptr(), self.V.data_ptr(), self.V.stride(0))
+    self._tail = (float(owner.eta), self.z.data_ptr(), self.w.data_ptr())
+    self._cols_ptr, self._mapped_ptr, self._row = self.cols.data_ptr(), self.mapped.dev_ptr, 8 * (self.m + 2)
+
+  def run(self, j, body, on_replay=None):
+    rc = self._fn(*self._head, j, *self._tail, self._cols_ptr + j * self._row, self._mapped_ptr + j * self._row)
+    if rc != 0:
+      from . import _lib
+      _lib.check(rc)
+    if on_replay is not None:
+      on_replay()
+    self.steps += 1
+    self.steps_this_solve += 1
+
+  def close(self):
+    self.owner = None
+    if self.mapped is not None:
+      self.host_cols = None
+      self.mapped.close()
+      self.mapped = None
+
+
 class _ArnoldiGraphs(object):
   """Static workspace of GMRES(restart) on one system size and, per iteration index j, a captured hipGraph of everything
   the DEVICE does in that iteration.  On systems of a few thousand blobs an iteration is ~16 small launches whose
@@ -828,6 +922,10 @@ class _ArnoldiGraphs(object):
     self.V = torch.zeros((self.m + 1, self.n), dtype=torch.float64, device=device)
     self.cols = torch.zeros((self.m, self.m + 2), dtype=torch.float64, device=device)
     self.host_cols = torch.zeros((self.m, self.m + 2), dtype=torch.float64).pin_memory()
+    # The fused Gram-Schmidt kernel can store the new Hessenberg column straight into page-locked memory that is mapped
+    # into the device's address space (context.MappedHostArray): one graph node (the copy) less per iteration.  Set up by
+    # the owner when its context has the entry point; host_cols then IS that memory (a numpy array).
+    self.mapped_cols = None
     self.stream = torch.cuda.Stream(device)
     self.graphs, self.seen, self.signature = {}, set(), None
     self.solves = self.captures = self.replays = self.replays_this_solve = 0
@@ -839,6 +937,16 @@ class _ArnoldiGraphs(object):
     if signature != self.signature:
       self.release()
       self.signature = signature
+
+  def use_mapped_columns(self):
+    if self.mapped_cols is None:
+      from .context import MappedHostArray
+      self.mapped_cols = MappedHostArray((self.m, self.m + 2))
+      self.host_cols = self.mapped_cols.array
+
+  def col_mapped_ptr(self, j):
+    """Device address of row j of the mapped column buffer, or 0."""
+    return 0 if self.mapped_cols is None else self.mapped_cols.dev_ptr + 8 * j * (self.m + 2)
 
   def release(self):
     """Destroy the graphs now (a safe point: nothing is capturing) rather than whenever the collector finds them."""
@@ -1014,11 +1122,16 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
         if ws is not None:
           def device_side(j=j):
             w = A(Minv(V[j]))
+            mapped = ws.col_mapped_ptr(j) if ortho is not None else 0
             if ortho is not None:
-              ortho(V, j + 1, w, cols[j], V[j + 1])
+              if mapped:
+                ortho(V, j + 1, w, cols[j], V[j + 1], mapped)       # the kernel stores the column into host memory itself
+              else:
+                ortho(V, j + 1, w, cols[j], V[j + 1])
             else:
               torch.div(orthogonalise(j, w), cols[j, j + 1], out=V[j + 1])
-            host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
+            if not mapped:
+              host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
           ws.run(j, device_side, on_replay)
         else:
           w = yield Minv(V[j])
