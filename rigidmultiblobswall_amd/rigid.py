@@ -1053,6 +1053,9 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
   wasted = 0
   host_cols = ws.host_cols if ws is not None else (_pinned_columns(restart + 1, restart + 2) if lag else None)
   events = [torch.cuda.Event(), torch.cuda.Event()] if lag else None
+  # the stream the iterations are enqueued on: looked up once (a solve does not change streams; the lookup is 4 us of the
+  # ~45 us of host time an iteration of a small deck costs)
+  ev_stream = torch.cuda.current_stream(dev) if lag else None
   try:
     while its < maxiter and res > tol:
       m = min(restart, maxiter - its)
@@ -1148,7 +1151,7 @@ def _gmres_steps(Minv, b, tol, restart, maxiter, x0, sync, lag=None, ws=None, A=
             host_cols[j, :j + 2].copy_(cols[j, :j + 2], non_blocking=True)
           # fence on the stream the copy was enqueued on: the current stream of the VECTORS' device, which need not
           # be the process's current device (a suspension built on cuda:1 while cuda:0 is current)
-          events[j & 1].record(torch.cuda.current_stream(dev))
+          events[j & 1].record(ev_stream)
           if pending is not None:
             stop, pending = finish(pending), None
             if stop:
