@@ -118,8 +118,12 @@ class RigidIntegrator(object):
     self.rfd_solve_tolerance = None
     # Slip schemes: advance everything that shares the mobility of time level n (M W_slip, the Lanczos forcing(s), the RFD
     # solve) in lockstep, one k-vector pass over the blob pairs per round.
-    # Numerically neutral: each solve sees exactly its own GMRES iterates.
-    self.lockstep_solves = True
+    # Numerically neutral: each solve sees exactly its own GMRES iterates.  None = automatic: from `lockstep_min_blobs`
+    # blobs on, where a pass over the pairs costs more than the host work of a solver iteration; below, the solves run one
+    # after the other through the one-call Arnoldi step (64 shells: 5.7 -> 4.8 ms per stochastic_Slip_Trapz step, 256 shells
+    # 6.6 -> 5.9; 1024 shells 16.3 against 17.4 the other way: tools/experiments/exp_lockstep_small.py).
+    self.lockstep_solves = None
+    self.lockstep_min_blobs = 6000
     self.print_residual = False
     self.max_retries = 1000              # total rejected configurations over the life of the integrator
     self.max_consecutive_retries = 20    # in a row (one step, or its midpoint / predictor stages)
@@ -552,7 +556,7 @@ class RigidIntegrator(object):
       rhs = torch.cat([-W_slip, torch.zeros(6 * self.Nbodies, dtype=torch.float64, device=self.device)])
       f1 = math.sqrt(2 * self.kT / dt) if trapezoidal else math.sqrt(4 * self.kT / dt)
       rfd_tol = self.tolerance if self.rfd_solve_tolerance is None else self.rfd_solve_tolerance
-      if self.lockstep_solves:
+      if self.lockstep_solves if self.lockstep_solves is not None else self.Nblobs >= self.lockstep_min_blobs:
         # Everything at time level n that needs the mobility M(q^n) and does not depend on another result: the product
         # M W_slip, the Brownian forcing(s) (Lanczos) and the RFD solve advance together, one k-vector pass over the
         # pairs per round.  The Brownian-slip solve needs the forcing and follows; the corrector solve and the second
