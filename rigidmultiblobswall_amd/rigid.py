@@ -949,7 +949,12 @@ class _ArnoldiGraphs(object):
     return 0 if self.mapped_cols is None else self.mapped_cols.dev_ptr + 8 * j * (self.m + 2)
 
   def release(self):
-    """Destroy the graphs now (a safe point: nothing is capturing) rather than whenever the collector finds them."""
+    """Destroy the graphs now (a safe point: nothing is capturing) rather than whenever the collector finds them.  A graph
+    of the previous solve may still be executing -- the lagged bookkeeping leaves its last, discarded iteration in flight,
+    and a stale-buffer drop happens in the middle of a solve: wait for the device first, destroying an executing
+    hipGraphExec is not something to rely on (an intermittent hang of a slip-scheme test on the box was traced to here)."""
+    if self.graphs and self.device.type == "cuda":
+      torch.cuda.synchronize(self.device)
     self.graphs.clear()
     self.seen.clear()
     self.solves = 0
