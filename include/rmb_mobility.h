@@ -282,6 +282,15 @@ int rmb_rigid_operator_device(rmb_ctx* ctx, long n_bodies, long n_b, const doubl
 int rmb_rigid_arnoldi_step_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev,
                                   const double* A21_dev, const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j,
                                   double eta, double* z_dev, double* w_dev, double* col_dev, double* col_mapped_dev);
+/* One step of the preconditioned Lanczos recursion for the Brownian forcing (P^T M P)^{1/2} z, P = blockdiag(L_b^-T)
+ * (stochastic_forcing/stochastic_forcing.py:112-264 driven by multi_bodies/multi_bodies.py:590-614), enqueued by ONE call:
+ *   y = P v_i,  w = M_tt y,  w <- P^T w   (two block launches around the pair sweep),
+ *   two classical Gram-Schmidt passes of w against v_0 .. v_i: col_dev[i] = h_ii, col_dev[i + 1] = h_{i+1,i} (also to
+ *   col_mapped_dev when not NULL), v_{i+1} = w / |w|.
+ * Linv_dev: (n_bodies, 3 n_b, 3 n_b) = L_b^-1 as rmb_rigid_preconditioner_device writes it; V_dev rows of ldv >= 3 N doubles;
+ * y_dev, w_dev: 3 N doubles of scratch. */
+int rmb_rigid_lanczos_step_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i,
+                                  double eta, double* y_dev, double* w_dev, double* col_dev, double* col_mapped_dev);
 int rmb_rigid_configuration_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
                                    const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev);
 int rmb_rigid_advance_device(rmb_ctx* ctx, long n_bodies, const double* loc_dev, const double* quat_dev, const double* U_dev,

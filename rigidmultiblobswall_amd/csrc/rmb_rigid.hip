@@ -544,4 +544,24 @@ int rmb_rigid_arnoldi_step_device(rmb_ctx* c, long n_bodies, long n_b, const dou
   return rmb_krylov_orthogonalize2_device(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev);
 }
 
+int rmb_rigid_lanczos_step_device(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i,
+                                  double eta, double* y_dev, double* w_dev, double* col_dev, double* col_mapped_dev) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1 || i < 0) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_step_device: bad n_bodies / n_b / i");
+  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_lanczos_step_device: the resident configuration does not hold n_bodies x n_b blobs");
+  if (!Linv_dev || !V_dev || !y_dev || !w_dev || !col_dev) return fail(RMB_ERR_ARG, "null pointer");
+  const long nn = 3 * n_b, n3 = 3 * c->n;
+  if (ldv < n3) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_step_device: ldv < 3 N");
+  const double* v = V_dev + i * ldv;
+  // y = P v with P = blockdiag(L_b^-T): the transposed block is the same memory with the two strides exchanged
+  const rmb_block lt{Linv_dev, nn * nn, 1, nn}, l{Linv_dev, nn * nn, nn, 1};
+  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &lt, nullptr, nullptr, nullptr, v, nullptr, 1.0, 0.0, y_dev, 0.0, nullptr)) return rc;
+  // w = M y, then w <- P^T w (in y's place: y is free again)
+  if (int rc = matvec_device_impl(c, rmb::KIND_TT, 0, y_dev, nullptr, eta, w_dev)) return rc;
+  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, w_dev, nullptr, 1.0, 0.0, y_dev, 0.0, nullptr)) return rc;
+  // full re-orthogonalisation against v_0 .. v_i: col[i] = h_ii, col[i + 1] = h_{i+1,i} (the other coefficients vanish to
+  // rounding with an orthonormal basis), v_{i+1} = w / |w|
+  return rmb_krylov_orthogonalize2_device(c, n3, i + 1, V_dev, ldv, y_dev, col_dev, V_dev + (i + 1) * ldv, col_mapped_dev);
+}
+
 }  // extern "C"

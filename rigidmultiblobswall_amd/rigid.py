@@ -230,6 +230,10 @@ class RigidSuspension(object):
     if ns is not None:
       ns.close()
       self._arnoldi_native = None
+    lw = getattr(self, "_lanczos_ws", None)
+    if lw is not None:
+      lw["mapped"].close()
+      self._lanczos_ws = None
     if self._own_ctx:
       self.ctx.close()
 
@@ -833,10 +837,114 @@ class RigidSuspension(object):
     if self.groups[0].Lchol is None:
       self.build_preconditioner()
     self._stochastic_factors()
+    native = self._lanczos_native(z, factor, tol, print_residual)
+    if native is not None:
+      return native
     one, _ = self._pc_mobility()
     return stochastic_forcing_lanczos(factor=factor, tolerance=tol, dim=3 * self.n_blobs, mobility_mult=one,
                                       L_mult=lambda x: self._blockdiag(x, "Lchol"), z=z, print_residual=print_residual,
                                       device=self.device, sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho(0))
+
+  native_lanczos = None       # None = automatic, False = never: one C call per Lanczos iteration (_lanczos_native)
+  lanczos_native_rows = 48    # basis rows of the native loop; a forcing that needs more falls back to the generic loop
+  lanczos_native_max_blobs = 8192   # above, the iteration it discards at the end (a whole pair sweep) costs more than the host waits it saves
+
+  def _lanczos_native(self, z, factor, tol, print_residual, max_iter=1000):
+    """The preconditioned Lanczos forcing with ONE library call per iteration (rmb_rigid_lanczos_step_device: two block
+    launches around the pair sweep + the fused Gram-Schmidt, which also stores h_ii and h_{i+1,i} into mapped host
+    memory), the host side (the small tridiagonal eigenproblem and the reference's stopping rule,
+    stochastic_forcing.py:239-255) running ONE ITERATION LATE -- so the device never waits for numpy.  Same iterates,
+    coefficients and iteration count as stochastic.stochastic_forcing_lanczos; the price is one discarded iteration at
+    the end.  Returns (noise, iterations), or None when it does not apply (several body shapes, more than 32 blobs per
+    body, a facade context, an exact breakdown, more iterations than `lanczos_native_rows`) -- the caller then runs the
+    generic loop from the start."""
+    from .stochastic import _noise_coefficients
+    want = self.native_lanczos
+    if os.environ.get("RMB_NATIVE_LANCZOS", "") == "0":
+      want = False
+    if (want is False or factor == 0.0 or len(self.groups) != 1 or self.device.type != "cuda" or type(self.ctx) is not MobilityContext
+        or self._native_products() is not self.ctx or (want is None and self.n_blobs > self.lanczos_native_max_blobs)):
+      return None
+    g = self.groups[0]
+    n3, cap = 3 * self.n_blobs, int(self.lanczos_native_rows)
+    ws = getattr(self, "_lanczos_ws", None)
+    if ws is None or ws["n3"] != n3 or ws["cap"] != cap:
+      from .context import MappedHostArray
+      ws = self._lanczos_ws = dict(n3=n3, cap=cap, V=torch.empty((cap + 1, n3), dtype=torch.float64, device=self.device),
+                                   col=torch.zeros((cap, cap + 2), dtype=torch.float64, device=self.device),
+                                   y=torch.empty(n3, dtype=torch.float64, device=self.device),
+                                   w=torch.empty(n3, dtype=torch.float64, device=self.device), mapped=MappedHostArray((cap, cap + 2)),
+                                   events=[torch.cuda.Event(), torch.cuda.Event()])
+    V, host = ws["V"], ws["mapped"].array
+    z = torch.as_tensor(z, dtype=torch.float64, device=self.device).reshape(-1)
+    v_norm = float(torch.linalg.norm(z))
+    V[0] = z / v_norm
+    ctx = self.ctx
+    ctx._follow_torch_stream()
+    stream = torch.cuda.current_stream(self.device)
+    fn = ctx._lib.rmb_rigid_lanczos_step_device
+    head = (ctx._h, g.K.shape[0], g.n_b, g.Linv.data_ptr(), V.data_ptr(), V.stride(0))
+    tail = (float(self.eta), ws["y"].data_ptr(), ws["w"].data_ptr())
+    col_ptr, mapped_ptr, row = ws["col"].data_ptr(), ws["mapped"].dev_ptr, 8 * (cap + 2)
+    assert g.Linv.is_contiguous()
+    h_diag, h_sup = [], []
+    coef_old, coef, its, done = None, None, None, False
+
+    def enqueue(i):
+      rc = fn(*head, i, *tail, col_ptr + i * row, mapped_ptr + i * row)
+      if rc != 0:
+        from . import _lib
+        _lib.check(rc)
+      self.matvec_count += 1
+      self.sweep_count += 1
+      ws["events"][i & 1].record(stream)
+
+    def finish(i):
+      """Host side of iteration i (its two coefficients are in mapped memory once its event has completed).  True = stop."""
+      nonlocal coef_old, coef, its
+      ws["events"][i & 1].synchronize()
+      hd_f, hs_f = float(host[i, i]), float(host[i, i + 1])
+      if not (hs_f > 0 and np.isfinite(hs_f)):
+        return None                          # exact breakdown: rare; the generic loop handles it
+      h_diag.append(hd_f)
+      h_sup.append(hs_f)
+      coef = _noise_coefficients(h_diag, h_sup, i + 1, v_norm * factor)
+      if i > 0:
+        old = np.concatenate([coef_old, [0.0]])
+        old_norm = np.linalg.norm(old)
+        diff = np.linalg.norm(coef - old)
+        if print_residual:
+          if i == 1:
+            print('lanczos =  0 1')
+          print('lanczos = ', i, diff / old_norm)
+        if diff / max(old_norm, np.finfo(float).eps) < tol:
+          its = i
+          return True
+      coef_old = coef
+      return False
+
+    enqueue(0)
+    i = 0
+    while True:
+      nxt = i + 1
+      if nxt < cap and nxt <= max_iter:
+        enqueue(nxt)                         # the device goes on while the host looks at iteration i
+      stop = finish(i)
+      if stop is None:
+        torch.cuda.synchronize(self.device)
+        return None
+      if stop:
+        break
+      if nxt >= cap or nxt > max_iter:
+        if nxt > max_iter:
+          its = max_iter
+          break
+        torch.cuda.synchronize(self.device)  # more basis rows needed than the workspace holds: generic loop
+        return None
+      i = nxt
+    k = len(coef)
+    noise = V[:k].t() @ torch.as_tensor(coef, dtype=torch.float64, device=self.device)
+    return self._blockdiag(noise, "Lchol").reshape(-1), its
 
   def stochastic_forcing_pair(self, z_a, factor_a, z_b, factor_b, tol=1e-8, print_residual=False):
     """Two forcings with the same mobility in lockstep (stochastic_forcing_lanczos_pair): one two-vector pair sweep per
