@@ -438,6 +438,34 @@ def test_captured_iterations_survive_longer_solves_and_a_shared_context():
     ctx.close()
 
 
+def test_native_lanczos_loop_equals_the_generic_one():
+  """RigidSuspension.stochastic_forcing through rmb_rigid_lanczos_step_device (one call per iteration, host one iteration
+  late, coefficients through mapped memory) against the generic coroutine loop: same iteration count, same noise to
+  rounding, at several tolerances; a workspace with too few basis rows falls back to the generic loop."""
+  import torch
+  nat, _, _ = _shell_suspension(40)
+  gen, _, _ = _shell_suspension(40)
+  gen.native_lanczos = False
+  rng = np.random.RandomState(11)
+  try:
+    for tol, factor in ((1e-3, 1.0), (1e-6, 0.37), (1e-10, 2.5)):
+      z = torch.as_tensor(rng.randn(3 * nat.n_blobs), device="cuda:0")
+      m0 = nat.matvec_count
+      a, ia = nat.stochastic_forcing(z, factor, tol=tol)
+      b, ib = gen.stochastic_forcing(z, factor, tol=tol)
+      assert ia == ib and ia >= 2, (tol, ia, ib)
+      assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11, (tol, rel_err(a.cpu().numpy(), b.cpu().numpy()))
+      assert nat.matvec_count - m0 in (ia + 1, ia + 2)          # its + 1 products as the generic loop, + the discarded one
+      assert nat._lanczos_ws is not None
+    nat.lanczos_native_rows = 3
+    z = torch.as_tensor(rng.randn(3 * nat.n_blobs), device="cuda:0")
+    a, ia = nat.stochastic_forcing(z, 1.0, tol=1e-8)
+    b, ib = gen.stochastic_forcing(z, 1.0, tol=1e-8)
+    assert ia == ib and ia > 3 and rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
+  finally:
+    nat.close(); gen.close()
+
+
 def test_captured_arnoldi_iterations_with_mixed_shapes_and_prescribed_bodies():
   """The general operator path (two body shapes: gathers / scatters, torch.cat; an obstacle with prescribed kinematics)
   under the captured iterations, against the eager loop; and the automatic switch: on below gmres_graph_max_blobs for a
