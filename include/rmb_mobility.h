@@ -291,6 +291,22 @@ int rmb_rigid_arnoldi_step_device(rmb_ctx* ctx, long n_bodies, long n_b, const d
  * y_dev, w_dev: 3 N doubles of scratch. */
 int rmb_rigid_lanczos_step_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i,
                                   double eta, double* y_dev, double* w_dev, double* col_dev, double* col_mapped_dev);
+/* The whole right-preconditioned GMRES(restart) of [[M, -K], [-K^T, 0]] x = b (quaternion_integrator_multi_bodies.py:1441-1547
+ * -> general_application_utils.py:608-627 -> scipy; all bodies free, one body shape) as ONE call: per iteration one
+ * rmb_rigid_arnoldi_step_device and an event; the Givens rotations and the convergence test run on the host INSIDE the
+ * library, one iteration behind the device, on the Hessenberg column the Gram-Schmidt kernel stored into mapped host
+ * memory.  Stops when |b - A x| <= tol |b| by the rotated residual (scipy's tol, atol = 0), on an exact breakdown, or
+ * after maxiter INNER iterations; the true residual is formed at every restart.  b_dev: n = 3 n_bodies n_b + 6 n_bodies
+ * doubles (the caller normalises it as the reference does, :1518-1521); x_dev: the solution P^-1 y.  *iterations, *residual
+ * (relative), *discarded (steps enqueued for nothing: at most one per restart cycle), *products (operator applications),
+ * history[0 .. min(iterations, history_cap)) = the relative residual after every iteration (NULL: not wanted).
+ * rhs_norm: NULL = b_dev is used as given; otherwise b_dev is the RAW right-hand side: it is scaled to unit norm inside,
+ * the solution scaled back, and *rhs_norm = |b| (0: x = 0, no iteration).
+ * Synchronous: returns when x_dev is enqueued on the context's stream and every scalar is final. */
+int rmb_rigid_gmres_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
+                           const double* A22_dev, const double* K_dev, const double* b_dev, double tol, long restart, long maxiter,
+                           double eta, double* x_dev, long* iterations, double* residual, long* discarded, long* products,
+                           double* history, long history_cap, double* rhs_norm);
 int rmb_rigid_configuration_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
                                    const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev);
 int rmb_rigid_advance_device(rmb_ctx* ctx, long n_bodies, const double* loc_dev, const double* quat_dev, const double* U_dev,

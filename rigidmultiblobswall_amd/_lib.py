@@ -57,6 +57,8 @@ SYMBOLS = {
     "rmb_host_mapped_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "rmb_host_mapped_free": (ctypes.c_int, [_vp]),
     "rmb_rigid_operator_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, ctypes.c_double, _vp]),
+    "rmb_rigid_gmres_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_long,
+                                             ctypes.c_long, ctypes.c_double, _vp, _lp, _dp, _lp, _lp, _dp, ctypes.c_long, _dp]),
     "rmb_rigid_lanczos_step_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, ctypes.c_long, ctypes.c_long, ctypes.c_double,
                                                     _vp, _vp, _vp, _vp]),
     "rmb_rigid_arnoldi_step_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long,

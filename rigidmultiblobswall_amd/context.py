@@ -327,6 +327,29 @@ class MobilityContext(object):
     _lib.check(self._lib.rmb_rigid_arnoldi_step_device(self._h, nb, n_b, p(A11), p(A12), p(A21), p(A22), p(K), p(V), V.stride(0), int(j),
                                                        float(eta), p(z), p(w), p(col), ctypes.c_void_p(col_mapped) if col_mapped else None))
 
+  def rigid_gmres_device(self, A11, A12, A21, A22, K, b, tol, restart, maxiter, eta):
+    """The whole right-preconditioned GMRES of the rigid-body problem in one library call (rmb_rigid_gmres_device); b is
+    the RAW right-hand side (scaled to unit norm inside, the solution scaled back).  Returns (x tensor, info dict as
+    rigid.gmres_right_preconditioned, plus rhs_norm)."""
+    import torch
+    nb, n_b = K.shape[0], K.shape[1] // 3
+    for t in (A11, A12, A21, A22, K, b):
+      assert t.is_contiguous()
+    assert b.numel() == 3 * nb * n_b + 6 * nb
+    x = torch.empty_like(b)
+    its, disc, prod = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0)
+    res, nrm = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    cap = int(maxiter) + 1
+    hist = (ctypes.c_double * cap)()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_gmres_device(self._h, nb, n_b, p(A11), p(A12), p(A21), p(A22), p(K), p(b), float(tol), int(restart),
+                                                int(maxiter), float(eta), p(x), ctypes.byref(its), ctypes.byref(res), ctypes.byref(disc),
+                                                ctypes.byref(prod), hist, cap, ctypes.byref(nrm)))
+    k = min(its.value, cap)
+    return x, dict(iterations=int(its.value), residual=float(res.value), converged=bool(res.value <= tol), history=list(hist[:k]),
+                   discarded_sweeps=int(disc.value), operator_applications=int(prod.value), rhs_norm=float(nrm.value))
+
   def rigid_operator_device(self, K, x, eta, out):
     """out = [M_tt lambda - K U; -K^T lambda] for x = [lambda; U] on the resident configuration (all bodies free, one body
     shape; rmb_rigid_operator_device): the pair sweep + one finishing launch.  K (n_bodies, 3 n_b, 6) contiguous."""

@@ -123,6 +123,7 @@ int rmb_ctx_destroy(rmb_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  rmbi::gmres_release(c);
   c->wave_clock.release(); c->tile_bounds.release(); c->fpos.release(); c->fperm.release(); c->fsort_keys.release(); c->fsort_vals.release(); c->fsort_tmp.release(); c->fsort_box.release(); for (auto& b : c->st) b.release(); c->symbuf.release(); if (c->host_out) { (void)hipHostFree(c->host_out); c->host_out = nullptr; c->host_out_cap = 0; } if (c->host_in) { (void)hipHostFree(c->host_in); c->host_in = nullptr; c->host_in_cap = 0; } c->pos.release(); c->r_stage.release(); c->vec.release(); c->vec2.release(); c->out.release(); c->partial.release(); c->tmp3n.release(); c->det_ws.release(); c->krylov.release();
   if (c->stream_switch) (void)hipEventDestroy(c->stream_switch);
   for (auto e : c->ev0) (void)hipEventDestroy(e);

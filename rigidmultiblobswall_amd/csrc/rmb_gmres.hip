@@ -1,0 +1,288 @@
+// rmb_gmres.hip -- the whole right-preconditioned GMRES(restart) of the rigid-body saddle-point problem as ONE library call
+// (gfx950, fp64): rmb_rigid_gmres_device.
+//
+// The reference solves [[M, -K], [-K^T, 0]] [lambda; U] = [slip; -F] with scipy's compiled GMRES around Python callbacks
+// (quaternion_integrator/quaternion_integrator_multi_bodies.py:1441-1547 -> general_application_utils.py:608-627, restart
+// 60, right preconditioning with the per-body block inverse of multi_bodies.py:548-560).  On the decks it is mostly run on
+// -- tens to hundreds of bodies -- an iteration is seven launches of a few microseconds, so what an iteration costs is
+// the HOST: with the loop in Python (rigid.py: _gmres_steps, one rmb_rigid_arnoldi_step_device call per iteration) 49 us
+// per iteration against 32-36 us of GPU time (profiles/r5_gmres_step.txt).  Here the loop itself is native: per iteration
+// one rmb_rigid_arnoldi_step_device, one event record, and -- ONE ITERATION LATE, while the device runs the next step --
+// the Givens rotations and the convergence test on the column the Gram-Schmidt kernel stored into mapped host memory.
+// Same algorithm, same stopping rule, same lag policy as rigid.py's loop (which stays for everything this entry does not
+// cover: several body shapes, prescribed bodies, an initial guess, multi-rank facades):
+//   * two passes of classical Gram-Schmidt per step (rmb_krylov_orthogonalize2_device);
+//   * stop when |g_{j+1}| <= tol |b| (scipy's `tol`, atol = 0), or on an exact breakdown, or after maxiter inner iterations;
+//   * the host reads column j after step j + 1 has been enqueued, unless the last observed reduction rate says column j may
+//     already meet the tolerance (then it waits first): at most one discarded step per solve;
+//   * at a restart the TRUE residual b - A P^-1 y is formed.
+#include "rmb_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace rmbi {
+namespace {
+
+constexpr int kVecT = 256;
+
+__global__ __launch_bounds__(kVecT) void vec_scale_kernel(double* out, const double* in, double alpha, long n) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = in[e] * alpha;
+}
+
+__global__ __launch_bounds__(kVecT) void vec_sub_kernel(double* out, const double* a, const double* b, long n) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = a[e] - b[e];
+}
+
+__global__ __launch_bounds__(kVecT) void vec_zero_kernel(double* out, long n) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = 0.0;
+}
+
+// y[e] += sum_{i < k} coef[i] V[i][e]; coef lives in mapped host memory (k <= 256 doubles read once per workgroup)
+__global__ __launch_bounds__(kVecT) void vec_lincomb_kernel(double* y, const double* V, long ldv, const double* coef, int k, long n) {
+  __shared__ double cl[256];
+  for (int i = threadIdx.x; i < k; i += kVecT) cl[i] = coef[i];
+  __syncthreads();
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double s = y[e];
+  for (int i = 0; i < k; ++i) s += cl[i] * V[(long)i * ldv + e];
+  y[e] = s;
+}
+
+// |v| to mapped host memory: one workgroup of 1024 threads, fixed-order sums (systems here are <= ~1e6 unknowns)
+__global__ __launch_bounds__(1024) void vec_norm_kernel(const double* v, long n, double* out_mapped) {
+  __shared__ double ws[16];
+  double s = 0.0;
+  for (long e = threadIdx.x; e < n; e += 1024) s += v[e] * v[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 16; ++q) t += ws[q];
+    *out_mapped = sqrt(t);
+  }
+}
+
+inline unsigned blocks_of(long n) { return (unsigned)((n + kVecT - 1) / kVecT); }
+
+struct Mapped {
+  void* host = nullptr;
+  void* dev = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+}  // namespace rmbi
+
+using namespace rmbi;
+
+// Per-context workspace of the native GMRES: device vectors in one DevBuf, mapped host memory for the Hessenberg columns, the
+// back-substitution coefficients and one scalar.  Grows, never shrinks; freed with the context (rmb_ctx_destroy calls
+// rmb_gmres_release).
+struct rmb_gmres_ws {
+  DevBuf dev;
+  Mapped mapped;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace rmbi {
+void gmres_release(rmb_ctx* c) {
+  rmb_gmres_ws* w = (rmb_gmres_ws*)c->gmres_ws;
+  if (!w) return;
+  w->dev.release();
+  if (w->mapped.host) (void)hipHostFree(w->mapped.host);
+  for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
+  delete w;
+  c->gmres_ws = nullptr;
+}
+}  // namespace rmbi
+
+extern "C" {
+
+int rmb_rigid_gmres_device(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
+                           const double* A22_dev, const double* K_dev, const double* b_dev, double tol, long restart, long maxiter,
+                           double eta, double* x_dev, long* iterations, double* residual, long* discarded, long* products,
+                           double* history, long history_cap, double* rhs_norm) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_gmres_device: bad n_bodies / n_b");
+  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_gmres_device: the resident configuration does not hold n_bodies x n_b blobs");
+  if (!A11_dev || !A12_dev || !A21_dev || !A22_dev || !K_dev || !b_dev || !x_dev || !iterations || !residual)
+    return fail(RMB_ERR_ARG, "null pointer");
+  if (restart < 1 || restart > 255 || maxiter < 0 || !(tol >= 0.0)) return fail(RMB_ERR_ARG, "rmb_rigid_gmres_device: need 1 <= restart <= 255, maxiter >= 0, tol >= 0");
+  RMB_HIP(hipSetDevice(c->device));
+  const long nn = 3 * n_b, n3 = 3 * c->n, n = n3 + 6 * n_bodies, ldv = n;
+  const long m_max = restart;
+  // ---- workspace ----
+  if (!c->gmres_ws) c->gmres_ws = new rmb_gmres_ws();
+  rmb_gmres_ws* ws = (rmb_gmres_ws*)c->gmres_ws;
+  const size_t col_row = (size_t)(m_max + 2);
+  const size_t dev_doubles = (size_t)(m_max + 1) * n + (size_t)5 * n + (size_t)m_max * col_row;
+  if (int rc = ws->dev.reserve(dev_doubles * sizeof(double))) return rc;
+  const size_t map_doubles = (size_t)m_max * col_row + 256 + 8;
+  if (map_doubles * sizeof(double) > ws->mapped.cap) {
+    if (ws->mapped.host) { RMB_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(ws->mapped.host); ws->mapped = Mapped(); }
+    RMB_HIP(hipHostMalloc(&ws->mapped.host, map_doubles * sizeof(double), hipHostMallocMapped));
+    RMB_HIP(hipHostGetDevicePointer(&ws->mapped.dev, ws->mapped.host, 0));
+    ws->mapped.cap = map_doubles * sizeof(double);
+  }
+  for (auto& e : ws->ev) if (!e) RMB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  double* V = (double*)ws->dev.p;
+  double* z = V + (size_t)(m_max + 1) * n;
+  double* w = z + n;
+  double* y = w + n;
+  double* r = y + n;
+  double* bs = r + n;                                          // the right-hand side scaled to unit norm (rhs_norm != NULL)
+  double* cols = bs + n;                                       // [m_max][m_max + 2] on the device
+  double* hcols = (double*)ws->mapped.host;                    // the same rows in mapped host memory
+  double* hcols_dev = (double*)ws->mapped.dev;
+  double* hcoef = hcols + (size_t)m_max * col_row;             // back-substitution coefficients (host writes, kernel reads)
+  double* hcoef_dev = hcols_dev + (size_t)m_max * col_row;
+  double* hscal = hcoef + 256;                                 // one scalar (a norm)
+  double* hscal_dev = hcoef_dev + 256;
+  hipStream_t s = c->stream;
+  const rmb_block b11{A11_dev, nn * nn, nn, 1}, b12{A12_dev, nn * 6, 6, 1}, b21{A21_dev, 6 * nn, nn, 1}, b22{A22_dev, 36, 6, 1};
+  long n_products = 0;
+
+  auto host_norm = [&](const double* v, double* out) -> int {
+    hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(1024), 0, s, v, n, hscal_dev);
+    RMB_HIP(hipGetLastError());
+    RMB_HIP(hipStreamSynchronize(s));
+    *out = *hscal;
+    return 0;
+  };
+  auto precondition = [&](const double* in, double* out) -> int {       // out = P^-1 in
+    return rmb_block_apply_device(c, n_bodies, nn, nn, 6, 6, &b11, &b12, &b21, &b22, in, in + n3, 1.0, 0.0, out, 0.0, out + n3);
+  };
+
+  // rhs_norm != NULL: b_dev is the raw right-hand side; it is scaled to unit norm here, as the reference does before its
+  // GMRES (:1518-1521), and the solution scaled back -- one norm + host wait instead of the caller's and ours
+  double bnorm = 0.0, scale_back = 1.0;
+  if (int rc = host_norm(b_dev, &bnorm)) return rc;
+  const double* b_use = b_dev;
+  if (rhs_norm) {
+    *rhs_norm = bnorm;
+    if (bnorm == 0.0) {
+      hipLaunchKernelGGL(vec_zero_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, x_dev, n);
+      RMB_HIP(hipGetLastError());
+      *iterations = 0; *residual = 0.0;
+      if (discarded) *discarded = 0;
+      if (products) *products = 0;
+      return 0;
+    }
+    hipLaunchKernelGGL(vec_scale_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, bs, b_dev, 1.0 / bnorm, n);
+    b_use = bs;
+    scale_back = bnorm;
+    bnorm = 1.0;       // |rhs / |rhs|| (the Python loop measures it again and finds 1 to rounding)
+  }
+  hipLaunchKernelGGL(vec_zero_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, y, n);
+  RMB_HIP(hipMemcpyAsync(r, b_use, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  double beta = bnorm;
+  long its = 0, wasted = 0, n_hist = 0;
+  double res = bnorm > 0.0 ? beta / bnorm : 0.0;
+  std::vector<double> H((size_t)(m_max + 1) * m_max), cs(m_max), sn(m_max), g(m_max + 1), col(m_max + 2);
+
+  while (its < maxiter && res > tol) {
+    const long m = restart < maxiter - its ? restart : maxiter - its;
+    hipLaunchKernelGGL(vec_scale_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, V, r, 1.0 / beta, n);
+    RMB_HIP(hipGetLastError());
+    std::fill(H.begin(), H.end(), 0.0);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    long k_used = 0;
+    double prev_res = -1.0;           // < 0: none yet
+    long pending = -1;
+    bool stop = false;
+
+    // Host side of iteration j: wait for its column, rotate, test.  true = stop after this column.
+    auto finish = [&](long j, bool* out_stop) -> int {
+      RMB_HIP(hipEventSynchronize(ws->ev[j & 1]));
+      memcpy(col.data(), hcols + (size_t)j * col_row, (size_t)(j + 2) * sizeof(double));
+      const double w_norm = col[j + 1];
+      for (long i = 0; i < j; ++i) {
+        const double t = cs[i] * col[i] + sn[i] * col[i + 1];
+        col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+        col[i] = t;
+      }
+      const double d = hypot(col[j], col[j + 1]);
+      if (d > 0.0) { cs[j] = col[j] / d; sn[j] = col[j + 1] / d; } else { cs[j] = 1.0; sn[j] = 0.0; }
+      col[j] = d;
+      col[j + 1] = 0.0;
+      for (long i = 0; i < j + 2; ++i) H[(size_t)i * m_max + j] = col[i];
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      its += 1;
+      k_used = j + 1;
+      prev_res = res;
+      res = fabs(g[j + 1]) / bnorm;
+      if (history && n_hist < history_cap) history[n_hist] = res;
+      ++n_hist;
+      *out_stop = res <= tol || w_norm == 0.0 || !std::isfinite(w_norm);
+      return 0;
+    };
+    auto may_defer = [&]() {
+      const double rate = prev_res > 0.0 ? (res / prev_res < 1.0 ? res / prev_res : 1.0) : 1.0;
+      return res * rate > 20.0 * tol;
+    };
+
+    for (long j = 0; j < m; ++j) {
+      if (pending >= 0 && !may_defer()) {
+        if (int rc = finish(pending, &stop)) return rc;
+        pending = -1;
+        if (stop) break;
+      }
+      if (int rc = rmb_rigid_arnoldi_step_device(c, n_bodies, n_b, A11_dev, A12_dev, A21_dev, A22_dev, K_dev, V, ldv, j, eta, z, w,
+                                                 cols + (size_t)j * col_row, hcols_dev + (size_t)j * col_row))
+        return rc;
+      ++n_products;
+      RMB_HIP(hipEventRecord(ws->ev[j & 1], s));
+      if (pending >= 0) {
+        if (int rc = finish(pending, &stop)) return rc;
+        pending = -1;
+        if (stop) { ++wasted; break; }      // step j was enqueued for nothing
+      }
+      pending = j;
+    }
+    if (pending >= 0 && !stop) {
+      if (int rc = finish(pending, &stop)) return rc;
+    }
+    // y += V[:k]^T coef,  coef = triu(H[:k, :k])^-1 g[:k]
+    if (k_used > 0) {
+      for (long i = k_used - 1; i >= 0; --i) {
+        double t = g[i];
+        for (long q = i + 1; q < k_used; ++q) t -= H[(size_t)i * m_max + q] * hcoef[q];
+        hcoef[i] = t / H[(size_t)i * m_max + i];
+      }
+      hipLaunchKernelGGL(vec_lincomb_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, y, V, ldv, hcoef_dev, (int)k_used, n);
+      RMB_HIP(hipGetLastError());
+      RMB_HIP(hipStreamSynchronize(s));         // hcoef is rewritten by the next cycle: the kernel must have read it
+    }
+    if (res > tol && its < maxiter) {           // restart: true residual
+      if (int rc = precondition(y, z)) return rc;
+      if (int rc = rmb_rigid_operator_device(c, n_bodies, n_b, K_dev, z, eta, w)) return rc;
+      ++n_products;
+      hipLaunchKernelGGL(vec_sub_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, r, b_use, w, n);
+      RMB_HIP(hipGetLastError());
+      if (int rc = host_norm(r, &beta)) return rc;
+      res = beta / bnorm;
+    }
+  }
+  if (scale_back != 1.0) {                                // x = |rhs| P^-1 y
+    hipLaunchKernelGGL(vec_scale_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, y, y, scale_back, n);
+    RMB_HIP(hipGetLastError());
+  }
+  if (int rc = precondition(y, x_dev)) return rc;        // x = P^-1 y
+  *iterations = its;
+  *residual = res;
+  if (discarded) *discarded = wasted;
+  if (products) *products = n_products;
+  return 0;
+}
+
+}  // extern "C"

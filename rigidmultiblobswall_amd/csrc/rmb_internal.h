@@ -16,6 +16,7 @@
 //   rmb_multi.hip    the single-process multi-device engine (rmb_multi_*)
 //   rmb_rigid.hip    per-body geometry (positions, K) and the per-body factors of the block-diagonal preconditioner
 //   rmb_krylov.hip   O(N) helpers of the rigid-body solve: batched 2 x 2 block product, fused Gram-Schmidt step
+//   rmb_gmres.hip    the whole right-preconditioned GMRES of the rigid-body problem as one call (host loop native too)
 #pragma once
 #include "../../include/rmb_mobility.h"
 
@@ -83,6 +84,7 @@ struct rmb_ctx {
   long opt_wave_clock = 0;
   long opt_skip_pairs = 0;
   rmbi::DevBuf krylov;   // partial sums of rmb_krylov_orthogonalize_device
+  void* gmres_ws = nullptr;   // workspace of rmb_rigid_gmres_device (rmb_gmres.hip), freed by gmres_release
   rmbi::DevBuf symbuf;   // acc[3][n_pad] doubles for the symmetric tt kernel (kept zero between calls)
   // result hand-off of the synchronous host entry point (rmb_matvec): page-locked, device-mapped host memory the finalize
   // kernel stores into directly (coalesced), for results up to opt_host_zero_copy bytes
@@ -135,6 +137,9 @@ int check_ready(rmb_ctx* c);
 // the library's default context (stateless entry points); created on first use on the device RMB_DEVICE names (0)
 extern std::mutex g_default_mu;
 int default_ctx(rmb_ctx** out);   // call with g_default_mu held
+
+// ---- rmb_gmres.hip ----------------------------------------------------------------------------------------
+void gmres_release(rmb_ctx* c);
 
 // ---- rmb_plan.hip ------------------------------------------------------------------------------------------
 rmb::PairConsts make_pair_consts(double a);

@@ -500,6 +500,20 @@ class RigidSuspension(object):
     x0: optional initial guess in the units of x.  Returns (x tensor, info)."""
     if self.groups[0].Lchol is None:
       self.build_preconditioner()
+    if (x0 is None and self.native_gmres is not False and os.environ.get("RMB_NATIVE_GMRES", "") != "0"
+        and self._native_step_applies(restart)):
+      # The whole loop inside the library (rmb_rigid_gmres_device): the norm of the right-hand side, per iteration one step
+      # call and one event, the Givens rotations and the convergence test in C one iteration behind the device -- the
+      # Python loop below costs 49 us of host time per iteration against 32-36 us of GPU time on a small deck
+      # (profiles/r5_gmres_step.txt).
+      g = self.groups[0]
+      sol, info = self.ctx.rigid_gmres_device(g.A11, g.A12, g.A21, g.A22, g.K, rhs.contiguous(), tol, restart, maxiter, self.eta)
+      if info["rhs_norm"] == 0.0:
+        return sol, dict(iterations=0, residual=0.0, converged=True, history=[])
+      self.matvec_count += info["operator_applications"]
+      self.sweep_count += info["operator_applications"]
+      info["native_gmres"] = True
+      return sol, info
     nrm = float(torch.linalg.norm(rhs))
     if nrm == 0.0:
       return torch.zeros_like(rhs), dict(iterations=0, residual=0.0, converged=True, history=[])
@@ -545,17 +559,21 @@ class RigidSuspension(object):
 
   fused_operator = True       # False: the product and the K products as separate launches (A/B, tests)
   native_step = None          # None = automatic, False = never: one C call per Arnoldi iteration (_ArnoldiNative)
+  native_gmres = None         # None = automatic, False = never: the whole GMRES loop in one C call (rmb_rigid_gmres_device)
+
+  def _native_step_applies(self, restart):
+    want = self.native_step
+    if os.environ.get("RMB_NATIVE_STEP", "") == "0":
+      want = False
+    return not (want is False or self.gmres_graph is True or self.free is not None or len(self.groups) != 1 or self.device.type != "cuda"
+                or type(self.ctx) is not MobilityContext or self._native_products() is not self.ctx or not self.fused_operator
+                or getattr(self, "gmres_lag", None) is False or not (0 < restart < 256))
 
   def _native_arnoldi(self, restart):
     """The one-call-per-iteration workspace for solve(), or None.  Applies to what rmb_rigid_arnoldi_step_device covers: one
     body shape of at most 32 blobs, all bodies free, a plain single-GPU context, the host bookkeeping one iteration late.
     `gmres_graph = True` (forced captured iterations) and `native_step = False` / RMB_NATIVE_STEP=0 turn it off."""
-    want = self.native_step
-    if os.environ.get("RMB_NATIVE_STEP", "") == "0":
-      want = False
-    if (want is False or self.gmres_graph is True or self.free is not None or len(self.groups) != 1 or self.device.type != "cuda"
-        or type(self.ctx) is not MobilityContext or self._native_products() is not self.ctx or not self.fused_operator
-        or getattr(self, "gmres_lag", None) is False or not (0 < restart < 256)):
+    if not self._native_step_applies(restart):
       return None
     ns = getattr(self, "_arnoldi_native", None)
     if ns is None or ns.m != restart or ns.n != self.size:

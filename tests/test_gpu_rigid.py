@@ -438,6 +438,47 @@ def test_captured_iterations_survive_longer_solves_and_a_shared_context():
     ctx.close()
 
 
+def test_native_gmres_loop_equals_the_python_loop():
+  """rmb_rigid_gmres_device (the whole right-preconditioned GMRES in one library call: rotations and convergence test in
+  C, one iteration behind the device) against rigid.py's loop over rmb_rigid_arnoldi_step_device: same iteration counts,
+  residual histories and solutions -- full cycle, several restarts, an iteration cap, a loose and a tight tolerance --
+  and the result solves the system (true residual by the separate operator)."""
+  import torch
+  nb = 40
+  nat, loc, quat = _shell_suspension(nb)
+  pyl, _, _ = _shell_suspension(nb)
+  pyl.native_gmres = False
+  rng = np.random.RandomState(5)
+  try:
+    for kw in (dict(tol=1e-9, restart=60), dict(tol=1e-9, restart=5), dict(tol=1e-2, restart=60), dict(tol=1e-12, restart=7),
+               dict(tol=1e-10, restart=60, maxiter=9), dict(tol=1e-10, restart=4, maxiter=10)):
+      rhs = torch.as_tensor(rng.randn(nat.size), device="cuda:0")
+      m0 = (nat.matvec_count, pyl.matvec_count)
+      xn, inn = nat.solve(rhs, **kw)
+      xp, ip = pyl.solve(rhs, **kw)
+      assert inn.get("native_gmres") and "native_gmres" not in ip and ip.get("native_steps", 0) > 0
+      assert inn["iterations"] == ip["iterations"], (kw, inn["iterations"], ip["iterations"])
+      assert inn["converged"] == ip["converged"] and len(inn["history"]) == inn["iterations"]
+      assert np.allclose(inn["history"], ip["history"], rtol=1e-6, atol=1e-13), kw       # (round-off level near 1e-12)
+      assert rel_err(xn.cpu().numpy(), xp.cpu().numpy()) < 1e-8, (kw, rel_err(xn.cpu().numpy(), xp.cpu().numpy()))
+      assert nat.matvec_count - m0[0] == pyl.matvec_count - m0[1], kw       # same number of operator applications
+      if inn["converged"]:
+        true_res = float(torch.linalg.norm(pyl.apply_operator(xn) - rhs) / torch.linalg.norm(rhs))
+        assert true_res < 5 * kw["tol"] + 1e-13, (kw, true_res)
+    # a zero right-hand side and moved bodies (the blocks are rewritten in place; the library reads them afresh)
+    loc2 = loc + 0.03 * rng.randn(*loc.shape) * np.array([1.0, 1.0, 0.2])
+    for s_ in (nat, pyl):
+      s_.set_configuration(loc2, quat); s_.build_preconditioner()
+    rhs = torch.as_tensor(rng.randn(nat.size), device="cuda:0")
+    xn, inn = nat.solve(rhs, tol=1e-9)
+    xp, ip = pyl.solve(rhs, tol=1e-9)
+    assert inn["iterations"] == ip["iterations"] and rel_err(xn.cpu().numpy(), xp.cpu().numpy()) < 1e-8
+    x0, i0 = nat.solve(torch.zeros(nat.size, dtype=torch.float64, device="cuda:0"), tol=1e-9)
+    assert i0["iterations"] == 0 and float(x0.abs().max()) == 0.0
+  finally:
+    nat.close(); pyl.close()
+
+
 def test_native_lanczos_loop_equals_the_generic_one():
   """RigidSuspension.stochastic_forcing through rmb_rigid_lanczos_step_device (one call per iteration, host one iteration
   late, coefficients through mapped memory) against the generic coroutine loop: same iteration count, same noise to
