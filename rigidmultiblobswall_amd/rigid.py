@@ -812,7 +812,7 @@ class RigidSuspension(object):
     for g in self.groups:
       if g.Linv is None:
         eye = torch.eye(3 * g.n_b, dtype=torch.float64, device=self.device).expand(len(g.body_idx), -1, -1)
-        g.Linv = torch.linalg.solve_triangular(g.Lchol, eye, upper=False)
+        g.Linv = torch.linalg.solve_triangular(g.Lchol, eye, upper=False).contiguous()    # (the library's step kernels address it by strides of a dense batch)
 
   def _blockdiag(self, x, which, transpose=False):
     out = torch.empty_like(x)
@@ -901,10 +901,13 @@ class RigidSuspension(object):
     ctx._follow_torch_stream()
     stream = torch.cuda.current_stream(self.device)
     fn = ctx._lib.rmb_rigid_lanczos_step_device
+    if not g.Linv.is_contiguous():
+      g.Linv = g.Linv.contiguous()
     head = (ctx._h, g.K.shape[0], g.n_b, g.Linv.data_ptr(), V.data_ptr(), V.stride(0))
     tail = (float(self.eta), ws["y"].data_ptr(), ws["w"].data_ptr())
     col_ptr, mapped_ptr, row = ws["col"].data_ptr(), ws["mapped"].dev_ptr, 8 * (cap + 2)
-    assert g.Linv.is_contiguous()
+    if not g.Linv.is_contiguous():
+      g.Linv = g.Linv.contiguous()
     h_diag, h_sup = [], []
     coef_old, coef, its, done = None, None, None, False
 
