@@ -193,12 +193,14 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
         const int jj = (lane + k) & 63;
         const double2* r = reinterpret_cast<const double2*>(rec_bytes + jj * kSymRecBytes);
         const double2 q0 = r[0], q1 = r[1], q2 = r[2];
-        double ax, ay, az, bx, by, bz;
+        // the second pair ACCUMULATES its transposed rows into the first one's (the multiplies that start them become fused
+        // multiply-adds: three v_add_f64 less per step than summing two finished contributions)
+        double ax, ay, az;
         pair_sym<KIND, WALL>(a.k, x0 - q0.x, y0 - q0.y, z0 - q1.x, z0, q1.x, v0x, v0y, v0z, q1.y, q2.x, q2.y, u0, ax, ay, az);
-        pair_sym<KIND, WALL>(a.k, x1 - q0.x, y1 - q0.y, z1 - q1.x, z1, q1.x, v1x, v1y, v1z, q1.y, q2.x, q2.y, u1, bx, by, bz);
-        __hip_atomic_fetch_add(&accj[jj], ax + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&accj[64 + jj], ay + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&accj[128 + jj], az + bz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        pair_sym<KIND, WALL, true>(a.k, x1 - q0.x, y1 - q0.y, z1 - q1.x, z1, q1.x, v1x, v1y, v1z, q1.y, q2.x, q2.y, u1, ax, ay, az);
+        __hip_atomic_fetch_add(&accj[jj], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[64 + jj], ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&accj[128 + jj], az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
     } else {
       // the two columns at the diagonal of this row pair, row by row (the loops of sym_kernel)

@@ -58,7 +58,9 @@ constexpr int kSymRecBytes = 48;
 // Both directions of one pair.  (vix..) = target's own vector, (vjx..) = source vector.
 // Adds M_ij v_j to ui and returns M_ij^T v_i in (tx,ty,tz).  The block is built once in the form of pair_blocks.h
 // (BlockM: F, P, Q3, Q4, Szz) and contracted with ten instructions per direction.
-template <bool WALL>
+// ACC: the transposed rows are ADDED to (tx, ty, tz) instead of written -- the second target blob of sym2t_kernel folds its
+// contribution into the first one's with the fused multiply-adds that build it (three v_add_f64 less per rotation step).
+template <bool WALL, bool ACC = false>
 __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                             double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                             Vec3& ui, double& tx, double& ty, double& tz) {
@@ -66,13 +68,14 @@ __device__ __forceinline__ void pair_tt_sym(const PairConsts& k, double dx, doub
   const TTc c = tt_coeffs<WALL>(k, g, zi, zj);
   const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
   double u[3] = {ui.x, ui.y, ui.z}, t[3];
-  tt_apply<WALL, false>(c, g, vi, vj, u, t);
+  if constexpr (ACC) { t[0] = tx; t[1] = ty; t[2] = tz; }
+  tt_apply<WALL, ACC>(c, g, vi, vj, u, t);
   ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
   tx = t[0]; ty = t[1]; tz = t[2];
 }
 
 // rr, both directions (same block form, pair_blocks.h: rr_coeffs).
-template <bool WALL>
+template <bool WALL, bool ACC = false>
 __device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                             double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                             Vec3& ui, double& tx, double& ty, double& tz) {
@@ -80,7 +83,8 @@ __device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, doub
   const RRc c = rr_coeffs<WALL>(k, g);
   const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
   double u[3] = {ui.x, ui.y, ui.z}, t[3];
-  rr_apply<WALL, false>(c, g, vi, vj, u, t);
+  if constexpr (ACC) { t[0] = tx; t[1] = ty; t[2] = tz; }
+  rr_apply<WALL, ACC>(c, g, vi, vj, u, t);
   ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
   tx = t[0]; ty = t[1]; tz = t[2];
 }
@@ -89,7 +93,7 @@ __device__ __forceinline__ void pair_rr_sym(const PairConsts& k, double dx, doub
 // direction (z_i forward, z_j transposed); KIND_RT: w = M_rt f, anchored on the SOURCE height (z_j forward,
 // z_i transposed).  The two directions share both rsqrt, tau, e and differ only in g = z iR, which enters
 // p, s, f3 linearly (pair_blocks.h: cpl_coeffs / tr_apply / rt_apply on the unnormalised separation).
-template <bool TR, bool WALL>
+template <bool TR, bool WALL, bool ACC = false>
 __device__ __forceinline__ void pair_coupling_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                                   double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                                   Vec3& ui, double& tx, double& ty, double& tz) {
@@ -97,21 +101,22 @@ __device__ __forceinline__ void pair_coupling_sym(const PairConsts& k, double dx
   const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
   const double vi[3] = {vix, viy, viz}, vj[3] = {vjx, vjy, vjz};
   double u[3] = {ui.x, ui.y, ui.z}, t[3];
-  if constexpr (TR) tr_apply<WALL, false>(C, g, vi, vj, u, t);
-  else              rt_apply<WALL, false>(C, g, vi, vj, u, t);
+  if constexpr (ACC) { t[0] = tx; t[1] = ty; t[2] = tz; }
+  if constexpr (TR) tr_apply<WALL, ACC>(C, g, vi, vj, u, t);
+  else              rt_apply<WALL, ACC>(C, g, vi, vj, u, t);
   ui.x = u[0]; ui.y = u[1]; ui.z = u[2];
   tx = t[0]; ty = t[1]; tz = t[2];
 }
 
 // dispatcher
-template <int KIND, bool WALL>
+template <int KIND, bool WALL, bool ACC = false>
 __device__ __forceinline__ void pair_sym(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                          double vix, double viy, double viz, double vjx, double vjy, double vjz,
                                          Vec3& ui, double& tx, double& ty, double& tz) {
-  if constexpr (KIND == KIND_TT) pair_tt_sym<WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
-  if constexpr (KIND == KIND_RR) pair_rr_sym<WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
-  if constexpr (KIND == KIND_TR) pair_coupling_sym<true, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
-  if constexpr (KIND == KIND_RT) pair_coupling_sym<false, WALL>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_TT) pair_tt_sym<WALL, ACC>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_RR) pair_rr_sym<WALL, ACC>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_TR) pair_coupling_sym<true, WALL, ACC>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
+  if constexpr (KIND == KIND_RT) pair_coupling_sym<false, WALL, ACC>(k, dx, dy, dz, zi, zj, vix, viy, viz, vjx, vjy, vjz, ui, tx, ty, tz);
 }
 
 __device__ __forceinline__ double wrap_nearest_sym(double r, double L, double invL) {

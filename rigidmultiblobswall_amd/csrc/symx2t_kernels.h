@@ -96,14 +96,9 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
                       auto acc) {
     double dx = xi - rd[0], dy = yi - rd[1], dz = zi - rd[2];
     if constexpr (!PERIODIC) {
-      if constexpr (decltype(acc)::value) {
-        double sx[3 * NO];
-        OP::template pair<WALL>(a.k, dx, dy, dz, zi, rd[2], vi, rd + 3, ui, sx);
-#pragma unroll
-        for (int c = 0; c < 3 * NO; ++c) t[c] += sx[c];
-      } else {
-        OP::template pair<WALL>(a.k, dx, dy, dz, zi, rd[2], vi, rd + 3, ui, t);
-      }
+      // the second row ACCUMULATES its transposed rows into the first one's inside the contraction (fused multiply-adds
+      // instead of finished contributions summed afterwards: 3 NOUT v_add_f64 less per step)
+      OP::template pair<WALL, decltype(acc)::value>(a.k, dx, dy, dz, zi, rd[2], vi, rd + 3, ui, t);
     } else {
       if (px) dx = wrap_nearest_pad_safe(dx, a.Lx, a.iLx);
       if (py) dy = wrap_nearest_pad_safe(dy, a.Ly, a.iLy);
@@ -112,10 +107,7 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
         for (int by = -py; by <= py; ++by)
           for (int bz = -pz; bz <= pz; ++bz) {
             if (skip_self && bx == 0 && by == 0 && bz == 0) continue;
-            double sx[3 * NO];
-            OP::template pair<WALL>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, rd[2], vi, rd + 3, ui, sx);
-#pragma unroll
-            for (int c = 0; c < 3 * NO; ++c) t[c] += sx[c];
+            OP::template pair<WALL, true>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, rd[2], vi, rd + 3, ui, t);   // t +=
           }
     }
   };

@@ -22,7 +22,7 @@
 // transposed contributions through ds_add_f64 into a per-wave LDS accumulator, static exactly balanced step
 // schedule, pair-shard step ranges, global SoA accumulators + finalize.  An operation is a policy class OP:
 //   OP::NIN / OP::NOUT   3-vectors per blob going in (LDS record) / coming out (accumulators)
-//   OP::pair<WALL>(k, dx,dy,dz, zi,zj, vi, vj, ui, t)   ui += (M_ij v_j) rows,  t = (M_ji v_i) rows
+//   OP::pair<WALL, ACC = false>(k, dx,dy,dz, zi,zj, vi, vj, ui, t)   ui += (M_ij v_j) rows,  t = (M_ji v_i) rows (ACC: t +=)
 //   OP::self<WALL>(k, zi, vi, ui)                        the i == j term, added once per target in finalize
 #pragma once
 #include "sym_kernels.h"
@@ -65,11 +65,11 @@ template <int KIND>
 struct OpSingle {
   static constexpr int NIN = 1, NOUT = 1;
   static constexpr bool IMAGE_NO_WALL = false;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     Vec3 u = {ui[0], ui[1], ui[2]};
-    pair_sym<KIND, WALL>(k, dx, dy, dz, zi, zj, vi[0], vi[1], vi[2], vj[0], vj[1], vj[2], u, t[0], t[1], t[2]);
+    pair_sym<KIND, WALL, ACC>(k, dx, dy, dz, zi, zj, vi[0], vi[1], vi[2], vj[0], vj[1], vj[2], u, t[0], t[1], t[2]);
     ui[0] = u.x; ui[1] = u.y; ui[2] = u.z;
   }
   template <bool WALL>
@@ -83,13 +83,13 @@ struct OpSingle {
 // u = M_tt f + M_tr tau    (in: f, tau; out: u)   -- K11 / K12
 struct OpFusedRow {
   static constexpr int NIN = 2, NOUT = 1;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
     const Rpy p = rpy_coeffs<true, true, false>(k, g);          // one overlap patch for both blocks
     const TTc a = tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
-    tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    tt_apply<WALL, ACC>(a, g, vi, vj, ui, t);
     const CPc C = cpl_block<WALL>(k, g, zi, zj, p.c);
     tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
   }
@@ -104,16 +104,16 @@ struct OpFusedRow {
 // [u; w] = [[M_tt, M_tr], [M_rt, M_rr]] [f; tau]    (in: f, tau; out: u, w)
 struct OpGrand {
   static constexpr int NIN = 2, NOUT = 2;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
     const Rpy p = rpy_coeffs<true, true, true>(k, g);
     const TTc a = tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
-    tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    tt_apply<WALL, ACC>(a, g, vi, vj, ui, t);
     const CPc C = cpl_block<WALL>(k, g, zi, zj, p.c);
     tr_apply<WALL, true>(C, g, vi + 3, vj + 3, ui, t);
-    rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+    rt_apply<WALL, ACC>(C, g, vi, vj, ui + 3, t + 3);
     const RRc b = rr_block<WALL>(k, g, p.rF, p.rD);
     rr_apply<WALL, true>(b, g, vi + 3, vj + 3, ui + 3, t + 3);
   }
@@ -130,15 +130,15 @@ struct OpGrand {
 // [u; w] = [M_tt; M_rt] f    (in: f; out: u, w)  -- both random-finite-difference products of one draw
 struct OpColumnF {
   static constexpr int NIN = 1, NOUT = 2;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
     const Rpy p = rpy_coeffs<true, true, false>(k, g);
     const TTc a = tt_block<WALL>(k, g, zi, zj, p.cF, p.cD);
-    tt_apply<WALL, false>(a, g, vi, vj, ui, t);
+    tt_apply<WALL, ACC>(a, g, vi, vj, ui, t);
     const CPc C = cpl_block<WALL>(k, g, zi, zj, p.c);
-    rt_apply<WALL, false>(C, g, vi, vj, ui + 3, t + 3);
+    rt_apply<WALL, ACC>(C, g, vi, vj, ui + 3, t + 3);
   }
   template <bool WALL>
   static __device__ __forceinline__ void self(const PairConsts& k, double zi, const double* vi, double* ui) {
@@ -154,24 +154,24 @@ struct OpColumnF {
 template <int KIND, int K>
 struct OpKindK {
   static constexpr int NIN = K, NOUT = K;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<WALL>(dx, dy, dz, zi, zj);
     if constexpr (KIND == KIND_TT) {
       const TTc a = tt_coeffs<WALL>(k, g, zi, zj);
 #pragma unroll
-      for (int v = 0; v < K; ++v) tt_apply<WALL, false>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      for (int v = 0; v < K; ++v) tt_apply<WALL, ACC>(a, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else if constexpr (KIND == KIND_RR) {
       const RRc b = rr_coeffs<WALL>(k, g);
 #pragma unroll
-      for (int v = 0; v < K; ++v) rr_apply<WALL, false>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+      for (int v = 0; v < K; ++v) rr_apply<WALL, ACC>(b, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
     } else {
       const CPc C = cpl_coeffs<WALL>(k, g, zi, zj);
 #pragma unroll
       for (int v = 0; v < K; ++v) {
-        if constexpr (KIND == KIND_TR) tr_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
-        else                           rt_apply<WALL, false>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+        if constexpr (KIND == KIND_TR) tr_apply<WALL, ACC>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
+        else                           rt_apply<WALL, ACC>(C, g, vi + 3 * v, vj + 3 * v, ui + 3 * v, t + 3 * v);
       }
     }
   }
@@ -192,12 +192,12 @@ template <int K> using OpTTk = OpKindK<KIND_TT, K>;
 // reciprocal, both directions from one set of coefficients.  Raw heights (set_positions with wall = 0).
 struct OpFreeSurface {
   static constexpr int NIN = 1, NOUT = 1;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts& k, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const Geom g = make_geom<true>(dx, dy, dz, zi, zj);
     const TTc a = tt_coeffs<false>(k, g, zi, zj);
-    tt_apply<false, false>(a, g, vi, vj, ui, t);
+    tt_apply<false, ACC>(a, g, vi, vj, ui, t);
     double cF, cD;
     rpy_tt_coeffs(k, __builtin_fma(g.Rz, g.Rz, g.rho2), g.iR, g.iR2, cF, cD);
     // forward: cF P vj + cD (R . P vj) R ;  reversed: cF P vi + cD (R' . P vi) R'
@@ -301,12 +301,12 @@ __device__ __forceinline__ void st_apply(const STc& c, double dx, double dy, dou
 
 struct OpRadiiTT {
   static constexpr int NIN = 1, NOUT = 1, NEXTRA = 1;
-  template <bool WALL>
+  template <bool WALL, bool ACC = false>
   static __device__ __forceinline__ void pair(const PairConsts&, double dx, double dy, double dz, double zi, double zj,
                                               const double* vi, const double* vj, double* ui, double* t) {
     const STc c = st_coeffs<WALL>(dx, dy, dz, zi, zj, vi[3], vj[3]);
     st_apply<WALL>(c, dx, dy, dz, 1.0, c.gamma, c.delta, vj, ui);
-    t[0] = 0.0; t[1] = 0.0; t[2] = 0.0;
+    if constexpr (!ACC) { t[0] = 0.0; t[1] = 0.0; t[2] = 0.0; }
     st_apply<WALL>(c, dx, dy, dz, -1.0, c.delta, c.gamma, vi, t);   // reversed pair: gamma <-> delta, R' = (-d_x, -d_y, r_z)
   }
   // i == j is an ordinary pair of the formulas (r = 0 is the third Zuk regime; the blob's own wall image)
