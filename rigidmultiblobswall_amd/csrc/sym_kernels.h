@@ -305,10 +305,8 @@ __global__ __launch_bounds__(64 * kSymWaves) __attribute__((amdgpu_waves_per_eu(
           for (int bx = -px; bx <= px; ++bx)
             for (int by = -py; by <= py; ++by)
               for (int bz = -pz; bz <= pz; ++bz) {
-                double sx, sy, sz;
-                pair_sym<KIND, WALL>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, q1.x, vix, viy, viz, q1.y, q2.x,
-                                     q2.y, ui, sx, sy, sz);
-                tx += sx; ty += sy; tz += sz;
+                pair_sym<KIND, WALL, true>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, q1.x, vix, viy, viz, q1.y, q2.x,
+                                           q2.y, ui, tx, ty, tz);      // accumulates (fused multiply-adds)
               }
         }
         __hip_atomic_fetch_add(&accj[jj], tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -461,10 +461,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void symx_kernel(const SymXArgs a) 
           for (int by = -py; by <= py; ++by)
             for (int bz = -pz; bz <= pz; ++bz) {
               if (diag && k == 0 && bx == 0 && by == 0 && bz == 0) continue;
-              double sx[3 * NO];
-              OP::template pair<WALL>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, rd[2], vi, rd + 3, ui, sx);
-#pragma unroll
-              for (int c = 0; c < 3 * NO; ++c) t[c] += sx[c];
+              OP::template pair<WALL, true>(a.k, dx + bx * a.Lx, dy + by * a.Ly, dz + bz * a.Lz, zi, rd[2], vi, rd + 3, ui, t);      // accumulates (fused multiply-adds)
             }
       }
       if (!diag) {   // wave-uniform
