@@ -144,6 +144,9 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *   "sym_chunk_steps" [1024]  symmetric kernels: a wave's share of the rotation steps is cut into equal strided chunks of about
  *                          this many steps (wave w takes chunks w, w + W, w + 2 W, ...), so that the waves running at the same
  *                          time work on neighbouring tile pairs at any problem size; 0 = one contiguous range per wave
+ *   "gmres_fuse_pc"   [1]  rmb_rigid_gmres_device: the last launch of an Arnoldi step (normalisation, workgroup = body) also applies
+ *                          the block-diagonal preconditioner to the vector it has just normalised, so every step but the first
+ *                          of a restart cycle is six launches instead of seven; 0 = separate launches (same arithmetic)
  *   "sym_wps"         [0]  symmetric kernels: cap on resident workgroups per CU (0 = occupancy limit)
  *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
  *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics

@@ -231,14 +231,16 @@ int rmb_rigid_gmres_device(rmb_ctx* c, long n_bodies, long n_b, const double* A1
       return res * rate > 20.0 * tol;
     };
 
+    const bool fuse_pc = c->opt_gmres_fuse_pc != 0;
     for (long j = 0; j < m; ++j) {
       if (pending >= 0 && !may_defer()) {
         if (int rc = finish(pending, &stop)) return rc;
         pending = -1;
         if (stop) break;
       }
-      if (int rc = rmb_rigid_arnoldi_step_device(c, n_bodies, n_b, A11_dev, A12_dev, A21_dev, A22_dev, K_dev, V, ldv, j, eta, z, w,
-                                                 cols + (size_t)j * col_row, hcols_dev + (size_t)j * col_row))
+      // (from the second step of a cycle on, z = P^-1 v_j was left behind by the previous step's last launch: six launches)
+      if (int rc = arnoldi_step_impl(c, n_bodies, n_b, A11_dev, A12_dev, A21_dev, A22_dev, K_dev, V, ldv, j, eta, z, w,
+                                     cols + (size_t)j * col_row, hcols_dev + (size_t)j * col_row, fuse_pc && j > 0, fuse_pc))
         return rc;
       ++n_products;
       RMB_HIP(hipEventRecord(ws->ev[j & 1], s));

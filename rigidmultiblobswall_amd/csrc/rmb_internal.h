@@ -94,6 +94,7 @@ struct rmb_ctx {
   void* host_in = nullptr;       // ... and the same for its input vectors (two of them: RMB_TT_TR)
   double* host_in_dev = nullptr;
   size_t host_in_cap = 0;
+  long opt_gmres_fuse_pc = 1;       // rmb_rigid_gmres_device: the normalisation launch also applies the preconditioner for the next step
   long opt_host_zero_copy_in = 1;   // inputs of rmb_matvec through mapped memory + a pull kernel (sizes as host_zero_copy)
   long opt_host_zero_copy = 768 << 10;   // bytes (32 768 blobs: level at 43 000, +1 % at 1e5); 0 = always a device-to-host copy command
   long symbuf_zeroed_for = -1;
@@ -140,6 +141,17 @@ int default_ctx(rmb_ctx** out);   // call with g_default_mu held
 
 // ---- rmb_gmres.hip ----------------------------------------------------------------------------------------
 void gmres_release(rmb_ctx* c);
+// ---- rmb_krylov.hip / rmb_rigid.hip: pieces the native GMRES composes ------------------------------------------------
+// The preconditioner's four blocks of every body (contiguous (n_bodies, nn, nn), (n_bodies, nn, 6), (n_bodies, 6, nn),
+// (n_bodies, 6, 6)) and where z = P^-1 v goes: handed to the Gram-Schmidt step, its LAST launch (normalisation, workgroup =
+// body instead of chunk) also applies the blocks to the vector it has just normalised -- the next iteration's first launch.
+struct PcBlocks { long n_bodies, nn; const double *A11, *A12, *A21, *A22; double* z; };
+int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
+                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc);
+// z_ready: z_dev already holds P^-1 v_j (the previous step's fused launch); fuse_pc: leave P^-1 v_{j+1} in z_dev
+int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
+                      const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j, double eta, double* z_dev, double* w_dev,
+                      double* col_dev, double* col_mapped_dev, bool z_ready, bool fuse_pc);
 
 // ---- rmb_plan.hip ------------------------------------------------------------------------------------------
 rmb::PairConsts make_pair_consts(double a);

@@ -144,6 +144,54 @@ __global__ __launch_bounds__(kKrT) void ortho_normalise_kernel(const OrthoArgs a
   for (long e = threadIdx.x; e < len; e += kKrT) a.v_next[base + e] = a.w[base + e] * inv;
 }
 
+// The normalisation with the preconditioner fused in (rmb_rigid_gmres_device): workgroup = body.  Every workgroup re-sums the
+// chunk partials of |w|^2 (fixed order), normalises ITS slices of w -- the body's 3 n_b rows of the lambda part and its 6
+// rows of the U part: together the workgroups cover the whole vector -- into v_next, keeps them in LDS and applies the four
+// blocks of the body's [[M_b, -K], [-K^T, 0]]^-1 to them: z = P^-1 v_next, the first launch of the NEXT iteration.
+struct NormPcArgs {
+  OrthoArgs o;
+  long n_bodies, nn, n3;
+  const double *A11, *A12, *A21, *A22;
+  double* z;
+};
+
+__global__ void ortho_normalise_pc_kernel(const NormPcArgs a) {
+  extern __shared__ double xl[];          // nn + 6: the body's slices of v_next
+  __shared__ double nrm;
+  const long b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (long c = 0; c < a.o.n_chunks; ++c) s += a.o.part3[c];
+    nrm = sqrt(s);
+    if (b == 0) {
+      a.o.col[a.o.rows] = nrm;
+      if (a.o.col_host) a.o.col_host[a.o.rows] = nrm;
+    }
+  }
+  if (a.o.col_host && b == 0)
+    for (long r = threadIdx.x; r < a.o.rows; r += blockDim.x) a.o.col_host[r] = a.o.col[r];
+  __syncthreads();
+  const double inv = 1.0 / nrm;
+  const long nn = a.nn;
+  for (long k = threadIdx.x; k < nn + 6; k += blockDim.x) {
+    const long e = k < nn ? b * nn + k : a.n3 + 6 * b + (k - nn);
+    const double v = a.o.w[e] * inv;
+    a.o.v_next[e] = v;
+    xl[k] = v;
+  }
+  __syncthreads();
+  for (long row = threadIdx.x; row < nn + 6; row += blockDim.x) {
+    const bool top = row < nn;
+    const long r = top ? row : row - nn;
+    const double* left = top ? a.A11 + (b * nn + r) * nn : a.A21 + (b * 6 + r) * nn;
+    const double* right = top ? a.A12 + (b * nn + r) * 6 : a.A22 + (b * 6 + r) * 6;
+    double s = 0.0;
+    for (long k = 0; k < nn; ++k) s += left[k] * xl[k];
+    for (long k = 0; k < 6; ++k) s += right[k] * xl[nn + k];
+    a.z[top ? b * nn + r : a.n3 + 6 * b + r] = s;
+  }
+}
+
 // (Round 5 measured the whole step in ONE workgroup for systems of up to 6144 unknowns -- workgroup barriers instead of
 //  kernel boundaries -- and dropped it: one CU pulls the (rows x n) basis four times through its own L2 port, 17-24 us per
 //  step at 17 basis rows growing to 40 us at 60 (wave = row), 23-40 us with thread = unknown, against 4 x 4.5 us for the
@@ -200,6 +248,14 @@ int rmb_krylov_orthogonalize_device(rmb_ctx* c, long n, long rows, const double*
 
 int rmb_krylov_orthogonalize2_device(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
                                      double* v_next_dev, double* col_mapped_dev) {
+  return krylov_orthogonalize_impl(c, n, rows, V_dev, ldv, w_dev, col_dev, v_next_dev, col_mapped_dev, nullptr);
+}
+
+}  // extern "C"
+
+namespace rmbi {
+int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
+                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
   if (n < 1 || rows < 1 || rows > kKrMaxRows || ldv < n)
     return fail(RMB_ERR_ARG, "rmb_krylov_orthogonalize_device: need n >= 1, 1 <= rows <= 256, ldv >= n");
@@ -230,10 +286,23 @@ int rmb_krylov_orthogonalize2_device(rmb_ctx* c, long n, long rows, const double
   hipLaunchKernelGGL(ortho_dots_kernel, grid, block, lds_w, c->stream, a);
   hipLaunchKernelGGL(ortho_update_kernel<1>, grid, block, lds_wh, c->stream, a);
   hipLaunchKernelGGL(ortho_update_kernel<2>, grid, block, lds_wh, c->stream, a);
-  hipLaunchKernelGGL(ortho_normalise_kernel, grid, block, 0, c->stream, a);
+  if (pc) {
+    if (pc->n_bodies * (pc->nn + 6) != n) return fail(RMB_ERR_ARG, "krylov_orthogonalize_impl: the blocks do not cover the vector (internal)");
+    NormPcArgs q;
+    q.o = a; q.n_bodies = pc->n_bodies; q.nn = pc->nn; q.n3 = pc->n_bodies * pc->nn;
+    q.A11 = pc->A11; q.A12 = pc->A12; q.A21 = pc->A21; q.A22 = pc->A22; q.z = pc->z;
+    const long rws = pc->nn + 6;
+    const unsigned threads = rws <= 64 ? 64u : (rws <= 128 ? 128u : 256u);
+    hipLaunchKernelGGL(ortho_normalise_pc_kernel, dim3((unsigned)pc->n_bodies), dim3(threads), (size_t)rws * sizeof(double), c->stream, q);
+  } else {
+    hipLaunchKernelGGL(ortho_normalise_kernel, grid, block, 0, c->stream, a);
+  }
   RMB_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace rmbi
+
+extern "C" {
 
 // Page-locked host memory mapped into the device's address space: what a kernel may store into so that the host reads a
 // result after one event / stream wait, without a copy command (the Hessenberg column of an Arnoldi step; rmb_matvec does

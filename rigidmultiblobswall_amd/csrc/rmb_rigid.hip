@@ -429,6 +429,28 @@ __global__ __launch_bounds__(256) void rigid_operator_finish_kernel(const OpFinA
 }
 
 }  // namespace
+
+int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
+                      const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j, double eta, double* z_dev, double* w_dev,
+                      double* col_dev, double* col_mapped_dev, bool z_ready, bool fuse_pc) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1 || j < 0) return fail(RMB_ERR_ARG, "rmb_rigid_arnoldi_step_device: bad n_bodies / n_b / j");
+  if (!A11_dev || !A12_dev || !A21_dev || !A22_dev || !K_dev || !V_dev || !z_dev || !w_dev || !col_dev) return fail(RMB_ERR_ARG, "null pointer");
+  const long nn = 3 * n_b, n3 = 3 * n_bodies * n_b, n = n3 + 6 * n_bodies;
+  if (ldv < n) return fail(RMB_ERR_ARG, "rmb_rigid_arnoldi_step_device: ldv < 3 N + 6 n_bodies");
+  if (!z_ready) {
+    // z = P^-1 v_j: the four blocks of every body's [[M_b, -K], [-K^T, 0]]^-1 in one launch
+    const double* v = V_dev + j * ldv;
+    const rmb_block b11{A11_dev, nn * nn, nn, 1}, b12{A12_dev, nn * 6, 6, 1}, b21{A21_dev, 6 * nn, nn, 1}, b22{A22_dev, 36, 6, 1};
+    if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 6, 6, &b11, &b12, &b21, &b22, v, v + n3, 1.0, 0.0, z_dev, 0.0, z_dev + n3)) return rc;
+  }
+  // w = A z: pair sweep + one finishing launch
+  if (int rc = rmb_rigid_operator_device(c, n_bodies, n_b, K_dev, z_dev, eta, w_dev)) return rc;
+  // two Gram-Schmidt passes against v_0 .. v_j, Hessenberg column, |w|, v_{j+1} (and, fused, z = P^-1 v_{j+1})
+  const PcBlocks pc{n_bodies, nn, A11_dev, A12_dev, A21_dev, A22_dev, z_dev};
+  return krylov_orthogonalize_impl(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev, fuse_pc ? &pc : nullptr);
+}
+
 }  // namespace rmbi
 
 using namespace rmbi;
@@ -529,19 +551,8 @@ int rmb_rigid_operator_device(rmb_ctx* c, long n_bodies, long n_b, const double*
 int rmb_rigid_arnoldi_step_device(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev,
                                   const double* A21_dev, const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j,
                                   double eta, double* z_dev, double* w_dev, double* col_dev, double* col_mapped_dev) {
-  if (int rc = check_ready(c)) return rc;
-  if (n_bodies < 1 || n_b < 1 || j < 0) return fail(RMB_ERR_ARG, "rmb_rigid_arnoldi_step_device: bad n_bodies / n_b / j");
-  if (!A11_dev || !A12_dev || !A21_dev || !A22_dev || !K_dev || !V_dev || !z_dev || !w_dev || !col_dev) return fail(RMB_ERR_ARG, "null pointer");
-  const long nn = 3 * n_b, n3 = 3 * n_bodies * n_b, n = n3 + 6 * n_bodies;
-  if (ldv < n) return fail(RMB_ERR_ARG, "rmb_rigid_arnoldi_step_device: ldv < 3 N + 6 n_bodies");
-  const double* v = V_dev + j * ldv;
-  // z = P^-1 v_j: the four blocks of every body's [[M_b, -K], [-K^T, 0]]^-1 in one launch
-  const rmb_block b11{A11_dev, nn * nn, nn, 1}, b12{A12_dev, nn * 6, 6, 1}, b21{A21_dev, 6 * nn, nn, 1}, b22{A22_dev, 36, 6, 1};
-  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 6, 6, &b11, &b12, &b21, &b22, v, v + n3, 1.0, 0.0, z_dev, 0.0, z_dev + n3)) return rc;
-  // w = A z: pair sweep + one finishing launch
-  if (int rc = rmb_rigid_operator_device(c, n_bodies, n_b, K_dev, z_dev, eta, w_dev)) return rc;
-  // two Gram-Schmidt passes against v_0 .. v_j, Hessenberg column, |w|, v_{j+1}
-  return rmb_krylov_orthogonalize2_device(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev);
+  return arnoldi_step_impl(c, n_bodies, n_b, A11_dev, A12_dev, A21_dev, A22_dev, K_dev, V_dev, ldv, j, eta, z_dev, w_dev, col_dev,
+                           col_mapped_dev, false, false);
 }
 
 int rmb_rigid_lanczos_step_device(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i,
