@@ -230,7 +230,7 @@ int rmb_body_mobility_dense_device(rmb_ctx* ctx, const long* first_blob_dev, lon
  *     y2_b = beta2 y2_b + alpha (A21_b x1_b + A22_b x2_b)       y2_b: r2 values at y2 + b r2,  x2_b: c2 values at x2 + b c2
  * in ONE launch.  A block is addressed as p[b batch_stride + row row_stride + col col_stride] (a transposed block is
  * the same memory with the two strides exchanged); a NULL rmb_block* or p == NULL is a zero block; beta == 0 does not
- * read y.  x and y must not overlap.  c1 + c2 <= 8192.  Replaces the four batched products of the block-diagonal
+ * read y.  x and y must not overlap.  c1 + c2 + r1 + r2 <= 8192.  Replaces the four batched products of the block-diagonal
  * preconditioner (multi_bodies/multi_bodies.py:548-560: A = the blocks of [[M, -K], [-K^T, 0]]^-1 per body) and the
  * K U / K^T lambda products of the operator (multi_bodies/multi_bodies.py:327-375 called from :424-471).
  *

@@ -231,7 +231,9 @@ int rmb_rigid_gmres_device(rmb_ctx* c, long n_bodies, long n_b, const double* A1
       return res * rate > 20.0 * tol;
     };
 
-    const bool fuse_pc = c->opt_gmres_fuse_pc != 0;
+    // (wide blocks -- bodies of more than 32 blobs -- keep the separate launch: their product is no longer a 4.5 us kernel
+    //  and the fused one measured 4 % slower, profiles/r5_gmres_fuse_pc.txt)
+    const bool fuse_pc = c->opt_gmres_fuse_pc != 0 && 3 * n_b <= 96;
     for (long j = 0; j < m; ++j) {
       if (pending >= 0 && !may_defer()) {
         if (int rc = finish(pending, &stop)) return rc;

@@ -144,6 +144,83 @@ __global__ __launch_bounds__(kKrT) void ortho_normalise_kernel(const OrthoArgs a
   for (long e = threadIdx.x; e < len; e += kKrT) a.v_next[base + e] = a.w[base + e] * inv;
 }
 
+// ---- one batch entry's two-by-two block matvec, operand in LDS (block_apply_kernel, ortho_normalise_pc_kernel) --------
+// Two ways to walk a block.  THREAD = ROW: a thread runs along its row; right for narrow blocks (the 6 columns of K, A12)
+// and for blocks of up to 96 columns, where every row a workgroup touches stays in the CU's cache.  WAVE = ROW: the lanes
+// of a wave take the columns 64 at a time (coalesced when the row is contiguous) and a butterfly sums them; right for wide
+// blocks -- the 126 x 126 blocks of the reference's 42-blob shells, where thread = row makes every load instruction touch 64
+// different cache lines -- and for the few long rows of K^T / A21 (6 rows of 3 n_b entries).  Four rows per wave are loaded
+// before the first butterfly so that their loads are in flight together.
+struct BlockRef { const double* p; long bs, rs, cs; };
+constexpr long kWaveRowMinCols = 97;
+
+__host__ __device__ inline bool wave_rows(const BlockRef& m, long rows, long cols) {
+  return m.p && cols >= kWaveRowMinCols && (m.cs == 1 || rows <= 8);
+}
+
+// xl: operand (c1 then c2 entries); yl: r1 + r2 doubles of LDS (only touched when a block is walked wave = row);
+// store(row, sum) is called once per row by the thread that owns it
+template <class Store>
+__device__ inline void two_by_two_rows(const BlockRef& a11, const BlockRef& a12, const BlockRef& a21, const BlockRef& a22, long b, long r1,
+                                       long c1, long r2, long c2, const double* xl, double* yl, Store store) {
+  const long rows = r1 + r2;
+  const bool w11 = wave_rows(a11, r1, c1), w12 = wave_rows(a12, r1, c2), w21 = wave_rows(a21, r2, c1), w22 = wave_rows(a22, r2, c2);
+  const bool any_wave = w11 || w12 || w21 || w22;
+  if (any_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (long row0 = 4L * wave; row0 < rows; row0 += 4L * n_waves) {
+      double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long row = row0 + q;
+        if (row < rows) {
+          const bool top = row < r1;
+          const long r = top ? row : row - r1;
+          const BlockRef& left = top ? a11 : a21;
+          const BlockRef& right = top ? a12 : a22;
+          if (top ? w11 : w21) {
+            const double* m = left.p + b * left.bs + r * left.rs;
+            for (long k = lane; k < c1; k += 64) s[q] += m[k * left.cs] * xl[k];
+          }
+          if (top ? w12 : w22) {
+            const double* m = right.p + b * right.bs + r * right.rs;
+            for (long k = lane; k < c2; k += 64) s[q] += m[k * right.cs] * xl[c1 + k];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_xor(s[q], off, 64);
+        if (lane == 0 && row0 + q < rows) yl[row0 + q] = s[q];
+      }
+    }
+    __syncthreads();
+  }
+  for (long row = threadIdx.x; row < rows; row += blockDim.x) {
+    const bool top = row < r1;
+    const long r = top ? row : row - r1;
+    const BlockRef& left = top ? a11 : a21;
+    const BlockRef& right = top ? a12 : a22;
+    double sum = any_wave ? yl[row] : 0.0;
+    if (left.p && !(top ? w11 : w21)) {
+      const double* m = left.p + b * left.bs + r * left.rs;
+      for (long k = 0; k < c1; ++k) sum += m[k * left.cs] * xl[k];
+    }
+    if (right.p && !(top ? w12 : w22)) {
+      const double* m = right.p + b * right.bs + r * right.rs;
+      for (long k = 0; k < c2; ++k) sum += m[k * right.cs] * xl[c1 + k];
+    }
+    store(row, sum);
+  }
+}
+
+// threads of a workgroup that runs two_by_two_rows
+inline unsigned two_by_two_threads(long rows, bool any_wave) {
+  if (any_wave) return rows > 64 ? 1024u : 256u;
+  return rows <= 64 ? 64u : (rows <= 128 ? 128u : 256u);
+}
+
 // The normalisation with the preconditioner fused in (rmb_rigid_gmres_device): workgroup = body.  Every workgroup re-sums the
 // chunk partials of |w|^2 (fixed order), normalises ITS slices of w -- the body's 3 n_b rows of the lambda part and its 6
 // rows of the U part: together the workgroups cover the whole vector -- into v_next, keeps them in LDS and applies the four
@@ -155,8 +232,8 @@ struct NormPcArgs {
   double* z;
 };
 
-__global__ void ortho_normalise_pc_kernel(const NormPcArgs a) {
-  extern __shared__ double xl[];          // nn + 6: the body's slices of v_next
+__global__ __launch_bounds__(1024) void ortho_normalise_pc_kernel(const NormPcArgs a) {
+  extern __shared__ double xl[];          // nn + 6: the body's slices of v_next; then nn + 6 row sums (two_by_two_rows)
   __shared__ double nrm;
   const long b = blockIdx.x;
   if (threadIdx.x == 0) {
@@ -180,16 +257,9 @@ __global__ void ortho_normalise_pc_kernel(const NormPcArgs a) {
     xl[k] = v;
   }
   __syncthreads();
-  for (long row = threadIdx.x; row < nn + 6; row += blockDim.x) {
-    const bool top = row < nn;
-    const long r = top ? row : row - nn;
-    const double* left = top ? a.A11 + (b * nn + r) * nn : a.A21 + (b * 6 + r) * nn;
-    const double* right = top ? a.A12 + (b * nn + r) * 6 : a.A22 + (b * 6 + r) * 6;
-    double s = 0.0;
-    for (long k = 0; k < nn; ++k) s += left[k] * xl[k];
-    for (long k = 0; k < 6; ++k) s += right[k] * xl[nn + k];
-    a.z[top ? b * nn + r : a.n3 + 6 * b + r] = s;
-  }
+  const BlockRef a11{a.A11, nn * nn, nn, 1}, a12{a.A12, nn * 6, 6, 1}, a21{a.A21, 6 * nn, nn, 1}, a22{a.A22, 36, 6, 1};
+  two_by_two_rows(a11, a12, a21, a22, b, nn, nn, 6, 6, xl, xl + nn + 6,
+                  [&](long row, double sum) { a.z[row < nn ? b * nn + row : a.n3 + 6 * b + (row - nn)] = sum; });
 }
 
 // (Round 5 measured the whole step in ONE workgroup for systems of up to 6144 unknowns -- workgroup barriers instead of
@@ -199,7 +269,6 @@ __global__ void ortho_normalise_pc_kernel(const NormPcArgs a) {
 //  once they are queued -- what a tiny kernel costs is its ~4.5 us floor, not a gap.  profiles/r5_gmres_step.txt.)
 
 // ---- batched two-by-two block matvec ---------------------------------------------------------------------------
-struct BlockRef { const double* p; long bs, rs, cs; };
 struct BlockApplyArgs {
   long n_batch, r1, c1, r2, c2;
   BlockRef a11, a12, a21, a22;
@@ -208,30 +277,18 @@ struct BlockApplyArgs {
   double alpha, beta1, beta2;
 };
 
-__global__ void block_apply_kernel(const BlockApplyArgs a) {
-  extern __shared__ double xl[];          // x1_b then x2_b
+__global__ __launch_bounds__(1024) void block_apply_kernel(const BlockApplyArgs a) {
+  extern __shared__ double xl[];          // x1_b then x2_b; then r1 + r2 row sums (two_by_two_rows)
   const long b = blockIdx.x;
   for (long k = threadIdx.x; k < a.c1; k += blockDim.x) xl[k] = a.x1[b * a.c1 + k];
   for (long k = threadIdx.x; k < a.c2; k += blockDim.x) xl[a.c1 + k] = a.x2[b * a.c2 + k];
   __syncthreads();
-  for (long row = threadIdx.x; row < a.r1 + a.r2; row += blockDim.x) {
+  two_by_two_rows(a.a11, a.a12, a.a21, a.a22, b, a.r1, a.c1, a.r2, a.c2, xl, xl + a.c1 + a.c2, [&](long row, double sum) {
     const bool top = row < a.r1;
-    const long r = top ? row : row - a.r1;
-    const BlockRef& left = top ? a.a11 : a.a21;
-    const BlockRef& right = top ? a.a12 : a.a22;
-    double s = 0.0;
-    if (left.p) {
-      const double* m = left.p + b * left.bs + r * left.rs;
-      for (long k = 0; k < a.c1; ++k) s += m[k * left.cs] * xl[k];
-    }
-    if (right.p) {
-      const double* m = right.p + b * right.bs + r * right.rs;
-      for (long k = 0; k < a.c2; ++k) s += m[k * right.cs] * xl[a.c1 + k];
-    }
-    double* y = top ? a.y1 + b * a.r1 + r : a.y2 + b * a.r2 + r;
+    double* y = top ? a.y1 + b * a.r1 + row : a.y2 + b * a.r2 + (row - a.r1);
     const double beta = top ? a.beta1 : a.beta2;
-    *y = (beta == 0.0 ? 0.0 : beta * *y) + a.alpha * s;
-  }
+    *y = (beta == 0.0 ? 0.0 : beta * *y) + a.alpha * sum;
+  });
 }
 
 }  // namespace
@@ -292,8 +349,8 @@ int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev
     q.o = a; q.n_bodies = pc->n_bodies; q.nn = pc->nn; q.n3 = pc->n_bodies * pc->nn;
     q.A11 = pc->A11; q.A12 = pc->A12; q.A21 = pc->A21; q.A22 = pc->A22; q.z = pc->z;
     const long rws = pc->nn + 6;
-    const unsigned threads = rws <= 64 ? 64u : (rws <= 128 ? 128u : 256u);
-    hipLaunchKernelGGL(ortho_normalise_pc_kernel, dim3((unsigned)pc->n_bodies), dim3(threads), (size_t)rws * sizeof(double), c->stream, q);
+    const unsigned threads = two_by_two_threads(rws, pc->nn >= kWaveRowMinCols);
+    hipLaunchKernelGGL(ortho_normalise_pc_kernel, dim3((unsigned)pc->n_bodies), dim3(threads), (size_t)(2 * rws) * sizeof(double), c->stream, q);
   } else {
     hipLaunchKernelGGL(ortho_normalise_kernel, grid, block, 0, c->stream, a);
   }
@@ -331,8 +388,8 @@ int rmb_block_apply_device(rmb_ctx* c, long n_batch, long r1, long c1, long r2, 
   if (!c) return fail(RMB_ERR_ARG, "null context");
   if (n_batch < 0 || r1 < 0 || c1 < 0 || r2 < 0 || c2 < 0) return fail(RMB_ERR_ARG, "rmb_block_apply_device: negative size");
   if (n_batch == 0 || r1 + r2 == 0) return 0;
-  if ((size_t)(c1 + c2) * sizeof(double) > 64 * 1024)
-    return fail(RMB_ERR_ARG, "rmb_block_apply_device: c1 + c2 above 8192 (the operand of one batch entry is kept in LDS)");
+  if ((size_t)(c1 + c2 + r1 + r2) * sizeof(double) > 64 * 1024)
+    return fail(RMB_ERR_ARG, "rmb_block_apply_device: c1 + c2 + r1 + r2 above 8192 (operand and row sums of one batch entry are kept in LDS)");
   if ((c1 > 0 && !x1_dev) || (c2 > 0 && !x2_dev) || (r1 > 0 && !y1_dev) || (r2 > 0 && !y2_dev)) return fail(RMB_ERR_ARG, "null pointer");
   RMB_HIP(hipSetDevice(c->device));
   BlockApplyArgs a;
@@ -342,8 +399,9 @@ int rmb_block_apply_device(rmb_ctx* c, long n_batch, long r1, long c1, long r2, 
   a.x1 = x1_dev; a.x2 = x2_dev; a.y1 = y1_dev; a.y2 = y2_dev;
   a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2;
   const long rows = r1 + r2;
-  const unsigned threads = rows <= 64 ? 64u : (rows <= 128 ? 128u : 256u);
-  hipLaunchKernelGGL(block_apply_kernel, dim3((unsigned)n_batch), dim3(threads), (size_t)(c1 + c2) * sizeof(double), c->stream, a);
+  const bool any_wave = wave_rows(a.a11, r1, c1) || wave_rows(a.a12, r1, c2) || wave_rows(a.a21, r2, c1) || wave_rows(a.a22, r2, c2);
+  const unsigned threads = two_by_two_threads(rows, any_wave);
+  hipLaunchKernelGGL(block_apply_kernel, dim3((unsigned)n_batch), dim3(threads), (size_t)(c1 + c2 + rows) * sizeof(double), c->stream, a);
   RMB_HIP(hipGetLastError());
   return 0;
 }

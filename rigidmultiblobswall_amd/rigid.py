@@ -571,7 +571,7 @@ class RigidSuspension(object):
 
   def _native_arnoldi(self, restart):
     """The one-call-per-iteration workspace for solve(), or None.  Applies to what rmb_rigid_arnoldi_step_device covers: one
-    body shape of at most 32 blobs, all bodies free, a plain single-GPU context, the host bookkeeping one iteration late.
+    body shape of at most `native_products_max_blobs` blobs, all bodies free, a plain single-GPU context, the host bookkeeping one iteration late.
     `gmres_graph = True` (forced captured iterations) and `native_step = False` / RMB_NATIVE_STEP=0 turn it off."""
     if not self._native_step_applies(restart):
       return None
@@ -602,9 +602,12 @@ class RigidSuspension(object):
     return h if type(h) is MobilityContext else None
 
   def _native_products(self):
-    """_native_blocks() for the batched block products, which walk a block with one thread per row: fine while a body's
-    block stays cache-sized (up to 32 blobs per body), rocBLAS batched GEMM beyond."""
-    return self._native_blocks() if max(g.n_b for g in self.groups) <= 32 else None
+    """_native_blocks() for the batched block products (one workgroup per body: thread = row up to 32 blobs per body,
+    wave = row with coalesced loads above, csrc/rmb_krylov.hip two_by_two_rows), rocBLAS batched GEMM beyond
+    `native_products_max_blobs` per body, where one CU per body no longer carries the block's bytes."""
+    return self._native_blocks() if max(g.n_b for g in self.groups) <= self.native_products_max_blobs else None
+
+  native_products_max_blobs = 64
 
   def _ortho(self, restart):
     """The fused Gram-Schmidt step for _gmres_steps, or None (torch operations)."""

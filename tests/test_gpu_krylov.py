@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("nb,r1,c1,r2,c2", [(1, 1, 1, 1, 1), (5, 36, 36, 6, 6), (300, 36, 36, 6, 6), (7, 150, 150, 6, 6), (3, 700, 640, 9, 5),
-                                            (4, 5, 0, 3, 2), (2048, 36, 36, 6, 6)])
+                                            (4, 5, 0, 3, 2), (2048, 36, 36, 6, 6), (32, 126, 126, 6, 6), (5, 96, 96, 6, 6), (5, 97, 97, 6, 6), (3, 129, 257, 5, 130)])
 def test_block_apply_matches_batched_products(nb, r1, c1, r2, c2):
   import torch
   from rigidmultiblobswall_amd import MobilityContext

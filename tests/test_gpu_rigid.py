@@ -479,6 +479,47 @@ def test_native_gmres_loop_equals_the_python_loop():
     nat.close(); pyl.close()
 
 
+def test_native_loops_cover_the_references_42_blob_shells():
+  """Bodies of 33 .. 64 blobs (the reference's shell_N_42 structures) take the library's block kernels with wave = row
+  (csrc/rmb_krylov.hip two_by_two_rows) and therefore the one-call GMRES and the native Lanczos loop, instead of batched
+  GEMMs under the Python loops: same iteration counts and answers as that path (native_products_max_blobs = 32 restores it)."""
+  import os
+  import torch
+  from rigidmultiblobswall_amd import structures as st
+  from rigidmultiblobswall_amd.rigid import RigidSuspension
+  shell = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_rigid_det_euler_42blob_shells.npz"))["vertex_shell42"]
+  assert shell.shape == (42, 3)
+  R, eta, nb = 1.0155, 0.957e-3, 24
+  a = st.min_blob_separation(shell) / 2
+  loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=9)
+  nat = RigidSuspension([shell] * nb, loc, quat, a, eta, device=torch.device("cuda:0"))
+  ref = RigidSuspension([shell] * nb, loc, quat, a, eta, device=torch.device("cuda:0"))
+  ref.native_products_max_blobs = 32
+  rng = np.random.RandomState(3)
+  try:
+    assert nat._native_products() is nat.ctx and ref._native_products() is None
+    for kw in (dict(tol=1e-9, restart=60), dict(tol=1e-6, restart=6)):
+      rhs = torch.as_tensor(rng.randn(nat.size), device="cuda:0")
+      xn, inn = nat.solve(rhs, **kw)
+      xr, ir = ref.solve(rhs, **kw)
+      assert inn.get("native_gmres") and not ir.get("native_gmres") and not ir.get("native_steps")
+      assert inn["iterations"] == ir["iterations"], (kw, inn["iterations"], ir["iterations"])
+      assert np.allclose(inn["history"], ir["history"], rtol=1e-6, atol=1e-13), kw
+      assert rel_err(xn.cpu().numpy(), xr.cpu().numpy()) < 1e-8
+      true_res = float(torch.linalg.norm(ref.apply_operator(xn) - rhs) / torch.linalg.norm(rhs))
+      assert true_res < 5 * kw["tol"], (kw, true_res)
+    x = torch.as_tensor(rng.randn(nat.size), device="cuda:0")
+    assert rel_err(nat.apply_operator(x).cpu().numpy(), ref.apply_operator(x).cpu().numpy()) < 1e-13
+    assert rel_err(nat.apply_preconditioner(x).cpu().numpy(), ref.apply_preconditioner(x).cpu().numpy()) < 1e-11
+    z = torch.as_tensor(rng.randn(3 * nat.n_blobs), device="cuda:0")
+    fa, ia = nat.stochastic_forcing(z, 1.3, tol=1e-8)
+    fb, ib = ref.stochastic_forcing(z, 1.3, tol=1e-8)
+    assert ia == ib and rel_err(fa.cpu().numpy(), fb.cpu().numpy()) < 1e-10, (ia, ib)
+    assert nat._lanczos_ws is not None and getattr(ref, "_lanczos_ws", None) is None
+  finally:
+    nat.close(); ref.close()
+
+
 def test_native_lanczos_loop_equals_the_generic_one():
   """RigidSuspension.stochastic_forcing through rmb_rigid_lanczos_step_device (one call per iteration, host one iteration
   late, coefficients through mapped memory) against the generic coroutine loop: same iteration count, same noise to
