@@ -310,6 +310,24 @@ int rmb_rigid_gmres_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* 
                            const double* A22_dev, const double* K_dev, const double* b_dev, double tol, long restart, long maxiter,
                            double eta, double* x_dev, long* iterations, double* residual, long* discarded, long* products,
                            double* history, long history_cap, double* rhs_norm);
+/* The whole preconditioned Lanczos forcing  noise = factor * blockdiag(L_b) (P^T M P)^{1/2} z,  P = blockdiag(L_b^-T), of the
+ * Brownian rigid-body schemes (quaternion_integrator_multi_bodies.py:966-973 -> stochastic_forcing/stochastic_forcing.py:112-264
+ * with the preconditioner of multi_bodies.py:590-614; covariance factor^2 M) as ONE call: per iteration one
+ * rmb_rigid_lanczos_step_device and an event; the small tridiagonal eigenproblem (QL sweeps inside the library) and the
+ * reference's stopping rule (:239-255: relative change of the noise estimate below tol) run on the host one iteration
+ * behind the device.  Linv_dev / Lchol_dev: (n_bodies, 3 n_b, 3 n_b) contiguous factors of the body mobilities
+ * (rmb_rigid_preconditioner_device); z_dev: 3 N standard normals; noise_dev: 3 N doubles out; max_rows: basis vectors the
+ * workspace may hold (2 .. 254).  *status: 0 = noise_dev written, *iterations as the reference counts them; 1 = exact
+ * breakdown / eigen-solve failure, 2 = more than max_rows basis vectors needed -- then nothing is written, the stream is
+ * drained and the caller runs its general loop.  *products = pair sweeps enqueued (iterations + 1, + 1 discarded).
+ * Synchronous. */
+int rmb_rigid_lanczos_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Linv_dev, const double* Lchol_dev,
+                             const double* z_dev, double factor, double tol, long max_iter, long max_rows, double eta,
+                             double* noise_dev, long* iterations, long* products, int* status);
+/* HOST function, no GPU work: coef = scale * Q sqrt(max(lambda, 0)) Q^T e_1 of the k x k symmetric tridiagonal matrix with
+ * diagonal h_diag[0 .. k) and off-diagonal h_sup[0 .. k-1) -- the coordinates of the Lanczos noise estimate in the Krylov
+ * basis after k iterations (stochastic_forcing.py:215-229), as rmb_rigid_lanczos_device computes them. */
+int rmb_lanczos_noise_coefficients(long k, const double* h_diag, const double* h_sup, double scale, double* coef_out);
 int rmb_rigid_configuration_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* ref_dev, const double* loc_dev,
                                    const double* quat_dev, double* r_dev, double* rel_dev, double* K_dev);
 int rmb_rigid_advance_device(rmb_ctx* ctx, long n_bodies, const double* loc_dev, const double* quat_dev, const double* U_dev,

@@ -350,6 +350,23 @@ class MobilityContext(object):
     return x, dict(iterations=int(its.value), residual=float(res.value), converged=bool(res.value <= tol), history=list(hist[:k]),
                    discarded_sweeps=int(disc.value), operator_applications=int(prod.value), rhs_norm=float(nrm.value))
 
+  def rigid_lanczos_device(self, Linv, Lchol, z, factor, tol, max_iter, max_rows, eta):
+    """The whole preconditioned Lanczos forcing in one library call (rmb_rigid_lanczos_device).  Returns (noise, iterations,
+    products) or (None, status, products) when the library hands the forcing back (breakdown, more basis rows needed)."""
+    import torch
+    nb, n_b = Linv.shape[0], Linv.shape[1] // 3
+    assert Linv.is_contiguous() and Lchol.is_contiguous() and z.is_contiguous() and z.numel() == 3 * nb * n_b
+    noise = torch.empty_like(z)
+    its, prod, status = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_int(0)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_rigid_lanczos_device(self._h, nb, n_b, p(Linv), p(Lchol), p(z), float(factor), float(tol), int(max_iter),
+                                                  int(max_rows), float(eta), p(noise), ctypes.byref(its), ctypes.byref(prod),
+                                                  ctypes.byref(status)))
+    if status.value != 0:
+      return None, int(status.value), int(prod.value)
+    return noise, int(its.value), int(prod.value)
+
   def rigid_operator_device(self, K, x, eta, out):
     """out = [M_tt lambda - K U; -K^T lambda] for x = [lambda; U] on the resident configuration (all bodies free, one body
     shape; rmb_rigid_operator_device): the pair sweep + one finishing launch.  K (n_bodies, 3 n_b, 6) contiguous."""

@@ -18,6 +18,7 @@
 //   * at a restart the TRUE residual b - A P^-1 y is formed.
 #include "rmb_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -70,7 +71,82 @@ __global__ __launch_bounds__(1024) void vec_norm_kernel(const double* v, long n,
   }
 }
 
+__global__ __launch_bounds__(kVecT) void vec_div_kernel(double* out, const double* in, double alpha, long n) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = in[e] / alpha;
+}
+
 inline unsigned blocks_of(long n) { return (unsigned)((n + kVecT - 1) / kVecT); }
+
+// Eigen-decomposition of a symmetric tridiagonal matrix by QL sweeps with implicit Wilkinson shifts (the classical tql2
+// scheme): d = diagonal (n), e = sub-diagonal in e[0 .. n-2] (e[n-1] is scratch), z = n x n row-major, identity on entry,
+// eigenvector j in COLUMN j on exit; d holds the eigenvalues (unsorted).  false = a sweep did not converge in 60 rounds.
+bool tridiagonal_ql(int n, double* d, double* e, double* z) {
+  if (n > 0) e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 60) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + copysign(r, g));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          r = hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {          // an exact zero on the sub-diagonal: deflate and start the sweep again
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = z[(size_t)k * n + i + 1];
+            z[(size_t)k * n + i + 1] = s * z[(size_t)k * n + i] + c * f;
+            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return true;
+}
+
+// coef = scale * Q sqrt(max(lambda, 0)) Q^T e_1 for the k x k tridiagonal (h_diag, h_sup): the Lanczos noise estimate's
+// coordinates in the Krylov basis (stochastic_forcing/stochastic_forcing.py:215-229 forms Q sqrt(L) Q^T e_1 |z| the same way)
+bool noise_coefficients(long k, const double* h_diag, const double* h_sup, double scale, double* coef, std::vector<double>& work) {
+  work.resize((size_t)k * k + 2 * (size_t)k);
+  double* z = work.data();
+  double* d = z + (size_t)k * k;
+  double* e = d + k;
+  std::fill(z, z + (size_t)k * k, 0.0);
+  for (long i = 0; i < k; ++i) { z[(size_t)i * k + i] = 1.0; d[i] = h_diag[i]; e[i] = i + 1 < k ? h_sup[i] : 0.0; }
+  if (!tridiagonal_ql((int)k, d, e, z)) return false;
+  for (long r = 0; r < k; ++r) {
+    double s = 0.0;
+    for (long j = 0; j < k; ++j) s += z[(size_t)r * k + j] * (sqrt(d[j] > 0.0 ? d[j] : 0.0) * z[j]);      // z[j] = Q[0][j]
+    coef[r] = s * scale;
+  }
+  return true;
+}
 
 struct Mapped {
   void* host = nullptr;
@@ -285,6 +361,135 @@ int rmb_rigid_gmres_device(rmb_ctx* c, long n_bodies, long n_b, const double* A1
   *iterations = its;
   *residual = res;
   if (discarded) *discarded = wasted;
+  if (products) *products = n_products;
+  return 0;
+}
+
+// Host function (no GPU work): the coefficients rmb_rigid_lanczos_device derives from the tridiagonal matrix after k
+// iterations; exported so that the CPU test suite can hold the library's eigen-solver against LAPACK.
+int rmb_lanczos_noise_coefficients(long k, const double* h_diag, const double* h_sup, double scale, double* coef_out) {
+  if (k < 1 || k > 4096 || !h_diag || (k > 1 && !h_sup) || !coef_out) return fail(RMB_ERR_ARG, "rmb_lanczos_noise_coefficients: bad arguments");
+  std::vector<double> work;
+  if (!noise_coefficients(k, h_diag, h_sup, scale, coef_out, work)) return fail(RMB_ERR_STATE, "rmb_lanczos_noise_coefficients: the QL sweeps did not converge");
+  return 0;
+}
+
+// The whole preconditioned Lanczos forcing  noise = factor * blockdiag(L_b) (P^T M P)^{1/2} z,  P = blockdiag(L_b^-T), as ONE
+// library call (quaternion_integrator_multi_bodies.py:966-973 -> stochastic_forcing/stochastic_forcing.py:112-264, with the
+// preconditioner of multi_bodies.py:590-614).  Per iteration one rmb_rigid_lanczos_step_device and one event; the host
+// side -- the small tridiagonal eigenproblem and the reference's stopping rule (:239-255: relative change of the noise
+// estimate, measured on its coordinates in the orthonormal basis) -- runs ONE ITERATION LATE, while the device works on the
+// next step: rigid.py's _lanczos_native loop, natively (a Python iteration costs ~60 us of host time against ~35 us of
+// launches).  status: 0 = done; 1 = exact breakdown or a failed eigen-solve, 2 = more than max_rows basis vectors needed --
+// in both cases nothing was written to noise_dev, the stream has been drained and the caller runs its generic loop.
+int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, const double* Lchol_dev, const double* z_dev,
+                             double factor, double tol, long max_iter, long max_rows, double eta, double* noise_dev, long* iterations,
+                             long* products, int* status) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_device: bad n_bodies / n_b");
+  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_lanczos_device: the resident configuration does not hold n_bodies x n_b blobs");
+  if (!Linv_dev || !Lchol_dev || !z_dev || !noise_dev || !iterations || !status) return fail(RMB_ERR_ARG, "null pointer");
+  if (max_rows < 2 || max_rows > 254 || max_iter < 1 || !(tol >= 0.0)) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_device: need 2 <= max_rows <= 254, max_iter >= 1, tol >= 0");
+  RMB_HIP(hipSetDevice(c->device));
+  const long nn = 3 * n_b, n3 = 3 * c->n, ldv = n3, cap = max_rows;
+  if (!c->gmres_ws) c->gmres_ws = new rmb_gmres_ws();
+  rmb_gmres_ws* ws = (rmb_gmres_ws*)c->gmres_ws;
+  const size_t col_row = (size_t)(cap + 2);
+  const size_t dev_doubles = (size_t)(cap + 1) * n3 + (size_t)2 * n3 + (size_t)cap * col_row;
+  if (int rc = ws->dev.reserve(dev_doubles * sizeof(double))) return rc;
+  const size_t map_doubles = (size_t)cap * col_row + 256 + 8;
+  if (map_doubles * sizeof(double) > ws->mapped.cap) {
+    if (ws->mapped.host) { RMB_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(ws->mapped.host); ws->mapped = Mapped(); }
+    RMB_HIP(hipHostMalloc(&ws->mapped.host, map_doubles * sizeof(double), hipHostMallocMapped));
+    RMB_HIP(hipHostGetDevicePointer(&ws->mapped.dev, ws->mapped.host, 0));
+    ws->mapped.cap = map_doubles * sizeof(double);
+  }
+  for (auto& e : ws->ev) if (!e) RMB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  double* V = (double*)ws->dev.p;
+  double* y = V + (size_t)(cap + 1) * n3;
+  double* w = y + n3;
+  double* cols = w + n3;
+  double* hcols = (double*)ws->mapped.host;
+  double* hcols_dev = (double*)ws->mapped.dev;
+  double* hcoef = hcols + (size_t)cap * col_row;
+  double* hcoef_dev = hcols_dev + (size_t)cap * col_row;
+  double* hscal = hcoef + 256;
+  double* hscal_dev = hcoef_dev + 256;
+  hipStream_t s = c->stream;
+  *status = 0;
+  *iterations = 0;
+  long n_products = 0;
+  auto give_up = [&](int st) -> int {
+    RMB_HIP(hipStreamSynchronize(s));
+    *status = st;
+    if (products) *products = n_products;
+    return 0;
+  };
+
+  hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(1024), 0, s, z_dev, n3, hscal_dev);
+  RMB_HIP(hipGetLastError());
+  RMB_HIP(hipStreamSynchronize(s));
+  const double v_norm = *hscal;
+  if (!(v_norm > 0.0) || !std::isfinite(v_norm)) return give_up(1);
+  hipLaunchKernelGGL(vec_div_kernel, dim3(blocks_of(n3)), dim3(kVecT), 0, s, V, z_dev, v_norm, n3);
+  RMB_HIP(hipGetLastError());
+
+  std::vector<double> h_diag, h_sup, coef, coef_old, work;
+  auto enqueue = [&](long i) -> int {
+    if (int rc = rmb_rigid_lanczos_step_device(c, n_bodies, n_b, Linv_dev, V, ldv, i, eta, y, w, cols + (size_t)i * col_row,
+                                               hcols_dev + (size_t)i * col_row))
+      return rc;
+    ++n_products;
+    RMB_HIP(hipEventRecord(ws->ev[i & 1], s));
+    return 0;
+  };
+  // host side of iteration i: 1 = stop (converged), 0 = go on, -1 = breakdown
+  long its = -1;
+  auto finish = [&](long i, int* verdict) -> int {
+    RMB_HIP(hipEventSynchronize(ws->ev[i & 1]));
+    const double hd = hcols[(size_t)i * col_row + i], hs = hcols[(size_t)i * col_row + i + 1];
+    if (!(hs > 0.0) || !std::isfinite(hs)) { *verdict = -1; return 0; }
+    h_diag.push_back(hd);
+    h_sup.push_back(hs);
+    coef.resize((size_t)i + 1);
+    if (!noise_coefficients(i + 1, h_diag.data(), h_sup.data(), v_norm * factor, coef.data(), work)) { *verdict = -1; return 0; }
+    if (i > 0) {
+      double old2 = 0.0, diff2 = 0.0;
+      for (long q = 0; q < i; ++q) { old2 += coef_old[q] * coef_old[q]; const double t = coef[q] - coef_old[q]; diff2 += t * t; }
+      diff2 += coef[i] * coef[i];
+      const double old_norm = sqrt(old2), diff = sqrt(diff2);
+      if (diff / (old_norm > 2.220446049250313e-16 ? old_norm : 2.220446049250313e-16) < tol) { its = i; *verdict = 1; return 0; }
+    }
+    coef_old = coef;
+    *verdict = 0;
+    return 0;
+  };
+
+  if (int rc = enqueue(0)) return rc;
+  long i = 0;
+  while (true) {
+    const long nxt = i + 1;
+    if (nxt < cap && nxt <= max_iter) {
+      if (int rc = enqueue(nxt)) return rc;        // the device goes on while the host looks at iteration i
+    }
+    int verdict = 0;
+    if (int rc = finish(i, &verdict)) return rc;
+    if (verdict < 0) return give_up(1);
+    if (verdict > 0) break;
+    if (nxt > max_iter) { its = max_iter; break; }
+    if (nxt >= cap) return give_up(2);
+    i = nxt;
+  }
+  // noise = blockdiag(L_b) V[:k]^T coef
+  const long k = (long)coef.size();
+  memcpy(hcoef, coef.data(), (size_t)k * sizeof(double));
+  hipLaunchKernelGGL(vec_zero_kernel, dim3(blocks_of(n3)), dim3(kVecT), 0, s, w, n3);
+  hipLaunchKernelGGL(vec_lincomb_kernel, dim3(blocks_of(n3)), dim3(kVecT), 0, s, w, V, ldv, hcoef_dev, (int)k, n3);
+  RMB_HIP(hipGetLastError());
+  const rmb_block l{Lchol_dev, nn * nn, nn, 1};
+  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, w, nullptr, 1.0, 0.0, noise_dev, 0.0, nullptr)) return rc;
+  RMB_HIP(hipStreamSynchronize(s));               // hcoef belongs to the next call from here on; a discarded step may still be running
+  *iterations = its;
   if (products) *products = n_products;
   return 0;
 }

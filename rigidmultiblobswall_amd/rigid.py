@@ -866,12 +866,16 @@ class RigidSuspension(object):
                                       L_mult=lambda x: self._blockdiag(x, "Lchol"), z=z, print_residual=print_residual,
                                       device=self.device, sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho(0))
 
-  native_lanczos = None       # None = automatic, False = never: one C call per Lanczos iteration (_lanczos_native)
+  native_lanczos = None       # None = automatic, False = never: the library's Lanczos step / loop (_lanczos_native)
+  native_lanczos_loop = None  # None = automatic, False = one C call per iteration under a Python loop instead of rmb_rigid_lanczos_device
+  lanczos_native_loop_calls = 0
   lanczos_native_rows = 48    # basis rows of the native loop; a forcing that needs more falls back to the generic loop
   lanczos_native_max_blobs = 8192   # above, the iteration it discards at the end (a whole pair sweep) costs more than the host waits it saves
 
   def _lanczos_native(self, z, factor, tol, print_residual, max_iter=1000):
-    """The preconditioned Lanczos forcing with ONE library call per iteration (rmb_rigid_lanczos_step_device: two block
+    """The preconditioned Lanczos forcing inside the library: the whole loop in one call (rmb_rigid_lanczos_device, the
+    default), or -- `native_lanczos_loop = False`, RMB_NATIVE_LANCZOS_LOOP=0, print_residual -- the loop below with
+    ONE library call per iteration (rmb_rigid_lanczos_step_device: two block
     launches around the pair sweep + the fused Gram-Schmidt, which also stores h_ii and h_{i+1,i} into mapped host
     memory), the host side (the small tridiagonal eigenproblem and the reference's stopping rule,
     stochastic_forcing.py:239-255) running ONE ITERATION LATE -- so the device never waits for numpy.  Same iterates,
@@ -888,6 +892,19 @@ class RigidSuspension(object):
       return None
     g = self.groups[0]
     n3, cap = 3 * self.n_blobs, int(self.lanczos_native_rows)
+    if not g.Linv.is_contiguous():
+      g.Linv = g.Linv.contiguous()
+    loop = self.native_lanczos_loop
+    if os.environ.get("RMB_NATIVE_LANCZOS_LOOP", "") == "0":
+      loop = False
+    if loop is not False and not print_residual and 2 <= cap <= 254 and g.Lchol.is_contiguous():
+      # the loop itself inside the library (rmb_rigid_lanczos_device): no Python between the iterations
+      zt = torch.as_tensor(z, dtype=torch.float64, device=self.device).reshape(-1).contiguous()
+      noise, its, products = self.ctx.rigid_lanczos_device(g.Linv, g.Lchol, zt, factor, tol, max_iter, cap, self.eta)
+      self.matvec_count += products
+      self.sweep_count += products
+      self.lanczos_native_loop_calls += 1
+      return None if noise is None else (noise, its)
     ws = getattr(self, "_lanczos_ws", None)
     if ws is None or ws["n3"] != n3 or ws["cap"] != cap:
       from .context import MappedHostArray

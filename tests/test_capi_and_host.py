@@ -112,3 +112,52 @@ def test_multi_engine_and_device_selection_fail_loudly_without_a_gpu(monkeypatch
   from rigidmultiblobswall_amd.multi import MultiContext
   with pytest.raises(_lib.RmbError):
     MultiContext([0, 1])
+
+
+def test_library_tridiagonal_eigen_solver_matches_lapack():
+  """rmb_lanczos_noise_coefficients (host function of the native Lanczos loop, csrc/rmb_gmres.hip: QL sweeps with implicit
+  shifts) against numpy's eigh on the matrices the loop meets: Lanczos tridiagonals of SPD operators of every size the
+  workspace allows, plus the awkward ones -- k = 1, decoupled blocks (zero off-diagonals), clustered and repeated
+  eigenvalues, a slightly indefinite matrix (negative eigenvalues are clipped as stochastic.py does)."""
+  import ctypes
+  from rigidmultiblobswall_amd import _lib
+  from rigidmultiblobswall_amd.stochastic import _noise_coefficients
+  lib = _lib.load()
+  dp = ctypes.POINTER(ctypes.c_double)
+
+  def native(h_diag, h_sup, scale):
+    k = len(h_diag)
+    d = np.ascontiguousarray(h_diag, dtype=np.float64)
+    e = np.ascontiguousarray(np.concatenate([h_sup, [0.0]])[:max(k, 1)], dtype=np.float64)
+    out = np.empty(k)
+    _lib.check(lib.rmb_lanczos_noise_coefficients(k, d.ctypes.data_as(dp), e.ctypes.data_as(dp), float(scale), out.ctypes.data_as(dp)))
+    return out
+
+  rng = np.random.RandomState(4)
+  cases = []
+  for n in (1, 2, 3, 7, 20, 48, 120, 254):
+    # a real Lanczos run on an SPD matrix with a wide spectrum
+    m = max(n, 4) + 6
+    Q, _ = np.linalg.qr(rng.randn(m, m))
+    A = (Q * np.logspace(-4, 1, m)) @ Q.T
+    v = rng.randn(m); v /= np.linalg.norm(v)
+    V, hd, hs = [v], [], []
+    for i in range(n):
+      w = A @ V[i] - (hs[i - 1] * V[i - 1] if i else 0.0)
+      hd.append(float(w @ V[i])); w = w - hd[-1] * V[i]
+      for u in V: w = w - (w @ u) * u
+      hs.append(float(np.linalg.norm(w)))
+      if hs[-1] < 1e-13 or len(V) == m: break
+      V.append(w / hs[-1])
+    cases.append((hd, hs[:len(hd)]))
+  cases.append(([2.0, 3.0, 5.0, 7.0], [0.0, 0.0, 0.0, 0.0]))                        # diagonal
+  cases.append(([1.0, 1.0, 1.0, 1.0, 1.0], [0.5, 0.0, 0.5, 1e-9, 0.0]))             # decoupled blocks, repeated eigenvalues
+  cases.append(([1.0] * 30, [1e-7] * 30))                                            # one tight cluster
+  cases.append(([1.0, -0.01, 2.0], [0.1, 0.2, 0.0]))                                 # indefinite: clipped
+  for hd, hs in cases:
+    k = len(hd)
+    got = native(hd, hs[:max(k - 1, 0)], 1.7)
+    ref = _noise_coefficients(hd, list(hs) + [0.0], k, 1.7)
+    assert np.linalg.norm(got - ref) <= 1e-13 * max(np.linalg.norm(ref), 1e-300) + 1e-15, (k, np.linalg.norm(got - ref), np.linalg.norm(ref))
+  with pytest.raises(_lib.RmbError):
+    native([], [], 1.0)

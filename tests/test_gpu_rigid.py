@@ -515,37 +515,56 @@ def test_native_loops_cover_the_references_42_blob_shells():
     fa, ia = nat.stochastic_forcing(z, 1.3, tol=1e-8)
     fb, ib = ref.stochastic_forcing(z, 1.3, tol=1e-8)
     assert ia == ib and rel_err(fa.cpu().numpy(), fb.cpu().numpy()) < 1e-10, (ia, ib)
-    assert nat._lanczos_ws is not None and getattr(ref, "_lanczos_ws", None) is None
+    assert nat.lanczos_native_loop_calls == 1 and ref.lanczos_native_loop_calls == 0
   finally:
     nat.close(); ref.close()
 
 
 def test_native_lanczos_loop_equals_the_generic_one():
-  """RigidSuspension.stochastic_forcing through rmb_rigid_lanczos_step_device (one call per iteration, host one iteration
-  late, coefficients through mapped memory) against the generic coroutine loop: same iteration count, same noise to
-  rounding, at several tolerances; a workspace with too few basis rows falls back to the generic loop."""
+  """RigidSuspension.stochastic_forcing three ways: the whole loop inside the library (rmb_rigid_lanczos_device: tridiagonal
+  eigen-solve and stopping rule in C, one iteration behind the device), one rmb_rigid_lanczos_step_device call per iteration
+  under the Python loop (coefficients through mapped memory), and the generic coroutine loop: same iteration count, same
+  noise to rounding, at several tolerances, with an iteration cap; a workspace with too few basis rows hands the forcing
+  back to the generic loop from either native path."""
   import torch
   nat, _, _ = _shell_suspension(40)
+  stp, _, _ = _shell_suspension(40)
   gen, _, _ = _shell_suspension(40)
+  stp.native_lanczos_loop = False
   gen.native_lanczos = False
   rng = np.random.RandomState(11)
   try:
     for tol, factor in ((1e-3, 1.0), (1e-6, 0.37), (1e-10, 2.5)):
       z = torch.as_tensor(rng.randn(3 * nat.n_blobs), device="cuda:0")
-      m0 = nat.matvec_count
+      m0, m1, calls = nat.matvec_count, stp.matvec_count, nat.lanczos_native_loop_calls
       a, ia = nat.stochastic_forcing(z, factor, tol=tol)
+      s_, is_ = stp.stochastic_forcing(z, factor, tol=tol)
       b, ib = gen.stochastic_forcing(z, factor, tol=tol)
-      assert ia == ib and ia >= 2, (tol, ia, ib)
+      assert ia == ib == is_ and ia >= 2, (tol, ia, is_, ib)
       assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11, (tol, rel_err(a.cpu().numpy(), b.cpu().numpy()))
+      assert rel_err(s_.cpu().numpy(), b.cpu().numpy()) < 1e-11
+      assert rel_err(a.cpu().numpy(), s_.cpu().numpy()) < 1e-12            # same device work, eigen-solvers differ in rounding
       assert nat.matvec_count - m0 in (ia + 1, ia + 2)          # its + 1 products as the generic loop, + the discarded one
-      assert nat._lanczos_ws is not None
-    nat.lanczos_native_rows = 3
+      assert stp.matvec_count - m1 in (ia + 1, ia + 2)
+      assert nat.lanczos_native_loop_calls == calls + 1 and stp.lanczos_native_loop_calls == 0
+      assert stp._lanczos_ws is not None and getattr(nat, "_lanczos_ws", None) is None
+    # the defining identity on the library's loop alone: with w = L^-1 noise = (P^T M P)^{1/2} z, |w|^2 = (P z).M.(P z), P = L^-T
+    z = torch.as_tensor(rng.randn(3 * nat.n_blobs), device="cuda:0")
+    a, ia = nat.stochastic_forcing(z, 1.0, tol=1e-10)
+    w = nat._blockdiag(a, "Linv")
+    Pz = nat._blockdiag(z, "Linv", transpose=True)
+    zMz = float(torch.dot(Pz, nat.ctx.matvec_device("tt", Pz.contiguous(), nat.eta)))
+    assert abs(float(torch.dot(w, w)) / zMz - 1.0) < 1e-8, float(torch.dot(w, w)) / zMz - 1.0
+    # too few basis rows: both native paths hand the forcing back to the generic loop
+    for s in (nat, stp):
+      s.lanczos_native_rows = 3
     z = torch.as_tensor(rng.randn(3 * nat.n_blobs), device="cuda:0")
     a, ia = nat.stochastic_forcing(z, 1.0, tol=1e-8)
+    s_, is_ = stp.stochastic_forcing(z, 1.0, tol=1e-8)
     b, ib = gen.stochastic_forcing(z, 1.0, tol=1e-8)
-    assert ia == ib and ia > 3 and rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
+    assert ia == ib == is_ and ia > 3 and rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11 and rel_err(s_.cpu().numpy(), b.cpu().numpy()) < 1e-11
   finally:
-    nat.close(); gen.close()
+    nat.close(); stp.close(); gen.close()
 
 
 def test_captured_arnoldi_iterations_with_mixed_shapes_and_prescribed_bodies():
