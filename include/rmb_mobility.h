@@ -359,6 +359,12 @@ int rmb_blob_blob_force(rmb_ctx* ctx, double repulsion_strength, double debye_le
                         double* out_host);
 int rmb_blob_blob_force_device(rmb_ctx* ctx, double repulsion_strength, double debye_length,
                                double blob_radius, double* out_dev);
+/* One-blob forces of the rigid-multiblob driver (multi_bodies/multi_bodies_functions.py:153-188, `blob_external_force`):
+ * f = (0, 0, -weight + wall repulsion), wall repulsion = (eps_wall / debye_wall) exp(-(h - a) / debye_wall) above contact
+ * (h > a), eps_wall / debye_wall below; r_dev: n x 3 raw coordinates (the caller's, not the resident ones); accumulate != 0
+ * adds to out_dev's z entries (e.g. on top of rmb_blob_blob_force_device's result), 0 overwrites all 3 n entries. */
+int rmb_one_blob_force_device(rmb_ctx* ctx, long n, const double* r_dev, double blob_radius, double weight, double eps_wall,
+                              double debye_wall, int accumulate, double* out_dev);
 /* Pair shard `shard` of `nshards` of the forces (each unordered pair once, F_ji = -F_ij) into a full-length partial
  * (n,3): the sum over shards is rmb_blob_blob_force_device's result (all-reduce on several GPUs).  Atomic flushes
  * whatever "deterministic" says. */

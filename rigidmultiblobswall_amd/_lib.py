@@ -72,6 +72,8 @@ SYMBOLS = {
                                                       ctypes.c_double, ctypes.c_long, ctypes.c_long]),
     "rmb_blob_blob_force": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "rmb_blob_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "rmb_one_blob_force_device": (ctypes.c_int, [_vp, ctypes.c_long, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                                ctypes.c_int, _vp]),
     "rmb_blob_blob_force_pairshard_device": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp,
                                                             ctypes.c_long, ctypes.c_long]),
     "rmb_blob_blob_force_radii": (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _vp]),

@@ -412,6 +412,21 @@ class MobilityContext(object):
                                                     float(blob_radius), ctypes.c_void_p(out.data_ptr())))
     return out
 
+  def one_blob_force_device(self, r, blob_radius, weight, eps_wall, debye_wall, out=None):
+    """(0, 0, -weight + wall repulsion) per blob on the caller's coordinates r (n x 3 CUDA tensor; rmb_one_blob_force_device);
+    `out` given = accumulate into it, None = a new tensor."""
+    import torch
+    assert _is_torch_cuda(r) and r.is_contiguous() and r.dtype == torch.float64
+    n = r.numel() // 3
+    acc = out is not None
+    if out is None:
+      out = torch.empty(3 * n, dtype=torch.float64, device=r.device)
+    assert out.is_contiguous() and out.numel() == 3 * n
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_one_blob_force_device(self._h, n, ctypes.c_void_p(r.data_ptr()), float(blob_radius), float(weight), float(eps_wall),
+                                                   float(debye_wall) if eps_wall != 0.0 else 1.0, 1 if acc else 0, ctypes.c_void_p(out.data_ptr())))
+    return out
+
   def blob_blob_force_pairshard_device(self, repulsion_strength, debye_length, blob_radius, shard, nshards, out=None, device=None):
     """Contribution of pair shard `shard` of `nshards` to the forces on ALL blobs (3n entries; sum over shards = forces)."""
     import torch

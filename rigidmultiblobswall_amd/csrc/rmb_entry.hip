@@ -159,7 +159,29 @@ int aux_stage(rmb_ctx* c, int n, const double* const* host, const size_t* bytes,
     dev[k] = (const double*)c->st[slot[k]].p;
   }
   return 0;
-}}  // namespace
+}
+
+// One-blob forces of the rigid-multiblob driver (multi_bodies/multi_bodies_functions.py:153-188): weight along -z and the
+// screened repulsion from the wall, f_z = -weight + (eps_w / b_w) exp(-(h - a) / b_w) for h > a, -weight + eps_w / b_w
+// at contact.  One thread per blob, on the caller's own coordinates (no clamp).
+__global__ __launch_bounds__(256) void one_blob_force_kernel(const double* r, long n, double a, double weight, double eps_wall,
+                                                             double debye_wall, int accumulate, double* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double fz = -weight;
+  if (eps_wall != 0.0) {
+    const double h = r[3 * i + 2], e = eps_wall / debye_wall;
+    fz = __dadd_rn(fz, h > a ? __dmul_rn(e, exp(-(h - a) / debye_wall)) : e);      // (no contraction: the bits of the tensor formula)
+  }
+  if (accumulate) {
+    out[3 * i + 2] += fz;
+  } else {
+    out[3 * i] = 0.0;
+    out[3 * i + 1] = 0.0;
+    out[3 * i + 2] = fz;
+  }
+}
+}  // namespace
 
 }  // namespace rmbi
 
@@ -346,6 +368,19 @@ int rmb_last_host_timing(rmb_ctx* c, double* us4) {
 
 int rmb_blob_blob_force_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out) {
   return force_device_impl(c, eps, b, blob_radius, out);
+}
+
+int rmb_one_blob_force_device(rmb_ctx* c, long n, const double* r_dev, double blob_radius, double weight, double eps_wall,
+                              double debye_wall, int accumulate, double* out_dev) {
+  if (!c) return fail(RMB_ERR_ARG, "null context");
+  if (n < 0 || (n > 0 && (!r_dev || !out_dev))) return fail(RMB_ERR_ARG, "rmb_one_blob_force_device: bad n / null pointer");
+  if (eps_wall != 0.0 && !(debye_wall > 0.0)) return fail(RMB_ERR_ARG, "rmb_one_blob_force_device: debye_wall must be positive");
+  if (n == 0) return 0;
+  RMB_HIP(hipSetDevice(c->device));
+  hipLaunchKernelGGL(one_blob_force_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, r_dev, n, blob_radius, weight,
+                     eps_wall, debye_wall, accumulate, out_dev);
+  RMB_HIP(hipGetLastError());
+  return 0;
 }
 
 int rmb_blob_blob_force_pairshard_device(rmb_ctx* c, double eps, double b, double blob_radius, double* out, long shard,

@@ -224,6 +224,16 @@ class RigidIntegrator(object):
   # ---- forces ---------------------------------------------------------------------------------------
   def _blob_forces(self, r):
     """One-blob forces (multi_bodies_functions.py:153-188) + blob-blob repulsion (forces_numba.py:12-55)."""
+    helper = self.susp._native_blocks()
+    if helper is not None and helper is self.susp.ctx and r.is_contiguous() and r.dtype == torch.float64:
+      # two launches: the pair repulsion, then weight + wall repulsion added to its z entries (rmb_one_blob_force_device)
+      f = None
+      if self.repulsion_strength != 0.0:
+        helper.set_positions(r.view(-1), self.a, self.periodic_length, False)   # true heights, no clamp
+        f = helper.blob_blob_force_device(self.repulsion_strength, self.debye_length, self.a)
+        helper.set_positions(self.susp.r_dev, self.a, self.periodic_length, self.susp.wall)  # back to the mobility view
+      return helper.one_blob_force_device(r, self.a, self.g * self.blob_mass, self.repulsion_strength_wall, self.debye_length_wall,
+                                          out=f).view(-1, 3)
     f = torch.zeros_like(r)
     f[:, 2] = -self.g * self.blob_mass
     if self.repulsion_strength_wall != 0.0:

@@ -165,3 +165,37 @@ def test_gpu_stack_equals_oracle_backed_stack_on_a_mid_size_suspension(oracle):
   assert np.abs(res[0][0] - res[1][0]).max() < 1e-6 * scale
   assert np.abs(res[0][1] - res[1][1]).max() < 1e-7
   assert abs(res[0][2] - res[1][2]) <= 2 and res[0][3] == res[1][3]
+
+
+def test_blob_forces_in_two_launches_equal_the_tensor_formula():
+  """_blob_forces through the library (pair repulsion, then rmb_one_blob_force_device adding weight and wall repulsion to its
+  z entries: multi_bodies_functions.py:153-188) against the tensor formula it replaces, to the last bit or two (torch divides
+  by a scalar through its reciprocal) -- blobs below contact (h < a) and far above included -- with and without either
+  repulsion, and on its own (overwrite)."""
+  from rigidmultiblobswall_amd import MobilityContext
+  from rigidmultiblobswall_amd.rigid_integrator import RigidIntegrator
+  nb = 20
+  shell, a, loc, quat = _suspension(nb, 6)
+  loc = loc.copy()
+  loc[0, 2] = 0.85            # lowest blobs of this shell end up below z = a
+  loc[1, 2] = 9.0
+  nat = RigidIntegrator([shell] * nb, loc, quat, "deterministic_forward_euler", a, 0.957e-3, tolerance=1e-6, device="cuda:0")
+  ref = RigidIntegrator([shell] * nb, loc, quat, "deterministic_forward_euler", a, 0.957e-3, tolerance=1e-6, device="cuda:0")
+  ref.susp.native_helpers = False
+  try:
+    r = nat.susp.r_dev.view(-1, 3)
+    assert float(r[:, 2].min()) < a < float(r[:, 2].max())
+    for g_, ew, eb in ((0.0024892 * 12, 0.0165677856, 0.0165677856), (0.03, 0.0, 0.0165677856), (0.03, 0.0165677856, 0.0), (0.0, 0.0, 0.0)):
+      for it in (nat, ref):
+        it.g, it.repulsion_strength_wall, it.debye_length_wall, it.repulsion_strength, it.debye_length = g_, ew, 0.0656, eb, 0.0656
+      fa, fb = nat._blob_forces(r), ref._blob_forces(ref.susp.r_dev.view(-1, 3))
+      assert fa.shape == fb.shape == (12 * nb, 3)
+      assert float((fa - fb).abs().max()) <= 1e-15 * max(float(fb.abs().max()), 1e-300), (g_, ew, eb, float((fa - fb).abs().max()))
+    ctx = MobilityContext(0)
+    out = ctx.one_blob_force_device(r.contiguous(), a, 0.5, 0.2, 0.1)
+    h = r[:, 2]
+    want = -0.5 + torch.where(h > a, 2.0 * torch.exp(-(h - a) / 0.1), torch.full_like(h, 2.0))
+    assert float((out.view(-1, 3)[:, 2] - want).abs().max()) <= 4e-16 * float(want.abs().max()) and float(out.view(-1, 3)[:, :2].abs().max()) == 0.0
+    ctx.close()
+  finally:
+    nat.close(); ref.close()

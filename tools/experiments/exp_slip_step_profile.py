@@ -23,4 +23,5 @@ print("%s, %d shells: %.3f ms per step (%.1f GMRES, %.1f Lanczos iterations per 
 pr = cProfile.Profile(); pr.enable()
 for step in range(24, 44): integ.advance_time_step(0.002, step=step)
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
