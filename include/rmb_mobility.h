@@ -320,7 +320,7 @@ int rmb_rigid_gmres_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* 
  * workspace may hold (2 .. 254).  *status: 0 = noise_dev written, *iterations as the reference counts them; 1 = exact
  * breakdown / eigen-solve failure, 2 = more than max_rows basis vectors needed -- then nothing is written, the stream is
  * drained and the caller runs its general loop.  *products = pair sweeps enqueued (iterations + 1, + 1 discarded).
- * Synchronous. */
+ * Returns when noise_dev is enqueued on the context's stream and every scalar is final. */
 int rmb_rigid_lanczos_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Linv_dev, const double* Lchol_dev,
                              const double* z_dev, double factor, double tol, long max_iter, long max_rows, double eta,
                              double* noise_dev, long* iterations, long* products, int* status);

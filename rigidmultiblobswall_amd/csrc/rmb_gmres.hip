@@ -341,7 +341,8 @@ int rmb_rigid_gmres_device(rmb_ctx* c, long n_bodies, long n_b, const double* A1
       }
       hipLaunchKernelGGL(vec_lincomb_kernel, dim3(blocks_of(n)), dim3(kVecT), 0, s, y, V, ldv, hcoef_dev, (int)k_used, n);
       RMB_HIP(hipGetLastError());
-      RMB_HIP(hipStreamSynchronize(s));         // hcoef is rewritten by the next cycle: the kernel must have read it
+      // (no wait here: the host writes hcoef again only after it has waited for an event of a LATER step of this stream --
+      //  of the next cycle, or of the next call on this context -- and by then this kernel has run)
     }
     if (res > tol && its < maxiter) {           // restart: true residual
       if (int rc = precondition(y, z)) return rc;
@@ -488,7 +489,8 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
   RMB_HIP(hipGetLastError());
   const rmb_block l{Lchol_dev, nn * nn, nn, 1};
   if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, w, nullptr, 1.0, 0.0, noise_dev, 0.0, nullptr)) return rc;
-  RMB_HIP(hipStreamSynchronize(s));               // hcoef belongs to the next call from here on; a discarded step may still be running
+  // (no wait: whoever writes hcoef next -- this entry or rmb_rigid_gmres_device -- has by then waited for an event recorded
+  //  later on this stream; noise_dev is enqueued, the scalars are final)
   *iterations = its;
   if (products) *products = n_products;
   return 0;
