@@ -147,6 +147,10 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *   "gmres_fuse_pc"   [1]  rmb_rigid_gmres_device: the last launch of an Arnoldi step (normalisation, workgroup = body) also applies
  *                          the block-diagonal preconditioner to the vector it has just normalised, so every step but the first
  *                          of a restart cycle is six launches instead of seven; 0 = separate launches (same arithmetic)
+ *                          Also governs rmb_rigid_lanczos_device (its normalisation launch applies L_b^-T for the next step)
+ *   "lanczos_fuse_finish" [1]  rmb_rigid_lanczos_step_device / rmb_rigid_lanczos_device: the sweep leaves its raw sums and ONE
+ *                          launch (workgroup = body) finishes them and multiplies by L_b^-1; 0 = finalize and block product as
+ *                          two launches (same arithmetic)
  *   "sym_wps"         [0]  symmetric kernels: cap on resident workgroups per CU (0 = occupancy limit)
  *   "sym_pin"         [1]  symmetric kernels: pad dynamic LDS so that residency is exactly that number
  *   "wave_clock"      [0]  1 = stamp every wave's start / end (rmb_wave_clock_collect); schedule diagnostics

@@ -1,0 +1,84 @@
+// block_rows.h -- one batch entry's two-by-two block matvec with the operand in LDS: shared by the batched block kernel and
+// the fused Krylov-step kernels (rmb_krylov.hip, rmb_rigid.hip).  Device code, gfx950.
+#pragma once
+#include "rmb_internal.h"
+
+namespace rmbi {
+
+// (block_apply_kernel, ortho_normalise_pc_kernel, lanczos_finish_kernel)
+// Two ways to walk a block.  THREAD = ROW: a thread runs along its row; right for narrow blocks (the 6 columns of K, A12)
+// and for blocks of up to 96 columns, where every row a workgroup touches stays in the CU's cache.  WAVE = ROW: the lanes
+// of a wave take the columns 64 at a time (coalesced when the row is contiguous) and a butterfly sums them; right for wide
+// blocks -- the 126 x 126 blocks of the reference's 42-blob shells, where thread = row makes every load instruction touch 64
+// different cache lines -- and for the few long rows of K^T / A21 (6 rows of 3 n_b entries).  Four rows per wave are loaded
+// before the first butterfly so that their loads are in flight together.
+constexpr long kWaveRowMinCols = 97;
+
+__host__ __device__ inline bool wave_rows(const BlockRef& m, long rows, long cols) {
+  return m.p && cols >= kWaveRowMinCols && (m.cs == 1 || rows <= 8);
+}
+
+// xl: operand (c1 then c2 entries); yl: r1 + r2 doubles of LDS (only touched when a block is walked wave = row);
+// store(row, sum) is called once per row by the thread that owns it
+template <class Store>
+__device__ inline void two_by_two_rows(const BlockRef& a11, const BlockRef& a12, const BlockRef& a21, const BlockRef& a22, long b, long r1,
+                                       long c1, long r2, long c2, const double* xl, double* yl, Store store) {
+  const long rows = r1 + r2;
+  const bool w11 = wave_rows(a11, r1, c1), w12 = wave_rows(a12, r1, c2), w21 = wave_rows(a21, r2, c1), w22 = wave_rows(a22, r2, c2);
+  const bool any_wave = w11 || w12 || w21 || w22;
+  if (any_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (long row0 = 4L * wave; row0 < rows; row0 += 4L * n_waves) {
+      double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long row = row0 + q;
+        if (row < rows) {
+          const bool top = row < r1;
+          const long r = top ? row : row - r1;
+          const BlockRef& left = top ? a11 : a21;
+          const BlockRef& right = top ? a12 : a22;
+          if (top ? w11 : w21) {
+            const double* m = left.p + b * left.bs + r * left.rs;
+            for (long k = lane; k < c1; k += 64) s[q] += m[k * left.cs] * xl[k];
+          }
+          if (top ? w12 : w22) {
+            const double* m = right.p + b * right.bs + r * right.rs;
+            for (long k = lane; k < c2; k += 64) s[q] += m[k * right.cs] * xl[c1 + k];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_xor(s[q], off, 64);
+        if (lane == 0 && row0 + q < rows) yl[row0 + q] = s[q];
+      }
+    }
+    __syncthreads();
+  }
+  for (long row = threadIdx.x; row < rows; row += blockDim.x) {
+    const bool top = row < r1;
+    const long r = top ? row : row - r1;
+    const BlockRef& left = top ? a11 : a21;
+    const BlockRef& right = top ? a12 : a22;
+    double sum = any_wave ? yl[row] : 0.0;
+    if (left.p && !(top ? w11 : w21)) {
+      const double* m = left.p + b * left.bs + r * left.rs;
+      for (long k = 0; k < c1; ++k) sum += m[k * left.cs] * xl[k];
+    }
+    if (right.p && !(top ? w12 : w22)) {
+      const double* m = right.p + b * right.bs + r * right.rs;
+      for (long k = 0; k < c2; ++k) sum += m[k * right.cs] * xl[c1 + k];
+    }
+    store(row, sum);
+  }
+}
+
+// threads of a workgroup that runs two_by_two_rows
+inline unsigned two_by_two_threads(long rows, bool any_wave) {
+  if (any_wave) return rows > 64 ? 1024u : 256u;
+  return rows <= 64 ? 64u : (rows <= 128 ? 128u : 256u);
+}
+
+}  // namespace rmbi

@@ -396,7 +396,7 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
   if (!c->gmres_ws) c->gmres_ws = new rmb_gmres_ws();
   rmb_gmres_ws* ws = (rmb_gmres_ws*)c->gmres_ws;
   const size_t col_row = (size_t)(cap + 2);
-  const size_t dev_doubles = (size_t)(cap + 1) * n3 + (size_t)2 * n3 + (size_t)cap * col_row;
+  const size_t dev_doubles = (size_t)(cap + 1) * n3 + (size_t)3 * n3 + (size_t)cap * col_row;
   if (int rc = ws->dev.reserve(dev_doubles * sizeof(double))) return rc;
   const size_t map_doubles = (size_t)cap * col_row + 256 + 8;
   if (map_doubles * sizeof(double) > ws->mapped.cap) {
@@ -407,9 +407,10 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
   }
   for (auto& e : ws->ev) if (!e) RMB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   double* V = (double*)ws->dev.p;
-  double* y = V + (size_t)(cap + 1) * n3;
-  double* w = y + n3;
-  double* cols = w + n3;
+  double* y = V + (size_t)(cap + 1) * n3;          // P v_i
+  double* w = y + n3;                              // the sweep's result / the final combination
+  double* d = w + n3;                              // P^T M P v_i, orthogonalised in place
+  double* cols = d + n3;
   double* hcols = (double*)ws->mapped.host;
   double* hcols_dev = (double*)ws->mapped.dev;
   double* hcoef = hcols + (size_t)cap * col_row;
@@ -436,9 +437,11 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
   RMB_HIP(hipGetLastError());
 
   std::vector<double> h_diag, h_sup, coef, coef_old, work;
+  const bool fuse_next = c->opt_gmres_fuse_pc != 0 && nn <= 96;      // (as in rmb_rigid_gmres_device)
   auto enqueue = [&](long i) -> int {
-    if (int rc = rmb_rigid_lanczos_step_device(c, n_bodies, n_b, Linv_dev, V, ldv, i, eta, y, w, cols + (size_t)i * col_row,
-                                               hcols_dev + (size_t)i * col_row))
+    // (from the second step on, P v_i was left in y by the previous step's normalisation launch: six launches per iteration)
+    if (int rc = lanczos_step_impl(c, n_bodies, n_b, Linv_dev, V, ldv, i, eta, y, w, d, cols + (size_t)i * col_row,
+                                   hcols_dev + (size_t)i * col_row, fuse_next && i > 0, fuse_next))
       return rc;
     ++n_products;
     RMB_HIP(hipEventRecord(ws->ev[i & 1], s));

@@ -94,6 +94,7 @@ struct rmb_ctx {
   void* host_in = nullptr;       // ... and the same for its input vectors (two of them: RMB_TT_TR)
   double* host_in_dev = nullptr;
   size_t host_in_cap = 0;
+  long opt_lanczos_fuse_finish = 1; // rmb_rigid_lanczos_step_device: finalize of the sweep + L_b^-1 product in one launch
   long opt_gmres_fuse_pc = 1;       // rmb_rigid_gmres_device: the normalisation launch also applies the preconditioner for the next step
   long opt_host_zero_copy_in = 1;   // inputs of rmb_matvec through mapped memory + a pull kernel (sizes as host_zero_copy)
   long opt_host_zero_copy = 768 << 10;   // bytes (32 768 blobs: level at 43 000, +1 % at 1e5); 0 = always a device-to-host copy command
@@ -142,13 +143,20 @@ int default_ctx(rmb_ctx** out);   // call with g_default_mu held
 // ---- rmb_gmres.hip ----------------------------------------------------------------------------------------
 void gmres_release(rmb_ctx* c);
 // ---- rmb_krylov.hip / rmb_rigid.hip: pieces the native GMRES composes ------------------------------------------------
-// The preconditioner's four blocks of every body (contiguous (n_bodies, nn, nn), (n_bodies, nn, 6), (n_bodies, 6, nn),
-// (n_bodies, 6, 6)) and where z = P^-1 v goes: handed to the Gram-Schmidt step, its LAST launch (normalisation, workgroup =
-// body instead of chunk) also applies the blocks to the vector it has just normalised -- the next iteration's first launch.
-struct PcBlocks { long n_bodies, nn; const double *A11, *A12, *A21, *A22; double* z; };
+// Per-body blocks (the preconditioner's four of the saddle-point system, or L_b^-T alone for the Lanczos forcing: r2 = 0,
+// absent blocks with p = nullptr) and where z = blocks * v goes: handed to the Gram-Schmidt step, its LAST launch
+// (normalisation, workgroup = body instead of chunk) also applies the blocks to the vector it has just normalised -- the
+// next iteration's first launch.  The vector is laid out as [n_bodies x r1; n_bodies x r2].
+struct BlockRef { const double* p; long bs, rs, cs; };       // one batched block: entry b at p + b * bs, element (r, c) at + r * rs + c * cs
+struct PcBlocks { long n_bodies, r1, r2; BlockRef a11, a12, a21, a22; double* z; };      // square: r1 x r1, r1 x r2, r2 x r1, r2 x r2
 int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
                               double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc);
 // z_ready: z_dev already holds P^-1 v_j (the previous step's fused launch); fuse_pc: leave P^-1 v_{j+1} in z_dev
+// One step of the preconditioned Lanczos forcing.  pv: P v_i (input of the sweep; pv_ready: left there by the previous step's
+// fused launch), mw: the sweep's result, d: P^T M P v_i, the vector that is orthogonalised (d may be pv when fuse_next is
+// false); fuse_next: the normalisation launch also leaves P v_{i+1} in pv.
+int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i, double eta, double* pv_dev,
+                      double* mw_dev, double* d_dev, double* col_dev, double* col_mapped_dev, bool pv_ready, bool fuse_next);
 int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
                       const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j, double eta, double* z_dev, double* w_dev,
                       double* col_dev, double* col_mapped_dev, bool z_ready, bool fuse_pc);

@@ -17,6 +17,7 @@
 // loop AROUND the sweep costs several times the sweep (profiles/r4_gmres_graph.txt).  Every reduction runs in a fixed
 // order: results are bit-reproducible.
 #include "rmb_internal.h"
+#include "block_rows.h"
 
 #include <cmath>
 #include <cstring>
@@ -144,96 +145,20 @@ __global__ __launch_bounds__(kKrT) void ortho_normalise_kernel(const OrthoArgs a
   for (long e = threadIdx.x; e < len; e += kKrT) a.v_next[base + e] = a.w[base + e] * inv;
 }
 
-// ---- one batch entry's two-by-two block matvec, operand in LDS (block_apply_kernel, ortho_normalise_pc_kernel) --------
-// Two ways to walk a block.  THREAD = ROW: a thread runs along its row; right for narrow blocks (the 6 columns of K, A12)
-// and for blocks of up to 96 columns, where every row a workgroup touches stays in the CU's cache.  WAVE = ROW: the lanes
-// of a wave take the columns 64 at a time (coalesced when the row is contiguous) and a butterfly sums them; right for wide
-// blocks -- the 126 x 126 blocks of the reference's 42-blob shells, where thread = row makes every load instruction touch 64
-// different cache lines -- and for the few long rows of K^T / A21 (6 rows of 3 n_b entries).  Four rows per wave are loaded
-// before the first butterfly so that their loads are in flight together.
-struct BlockRef { const double* p; long bs, rs, cs; };
-constexpr long kWaveRowMinCols = 97;
-
-__host__ __device__ inline bool wave_rows(const BlockRef& m, long rows, long cols) {
-  return m.p && cols >= kWaveRowMinCols && (m.cs == 1 || rows <= 8);
-}
-
-// xl: operand (c1 then c2 entries); yl: r1 + r2 doubles of LDS (only touched when a block is walked wave = row);
-// store(row, sum) is called once per row by the thread that owns it
-template <class Store>
-__device__ inline void two_by_two_rows(const BlockRef& a11, const BlockRef& a12, const BlockRef& a21, const BlockRef& a22, long b, long r1,
-                                       long c1, long r2, long c2, const double* xl, double* yl, Store store) {
-  const long rows = r1 + r2;
-  const bool w11 = wave_rows(a11, r1, c1), w12 = wave_rows(a12, r1, c2), w21 = wave_rows(a21, r2, c1), w22 = wave_rows(a22, r2, c2);
-  const bool any_wave = w11 || w12 || w21 || w22;
-  if (any_wave) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    for (long row0 = 4L * wave; row0 < rows; row0 += 4L * n_waves) {
-      double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long row = row0 + q;
-        if (row < rows) {
-          const bool top = row < r1;
-          const long r = top ? row : row - r1;
-          const BlockRef& left = top ? a11 : a21;
-          const BlockRef& right = top ? a12 : a22;
-          if (top ? w11 : w21) {
-            const double* m = left.p + b * left.bs + r * left.rs;
-            for (long k = lane; k < c1; k += 64) s[q] += m[k * left.cs] * xl[k];
-          }
-          if (top ? w12 : w22) {
-            const double* m = right.p + b * right.bs + r * right.rs;
-            for (long k = lane; k < c2; k += 64) s[q] += m[k * right.cs] * xl[c1 + k];
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_xor(s[q], off, 64);
-        if (lane == 0 && row0 + q < rows) yl[row0 + q] = s[q];
-      }
-    }
-    __syncthreads();
-  }
-  for (long row = threadIdx.x; row < rows; row += blockDim.x) {
-    const bool top = row < r1;
-    const long r = top ? row : row - r1;
-    const BlockRef& left = top ? a11 : a21;
-    const BlockRef& right = top ? a12 : a22;
-    double sum = any_wave ? yl[row] : 0.0;
-    if (left.p && !(top ? w11 : w21)) {
-      const double* m = left.p + b * left.bs + r * left.rs;
-      for (long k = 0; k < c1; ++k) sum += m[k * left.cs] * xl[k];
-    }
-    if (right.p && !(top ? w12 : w22)) {
-      const double* m = right.p + b * right.bs + r * right.rs;
-      for (long k = 0; k < c2; ++k) sum += m[k * right.cs] * xl[c1 + k];
-    }
-    store(row, sum);
-  }
-}
-
-// threads of a workgroup that runs two_by_two_rows
-inline unsigned two_by_two_threads(long rows, bool any_wave) {
-  if (any_wave) return rows > 64 ? 1024u : 256u;
-  return rows <= 64 ? 64u : (rows <= 128 ? 128u : 256u);
-}
-
-// The normalisation with the preconditioner fused in (rmb_rigid_gmres_device): workgroup = body.  Every workgroup re-sums the
-// chunk partials of |w|^2 (fixed order), normalises ITS slices of w -- the body's 3 n_b rows of the lambda part and its 6
-// rows of the U part: together the workgroups cover the whole vector -- into v_next, keeps them in LDS and applies the four
-// blocks of the body's [[M_b, -K], [-K^T, 0]]^-1 to them: z = P^-1 v_next, the first launch of the NEXT iteration.
+// The normalisation with the NEXT iteration's first launch fused in (rmb_rigid_gmres_device, rmb_rigid_lanczos_device):
+// workgroup = body.  Every workgroup re-sums the chunk partials of |w|^2 (fixed order), normalises ITS slices of w -- the
+// body's 3 n_b rows of the lambda part and, for the saddle-point system, its 6 rows of the U part: together the workgroups
+// cover the whole vector -- into v_next, keeps them in LDS and applies the body's blocks to them: z = P^-1 v_next with the
+// four blocks of [[M_b, -K], [-K^T, 0]]^-1 (GMRES), or z = L_b^-T v_next (Lanczos).
 struct NormPcArgs {
   OrthoArgs o;
-  long n_bodies, nn, n3;
-  const double *A11, *A12, *A21, *A22;
+  long n_bodies, r1, r2, n_top;      // the body's slices: r1 rows at b * r1, r2 rows at n_top + b * r2 (n_top = n_bodies * r1)
+  BlockRef a11, a12, a21, a22;
   double* z;
 };
 
 __global__ __launch_bounds__(1024) void ortho_normalise_pc_kernel(const NormPcArgs a) {
-  extern __shared__ double xl[];          // nn + 6: the body's slices of v_next; then nn + 6 row sums (two_by_two_rows)
+  extern __shared__ double xl[];          // r1 + r2: the body's slices of v_next; then r1 + r2 row sums (two_by_two_rows)
   __shared__ double nrm;
   const long b = blockIdx.x;
   if (threadIdx.x == 0) {
@@ -249,17 +174,16 @@ __global__ __launch_bounds__(1024) void ortho_normalise_pc_kernel(const NormPcAr
     for (long r = threadIdx.x; r < a.o.rows; r += blockDim.x) a.o.col_host[r] = a.o.col[r];
   __syncthreads();
   const double inv = 1.0 / nrm;
-  const long nn = a.nn;
-  for (long k = threadIdx.x; k < nn + 6; k += blockDim.x) {
-    const long e = k < nn ? b * nn + k : a.n3 + 6 * b + (k - nn);
+  const long r1 = a.r1, rows = a.r1 + a.r2;
+  for (long k = threadIdx.x; k < rows; k += blockDim.x) {
+    const long e = k < r1 ? b * r1 + k : a.n_top + a.r2 * b + (k - r1);
     const double v = a.o.w[e] * inv;
     a.o.v_next[e] = v;
     xl[k] = v;
   }
   __syncthreads();
-  const BlockRef a11{a.A11, nn * nn, nn, 1}, a12{a.A12, nn * 6, 6, 1}, a21{a.A21, 6 * nn, nn, 1}, a22{a.A22, 36, 6, 1};
-  two_by_two_rows(a11, a12, a21, a22, b, nn, nn, 6, 6, xl, xl + nn + 6,
-                  [&](long row, double sum) { a.z[row < nn ? b * nn + row : a.n3 + 6 * b + (row - nn)] = sum; });
+  two_by_two_rows(a.a11, a.a12, a.a21, a.a22, b, a.r1, a.r1, a.r2, a.r2, xl, xl + rows,
+                  [&](long row, double sum) { a.z[row < r1 ? b * r1 + row : a.n_top + a.r2 * b + (row - r1)] = sum; });
 }
 
 // (Round 5 measured the whole step in ONE workgroup for systems of up to 6144 unknowns -- workgroup barriers instead of
@@ -344,12 +268,13 @@ int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev
   hipLaunchKernelGGL(ortho_update_kernel<1>, grid, block, lds_wh, c->stream, a);
   hipLaunchKernelGGL(ortho_update_kernel<2>, grid, block, lds_wh, c->stream, a);
   if (pc) {
-    if (pc->n_bodies * (pc->nn + 6) != n) return fail(RMB_ERR_ARG, "krylov_orthogonalize_impl: the blocks do not cover the vector (internal)");
+    if (pc->n_bodies * (pc->r1 + pc->r2) != n) return fail(RMB_ERR_ARG, "krylov_orthogonalize_impl: the blocks do not cover the vector (internal)");
     NormPcArgs q;
-    q.o = a; q.n_bodies = pc->n_bodies; q.nn = pc->nn; q.n3 = pc->n_bodies * pc->nn;
-    q.A11 = pc->A11; q.A12 = pc->A12; q.A21 = pc->A21; q.A22 = pc->A22; q.z = pc->z;
-    const long rws = pc->nn + 6;
-    const unsigned threads = two_by_two_threads(rws, pc->nn >= kWaveRowMinCols);
+    q.o = a; q.n_bodies = pc->n_bodies; q.r1 = pc->r1; q.r2 = pc->r2; q.n_top = pc->n_bodies * pc->r1;
+    q.a11 = pc->a11; q.a12 = pc->a12; q.a21 = pc->a21; q.a22 = pc->a22; q.z = pc->z;
+    const long rws = pc->r1 + pc->r2;
+    const bool any_wave = wave_rows(q.a11, q.r1, q.r1) || wave_rows(q.a12, q.r1, q.r2) || wave_rows(q.a21, q.r2, q.r1) || wave_rows(q.a22, q.r2, q.r2);
+    const unsigned threads = two_by_two_threads(rws, any_wave);
     hipLaunchKernelGGL(ortho_normalise_pc_kernel, dim3((unsigned)pc->n_bodies), dim3(threads), (size_t)(2 * rws) * sizeof(double), c->stream, q);
   } else {
     hipLaunchKernelGGL(ortho_normalise_kernel, grid, block, 0, c->stream, a);

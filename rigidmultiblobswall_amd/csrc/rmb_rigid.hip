@@ -11,6 +11,7 @@
 //                                     [[M_b, -K], [-K^T, 0]]^-1 (multi_bodies.py:516-531 builds L and N once per step,
 //                                     :548-560 applies them); one workgroup per body, everything in LDS.
 #include "rmb_internal.h"
+#include "block_rows.h"
 
 #include <cmath>
 
@@ -428,7 +429,86 @@ __global__ __launch_bounds__(256) void rigid_operator_finish_kernel(const OpFinA
   }
 }
 
+// The Lanczos step's finishing launch: workgroup = body.  Thread l < n_b finishes blob i = body n_b + l as sym_finalize_kernel
+// does (self term of the B-damped input, scaling by b_i / (8 pi eta)) into LDS, then the workgroup multiplies the body's 3 n_b
+// entries by L_b^-1:  d = P^T (M pv),  P = blockdiag(L_b^-T) -- the sweep's finalize and the block product in one launch.
+struct LanFinArgs {
+  const double4* pos;
+  const double* x;        // the sweep's input (3N)
+  double* acc;            // [3][n_pad] raw sums of the symmetric tt sweep; re-zeroed here
+  BlockRef linv;          // (n_bodies, 3 n_b, 3 n_b)
+  double* out;            // 3N
+  long n, n_pad;
+  int n_b;
+  double prefactor;
+  rmb::PairConsts k;
+};
+
+template <bool WALL>
+__global__ __launch_bounds__(1024) void lanczos_finish_kernel(const LanFinArgs a) {
+  extern __shared__ double xl[];          // 3 n_b finished entries, then 3 n_b row sums (two_by_two_rows)
+  const long body = blockIdx.x;
+  const int l = threadIdx.x;
+  if (l < a.n_b) {
+    const long i = body * a.n_b + l;
+    rmb::Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
+    a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;     // ready for the next product
+    const double4 p = a.pos[i];
+    const double b = p.w;
+    rmb::self_term<rmb::KIND_TT, WALL>(a.k, p.z, a.x[3 * i] * b, a.x[3 * i + 1] * b, a.x[3 * i + 2] * b, 0, 0, 0, acc);
+    const double sc = a.prefactor * b;
+    xl[3 * l] = acc.x * sc; xl[3 * l + 1] = acc.y * sc; xl[3 * l + 2] = acc.z * sc;
+  }
+  __syncthreads();
+  const long nn = 3L * a.n_b;
+  const BlockRef none{nullptr, 0, 0, 0};
+  two_by_two_rows(a.linv, none, none, none, body, nn, nn, 0, 0, xl, xl + nn, [&](long row, double sum) { a.out[body * nn + row] = sum; });
+}
+
 }  // namespace
+
+int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i, double eta, double* pv_dev,
+                      double* mw_dev, double* d_dev, double* col_dev, double* col_mapped_dev, bool pv_ready, bool fuse_next) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1 || i < 0) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_step_device: bad n_bodies / n_b / i");
+  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_lanczos_step_device: the resident configuration does not hold n_bodies x n_b blobs");
+  if (!Linv_dev || !V_dev || !pv_dev || !mw_dev || !d_dev || !col_dev) return fail(RMB_ERR_ARG, "null pointer");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  const long nn = 3 * n_b, n = c->n, n3 = 3 * n;
+  if (ldv < n3) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_step_device: ldv < 3 N");
+  RMB_HIP(hipSetDevice(c->device));
+  const double* v = V_dev + i * ldv;
+  // pv = P v with P = blockdiag(L_b^-T): the transposed block is the same memory with the two strides exchanged
+  const rmb_block lt{Linv_dev, nn * nn, 1, nn}, l{Linv_dev, nn * nn, nn, 1};
+  if (!pv_ready)
+    if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &lt, nullptr, nullptr, nullptr, v, nullptr, 1.0, 0.0, pv_dev, 0.0, nullptr)) return rc;
+  // d = P^T (M pv)
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  if (c->opt_lanczos_fuse_finish && sym_applies(c) && !periodic && c->opt_deterministic == 0 && c->opt_precision == 64 && c->tgt_begin == 0 && c->tgt_end == n &&
+      n_b <= 256) {
+    // the pair sweep with the raw sums left in the accumulators, then ONE finishing launch (finalize + L_b^-1)
+    if (int rc = sym_device(c, rmb::KIND_TT, pv_dev, eta, mw_dev, 0, 1, false, true)) return rc;
+    LanFinArgs a;
+    a.pos = (const double4*)c->pos.p; a.x = pv_dev; a.acc = (double*)c->symbuf.p; a.linv = BlockRef{Linv_dev, nn * nn, nn, 1}; a.out = d_dev;
+    a.n = n; a.n_pad = 64 * ((n + 63) / 64); a.n_b = (int)n_b;
+    a.prefactor = 1.0 / (8.0 * M_PI * eta);
+    a.k = make_pair_consts(c->a);
+    unsigned threads = two_by_two_threads(nn, wave_rows(a.linv, nn, nn));
+    if (threads < (unsigned)(64 * ((n_b + 63) / 64))) threads = (unsigned)(64 * ((n_b + 63) / 64));
+    const size_t lds = (size_t)(2 * nn) * sizeof(double);
+    if (c->wall) hipLaunchKernelGGL(lanczos_finish_kernel<true>, dim3((unsigned)n_bodies), dim3(threads), lds, c->stream, a);
+    else         hipLaunchKernelGGL(lanczos_finish_kernel<false>, dim3((unsigned)n_bodies), dim3(threads), lds, c->stream, a);
+    RMB_HIP(hipGetLastError());
+  } else {
+    if (int rc = matvec_device_impl(c, rmb::KIND_TT, 0, pv_dev, nullptr, eta, mw_dev)) return rc;
+    if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, mw_dev, nullptr, 1.0, 0.0, d_dev, 0.0, nullptr)) return rc;
+  }
+  // full re-orthogonalisation against v_0 .. v_i: col[i] = h_ii, col[i + 1] = h_{i+1,i} (the other coefficients vanish to
+  // rounding with an orthonormal basis), v_{i+1} = d / |d| (and, fused, pv = P v_{i+1})
+  const BlockRef none{nullptr, 0, 0, 0};
+  const PcBlocks pc{n_bodies, nn, 0, {Linv_dev, nn * nn, 1, nn}, none, none, none, pv_dev};
+  return krylov_orthogonalize_impl(c, n3, i + 1, V_dev, ldv, d_dev, col_dev, V_dev + (i + 1) * ldv, col_mapped_dev, fuse_next ? &pc : nullptr);
+}
 
 int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
                       const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j, double eta, double* z_dev, double* w_dev,
@@ -447,7 +527,7 @@ int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev
   // w = A z: pair sweep + one finishing launch
   if (int rc = rmb_rigid_operator_device(c, n_bodies, n_b, K_dev, z_dev, eta, w_dev)) return rc;
   // two Gram-Schmidt passes against v_0 .. v_j, Hessenberg column, |w|, v_{j+1} (and, fused, z = P^-1 v_{j+1})
-  const PcBlocks pc{n_bodies, nn, A11_dev, A12_dev, A21_dev, A22_dev, z_dev};
+  const PcBlocks pc{n_bodies, nn, 6, {A11_dev, nn * nn, nn, 1}, {A12_dev, nn * 6, 6, 1}, {A21_dev, 6 * nn, nn, 1}, {A22_dev, 36, 6, 1}, z_dev};
   return krylov_orthogonalize_impl(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev, fuse_pc ? &pc : nullptr);
 }
 
@@ -557,22 +637,8 @@ int rmb_rigid_arnoldi_step_device(rmb_ctx* c, long n_bodies, long n_b, const dou
 
 int rmb_rigid_lanczos_step_device(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i,
                                   double eta, double* y_dev, double* w_dev, double* col_dev, double* col_mapped_dev) {
-  if (int rc = check_ready(c)) return rc;
-  if (n_bodies < 1 || n_b < 1 || i < 0) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_step_device: bad n_bodies / n_b / i");
-  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_lanczos_step_device: the resident configuration does not hold n_bodies x n_b blobs");
-  if (!Linv_dev || !V_dev || !y_dev || !w_dev || !col_dev) return fail(RMB_ERR_ARG, "null pointer");
-  const long nn = 3 * n_b, n3 = 3 * c->n;
-  if (ldv < n3) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_step_device: ldv < 3 N");
-  const double* v = V_dev + i * ldv;
-  // y = P v with P = blockdiag(L_b^-T): the transposed block is the same memory with the two strides exchanged
-  const rmb_block lt{Linv_dev, nn * nn, 1, nn}, l{Linv_dev, nn * nn, nn, 1};
-  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &lt, nullptr, nullptr, nullptr, v, nullptr, 1.0, 0.0, y_dev, 0.0, nullptr)) return rc;
-  // w = M y, then w <- P^T w (in y's place: y is free again)
-  if (int rc = matvec_device_impl(c, rmb::KIND_TT, 0, y_dev, nullptr, eta, w_dev)) return rc;
-  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, w_dev, nullptr, 1.0, 0.0, y_dev, 0.0, nullptr)) return rc;
-  // full re-orthogonalisation against v_0 .. v_i: col[i] = h_ii, col[i + 1] = h_{i+1,i} (the other coefficients vanish to
-  // rounding with an orthonormal basis), v_{i+1} = w / |w|
-  return rmb_krylov_orthogonalize2_device(c, n3, i + 1, V_dev, ldv, y_dev, col_dev, V_dev + (i + 1) * ldv, col_mapped_dev);
+  // y = P v_i, w = M y (or the raw sums of the sweep), then y <- P^T M y in y's place and its orthogonalisation
+  return lanczos_step_impl(c, n_bodies, n_b, Linv_dev, V_dev, ldv, i, eta, y_dev, w_dev, y_dev, col_dev, col_mapped_dev, false, false);
 }
 
 }  // extern "C"

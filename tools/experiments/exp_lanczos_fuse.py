@@ -1,0 +1,29 @@
+"""Same-run A/B of the Lanczos step's fused launches: "lanczos_fuse_finish" (finalize + L^-1 product) and "gmres_fuse_pc"
+(normalisation + next step's L^-T product) on small-deck forcings through rmb_rigid_lanczos_device."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from rigidmultiblobswall_amd import structures as st
+from rigidmultiblobswall_amd.rigid import RigidSuspension
+R, eta3 = 1.0155, 0.957e-3
+shell42 = np.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "g9_rigid_det_euler_42blob_shells.npz"))["vertex_shell42"]
+for nb, shell in ((64, st.icosahedron_shell(0.792079207921 * R)), (256, st.icosahedron_shell(0.792079207921 * R)), (32, shell42)):
+  a3 = st.min_blob_separation(shell) / 2
+  loc, quat, _ = st.roller_monolayer(nb, radius=R, seed=5)
+  rs = RigidSuspension([shell] * nb, loc, quat, a3, eta3, device=torch.device("cuda:0"))
+  rs.build_preconditioner()
+  z = torch.randn(3 * rs.n_blobs, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+  res, out = {}, {}
+  modes = ((0, 0), (1, 0), (0, 1), (1, 1))
+  for rnd in range(6):
+    for fin, nxt in (modes if rnd % 2 == 0 else modes[::-1]):
+      rs.ctx.set_option("lanczos_fuse_finish", fin); rs.ctx.set_option("gmres_fuse_pc", nxt)
+      for _ in range(20): rs.stochastic_forcing(z, 1.0, tol=1e-6)
+      torch.cuda.synchronize(); t0 = time.perf_counter()
+      for _ in range(100): noise, its = rs.stochastic_forcing(z, 1.0, tol=1e-6)
+      torch.cuda.synchronize()
+      res.setdefault((fin, nxt), []).append((time.perf_counter() - t0) / 100 * 1e3)
+      out[(fin, nxt)] = (noise.clone(), its)
+  base = out[(0, 0)][0]
+  print("bodies %4d x %d blobs, %d iterations: " % (nb, shell.shape[0], out[(0, 0)][1]) + "   ".join(
+      "finish %d next %d: %.3f ms (diff %.0e)" % (f, n, np.median(res[(f, n)]), float((out[(f, n)][0] - base).abs().max() / base.abs().max())) for f, n in modes), flush=True)
