@@ -475,6 +475,13 @@ def test_native_gmres_loop_equals_the_python_loop():
     assert inn["iterations"] == ip["iterations"] and rel_err(xn.cpu().numpy(), xp.cpu().numpy()) < 1e-8
     x0, i0 = nat.solve(torch.zeros(nat.size, dtype=torch.float64, device="cuda:0"), tol=1e-9)
     assert i0["iterations"] == 0 and float(x0.abs().max()) == 0.0
+    # the fused launch (normalisation + next step's preconditioner) off: same arithmetic in one launch more
+    nat.ctx.set_option("gmres_fuse_pc", 0)
+    xs, ins = nat.solve(rhs, tol=1e-9, restart=7)
+    nat.ctx.set_option("gmres_fuse_pc", 1)
+    xf, inf = nat.solve(rhs, tol=1e-9, restart=7)
+    assert ins["iterations"] == inf["iterations"] and rel_err(xs.cpu().numpy(), xf.cpu().numpy()) < 1e-9
+    assert np.allclose(ins["history"], inf["history"], rtol=1e-6, atol=1e-13)
   finally:
     nat.close(); pyl.close()
 
@@ -555,6 +562,14 @@ def test_native_lanczos_loop_equals_the_generic_one():
     Pz = nat._blockdiag(z, "Linv", transpose=True)
     zMz = float(torch.dot(Pz, nat.ctx.matvec_device("tt", Pz.contiguous(), nat.eta)))
     assert abs(float(torch.dot(w, w)) / zMz - 1.0) < 1e-8, float(torch.dot(w, w)) / zMz - 1.0
+    # the fused launches of the library's step off (finalize + L^-1, normalisation + next L^-T): same arithmetic
+    a0, i0 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
+    for key in ("lanczos_fuse_finish", "gmres_fuse_pc"):
+      nat.ctx.set_option(key, 0)
+    a1, i1 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
+    for key in ("lanczos_fuse_finish", "gmres_fuse_pc"):
+      nat.ctx.set_option(key, 1)
+    assert i0 == i1 == ia and rel_err(a0.cpu().numpy(), a1.cpu().numpy()) < 1e-13 and rel_err(a0.cpu().numpy(), a.cpu().numpy()) < 1e-13
     # too few basis rows: both native paths hand the forcing back to the generic loop
     for s in (nat, stp):
       s.lanczos_native_rows = 3
