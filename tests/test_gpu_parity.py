@@ -540,10 +540,12 @@ def test_large_linearity_symmetry_and_spot_check(Ctx, oracle, N):
   ctx.close()
 
 
-@pytest.mark.parametrize("N", [262144, 300007, 1000000])    # 300007: N % 64 = 39, a partial last tile
+# 300007: N % 64 = 39, a partial last tile;  2200007: past BASELINE's largest size -- 34 376 tiles, 3.8e10 rotation steps
+# (beyond 2^32), 2.4e12 pair evaluations, ~6.5 s per product
+@pytest.mark.parametrize("N", [262144, 300007, 1000000, 2200007])
 def test_baseline_full_sizes_spot_check_and_symmetry(Ctx, oracle, N):
-  """BASELINE.json configs[4] / configs[3] sizes on one GPU: oracle on a sample of targets (all N sources each),
-  reciprocity g.Mf = f.Mg, and the symmetric path against the one-sided sweep on the same sample."""
+  """BASELINE.json configs[4] / configs[3] sizes on one GPU (and one size beyond them): oracle on a sample of targets (all N
+  sources each), reciprocity g.Mf = f.Mg, and the symmetric path against the one-sided sweep on the same sample."""
   import torch
   r, f, eta, a = d2_cloud(N, seed=31)
   g = np.random.RandomState(32).randn(*f.shape)
