@@ -18,6 +18,21 @@ __host__ __device__ inline bool wave_rows(const BlockRef& m, long rows, long col
   return m.p && cols >= kWaveRowMinCols && (m.cs == 1 || rows <= 8);
 }
 
+// sum + m[0] x[0] + m[cs] x[1] + ..., in that order, eight loads in flight (a thread walking its row one load, one fma at a
+// time waits out a cache latency per entry)
+__device__ __forceinline__ double row_dot(const double* m, long cs, const double* x, long cols, double sum) {
+  long k = 0;
+  for (; k + 8 <= cols; k += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = m[(k + q) * cs];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += v[q] * x[k + q];
+  }
+  for (; k < cols; ++k) sum += m[k * cs] * x[k];
+  return sum;
+}
+
 // xl: operand (c1 then c2 entries); yl: r1 + r2 doubles of LDS (only touched when a block is walked wave = row);
 // store(row, sum) is called once per row by the thread that owns it
 template <class Store>
@@ -63,14 +78,8 @@ __device__ inline void two_by_two_rows(const BlockRef& a11, const BlockRef& a12,
     const BlockRef& left = top ? a11 : a21;
     const BlockRef& right = top ? a12 : a22;
     double sum = any_wave ? yl[row] : 0.0;
-    if (left.p && !(top ? w11 : w21)) {
-      const double* m = left.p + b * left.bs + r * left.rs;
-      for (long k = 0; k < c1; ++k) sum += m[k * left.cs] * xl[k];
-    }
-    if (right.p && !(top ? w12 : w22)) {
-      const double* m = right.p + b * right.bs + r * right.rs;
-      for (long k = 0; k < c2; ++k) sum += m[k * right.cs] * xl[c1 + k];
-    }
+    if (left.p && !(top ? w11 : w21)) sum = row_dot(left.p + b * left.bs + r * left.rs, left.cs, xl, c1, sum);
+    if (right.p && !(top ? w12 : w22)) sum = row_dot(right.p + b * right.bs + r * right.rs, right.cs, xl + c1, c2, sum);
     store(row, sum);
   }
 }

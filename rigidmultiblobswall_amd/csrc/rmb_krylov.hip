@@ -49,32 +49,95 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;       // lane 0 holds the sum
 }
 
-// partial dots of this workgroup's chunk (in LDS) with every basis row: wave q takes rows q, q + 4, ...
+// These helpers are LATENCY-bound, not bandwidth-bound (a mid-size deck's whole basis is a few MB): every loop over basis
+// rows / partials is written so that a group of independent loads is in flight before the first dependent instruction --
+// four rows per wave and pass in the dots, eight rows per thread in the update, 64 partials per wave in the sums.  Written
+// one load, one use per iteration they cost 8-13 us per launch at 256-512 bodies instead of ~5 (profiles/r5_gmres_step.txt).
+
+// s[q] = sum over e = lane, lane + 64, ... < len of row[q][e] * (x ? x[e] : 1), q = 0 .. 3, in ascending e: sixteen loads (four
+// rows, four strides) are issued before the first multiply.  Entries past `len` read a valid address and count as zero.
+template <bool WITH_X>
+__device__ __forceinline__ void four_row_sums(const double* r0, const double* r1, const double* r2, const double* r3, const double* x, long len,
+                                              double* s) {
+  const long lane = threadIdx.x & 63;
+  s[0] = s[1] = s[2] = s[3] = 0.0;
+  for (long e0 = lane; e0 < len; e0 += 256) {
+    long ee[4];
+    double xv[4], v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long e = e0 + 64 * j;
+      const bool ok = e < len;
+      ee[j] = ok ? e : e0;
+      xv[j] = ok ? (WITH_X ? x[ee[j]] : 1.0) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[0][j] = r0[ee[j]]; v[1][j] = r1[ee[j]]; v[2][j] = r2[ee[j]]; v[3][j] = r3[ee[j]]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += v[q][j] * xv[j];
+    }
+  }
+}
+
+// partial dots of this workgroup's chunk (in LDS) with every basis row: wave q takes rows 4q .. 4q + 3, then 4 (q + 4) ..
 __device__ __forceinline__ void chunk_dots(const OrthoArgs& a, const double* wl, long base, long len, double* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long r = wave; r < a.rows; r += kKrWaves) {
-    const double* row = a.V + r * a.ldv + base;
-    double s = 0.0;
-    for (long e = lane; e < len; e += 64) s += row[e] * wl[e];
-    s = wave_sum(s);
-    if (lane == 0) part[r * a.n_chunks + blockIdx.x] = s;
+  for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * kKrWaves) {
+    const double* row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row[q] = a.V + (r0 + q < a.rows ? r0 + q : r0) * a.ldv + base;      // past the last row: row r0 again, not stored
+    double s[4];
+    four_row_sums<true>(row[0], row[1], row[2], row[3], wl, len, s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double t = wave_sum(s[q]);
+      if (lane == 0 && r0 + q < a.rows) part[(r0 + q) * a.n_chunks + blockIdx.x] = t;
+    }
   }
 }
 
-// coefficients = fixed-order sums of the partials over the chunks, into LDS; thread t takes row t, t + 256, ...
+// coefficients = fixed-order sums of the partials over the chunks, into LDS: wave q takes rows 4q .. 4q + 3, ..., the lanes
+// stride over the chunks (lane l adds partials l, l + 64, ... in that order), then the butterfly -- the same order in every
+// workgroup and launch, so every workgroup holds the same bits
 __device__ __forceinline__ void reduce_partials(const OrthoArgs& a, const double* part, double* hl) {
-  for (long r = threadIdx.x; r < a.rows; r += kKrT) {
-    double s = 0.0;
-    for (long c = 0; c < a.n_chunks; ++c) s += part[r * a.n_chunks + c];
-    hl[r] = s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * kKrWaves) {
+    const double* row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row[q] = part + (r0 + q < a.rows ? r0 + q : r0) * a.n_chunks;
+    double s[4];
+    four_row_sums<false>(row[0], row[1], row[2], row[3], nullptr, a.n_chunks, s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double t = wave_sum(s[q]);
+      if (lane == 0 && r0 + q < a.rows) hl[r0 + q] = t;
+    }
   }
 }
 
-// wl[e] -= sum_r hl[r] V[r][base + e]
+// sum of n values by one wave (lanes stride, then the butterfly); every lane of the wave must call it; lane 0 holds the sum
+__device__ __forceinline__ double wave_strided_sum(const double* v, long n) {
+  double s = 0.0;
+  for (long c = threadIdx.x & 63; c < n; c += 64) s += v[c];
+  return wave_sum(s);
+}
+
+// wl[e] -= sum_r hl[r] V[r][base + e], rows in ascending order; eight rows' loads in flight per thread
 __device__ __forceinline__ void chunk_update(const OrthoArgs& a, double* wl, const double* hl, long base, long len) {
   for (long e = threadIdx.x; e < len; e += kKrT) {
     double s = wl[e];
-    for (long r = 0; r < a.rows; ++r) s -= hl[r] * a.V[r * a.ldv + base + e];
+    const double* col = a.V + base + e;
+    long r = 0;
+    for (; r + 8 <= a.rows; r += 8) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = col[(r + q) * a.ldv];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s -= hl[r + q] * v[q];
+    }
+    for (; r < a.rows; ++r) s -= hl[r] * col[r * a.ldv];
     wl[e] = s;
   }
 }
@@ -127,10 +190,11 @@ __global__ __launch_bounds__(kKrT) void ortho_update_kernel(const OrthoArgs a) {
 
 __global__ __launch_bounds__(kKrT) void ortho_normalise_kernel(const OrthoArgs a) {
   __shared__ double nrm;
+  if (threadIdx.x < 64) {
+    const double s = wave_strided_sum(a.part3, a.n_chunks);
+    if (threadIdx.x == 0) nrm = sqrt(s);
+  }
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (long c = 0; c < a.n_chunks; ++c) s += a.part3[c];
-    nrm = sqrt(s);
     if (blockIdx.x == 0) {
       a.col[a.rows] = nrm;
       if (a.col_host) a.col_host[a.rows] = nrm;
@@ -161,10 +225,11 @@ __global__ __launch_bounds__(1024) void ortho_normalise_pc_kernel(const NormPcAr
   extern __shared__ double xl[];          // r1 + r2: the body's slices of v_next; then r1 + r2 row sums (two_by_two_rows)
   __shared__ double nrm;
   const long b = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const double s = wave_strided_sum(a.o.part3, a.o.n_chunks);
+    if (threadIdx.x == 0) nrm = sqrt(s);
+  }
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (long c = 0; c < a.o.n_chunks; ++c) s += a.o.part3[c];
-    nrm = sqrt(s);
     if (b == 0) {
       a.o.col[a.o.rows] = nrm;
       if (a.o.col_host) a.o.col_host[a.o.rows] = nrm;
