@@ -51,7 +51,16 @@ __global__ __launch_bounds__(kVecT) void vec_lincomb_kernel(double* y, const dou
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   double s = y[e];
-  for (int i = 0; i < k; ++i) s += cl[i] * V[(long)i * ldv + e];
+  const double* col = V + e;
+  int i = 0;
+  for (; i + 8 <= k; i += 8) {             // eight rows' loads in flight (one load, one fma at a time waits out a latency per row)
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = col[(long)(i + q) * ldv];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += cl[i + q] * v[q];
+  }
+  for (; i < k; ++i) s += cl[i] * col[(long)i * ldv];
   y[e] = s;
 }
 
