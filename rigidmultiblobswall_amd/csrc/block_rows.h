@@ -18,6 +18,41 @@ __host__ __device__ inline bool wave_rows(const BlockRef& m, long rows, long col
   return m.p && cols >= kWaveRowMinCols && (m.cs == 1 || rows <= 8);
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;       // lane 0 holds the sum
+}
+
+// s[q] = sum over e = lane, lane + 64, ... < len of row_q[at(e)] * (x ? x[e] : 1), q = 0 .. 3, in ascending e: sixteen loads
+// (four rows, four strides) are issued before the first multiply.  Entries past `len` read a valid address and count as zero.
+// at(e): where entry e of the (logical) vector sits in a row (identity for a contiguous chunk).
+template <bool WITH_X, class At>
+__device__ __forceinline__ void four_row_sums(const double* r0, const double* r1, const double* r2, const double* r3, const double* x, long len,
+                                              double* s, At at) {
+  const long lane = threadIdx.x & 63;
+  s[0] = s[1] = s[2] = s[3] = 0.0;
+  for (long e0 = lane; e0 < len; e0 += 256) {
+    long ee[4];
+    double xv[4], v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long e = e0 + 64 * j;
+      const bool ok = e < len;
+      const long el = ok ? e : e0;
+      xv[j] = ok ? (WITH_X ? x[el] : 1.0) : 0.0;
+      ee[j] = at(el);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[0][j] = r0[ee[j]]; v[1][j] = r1[ee[j]]; v[2][j] = r2[ee[j]]; v[3][j] = r3[ee[j]]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += v[q][j] * xv[j];
+    }
+  }
+}
+
 // sum + m[0] x[0] + m[cs] x[1] + ..., in that order, eight loads in flight (a thread walking its row one load, one fma at a
 // time waits out a cache latency per entry)
 __device__ __forceinline__ double row_dot(const double* m, long cs, const double* x, long cols, double sum) {

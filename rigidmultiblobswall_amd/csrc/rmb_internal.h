@@ -95,6 +95,7 @@ struct rmb_ctx {
   double* host_in_dev = nullptr;
   size_t host_in_cap = 0;
   long opt_lanczos_fuse_finish = 1; // rmb_rigid_lanczos_step_device: finalize of the sweep + L_b^-1 product in one launch
+  long opt_gmres_fuse_dots = 1;     // rmb_rigid_gmres_device: the operator's finishing launch also takes the first Gram-Schmidt dots (<= 256 bodies)
   long opt_gmres_fuse_pc = 1;       // rmb_rigid_gmres_device: the normalisation launch also applies the preconditioner for the next step
   long opt_host_zero_copy_in = 1;   // inputs of rmb_matvec through mapped memory + a pull kernel (sizes as host_zero_copy)
   long opt_host_zero_copy = 768 << 10;   // bytes (32 768 blobs: level at 43 000, +1 % at 1e5); 0 = always a device-to-host copy command
@@ -149,8 +150,16 @@ void gmres_release(rmb_ctx* c);
 // next iteration's first launch.  The vector is laid out as [n_bodies x r1; n_bodies x r2].
 struct BlockRef { const double* p; long bs, rs, cs; };       // one batched block: entry b at p + b * bs, element (r, c) at + r * rs + c * cs
 struct PcBlocks { long n_bodies, r1, r2; BlockRef a11, a12, a21, a22; double* z; };      // square: r1 x r1, r1 x r2, r2 x r1, r2 x r2
+// part1_bodies > 0: the first pass's partial dots are already there, one per body and basis row (krylov_body_partials'
+// buffer, written by the operator's finishing launch): the step starts with the first update launch
 int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
-                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc);
+                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc, long part1_bodies = 0);
+constexpr long kKrBodyPartialsMax = 256;      // bodies up to which the finishing launch takes the first dots (every update workgroup re-sums them)
+int krylov_body_partials(rmb_ctx* c, long n, double** part_out);
+// the basis and where the partial dots of the vector the operator has just produced go: part[r * n_bodies + body]
+struct DotsFuse { const double* V; long ldv, rows; double* part; };
+int rigid_operator_impl(rmb_ctx* c, long n_bodies, long n_b, const double* K_dev, const double* x_dev, double eta, double* out_dev,
+                        const DotsFuse* dots, bool* dots_done);
 // z_ready: z_dev already holds P^-1 v_j (the previous step's fused launch); fuse_pc: leave P^-1 v_{j+1} in z_dev
 // One step of the preconditioned Lanczos forcing.  pv: P v_i (input of the sweep; pv_ready: left there by the previous step's
 // fused launch), mw: the sweep's result, d: P^T M P v_i, the vector that is orthogonalised (d may be pv when fuse_next is

@@ -32,6 +32,7 @@ constexpr long kKrMaxChunk = 4096;   // doubles of w a workgroup keeps in LDS (3
 
 struct OrthoArgs {
   long n, rows, ldv, chunk, n_chunks;
+  long n_part1;     // partials per row of pass 1: n_chunks, or the body count when the operator's finishing launch took them
   const double* V;
   double* w;
   double* col;      // rows coefficients, then |w|
@@ -43,43 +44,10 @@ struct OrthoArgs {
   double* h1;       // [rows] coefficients of pass 1
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;       // lane 0 holds the sum
-}
-
 // These helpers are LATENCY-bound, not bandwidth-bound (a mid-size deck's whole basis is a few MB): every loop over basis
 // rows / partials is written so that a group of independent loads is in flight before the first dependent instruction --
 // four rows per wave and pass in the dots, eight rows per thread in the update, 64 partials per wave in the sums.  Written
 // one load, one use per iteration they cost 8-13 us per launch at 256-512 bodies instead of ~5 (profiles/r5_gmres_step.txt).
-
-// s[q] = sum over e = lane, lane + 64, ... < len of row[q][e] * (x ? x[e] : 1), q = 0 .. 3, in ascending e: sixteen loads (four
-// rows, four strides) are issued before the first multiply.  Entries past `len` read a valid address and count as zero.
-template <bool WITH_X>
-__device__ __forceinline__ void four_row_sums(const double* r0, const double* r1, const double* r2, const double* r3, const double* x, long len,
-                                              double* s) {
-  const long lane = threadIdx.x & 63;
-  s[0] = s[1] = s[2] = s[3] = 0.0;
-  for (long e0 = lane; e0 < len; e0 += 256) {
-    long ee[4];
-    double xv[4], v[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long e = e0 + 64 * j;
-      const bool ok = e < len;
-      ee[j] = ok ? e : e0;
-      xv[j] = ok ? (WITH_X ? x[ee[j]] : 1.0) : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[0][j] = r0[ee[j]]; v[1][j] = r1[ee[j]]; v[2][j] = r2[ee[j]]; v[3][j] = r3[ee[j]]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s[q] += v[q][j] * xv[j];
-    }
-  }
-}
 
 // partial dots of this workgroup's chunk (in LDS) with every basis row: wave q takes rows 4q .. 4q + 3, then 4 (q + 4) ..
 __device__ __forceinline__ void chunk_dots(const OrthoArgs& a, const double* wl, long base, long len, double* part) {
@@ -89,7 +57,7 @@ __device__ __forceinline__ void chunk_dots(const OrthoArgs& a, const double* wl,
 #pragma unroll
     for (int q = 0; q < 4; ++q) row[q] = a.V + (r0 + q < a.rows ? r0 + q : r0) * a.ldv + base;      // past the last row: row r0 again, not stored
     double s[4];
-    four_row_sums<true>(row[0], row[1], row[2], row[3], wl, len, s);
+    four_row_sums<true>(row[0], row[1], row[2], row[3], wl, len, s, [](long e) { return e; });
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double t = wave_sum(s[q]);
@@ -101,14 +69,14 @@ __device__ __forceinline__ void chunk_dots(const OrthoArgs& a, const double* wl,
 // coefficients = fixed-order sums of the partials over the chunks, into LDS: wave q takes rows 4q .. 4q + 3, ..., the lanes
 // stride over the chunks (lane l adds partials l, l + 64, ... in that order), then the butterfly -- the same order in every
 // workgroup and launch, so every workgroup holds the same bits
-__device__ __forceinline__ void reduce_partials(const OrthoArgs& a, const double* part, double* hl) {
+__device__ __forceinline__ void reduce_partials(const OrthoArgs& a, const double* part, long count, double* hl) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * kKrWaves) {
     const double* row[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) row[q] = part + (r0 + q < a.rows ? r0 + q : r0) * a.n_chunks;
+    for (int q = 0; q < 4; ++q) row[q] = part + (r0 + q < a.rows ? r0 + q : r0) * count;
     double s[4];
-    four_row_sums<false>(row[0], row[1], row[2], row[3], nullptr, a.n_chunks, s);
+    four_row_sums<false>(row[0], row[1], row[2], row[3], nullptr, count, s, [](long e) { return e; });
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double t = wave_sum(s[q]);
@@ -161,7 +129,7 @@ __global__ __launch_bounds__(kKrT) void ortho_update_kernel(const OrthoArgs a) {
   const long base = blockIdx.x * a.chunk;
   const long len = (a.n - base) < a.chunk ? (a.n - base) : a.chunk;
   for (long e = threadIdx.x; e < len; e += kKrT) wl[e] = a.w[base + e];
-  reduce_partials(a, PASS == 1 ? a.part1 : a.part2, hl);
+  reduce_partials(a, PASS == 1 ? a.part1 : a.part2, PASS == 1 ? a.n_part1 : a.n_chunks, hl);
   __syncthreads();
   if (blockIdx.x == 0) {
     for (long r = threadIdx.x; r < a.rows; r += kKrT) {
@@ -300,8 +268,34 @@ int rmb_krylov_orthogonalize2_device(rmb_ctx* c, long n, long rows, const double
 }  // extern "C"
 
 namespace rmbi {
+// chunk length / count of the Gram-Schmidt launches and the scratch they share: functions of n only
+static void krylov_layout(long n, long* chunk_out, long* n_chunks_out, size_t* need_out) {
+  // chunks of 256 doubles (one per thread: small systems are latency-bound, 4608 unknowns are 18 workgroups instead of 5)
+  // while that gives at most 256 workgroups, larger ones (up to what fits LDS) beyond: every workgroup re-sums the
+  // per-chunk partials, so their number stays bounded
+  long chunk = 256;
+  while ((n + chunk - 1) / chunk > 256 && chunk < kKrMaxChunk) chunk *= 2;
+  const long n_chunks = (n + chunk - 1) / chunk;
+  *chunk_out = chunk;
+  *n_chunks_out = n_chunks;
+  // Sized for the LARGEST basis (kKrMaxRows) whatever `rows` is: the scratch then depends on n only and never moves
+  // while a solve walks up its iteration indices.  rigid.py captures one hipGraph per iteration index with these
+  // addresses baked in; a buffer that grew with `rows` was freed and reallocated every 2-3 indices, and the graphs
+  // captured for lower indices replayed into freed memory.  ~1 MB for up to 65 536 unknowns, + 512 KB for the
+  // per-body partials of the fused first pass.
+  *need_out = ((size_t)2 * kKrMaxRows * n_chunks + n_chunks + kKrMaxRows + (size_t)kKrMaxRows * kKrBodyPartialsMax) * sizeof(double);
+}
+
+int krylov_body_partials(rmb_ctx* c, long n, double** part_out) {
+  long chunk, n_chunks; size_t need;
+  krylov_layout(n, &chunk, &n_chunks, &need);
+  if (int rc = c->krylov.reserve(need)) return rc;
+  *part_out = (double*)c->krylov.p + (size_t)2 * kKrMaxRows * n_chunks + n_chunks + kKrMaxRows;
+  return 0;
+}
+
 int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
-                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc) {
+                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc, long part1_bodies) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
   if (n < 1 || rows < 1 || rows > kKrMaxRows || ldv < n)
     return fail(RMB_ERR_ARG, "rmb_krylov_orthogonalize_device: need n >= 1, 1 <= rows <= 256, ldv >= n");
@@ -310,26 +304,21 @@ int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev
   OrthoArgs a;
   a.n = n; a.rows = rows; a.ldv = ldv;
   a.V = V_dev; a.w = w_dev; a.col = col_dev; a.v_next = v_next_dev; a.col_host = col_mapped_dev;
-  // chunks of 256 doubles (one per thread: small systems are latency-bound, 4608 unknowns are 18 workgroups instead of 5)
-  // while that gives at most 256 workgroups, larger ones (up to what fits LDS) beyond: every workgroup re-sums the
-  // per-chunk partials, so their number stays bounded
-  long chunk = 256;
-  while ((n + chunk - 1) / chunk > 256 && chunk < kKrMaxChunk) chunk *= 2;
+  if (part1_bodies < 0 || part1_bodies > kKrBodyPartialsMax) return fail(RMB_ERR_ARG, "krylov_orthogonalize_impl: too many per-body partials (internal)");
+  long chunk; size_t need;
+  krylov_layout(n, &chunk, &a.n_chunks, &need);
   a.chunk = chunk;
-  a.n_chunks = (n + chunk - 1) / chunk;
-  // Sized for the LARGEST basis (kKrMaxRows) whatever `rows` is: the scratch then depends on n only and never moves
-  // while a solve walks up its iteration indices.  rigid.py captures one hipGraph per iteration index with these
-  // addresses baked in; a buffer that grew with `rows` was freed and reallocated every 2-3 indices, and the graphs
-  // captured for lower indices replayed into freed memory.  ~1 MB for up to 65 536 unknowns.
-  const size_t need = ((size_t)2 * kKrMaxRows * a.n_chunks + a.n_chunks + kKrMaxRows) * sizeof(double);
   if (int rc = c->krylov.reserve(need)) return rc;
-  a.part1 = (double*)c->krylov.p;
+  double* base = (double*)c->krylov.p;
+  a.part1 = base;
   a.part2 = a.part1 + rows * a.n_chunks;
   a.part3 = a.part2 + rows * a.n_chunks;
-  a.h1 = a.part3 + a.n_chunks;
+  a.h1 = base + (size_t)2 * kKrMaxRows * a.n_chunks + a.n_chunks;
+  a.n_part1 = a.n_chunks;
+  if (part1_bodies > 0) { a.part1 = a.h1 + kKrMaxRows; a.n_part1 = part1_bodies; }       // krylov_body_partials' buffer
   const dim3 grid((unsigned)a.n_chunks), block(kKrT);
   const size_t lds_w = (size_t)chunk * sizeof(double), lds_wh = lds_w + (size_t)rows * sizeof(double);
-  hipLaunchKernelGGL(ortho_dots_kernel, grid, block, lds_w, c->stream, a);
+  if (part1_bodies == 0) hipLaunchKernelGGL(ortho_dots_kernel, grid, block, lds_w, c->stream, a);
   hipLaunchKernelGGL(ortho_update_kernel<1>, grid, block, lds_wh, c->stream, a);
   hipLaunchKernelGGL(ortho_update_kernel<2>, grid, block, lds_wh, c->stream, a);
   if (pc) {

@@ -378,6 +378,11 @@ struct OpFinArgs {
   int n_b;
   double prefactor;
   rmb::PairConsts k;
+  // optional (part != nullptr): the first Gram-Schmidt pass's partial dots of the body's slices of `out` with the basis
+  // rows V[0 .. rows): part[r * n_bodies + body]
+  const double* V;
+  long ldv, rows;
+  double* part;
 };
 
 // Thread l < n_b finishes blob i = body n_b + l exactly as sym_finalize_kernel does (self term of the B-damped lambda,
@@ -385,6 +390,7 @@ struct OpFinArgs {
 // reduction over the body.
 template <bool WALL>
 __global__ __launch_bounds__(256) void rigid_operator_finish_kernel(const OpFinArgs a) {
+  extern __shared__ double wl[];          // 3 n_b + 6: the body's slices of the result (only with a.part)
   __shared__ double part[4][6];
   const long body = blockIdx.x;
   const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
@@ -412,6 +418,7 @@ __global__ __launch_bounds__(256) void rigid_operator_finish_kernel(const OpFinA
         kt[q] += Kr[6 * c + q] * lam[c];
       }
       a.out[3 * i + c] = u[c] - s;
+      if (a.part) wl[3 * l + c] = u[c] - s;
     }
   }
 #pragma unroll
@@ -426,6 +433,25 @@ __global__ __launch_bounds__(256) void rigid_operator_finish_kernel(const OpFinA
     double s = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w][l];
     a.out[n3 + 6 * body + l] = -s;
+    if (a.part) wl[3 * a.n_b + l] = -s;
+  }
+  if (a.part) {
+    // the body's share of V[r] . out for every basis row: wave q takes rows 4q .. 4q + 3, ... (sixteen loads in flight)
+    __syncthreads();
+    const long nn = 3L * a.n_b, len = nn + 6, top = body * nn, bot = n3 + 6 * body - nn;
+    const int n_waves = (int)(blockDim.x >> 6);
+    for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * n_waves) {
+      const double* row[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) row[q] = a.V + (r0 + q < a.rows ? r0 + q : r0) * a.ldv;
+      double s[4];
+      four_row_sums<true>(row[0], row[1], row[2], row[3], wl, len, s, [&](long k) { return k < nn ? top + k : bot + k; });
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double t = wave_sum(s[q]);
+        if (lane == 0 && r0 + q < a.rows) a.part[(r0 + q) * a.n_bodies + body] = t;
+      }
+    }
   }
 }
 
@@ -524,11 +550,16 @@ int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev
     const rmb_block b11{A11_dev, nn * nn, nn, 1}, b12{A12_dev, nn * 6, 6, 1}, b21{A21_dev, 6 * nn, nn, 1}, b22{A22_dev, 36, 6, 1};
     if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 6, 6, &b11, &b12, &b21, &b22, v, v + n3, 1.0, 0.0, z_dev, 0.0, z_dev + n3)) return rc;
   }
-  // w = A z: pair sweep + one finishing launch
-  if (int rc = rmb_rigid_operator_device(c, n_bodies, n_b, K_dev, z_dev, eta, w_dev)) return rc;
+  // w = A z: pair sweep + one finishing launch, which (small decks, inside the native GMRES) also takes the first pass's dots
+  DotsFuse df{V_dev, ldv, j + 1, nullptr};
+  bool dots_done = false;
+  if (fuse_pc && c->opt_gmres_fuse_dots && n_bodies <= kKrBodyPartialsMax)
+    if (int rc = krylov_body_partials(c, n, &df.part)) return rc;
+  if (int rc = rigid_operator_impl(c, n_bodies, n_b, K_dev, z_dev, eta, w_dev, df.part ? &df : nullptr, &dots_done)) return rc;
   // two Gram-Schmidt passes against v_0 .. v_j, Hessenberg column, |w|, v_{j+1} (and, fused, z = P^-1 v_{j+1})
   const PcBlocks pc{n_bodies, nn, 6, {A11_dev, nn * nn, nn, 1}, {A12_dev, nn * 6, 6, 1}, {A21_dev, 6 * nn, nn, 1}, {A22_dev, 36, 6, 1}, z_dev};
-  return krylov_orthogonalize_impl(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev, fuse_pc ? &pc : nullptr);
+  return krylov_orthogonalize_impl(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev, fuse_pc ? &pc : nullptr,
+                                   dots_done ? n_bodies : 0);
 }
 
 }  // namespace rmbi
@@ -596,6 +627,15 @@ int rmb_rigid_preconditioner_device(rmb_ctx* c, long n_bodies, long n_b, const d
 
 int rmb_rigid_operator_device(rmb_ctx* c, long n_bodies, long n_b, const double* K_dev, const double* x_dev, double eta,
                               double* out_dev) {
+  return rigid_operator_impl(c, n_bodies, n_b, K_dev, x_dev, eta, out_dev, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace rmbi {
+int rigid_operator_impl(rmb_ctx* c, long n_bodies, long n_b, const double* K_dev, const double* x_dev, double eta, double* out_dev,
+                        const DotsFuse* dots, bool* dots_done) {
+  if (dots_done) *dots_done = false;
   if (int rc = check_ready(c)) return rc;
   if (n_bodies < 1 || n_b < 1 || n_b > 256) return fail(RMB_ERR_ARG, "rmb_rigid_operator_device: need n_bodies >= 1 and 1 <= n_b <= 256");
   if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_operator_device: the resident configuration does not hold n_bodies x n_b blobs");
@@ -613,10 +653,18 @@ int rmb_rigid_operator_device(rmb_ctx* c, long n_bodies, long n_b, const double*
     a.n = n; a.n_pad = 64 * ((n + 63) / 64); a.n_bodies = n_bodies; a.n_b = (int)n_b;
     a.prefactor = 1.0 / (8.0 * M_PI * eta);
     a.k = make_pair_consts(c->a);
-    const unsigned threads = (unsigned)(64 * ((n_b + 63) / 64));
-    if (c->wall) hipLaunchKernelGGL(rigid_operator_finish_kernel<true>, dim3((unsigned)n_bodies), dim3(threads), 0, c->stream, a);
-    else         hipLaunchKernelGGL(rigid_operator_finish_kernel<false>, dim3((unsigned)n_bodies), dim3(threads), 0, c->stream, a);
+    a.V = nullptr; a.ldv = 0; a.rows = 0; a.part = nullptr;
+    unsigned threads = (unsigned)(64 * ((n_b + 63) / 64));
+    size_t lds = 0;
+    if (dots && dots->part && dots->rows > 0) {
+      a.V = dots->V; a.ldv = dots->ldv; a.rows = dots->rows; a.part = dots->part;
+      threads = 256;                                    // four waves share the basis rows
+      lds = (size_t)(3 * n_b + 6) * sizeof(double);
+    }
+    if (c->wall) hipLaunchKernelGGL(rigid_operator_finish_kernel<true>, dim3((unsigned)n_bodies), dim3(threads), lds, c->stream, a);
+    else         hipLaunchKernelGGL(rigid_operator_finish_kernel<false>, dim3((unsigned)n_bodies), dim3(threads), lds, c->stream, a);
     RMB_HIP(hipGetLastError());
+    if (a.part && dots_done) *dots_done = true;
     return 0;
   }
   // any other mode (one-sided sweep below 128 blobs, periodic images, deterministic / single-precision options): the
@@ -627,6 +675,9 @@ int rmb_rigid_operator_device(rmb_ctx* c, long n_bodies, long n_b, const double*
   return rmb_block_apply_device(c, n_bodies, 3 * n_b, 3 * n_b, 6, 6, nullptr, &kb, &kt, nullptr, x_dev, x_dev + n3, -1.0, 1.0, out_dev, 0.0,
                                 out_dev + n3);
 }
+}  // namespace rmbi
+
+extern "C" {
 
 int rmb_rigid_arnoldi_step_device(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev,
                                   const double* A21_dev, const double* A22_dev, const double* K_dev, double* V_dev, long ldv, long j,

@@ -476,12 +476,17 @@ def test_native_gmres_loop_equals_the_python_loop():
     x0, i0 = nat.solve(torch.zeros(nat.size, dtype=torch.float64, device="cuda:0"), tol=1e-9)
     assert i0["iterations"] == 0 and float(x0.abs().max()) == 0.0
     # the fused launch (normalisation + next step's preconditioner) off: same arithmetic in one launch more
-    nat.ctx.set_option("gmres_fuse_pc", 0)
-    xs, ins = nat.solve(rhs, tol=1e-9, restart=7)
-    nat.ctx.set_option("gmres_fuse_pc", 1)
     xf, inf = nat.solve(rhs, tol=1e-9, restart=7)
-    assert ins["iterations"] == inf["iterations"] and rel_err(xs.cpu().numpy(), xf.cpu().numpy()) < 1e-9
-    assert np.allclose(ins["history"], inf["history"], rtol=1e-6, atol=1e-13)
+    for opts in ({"gmres_fuse_pc": 0}, {"gmres_fuse_dots": 0}):
+      # (fuse_pc off: separate normalisation and preconditioner launches, and with them the separate dots; fuse_dots off: the
+      #  operator's finishing launch without the first pass's dots)
+      for key, val in opts.items():
+        nat.ctx.set_option(key, val)
+      xs, ins = nat.solve(rhs, tol=1e-9, restart=7)
+      for key in opts:
+        nat.ctx.set_option(key, 1)
+      assert ins["iterations"] == inf["iterations"] and rel_err(xs.cpu().numpy(), xf.cpu().numpy()) < 1e-9, opts
+      assert np.allclose(ins["history"], inf["history"], rtol=1e-6, atol=1e-13), opts
   finally:
     nat.close(); pyl.close()
 
