@@ -150,7 +150,8 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          Also governs rmb_rigid_lanczos_device (its normalisation launch applies L_b^-T for the next step)
  *   "gmres_fuse_dots" [1]  rmb_rigid_gmres_device, decks of up to 256 bodies: the operator's finishing launch (workgroup = body) also
  *                          takes the first Gram-Schmidt pass's dots of its slices with every basis row (one partial per body, summed
- *                          by the first update launch): five launches per iteration; 0 = a separate dots launch
+ *                          by the first update launch): five launches per iteration; 0 = a separate dots launch.  The Lanczos
+ *                          step's finishing launch ("lanczos_fuse_finish") does the same
  *   "lanczos_fuse_finish" [1]  rmb_rigid_lanczos_step_device / rmb_rigid_lanczos_device: the sweep leaves its raw sums and ONE
  *                          launch (workgroup = body) finishes them and multiplies by L_b^-1; 0 = finalize and block product as
  *                          two launches (same arithmetic)

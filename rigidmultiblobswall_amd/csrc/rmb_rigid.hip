@@ -468,11 +468,16 @@ struct LanFinArgs {
   int n_b;
   double prefactor;
   rmb::PairConsts k;
+  // optional (part != nullptr): the first Gram-Schmidt pass's partial dots of the body's 3 n_b entries of `out` with the
+  // basis rows V[0 .. rows): part[r * n_bodies + body]
+  const double* V;
+  long ldv, rows, n_bodies;
+  double* part;
 };
 
 template <bool WALL>
 __global__ __launch_bounds__(1024) void lanczos_finish_kernel(const LanFinArgs a) {
-  extern __shared__ double xl[];          // 3 n_b finished entries, then 3 n_b row sums (two_by_two_rows)
+  extern __shared__ double xl[];          // 3 n_b finished entries, 3 n_b row sums (two_by_two_rows), 3 n_b results (with a.part)
   const long body = blockIdx.x;
   const int l = threadIdx.x;
   if (l < a.n_b) {
@@ -488,7 +493,28 @@ __global__ __launch_bounds__(1024) void lanczos_finish_kernel(const LanFinArgs a
   __syncthreads();
   const long nn = 3L * a.n_b;
   const BlockRef none{nullptr, 0, 0, 0};
-  two_by_two_rows(a.linv, none, none, none, body, nn, nn, 0, 0, xl, xl + nn, [&](long row, double sum) { a.out[body * nn + row] = sum; });
+  double* res = xl + 2 * nn;
+  two_by_two_rows(a.linv, none, none, none, body, nn, nn, 0, 0, xl, xl + nn, [&](long row, double sum) {
+    a.out[body * nn + row] = sum;
+    if (a.part) res[row] = sum;
+  });
+  if (a.part) {
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
+    const long top = body * nn;
+    for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * n_waves) {
+      const double* row[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) row[q] = a.V + (r0 + q < a.rows ? r0 + q : r0) * a.ldv + top;
+      double s[4];
+      four_row_sums<true>(row[0], row[1], row[2], row[3], res, nn, s, [](long e) { return e; });
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double t = wave_sum(s[q]);
+        if (lane == 0 && r0 + q < a.rows) a.part[(r0 + q) * a.n_bodies + body] = t;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -509,6 +535,7 @@ int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_de
   if (!pv_ready)
     if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &lt, nullptr, nullptr, nullptr, v, nullptr, 1.0, 0.0, pv_dev, 0.0, nullptr)) return rc;
   // d = P^T (M pv)
+  long dots_bodies = 0;
   const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
   if (c->opt_lanczos_fuse_finish && sym_applies(c) && !periodic && c->opt_deterministic == 0 && c->opt_precision == 64 && c->tgt_begin == 0 && c->tgt_end == n &&
       n_b <= 256) {
@@ -521,7 +548,15 @@ int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_de
     a.k = make_pair_consts(c->a);
     unsigned threads = two_by_two_threads(nn, wave_rows(a.linv, nn, nn));
     if (threads < (unsigned)(64 * ((n_b + 63) / 64))) threads = (unsigned)(64 * ((n_b + 63) / 64));
-    const size_t lds = (size_t)(2 * nn) * sizeof(double);
+    // small decks: this launch also takes the first Gram-Schmidt pass's dots (one partial per body and basis row)
+    a.V = nullptr; a.ldv = 0; a.rows = 0; a.n_bodies = n_bodies; a.part = nullptr;
+    if (c->opt_gmres_fuse_dots && n_bodies <= kKrBodyPartialsMax) {
+      if (int rc = krylov_body_partials(c, n3, &a.part)) return rc;
+      a.V = V_dev; a.ldv = ldv; a.rows = i + 1;
+      if (threads < 256) threads = 256;
+      dots_bodies = n_bodies;
+    }
+    const size_t lds = (size_t)(3 * nn) * sizeof(double);
     if (c->wall) hipLaunchKernelGGL(lanczos_finish_kernel<true>, dim3((unsigned)n_bodies), dim3(threads), lds, c->stream, a);
     else         hipLaunchKernelGGL(lanczos_finish_kernel<false>, dim3((unsigned)n_bodies), dim3(threads), lds, c->stream, a);
     RMB_HIP(hipGetLastError());
@@ -533,7 +568,8 @@ int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_de
   // rounding with an orthonormal basis), v_{i+1} = d / |d| (and, fused, pv = P v_{i+1})
   const BlockRef none{nullptr, 0, 0, 0};
   const PcBlocks pc{n_bodies, nn, 0, {Linv_dev, nn * nn, 1, nn}, none, none, none, pv_dev};
-  return krylov_orthogonalize_impl(c, n3, i + 1, V_dev, ldv, d_dev, col_dev, V_dev + (i + 1) * ldv, col_mapped_dev, fuse_next ? &pc : nullptr);
+  return krylov_orthogonalize_impl(c, n3, i + 1, V_dev, ldv, d_dev, col_dev, V_dev + (i + 1) * ldv, col_mapped_dev, fuse_next ? &pc : nullptr,
+                                   dots_bodies);
 }
 
 int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,

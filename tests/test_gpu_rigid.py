@@ -569,12 +569,14 @@ def test_native_lanczos_loop_equals_the_generic_one():
     assert abs(float(torch.dot(w, w)) / zMz - 1.0) < 1e-8, float(torch.dot(w, w)) / zMz - 1.0
     # the fused launches of the library's step off (finalize + L^-1, normalisation + next L^-T): same arithmetic
     a0, i0 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
-    for key in ("lanczos_fuse_finish", "gmres_fuse_pc"):
-      nat.ctx.set_option(key, 0)
-    a1, i1 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
-    for key in ("lanczos_fuse_finish", "gmres_fuse_pc"):
-      nat.ctx.set_option(key, 1)
-    assert i0 == i1 == ia and rel_err(a0.cpu().numpy(), a1.cpu().numpy()) < 1e-13 and rel_err(a0.cpu().numpy(), a.cpu().numpy()) < 1e-13
+    for keys in (("lanczos_fuse_finish", "gmres_fuse_pc"), ("gmres_fuse_dots",), ("gmres_fuse_pc",)):
+      for key in keys:
+        nat.ctx.set_option(key, 0)
+      a1, i1 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
+      for key in keys:
+        nat.ctx.set_option(key, 1)
+      assert i0 == i1 == ia and rel_err(a0.cpu().numpy(), a1.cpu().numpy()) < 1e-13, keys
+    assert rel_err(a0.cpu().numpy(), a.cpu().numpy()) < 1e-13
     # too few basis rows: both native paths hand the forcing back to the generic loop
     for s in (nat, stp):
       s.lanczos_native_rows = 3

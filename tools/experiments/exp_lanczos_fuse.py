@@ -14,16 +14,16 @@ for nb, shell in ((64, st.icosahedron_shell(0.792079207921 * R)), (256, st.icosa
   rs.build_preconditioner()
   z = torch.randn(3 * rs.n_blobs, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
   res, out = {}, {}
-  modes = ((0, 0), (1, 0), (0, 1), (1, 1))
+  modes = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1))
   for rnd in range(6):
-    for fin, nxt in (modes if rnd % 2 == 0 else modes[::-1]):
-      rs.ctx.set_option("lanczos_fuse_finish", fin); rs.ctx.set_option("gmres_fuse_pc", nxt)
+    for fin, nxt, dots in (modes if rnd % 2 == 0 else modes[::-1]):
+      rs.ctx.set_option("lanczos_fuse_finish", fin); rs.ctx.set_option("gmres_fuse_pc", nxt); rs.ctx.set_option("gmres_fuse_dots", dots)
       for _ in range(20): rs.stochastic_forcing(z, 1.0, tol=1e-6)
       torch.cuda.synchronize(); t0 = time.perf_counter()
       for _ in range(100): noise, its = rs.stochastic_forcing(z, 1.0, tol=1e-6)
       torch.cuda.synchronize()
-      res.setdefault((fin, nxt), []).append((time.perf_counter() - t0) / 100 * 1e3)
-      out[(fin, nxt)] = (noise.clone(), its)
-  base = out[(0, 0)][0]
-  print("bodies %4d x %d blobs, %d iterations: " % (nb, shell.shape[0], out[(0, 0)][1]) + "   ".join(
-      "finish %d next %d: %.3f ms (diff %.0e)" % (f, n, np.median(res[(f, n)]), float((out[(f, n)][0] - base).abs().max() / base.abs().max())) for f, n in modes), flush=True)
+      res.setdefault((fin, nxt, dots), []).append((time.perf_counter() - t0) / 100 * 1e3)
+      out[(fin, nxt, dots)] = (noise.clone(), its)
+  base = out[modes[0]][0]
+  print("bodies %4d x %d blobs, %d iterations: " % (nb, shell.shape[0], out[modes[0]][1]) + "   ".join(
+      "finish %d next %d dots %d: %.3f ms (diff %.0e)" % (m + (np.median(res[m]), float((out[m][0] - base).abs().max() / base.abs().max()))) for m in modes), flush=True)
