@@ -42,7 +42,7 @@ Objects on the line
   two_targets_ops_ab  one-rank run: the fused row / grand product at 1e4 and 1e5 blobs and the pseudo-periodic tt / fused row at
                 24 576 blobs, one target per lane against two (the default), alternating in this process
   small_deck_steps  one-rank run: whole time steps of the rigid-multiblob integrators on 64 / 256 shells (the reference's
-                usual sizes), where the solver loop around the sweep decides (one library call per Arnoldi iteration)
+                usual sizes), where the solver loop around the sweep decides (the loop itself inside the library)
   rccl_one_rank  one-rank run: the N > 1 step's fp64 all-reduce through RCCL in a one-rank group, step timed with and
                 without it (child process, tools/rccl_one_rank_probe.py)
   multi_device_surface  one-rank run with several devices visible: the same call on the single-process multi-device
@@ -988,8 +988,9 @@ def rank_main(args):
                    "lanczos_iterations_per_step": round((integ.stoch_iterations_count - it0[1]) / n_steps, 1),
                    "rejected_steps": integ.invalid_configuration_count})
       integ.close()
-    return {"decks": rows, "note": "12-blob shells in a monolayer; defaults: helper kernels, one library call per Arnoldi iteration "
-                                    "(rmb_rigid_arnoldi_step_device: round 4, captured graphs: 1.69 / 6.33 / 2.25 ms per step)"}
+    return {"decks": rows, "note": "12-blob shells in a monolayer; defaults: the GMRES and Lanczos loops inside the library "
+                                    "(rmb_rigid_gmres_device / rmb_rigid_lanczos_device, five launches per iteration); round 4, captured "
+                                    "graphs: 1.69 / 6.33 / 2.25 ms per step"}
   if not args.no_sweep:
     stage("small_deck_steps", 8, small_deck_steps, single_rank_only=True)
 
