@@ -95,35 +95,70 @@ constexpr int kPcT = 256;          // threads per body: four wavefronts
 // rank-deficient resistance (single blobs, collinear rods) must take the pseudo-inverse route of the caller
 // (multi_bodies.py:531 uses pinv).
 __device__ bool invert_resistance(const double* R, double* Nl) {
+  // Every index below is a compile-time constant after unrolling (the pivot row is brought up by conditional exchanges with
+  // every candidate row, not by a run-time row index), so the 6 x 12 work matrix lives in registers.  With a run-time row
+  // index it sat in scratch memory, and ONE thread's ~1000 dependent accesses to it were most of the preconditioner kernel's
+  // time (profiles/r5_pc_42_blob_shells.txt, last part).  Same operations in the same order as before.
   bool ok = true;
   double w[6][12];
-  for (int i = 0; i < 6; ++i)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
     for (int j = 0; j < 6; ++j) { w[i][j] = R[i * 6 + j]; w[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+  }
+#pragma unroll
   for (int c = 0; c < 6; ++c) {
     int piv = c;
-    for (int i = c + 1; i < 6; ++i) if (fabs(w[i][c]) > fabs(w[piv][c])) piv = i;
-    if (piv != c) for (int j = 0; j < 12; ++j) { const double tmp = w[c][j]; w[c][j] = w[piv][j]; w[piv][j] = tmp; }
+    double best = fabs(w[c][c]);
+#pragma unroll
+    for (int i = c + 1; i < 6; ++i) {
+      const double cand = fabs(w[i][c]);
+      if (cand > best) { best = cand; piv = i; }
+    }
+#pragma unroll
+    for (int i = c + 1; i < 6; ++i) {
+      const bool sel = piv == i;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const double up = w[c][j], down = w[i][j];
+        w[c][j] = sel ? down : up;
+        w[i][j] = sel ? up : down;
+      }
+    }
     const double dgl = w[c][c];
-    if (!(fabs(dgl) > 0.0)) { ok = false; continue; }
-    const double inv = 1.0 / dgl;
-    for (int j = 0; j < 12; ++j) w[c][j] *= inv;
-    for (int i = 0; i < 6; ++i) {
-      if (i == c) continue;
-      const double f = w[i][c];
-      for (int j = 0; j < 12; ++j) w[i][j] -= f * w[c][j];
+    if (!(fabs(dgl) > 0.0)) {
+      ok = false;
+    } else {
+      const double inv = 1.0 / dgl;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) w[c][j] *= inv;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i == c) continue;
+        const double f = w[i][c];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) w[i][j] -= f * w[c][j];
+      }
     }
   }
   double worst = 0.0;
-  for (int i = 0; i < 6; ++i)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
       double s = 0.0;
+#pragma unroll
       for (int k = 0; k < 6; ++k) s += R[i * 6 + k] * w[k][6 + j];
       const double e = fabs(s - (i == j ? 1.0 : 0.0));
       if (!(e <= worst)) worst = e;       // NaN-propagating maximum
     }
+  }
   if (!(worst < 1e-8)) ok = false;
-  for (int i = 0; i < 6; ++i)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
     for (int j = 0; j < 6; ++j) Nl[i * 6 + j] = 0.5 * (w[i][6 + j] + w[j][6 + i]);
+  }
   return ok;
 }
 
