@@ -332,6 +332,12 @@ int rmb_rigid_gmres_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* 
 int rmb_rigid_lanczos_device(rmb_ctx* ctx, long n_bodies, long n_b, const double* Linv_dev, const double* Lchol_dev,
                              const double* z_dev, double factor, double tol, long max_iter, long max_rows, double eta,
                              double* noise_dev, long* iterations, long* products, int* status);
+/* The unpreconditioned forcing of the single-blob (roller) schemes as one call, same loop:  noise = factor * M^{1/2} z  with
+ * product 0: M = M_tt over 3 N unknowns (in_plane != 0: its in-plane variant), product 1: the 6 N x 6 N grand mobility
+ * [[M_tt, M_tr], [M_rt, M_rr]], z = [z_f; z_tau] (quaternion_integrator_rollers.py:1082-1121, :1203-1260, :1315-1353 ->
+ * stochastic_forcing_lanczos without preconditioner: 40-50 iterations at tol 1e-6).  Arguments and status as above. */
+int rmb_lanczos_device(rmb_ctx* ctx, int product, int in_plane, const double* z_dev, double factor, double tol, long max_iter,
+                       long max_rows, double eta, double* noise_dev, long* iterations, long* products, int* status);
 /* HOST function, no GPU work: coef = scale * Q sqrt(max(lambda, 0)) Q^T e_1 of the k x k symmetric tridiagonal matrix with
  * diagonal h_diag[0 .. k) and off-diagonal h_sup[0 .. k-1) -- the coordinates of the Lanczos noise estimate in the Krylov
  * basis after k iterations (stochastic_forcing.py:215-229), as rmb_rigid_lanczos_device computes them. */

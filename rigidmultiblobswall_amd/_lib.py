@@ -61,6 +61,8 @@ SYMBOLS = {
                                              ctypes.c_long, ctypes.c_double, _vp, _lp, _dp, _lp, _lp, _dp, ctypes.c_long, _dp]),
     "rmb_rigid_lanczos_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_long,
                                                ctypes.c_long, ctypes.c_double, _vp, _lp, _lp, ctypes.POINTER(ctypes.c_int)]),
+    "rmb_lanczos_device": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_long, ctypes.c_long,
+                                         ctypes.c_double, _vp, _lp, _lp, ctypes.POINTER(ctypes.c_int)]),
     "rmb_lanczos_noise_coefficients": (ctypes.c_int, [ctypes.c_long, _dp, _dp, ctypes.c_double, _dp]),
     "rmb_rigid_lanczos_step_device": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, _vp, _vp, ctypes.c_long, ctypes.c_long, ctypes.c_double,
                                                     _vp, _vp, _vp, _vp]),

@@ -367,6 +367,23 @@ class MobilityContext(object):
       return None, int(status.value), int(prod.value)
     return noise, int(its.value), int(prod.value)
 
+  def lanczos_device(self, product, z, factor, tol, max_iter, max_rows, eta, in_plane=False):
+    """factor * M^{1/2} z in one library call (rmb_lanczos_device): product "tt" (3n entries; in_plane: its in-plane variant) or
+    "grand" (6n entries: the grand mobility on [z_f; z_tau]).  Returns (noise, iterations, products), or (None, status,
+    products) when the library hands the forcing back (breakdown, more basis rows needed)."""
+    import torch
+    code = {"tt": 0, "grand": 1}[product]
+    assert _is_torch_cuda(z) and z.is_contiguous() and z.numel() == (6 if code else 3) * self.n
+    noise = torch.empty_like(z)
+    its, prod, status = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_int(0)
+    self._follow_torch_stream()
+    _lib.check(self._lib.rmb_lanczos_device(self._h, code, int(bool(in_plane)), ctypes.c_void_p(z.data_ptr()), float(factor), float(tol),
+                                            int(max_iter), int(max_rows), float(eta), ctypes.c_void_p(noise.data_ptr()), ctypes.byref(its),
+                                            ctypes.byref(prod), ctypes.byref(status)))
+    if status.value != 0:
+      return None, int(status.value), int(prod.value)
+    return noise, int(its.value), int(prod.value)
+
   def rigid_operator_device(self, K, x, eta, out):
     """out = [M_tt lambda - K U; -K^T lambda] for x = [lambda; U] on the resident configuration (all bodies free, one body
     shape; rmb_rigid_operator_device): the pair sweep + one finishing launch.  K (n_bodies, 3 n_b, 6) contiguous."""

@@ -88,8 +88,10 @@ __global__ __launch_bounds__(kVecT) void vec_div_kernel(double* out, const doubl
 inline unsigned blocks_of(long n) { return (unsigned)((n + kVecT - 1) / kVecT); }
 
 // Eigen-decomposition of a symmetric tridiagonal matrix by QL sweeps with implicit Wilkinson shifts (the classical tql2
-// scheme): d = diagonal (n), e = sub-diagonal in e[0 .. n-2] (e[n-1] is scratch), z = n x n row-major, identity on entry,
-// eigenvector j in COLUMN j on exit; d holds the eigenvalues (unsorted).  false = a sweep did not converge in 60 rounds.
+// scheme): d = diagonal (n), e = sub-diagonal in e[0 .. n-2] (e[n-1] is scratch), z = n x n, identity on entry, eigenvector j
+// in ROW j on exit (z[j * n + k] = its component k: the rotations then run over two contiguous rows -- the unpreconditioned
+// forcings of the roller schemes take 40-50 iterations, and an O(k^3) solve per iteration has to stay within the ~35 us the
+// device needs for one); d holds the eigenvalues (unsorted).  false = a sweep did not converge in 60 rounds.
 bool tridiagonal_ql(int n, double* d, double* e, double* z) {
   if (n > 0) e[n - 1] = 0.0;
   for (int l = 0; l < n; ++l) {
@@ -123,10 +125,12 @@ bool tridiagonal_ql(int n, double* d, double* e, double* z) {
           p = s * r;
           d[i + 1] = g + p;
           g = c * r - b;
+          double* __restrict__ zi = z + (size_t)i * n;              // eigenvector i and i + 1: contiguous, so this loop vectorises
+          double* __restrict__ zj = z + (size_t)(i + 1) * n;
           for (int k = 0; k < n; ++k) {
-            f = z[(size_t)k * n + i + 1];
-            z[(size_t)k * n + i + 1] = s * z[(size_t)k * n + i] + c * f;
-            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - s * f;
+            const double fk = zj[k];
+            zj[k] = s * zi[k] + c * fk;
+            zi[k] = c * zi[k] - s * fk;
           }
         }
         if (r == 0.0 && i >= l) continue;
@@ -149,11 +153,13 @@ bool noise_coefficients(long k, const double* h_diag, const double* h_sup, doubl
   std::fill(z, z + (size_t)k * k, 0.0);
   for (long i = 0; i < k; ++i) { z[(size_t)i * k + i] = 1.0; d[i] = h_diag[i]; e[i] = i + 1 < k ? h_sup[i] : 0.0; }
   if (!tridiagonal_ql((int)k, d, e, z)) return false;
-  for (long r = 0; r < k; ++r) {
-    double s = 0.0;
-    for (long j = 0; j < k; ++j) s += z[(size_t)r * k + j] * (sqrt(d[j] > 0.0 ? d[j] : 0.0) * z[j]);      // z[j] = Q[0][j]
-    coef[r] = s * scale;
+  for (long r = 0; r < k; ++r) coef[r] = 0.0;
+  for (long j = 0; j < k; ++j) {                  // coef[r] = sum_j Q[r][j] sqrt(lambda_j) Q[0][j], j ascending for every r
+    const double* zj = z + (size_t)j * k;
+    const double t = sqrt(d[j] > 0.0 ? d[j] : 0.0) * zj[0];
+    for (long r = 0; r < k; ++r) coef[r] += zj[r] * t;
   }
+  for (long r = 0; r < k; ++r) coef[r] *= scale;
   return true;
 }
 
@@ -384,28 +390,34 @@ int rmb_lanczos_noise_coefficients(long k, const double* h_diag, const double* h
   return 0;
 }
 
-// The whole preconditioned Lanczos forcing  noise = factor * blockdiag(L_b) (P^T M P)^{1/2} z,  P = blockdiag(L_b^-T), as ONE
-// library call (quaternion_integrator_multi_bodies.py:966-973 -> stochastic_forcing/stochastic_forcing.py:112-264, with the
-// preconditioner of multi_bodies.py:590-614).  Per iteration one rmb_rigid_lanczos_step_device and one event; the host
-// side -- the small tridiagonal eigenproblem and the reference's stopping rule (:239-255: relative change of the noise
-// estimate, measured on its coordinates in the orthonormal basis) -- runs ONE ITERATION LATE, while the device works on the
-// next step: rigid.py's _lanczos_native loop, natively (a Python iteration costs ~60 us of host time against ~35 us of
-// launches).  status: 0 = done; 1 = exact breakdown or a failed eigen-solve, 2 = more than max_rows basis vectors needed --
-// in both cases nothing was written to noise_dev, the stream has been drained and the caller runs its generic loop.
-int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, const double* Lchol_dev, const double* z_dev,
-                             double factor, double tol, long max_iter, long max_rows, double eta, double* noise_dev, long* iterations,
-                             long* products, int* status) {
-  if (int rc = check_ready(c)) return rc;
-  if (n_bodies < 1 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_device: bad n_bodies / n_b");
-  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_lanczos_device: the resident configuration does not hold n_bodies x n_b blobs");
-  if (!Linv_dev || !Lchol_dev || !z_dev || !noise_dev || !iterations || !status) return fail(RMB_ERR_ARG, "null pointer");
-  if (max_rows < 2 || max_rows > 254 || max_iter < 1 || !(tol >= 0.0)) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_device: need 2 <= max_rows <= 254, max_iter >= 1, tol >= 0");
-  RMB_HIP(hipSetDevice(c->device));
-  const long nn = 3 * n_b, n3 = 3 * c->n, ldv = n3, cap = max_rows;
+// ---- the Lanczos forcing loops ------------------------------------------------------------------------------------
+// factor * f(z) with the square root of an SPD operator applied through a Krylov basis (stochastic_forcing/stochastic_forcing.py:
+// 112-264): per iteration ONE step call (product + full re-orthogonalisation, which also stores h_ii and h_{i+1,i} into mapped
+// host memory) and one event; the host side -- the small tridiagonal eigenproblem and the reference's stopping rule (:239-255:
+// relative change of the noise estimate, measured on its coordinates in the orthonormal basis) -- runs ONE ITERATION LATE,
+// while the device works on the next step (a Python iteration costs 60-120 us of host time against ~35 us of launches).
+// status: 0 = done; 1 = exact breakdown or a failed eigen-solve, 2 = more than max_rows basis vectors needed -- in both cases
+// nothing was written to the result, the stream has been drained and the caller runs its general loop.
+}  // extern "C"
+
+namespace rmbi {
+namespace {
+struct LanczosBuffers {
+  double* V; long ldv;               // basis, (cap + 1) rows
+  double *x0, *x1, *x2;              // three work vectors of the step
+  double* cols; double* hcols_dev;   // coefficient rows: device copy and the mapped one
+  size_t col_row;
+};
+
+// step(i, buffers): enqueue iteration i (its coefficients go to cols + i * col_row and hcols_dev + i * col_row);
+// finish(combo, buffers): combo = V[:k]^T coef is enqueued in buffers.x1; write the result
+template <class Step, class Finish>
+int lanczos_loop(rmb_ctx* c, const char* who, long dim, const double* z_dev, double factor, double tol, long max_iter, long cap, Step step,
+                 Finish finish_result, long* iterations, long* products, int* status) {
   if (!c->gmres_ws) c->gmres_ws = new rmb_gmres_ws();
   rmb_gmres_ws* ws = (rmb_gmres_ws*)c->gmres_ws;
   const size_t col_row = (size_t)(cap + 2);
-  const size_t dev_doubles = (size_t)(cap + 1) * n3 + (size_t)3 * n3 + (size_t)cap * col_row;
+  const size_t dev_doubles = (size_t)(cap + 1) * dim + (size_t)3 * dim + (size_t)cap * col_row;
   if (int rc = ws->dev.reserve(dev_doubles * sizeof(double))) return rc;
   const size_t map_doubles = (size_t)cap * col_row + 256 + 8;
   if (map_doubles * sizeof(double) > ws->mapped.cap) {
@@ -415,18 +427,21 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
     ws->mapped.cap = map_doubles * sizeof(double);
   }
   for (auto& e : ws->ev) if (!e) RMB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  double* V = (double*)ws->dev.p;
-  double* y = V + (size_t)(cap + 1) * n3;          // P v_i
-  double* w = y + n3;                              // the sweep's result / the final combination
-  double* d = w + n3;                              // P^T M P v_i, orthogonalised in place
-  double* cols = d + n3;
+  LanczosBuffers b;
+  b.V = (double*)ws->dev.p; b.ldv = dim;
+  b.x0 = b.V + (size_t)(cap + 1) * dim;
+  b.x1 = b.x0 + dim;
+  b.x2 = b.x1 + dim;
+  b.cols = b.x2 + dim;
+  b.col_row = col_row;
   double* hcols = (double*)ws->mapped.host;
-  double* hcols_dev = (double*)ws->mapped.dev;
+  b.hcols_dev = (double*)ws->mapped.dev;
   double* hcoef = hcols + (size_t)cap * col_row;
-  double* hcoef_dev = hcols_dev + (size_t)cap * col_row;
+  double* hcoef_dev = b.hcols_dev + (size_t)cap * col_row;
   double* hscal = hcoef + 256;
   double* hscal_dev = hcoef_dev + 256;
   hipStream_t s = c->stream;
+  (void)who;
   *status = 0;
   *iterations = 0;
   long n_products = 0;
@@ -437,21 +452,17 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
     return 0;
   };
 
-  hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(1024), 0, s, z_dev, n3, hscal_dev);
+  hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(1024), 0, s, z_dev, dim, hscal_dev);
   RMB_HIP(hipGetLastError());
   RMB_HIP(hipStreamSynchronize(s));
   const double v_norm = *hscal;
   if (!(v_norm > 0.0) || !std::isfinite(v_norm)) return give_up(1);
-  hipLaunchKernelGGL(vec_div_kernel, dim3(blocks_of(n3)), dim3(kVecT), 0, s, V, z_dev, v_norm, n3);
+  hipLaunchKernelGGL(vec_div_kernel, dim3(blocks_of(dim)), dim3(kVecT), 0, s, b.V, z_dev, v_norm, dim);
   RMB_HIP(hipGetLastError());
 
   std::vector<double> h_diag, h_sup, coef, coef_old, work;
-  const bool fuse_next = c->opt_gmres_fuse_pc != 0 && nn <= 96;      // (as in rmb_rigid_gmres_device)
   auto enqueue = [&](long i) -> int {
-    // (from the second step on, P v_i was left in y by the previous step's normalisation launch: six launches per iteration)
-    if (int rc = lanczos_step_impl(c, n_bodies, n_b, Linv_dev, V, ldv, i, eta, y, w, d, cols + (size_t)i * col_row,
-                                   hcols_dev + (size_t)i * col_row, fuse_next && i > 0, fuse_next))
-      return rc;
+    if (int rc = step(i, b)) return rc;
     ++n_products;
     RMB_HIP(hipEventRecord(ws->ev[i & 1], s));
     return 0;
@@ -493,19 +504,82 @@ int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* 
     if (nxt >= cap) return give_up(2);
     i = nxt;
   }
-  // noise = blockdiag(L_b) V[:k]^T coef
+  // V[:k]^T coef
   const long k = (long)coef.size();
   memcpy(hcoef, coef.data(), (size_t)k * sizeof(double));
-  hipLaunchKernelGGL(vec_zero_kernel, dim3(blocks_of(n3)), dim3(kVecT), 0, s, w, n3);
-  hipLaunchKernelGGL(vec_lincomb_kernel, dim3(blocks_of(n3)), dim3(kVecT), 0, s, w, V, ldv, hcoef_dev, (int)k, n3);
+  hipLaunchKernelGGL(vec_zero_kernel, dim3(blocks_of(dim)), dim3(kVecT), 0, s, b.x1, dim);
+  hipLaunchKernelGGL(vec_lincomb_kernel, dim3(blocks_of(dim)), dim3(kVecT), 0, s, b.x1, b.V, b.ldv, hcoef_dev, (int)k, dim);
   RMB_HIP(hipGetLastError());
-  const rmb_block l{Lchol_dev, nn * nn, nn, 1};
-  if (int rc = rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, w, nullptr, 1.0, 0.0, noise_dev, 0.0, nullptr)) return rc;
-  // (no wait: whoever writes hcoef next -- this entry or rmb_rigid_gmres_device -- has by then waited for an event recorded
-  //  later on this stream; noise_dev is enqueued, the scalars are final)
+  if (int rc = finish_result(b.x1, b)) return rc;
+  // (no wait: whoever writes hcoef next -- a Lanczos entry or rmb_rigid_gmres_device -- has by then waited for an event recorded
+  //  later on this stream; the result is enqueued, the scalars are final)
   *iterations = its;
   if (products) *products = n_products;
   return 0;
+}
+}  // namespace
+}  // namespace rmbi
+
+extern "C" {
+
+// The preconditioned forcing of the rigid-body schemes:  noise = factor * blockdiag(L_b) (P^T M P)^{1/2} z,  P = blockdiag(L_b^-T)
+// (quaternion_integrator_multi_bodies.py:966-973 with the preconditioner of multi_bodies.py:590-614): rigid.py's _lanczos_native
+// loop, natively.
+int rmb_rigid_lanczos_device(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, const double* Lchol_dev, const double* z_dev,
+                             double factor, double tol, long max_iter, long max_rows, double eta, double* noise_dev, long* iterations,
+                             long* products, int* status) {
+  if (int rc = check_ready(c)) return rc;
+  if (n_bodies < 1 || n_b < 1) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_device: bad n_bodies / n_b");
+  if (n_bodies * n_b != c->n) return fail(RMB_ERR_STATE, "rmb_rigid_lanczos_device: the resident configuration does not hold n_bodies x n_b blobs");
+  if (!Linv_dev || !Lchol_dev || !z_dev || !noise_dev || !iterations || !status) return fail(RMB_ERR_ARG, "null pointer");
+  if (max_rows < 2 || max_rows > 254 || max_iter < 1 || !(tol >= 0.0)) return fail(RMB_ERR_ARG, "rmb_rigid_lanczos_device: need 2 <= max_rows <= 254, max_iter >= 1, tol >= 0");
+  RMB_HIP(hipSetDevice(c->device));
+  const long nn = 3 * n_b, n3 = 3 * c->n;
+  const bool fuse_next = c->opt_gmres_fuse_pc != 0 && nn <= 96;      // (as in rmb_rigid_gmres_device)
+  auto step = [&](long i, const LanczosBuffers& b) -> int {
+    // x0: P v_i (from the second step on left there by the previous step's normalisation launch), x1: the sweep's raw sums,
+    // x2: P^T M P v_i, orthogonalised in place -- five launches per iteration
+    return lanczos_step_impl(c, n_bodies, n_b, Linv_dev, b.V, b.ldv, i, eta, b.x0, b.x1, b.x2, b.cols + (size_t)i * b.col_row,
+                             b.hcols_dev + (size_t)i * b.col_row, fuse_next && i > 0, fuse_next);
+  };
+  auto result = [&](double* combo, const LanczosBuffers&) -> int {       // noise = blockdiag(L_b) V[:k]^T coef
+    const rmb_block l{Lchol_dev, nn * nn, nn, 1};
+    return rmb_block_apply_device(c, n_bodies, nn, nn, 0, 0, &l, nullptr, nullptr, nullptr, combo, nullptr, 1.0, 0.0, noise_dev, 0.0, nullptr);
+  };
+  return lanczos_loop(c, "rmb_rigid_lanczos_device", n3, z_dev, factor, tol, max_iter, max_rows, step, result, iterations, products, status);
+}
+
+// The plain forcing of the single-blob schemes:  noise = factor * M^{1/2} z  with M = M_tt (product 0; in_plane: its in-plane
+// variant) over 3 N unknowns, or the 6 N x 6 N grand mobility [[M_tt, M_tr], [M_rt, M_rr]] (product 1, z = [z_f; z_tau])
+// (quaternion_integrator_rollers.py:1082-1121, :1203-1260, :1315-1353 -> stochastic_forcing_lanczos without preconditioner).
+int rmb_lanczos_device(rmb_ctx* c, int product, int in_plane, const double* z_dev, double factor, double tol, long max_iter, long max_rows,
+                       double eta, double* noise_dev, long* iterations, long* products, int* status) {
+  if (int rc = check_ready(c)) return rc;
+  if (product != 0 && product != 1) return fail(RMB_ERR_ARG, "rmb_lanczos_device: product must be 0 (M_tt) or 1 (grand mobility)");
+  if (product == 1 && in_plane) return fail(RMB_ERR_ARG, "rmb_lanczos_device: the grand mobility has no in-plane variant");
+  if (c->tgt_begin != 0 || c->tgt_end != c->n) return fail(RMB_ERR_STATE, "rmb_lanczos_device: needs the full target range");
+  if (!z_dev || !noise_dev || !iterations || !status) return fail(RMB_ERR_ARG, "null pointer");
+  if (max_rows < 2 || max_rows > 254 || max_iter < 1 || !(tol >= 0.0)) return fail(RMB_ERR_ARG, "rmb_lanczos_device: need 2 <= max_rows <= 254, max_iter >= 1, tol >= 0");
+  if (!(eta > 0.0)) return fail(RMB_ERR_ARG, "eta must be positive");
+  RMB_HIP(hipSetDevice(c->device));
+  const long n3 = 3 * c->n, dim = product == 1 ? 2 * n3 : n3;
+  auto step = [&](long i, const LanczosBuffers& b) -> int {
+    const double* v = b.V + i * b.ldv;
+    if (product == 0) {
+      if (int rc = matvec_device_impl(c, rmb::KIND_TT, in_plane ? 1 : 0, v, nullptr, eta, b.x1)) return rc;
+    } else {
+      const double* in[2] = {v, v + n3};
+      double* out[2] = {b.x1, b.x1 + n3};
+      if (int rc = rmb_matvec_op_device(c, RMB_OP_GRAND, 0, 2, in, 2, out, eta)) return rc;
+    }
+    return krylov_orthogonalize_impl(c, dim, i + 1, b.V, b.ldv, b.x1, b.cols + (size_t)i * b.col_row, b.V + (i + 1) * b.ldv,
+                                     b.hcols_dev + (size_t)i * b.col_row, nullptr);
+  };
+  auto result = [&](double* combo, const LanczosBuffers&) -> int {
+    RMB_HIP(hipMemcpyAsync(noise_dev, combo, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+  };
+  return lanczos_loop(c, "rmb_lanczos_device", dim, z_dev, factor, tol, max_iter, max_rows, step, result, iterations, products, status);
 }
 
 }  // extern "C"

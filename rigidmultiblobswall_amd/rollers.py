@@ -23,6 +23,7 @@ stochastic_trapezoidal (:659).  The articulated schemes (:737-902) need the cons
 out of scope (constraints are not on the path).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -228,7 +229,7 @@ class RollersIntegrator(object):
         rhs = rhs / nrm
       sol, info = gmres_right_preconditioned(lambda x: self._product("rr", x), lambda x: x, rhs, tol=self.tolerance,
                                              restart=20, maxiter=1000, x0=self.deterministic_torque_previous_step,
-                                             sync=getattr(self.ctx, "sync_scalars", None))
+                                             sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho())
       self.det_iterations_count += info["iterations"]
       self.deterministic_torque_previous_step = sol
       torque = sol * nrm if nrm > 0 else sol
@@ -279,10 +280,37 @@ class RollersIntegrator(object):
     return velocity.reshape(-1), torque.reshape(-1)
 
   # ---- stochastic part ------------------------------------------------------------------------------
-  def _lanczos(self, mult, dim, z, dt):
+  fused_gram_schmidt = None      # None = automatic (a plain single-GPU context), False = tensor operations
+
+  def _ortho(self):
+    """The library's fused Gram-Schmidt step (rmb_krylov_orthogonalize_device: four launches and one 16-byte transfer per
+    Lanczos iteration instead of ~15 tensor operations), as RigidSuspension._ortho hands it to the same loop."""
+    if self.fused_gram_schmidt is False or type(self.ctx) is not MobilityContext or torch.device(self.device).type != "cuda":
+      return None
+    return self.ctx.krylov_orthogonalize_device
+
+  native_lanczos = None              # None = automatic, False = never: the whole loop inside the library (rmb_lanczos_device)
+  lanczos_native_rows = 128          # basis rows of the library's loop; a forcing that needs more falls back to the generic loop
+  lanczos_native_max_blobs = 32768   # above, the iteration the lagged loop discards (a whole pair sweep, 1.4 ms here) costs more than
+                                     # the host waits it saves (~70 us per iteration, 40-50 iterations per forcing)
+  lanczos_native_loop_calls = 0
+
+  def _lanczos(self, mult, dim, z, dt, product=None):
+    """factor M^{1/2} z; product ("tt" / "grand") names the operator `mult` applies when the library has it as ONE call."""
+    if (product is not None and self.native_lanczos is not False and os.environ.get("RMB_NATIVE_LANCZOS", "") != "0" and self.kT > 0.0
+        and self._ortho() is not None and not self.print_residual and self.Nblobs <= self.lanczos_native_max_blobs
+        and (product == "tt" or self.domain != "in_plane")):
+      zt = torch.as_tensor(z, dtype=torch.float64, device=self.device).reshape(-1).contiguous()
+      noise, its, products = self.ctx.lanczos_device(product, zt, math.sqrt(2 * self.kT / dt), self.tolerance, 1000,
+                                                     self.lanczos_native_rows, self.eta, in_plane=self.domain == "in_plane")
+      self.mobility_products += products
+      self.lanczos_native_loop_calls += 1
+      if noise is not None:
+        self.stoch_iterations_count += its
+        return noise
     noise, its = stochastic_forcing_lanczos(factor=math.sqrt(2 * self.kT / dt), tolerance=self.tolerance, dim=dim,
                                             mobility_mult=mult, z=z, print_residual=self.print_residual,
-                                            device=self.device, sync=getattr(self.ctx, "sync_scalars", None))
+                                            device=self.device, sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho())
     self.stoch_iterations_count += its
     return noise
 
@@ -300,7 +328,7 @@ class RollersIntegrator(object):
     """sqrt(2kT/dt) M_tt^{1/2} W + kT div(M_tt) by Lanczos + random finite difference (:1203-1260)."""
     z = self._randn(3 * self.Nblobs)
     self._bind(self.location)
-    noise = self._lanczos(lambda v: self._product("tt", v), 3 * self.Nblobs, z, dt)
+    noise = self._lanczos(lambda v: self._product("tt", v), 3 * self.Nblobs, z, dt, product="tt")
     if self.kT > 0.0 and self.domain != "no_wall":
       (div_M_tt,) = self._random_finite_difference(("tt",))
       return noise + (self.kT / (self.rf_delta * self.a)) * div_M_tt
@@ -310,7 +338,7 @@ class RollersIntegrator(object):
     """sqrt(2kT/dt) M_tt^{1/2} W (:1315-1353)."""
     z = self._randn(3 * self.Nblobs)
     self._bind(self.location)
-    return self._lanczos(lambda v: self._product("tt", v), 3 * self.Nblobs, z, dt)
+    return self._lanczos(lambda v: self._product("tt", v), 3 * self.Nblobs, z, dt, product="tt")
 
   def compute_linear_thermal_drift(self):
     """kT div(M_tt) by random finite difference (:1404-1434); zero without wall or at kT = 0."""
@@ -335,7 +363,7 @@ class RollersIntegrator(object):
     n3 = 3 * self.Nblobs
     z = self._randn(2 * n3)
     self._bind(self.location)
-    noise = self._lanczos(self.grand_mobility, 2 * n3, z, dt)
+    noise = self._lanczos(self.grand_mobility, 2 * n3, z, dt, product="grand")
     if self.kT > 0.0 and self.domain != "no_wall":
       div_M_rt, div_M_tt = self._random_finite_difference(("rt", "tt"))
     else:
@@ -349,7 +377,7 @@ class RollersIntegrator(object):
       if nrm > 0:
         rhs = rhs / nrm
       sol, info = gmres_right_preconditioned(lambda x: self._product("rr", x), lambda x: x, rhs, tol=self.tolerance,
-                                             restart=20, maxiter=1000, sync=getattr(self.ctx, "sync_scalars", None))
+                                             restart=20, maxiter=1000, sync=getattr(self.ctx, "sync_scalars", None), ortho=self._ortho())
       self.det_iterations_count += info["iterations"]
       torque = sol * nrm if nrm > 0 else sol
       v_stoch = self._product("tr", torque)
