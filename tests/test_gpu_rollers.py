@@ -184,3 +184,52 @@ def test_force_kernel_in_use_follows_the_precision_switches(oracle):
   assert err[("double", "follow")] < 1e-12 and err[("single", "double")] < 1e-12, err
   assert 1e-9 < err[("single", "follow")] < 1e-4 and 1e-9 < err[("double", "single")] < 1e-4, err
   integ.close()
+
+
+@pytest.mark.parametrize("N,domain", [(600, "single_wall"), (3000, "single_wall"), (700, "in_plane"), (500, "no_wall")])
+def test_library_lanczos_loop_equals_the_generic_one(N, domain):
+  """The unpreconditioned forcings of the roller schemes (M_tt^{1/2} z, its in-plane variant, and the 6N grand mobility's square
+  root) as ONE library call (rmb_lanczos_device: iterations, tridiagonal eigen-solve and stopping rule in C, one iteration
+  behind the device) against stochastic_forcing_lanczos with tensor operations: same iteration counts, same noise to rounding;
+  a workspace with too few basis rows hands the forcing back to the generic loop; the defining identity |noise|^2 =
+  factor^2 z.M.z."""
+  from rigidmultiblobswall_amd.rollers import RollersIntegrator
+  a, eta, dt = 0.4, 1.1, 0.01
+  r0 = _monolayer(N, a, 5)
+  mk = lambda: RollersIntegrator(r0, "stochastic_adams_bashforth_rollers", a, eta, tolerance=1e-8, domain=domain, device="cuda:0", seed=4)
+  nat, gen = mk(), mk()
+  gen.fused_gram_schmidt = False           # tensor operations, Python loop
+  try:
+    for it in (nat, gen):
+      it.kT = 0.0041
+      it._bind(it.location)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    factor = math.sqrt(2 * nat.kT / dt)
+    cases = [("tt", 3 * N, lambda it: (lambda v: it._product("tt", v)))]
+    if domain != "in_plane":
+      cases.append(("grand", 6 * N, lambda it: it.grand_mobility))
+    for product, dim, mult in cases:
+      z = torch.randn(dim, dtype=torch.float64, device="cuda", generator=g)
+      c0, i0, i1 = nat.lanczos_native_loop_calls, nat.stoch_iterations_count, gen.stoch_iterations_count
+      a_nat = nat._lanczos(mult(nat), dim, z, dt, product=product)
+      a_gen = gen._lanczos(mult(gen), dim, z, dt, product=product)
+      assert nat.lanczos_native_loop_calls == c0 + 1 and gen.lanczos_native_loop_calls == 0
+      its, its_gen = nat.stoch_iterations_count - i0, gen.stoch_iterations_count - i1
+      # (the in-plane mobility is singular -- it ignores and returns no z components -- and the square root is not smooth at
+      #  zero: rounding in the eigenvalues near zero shows at 1e-8, so that case gets the looser bounds)
+      slack, tol_rel, tol_id = (1, 1e-6, 1e-4) if domain == "in_plane" else (0, 1e-9, 1e-6)
+      assert abs(its - its_gen) <= slack and its >= 5, (product, its, its_gen)
+      err = rel_err(a_nat.cpu().numpy(), a_gen.cpu().numpy())
+      assert err < tol_rel, (product, err)
+      zMz = float(torch.dot(z, mult(gen)(z)))
+      ident = abs(float(torch.dot(a_nat, a_nat)) / (factor ** 2 * zMz) - 1.0)
+      assert ident < tol_id, (product, ident)
+    # too few basis rows: the library hands the forcing back (status 2) and the generic loop answers
+    nat.lanczos_native_rows = 4
+    z = torch.randn(3 * N, dtype=torch.float64, device="cuda", generator=g)
+    c0 = nat.lanczos_native_loop_calls
+    b_nat = nat._lanczos(lambda v: nat._product("tt", v), 3 * N, z, dt, product="tt")
+    b_gen = gen._lanczos(lambda v: gen._product("tt", v), 3 * N, z, dt, product="tt")
+    assert nat.lanczos_native_loop_calls == c0 + 1 and rel_err(b_nat.cpu().numpy(), b_gen.cpu().numpy()) < (1e-6 if domain == "in_plane" else 1e-9)
+  finally:
+    nat.close(); gen.close()
