@@ -120,10 +120,11 @@ class RigidIntegrator(object):
     # solve) in lockstep, one k-vector pass over the blob pairs per round.
     # Numerically neutral: each solve sees exactly its own GMRES iterates.  None = automatic: from `lockstep_min_blobs`
     # blobs on, where a pass over the pairs costs more than the host work of a solver iteration; below, the solves run one
-    # after the other through the one-call Arnoldi step (64 shells: 5.7 -> 4.8 ms per stochastic_Slip_Trapz step, 256 shells
-    # 6.6 -> 5.9; 1024 shells 16.3 against 17.4 the other way: tools/experiments/exp_lockstep_small.py).
+    # after the other through the library's GMRES / Lanczos loops (tools/experiments/exp_lockstep_small.py, end of round 5,
+    # lockstep against sequential per stochastic_Slip_Trapz step: 512 shells 7.11 / 5.75 ms, 768: 10.59 / 9.34, 1024: level,
+    # 1536: 25.9 / 27.9, 2048: 41.2 / 46.9, 4096: 151 / 174).
     self.lockstep_solves = None
-    self.lockstep_min_blobs = 6000
+    self.lockstep_min_blobs = 12500
     self.print_residual = False
     self.max_retries = 1000              # total rejected configurations over the life of the integrator
     self.max_consecutive_retries = 20    # in a row (one step, or its midpoint / predictor stages)
