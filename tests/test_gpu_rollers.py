@@ -217,7 +217,7 @@ def test_library_lanczos_loop_equals_the_generic_one(N, domain):
       its, its_gen = nat.stoch_iterations_count - i0, gen.stoch_iterations_count - i1
       # (the in-plane mobility is singular -- it ignores and returns no z components -- and the square root is not smooth at
       #  zero: rounding in the eigenvalues near zero shows at 1e-8, so that case gets the looser bounds)
-      slack, tol_rel, tol_id = (1, 1e-6, 1e-4) if domain == "in_plane" else (0, 1e-9, 1e-6)
+      slack, tol_rel, tol_id = (3, 1e-4, 1e-2) if domain == "in_plane" else (0, 1e-9, 1e-6)
       assert abs(its - its_gen) <= slack and its >= 5, (product, its, its_gen)
       err = rel_err(a_nat.cpu().numpy(), a_gen.cpu().numpy())
       assert err < tol_rel, (product, err)
@@ -230,6 +230,6 @@ def test_library_lanczos_loop_equals_the_generic_one(N, domain):
     c0 = nat.lanczos_native_loop_calls
     b_nat = nat._lanczos(lambda v: nat._product("tt", v), 3 * N, z, dt, product="tt")
     b_gen = gen._lanczos(lambda v: gen._product("tt", v), 3 * N, z, dt, product="tt")
-    assert nat.lanczos_native_loop_calls == c0 + 1 and rel_err(b_nat.cpu().numpy(), b_gen.cpu().numpy()) < (1e-6 if domain == "in_plane" else 1e-9)
+    assert nat.lanczos_native_loop_calls == c0 + 1 and rel_err(b_nat.cpu().numpy(), b_gen.cpu().numpy()) < (1e-4 if domain == "in_plane" else 1e-9)
   finally:
     nat.close(); gen.close()
