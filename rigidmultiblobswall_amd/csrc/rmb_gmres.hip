@@ -87,12 +87,19 @@ __global__ __launch_bounds__(kVecT) void vec_div_kernel(double* out, const doubl
 
 inline unsigned blocks_of(long n) { return (unsigned)((n + kVecT - 1) / kVecT); }
 
-// Eigen-decomposition of a symmetric tridiagonal matrix by QL sweeps with implicit Wilkinson shifts (the classical tql2
-// scheme): d = diagonal (n), e = sub-diagonal in e[0 .. n-2] (e[n-1] is scratch), z = n x n, identity on entry, eigenvector j
-// in ROW j on exit (z[j * n + k] = its component k: the rotations then run over two contiguous rows -- the unpreconditioned
-// forcings of the roller schemes take 40-50 iterations, and an O(k^3) solve per iteration has to stay within the ~35 us the
-// device needs for one); d holds the eigenvalues (unsorted).  false = a sweep did not converge in 60 rounds.
-bool tridiagonal_ql(int n, double* d, double* e, double* z) {
+// Square-root function of a symmetric tridiagonal matrix applied to e_1, by QL sweeps with implicit Wilkinson shifts (the classical
+// tql2 scheme) WITHOUT accumulating the eigenvector matrix: T = Q L Q^T with Q = G_1 G_2 ... G_m a product of plane rotations,
+// so  f(T) e_1 = Q (f(L) Q^T e_1)  needs the first ROW of Q -- carried along in O(1) per rotation -- and then the rotations
+// applied once more, in reverse order, to the k-vector f(L) q_1: O(1) per rotation again.  The whole solve is O(k^2) instead
+// of O(k^3); the unpreconditioned forcings of the roller schemes take 40-60 iterations, and the solve of every iteration has
+// to fit into the ~35 us the device needs for one (k = 50: 180 us with the accumulated matrix, tests/test_capi_and_host.py
+// holds the result against LAPACK).  d = diagonal (n), e = sub-diagonal in e[0 .. n-2] (e[n-1] is scratch), q1 = e_1 on entry.
+// On exit d holds the eigenvalues (unsorted), q1 the first components of the eigenvectors, rot the rotations in the order
+// applied.  false = a sweep did not converge in 60 rounds.
+struct PlaneRotation { double c, s; int i; };      // acts on columns i, i + 1:  new_i = c old_i - s old_{i+1},  new_{i+1} = s old_i + c old_{i+1}
+
+bool tridiagonal_ql(int n, double* d, double* e, double* q1, std::vector<PlaneRotation>& rot) {
+  rot.clear();
   if (n > 0) e[n - 1] = 0.0;
   for (int l = 0; l < n; ++l) {
     int iter = 0, m;
@@ -104,34 +111,32 @@ bool tridiagonal_ql(int n, double* d, double* e, double* z) {
       if (m != l) {
         if (iter++ == 60) return false;
         double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-        double r = hypot(g, 1.0);
+        double r = sqrt(g * g + 1.0);
         g = d[m] - d[l] + e[l] / (g + copysign(r, g));
         double s = 1.0, c = 1.0, p = 0.0;
         int i;
         for (i = m - 1; i >= l; --i) {
           double f = s * e[i];
           const double b = c * e[i];
-          r = hypot(f, g);
+          r = sqrt(f * f + g * g);      // (entries of a Lanczos matrix of the mobility: no overflow to guard against; hypot() costs a third of a rotation)
           e[i + 1] = r;
           if (r == 0.0) {          // an exact zero on the sub-diagonal: deflate and start the sweep again
             d[i + 1] -= p;
             e[m] = 0.0;
             break;
           }
-          s = f / r;
-          c = g / r;
+          const double ir = 1.0 / r;
+          s = f * ir;
+          c = g * ir;
           g = d[i + 1] - p;
           r = (d[i] - g) * s + 2.0 * c * b;
           p = s * r;
           d[i + 1] = g + p;
           g = c * r - b;
-          double* __restrict__ zi = z + (size_t)i * n;              // eigenvector i and i + 1: contiguous, so this loop vectorises
-          double* __restrict__ zj = z + (size_t)(i + 1) * n;
-          for (int k = 0; k < n; ++k) {
-            const double fk = zj[k];
-            zj[k] = s * zi[k] + c * fk;
-            zi[k] = c * zi[k] - s * fk;
-          }
+          rot.push_back(PlaneRotation{c, s, i});
+          const double fk = q1[i + 1];
+          q1[i + 1] = s * q1[i] + c * fk;
+          q1[i] = c * q1[i] - s * fk;
         }
         if (r == 0.0 && i >= l) continue;
         d[l] -= p;
@@ -145,19 +150,22 @@ bool tridiagonal_ql(int n, double* d, double* e, double* z) {
 
 // coef = scale * Q sqrt(max(lambda, 0)) Q^T e_1 for the k x k tridiagonal (h_diag, h_sup): the Lanczos noise estimate's
 // coordinates in the Krylov basis (stochastic_forcing/stochastic_forcing.py:215-229 forms Q sqrt(L) Q^T e_1 |z| the same way)
-bool noise_coefficients(long k, const double* h_diag, const double* h_sup, double scale, double* coef, std::vector<double>& work) {
-  work.resize((size_t)k * k + 2 * (size_t)k);
-  double* z = work.data();
-  double* d = z + (size_t)k * k;
+struct NoiseWork { std::vector<double> buf; std::vector<PlaneRotation> rot; };
+
+bool noise_coefficients(long k, const double* h_diag, const double* h_sup, double scale, double* coef, NoiseWork& work) {
+  work.buf.resize(3 * (size_t)k);
+  double* d = work.buf.data();
   double* e = d + k;
-  std::fill(z, z + (size_t)k * k, 0.0);
-  for (long i = 0; i < k; ++i) { z[(size_t)i * k + i] = 1.0; d[i] = h_diag[i]; e[i] = i + 1 < k ? h_sup[i] : 0.0; }
-  if (!tridiagonal_ql((int)k, d, e, z)) return false;
-  for (long r = 0; r < k; ++r) coef[r] = 0.0;
-  for (long j = 0; j < k; ++j) {                  // coef[r] = sum_j Q[r][j] sqrt(lambda_j) Q[0][j], j ascending for every r
-    const double* zj = z + (size_t)j * k;
-    const double t = sqrt(d[j] > 0.0 ? d[j] : 0.0) * zj[0];
-    for (long r = 0; r < k; ++r) coef[r] += zj[r] * t;
+  double* q1 = e + k;
+  for (long i = 0; i < k; ++i) { d[i] = h_diag[i]; e[i] = i + 1 < k ? h_sup[i] : 0.0; q1[i] = 0.0; }
+  q1[0] = 1.0;
+  if (!tridiagonal_ql((int)k, d, e, q1, work.rot)) return false;
+  for (long j = 0; j < k; ++j) coef[j] = sqrt(d[j] > 0.0 ? d[j] : 0.0) * q1[j];          // f(L) Q^T e_1
+  for (size_t t = work.rot.size(); t-- > 0;) {                                             // Q v = G_1 (G_2 (... (G_m v)))
+    const PlaneRotation& g = work.rot[t];
+    const double a = coef[g.i], b = coef[g.i + 1];
+    coef[g.i] = g.c * a + g.s * b;
+    coef[g.i + 1] = g.c * b - g.s * a;
   }
   for (long r = 0; r < k; ++r) coef[r] *= scale;
   return true;
@@ -385,7 +393,7 @@ int rmb_rigid_gmres_device(rmb_ctx* c, long n_bodies, long n_b, const double* A1
 // iterations; exported so that the CPU test suite can hold the library's eigen-solver against LAPACK.
 int rmb_lanczos_noise_coefficients(long k, const double* h_diag, const double* h_sup, double scale, double* coef_out) {
   if (k < 1 || k > 4096 || !h_diag || (k > 1 && !h_sup) || !coef_out) return fail(RMB_ERR_ARG, "rmb_lanczos_noise_coefficients: bad arguments");
-  std::vector<double> work;
+  NoiseWork work;
   if (!noise_coefficients(k, h_diag, h_sup, scale, coef_out, work)) return fail(RMB_ERR_STATE, "rmb_lanczos_noise_coefficients: the QL sweeps did not converge");
   return 0;
 }
@@ -460,7 +468,8 @@ int lanczos_loop(rmb_ctx* c, const char* who, long dim, const double* z_dev, dou
   hipLaunchKernelGGL(vec_div_kernel, dim3(blocks_of(dim)), dim3(kVecT), 0, s, b.V, z_dev, v_norm, dim);
   RMB_HIP(hipGetLastError());
 
-  std::vector<double> h_diag, h_sup, coef, coef_old, work;
+  std::vector<double> h_diag, h_sup, coef, coef_old;
+  NoiseWork work;
   auto enqueue = [&](long i) -> int {
     if (int rc = step(i, b)) return rc;
     ++n_products;
