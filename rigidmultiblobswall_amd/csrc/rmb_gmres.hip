@@ -574,15 +574,19 @@ int rmb_lanczos_device(rmb_ctx* c, int product, int in_plane, const double* z_de
   const long n3 = 3 * c->n, dim = product == 1 ? 2 * n3 : n3;
   auto step = [&](long i, const LanczosBuffers& b) -> int {
     const double* v = b.V + i * b.ldv;
-    if (product == 0) {
-      if (int rc = matvec_device_impl(c, rmb::KIND_TT, in_plane ? 1 : 0, v, nullptr, eta, b.x1)) return rc;
+    long tiles = 0;
+    if (product == 0 && !in_plane) {
+      // (small decks: the finishing launch also takes the first Gram-Schmidt pass's dots, five launches per iteration)
+      if (int rc = plain_tt_with_dots(c, v, eta, b.x1, b.V, b.ldv, i + 1, &tiles)) return rc;
+    } else if (product == 0) {
+      if (int rc = matvec_device_impl(c, rmb::KIND_TT, 1, v, nullptr, eta, b.x1)) return rc;
     } else {
       const double* in[2] = {v, v + n3};
       double* out[2] = {b.x1, b.x1 + n3};
       if (int rc = rmb_matvec_op_device(c, RMB_OP_GRAND, 0, 2, in, 2, out, eta)) return rc;
     }
     return krylov_orthogonalize_impl(c, dim, i + 1, b.V, b.ldv, b.x1, b.cols + (size_t)i * b.col_row, b.V + (i + 1) * b.ldv,
-                                     b.hcols_dev + (size_t)i * b.col_row, nullptr);
+                                     b.hcols_dev + (size_t)i * b.col_row, nullptr, tiles);
   };
   auto result = [&](double* combo, const LanczosBuffers&) -> int {
     RMB_HIP(hipMemcpyAsync(noise_dev, combo, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

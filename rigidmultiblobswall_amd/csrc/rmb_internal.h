@@ -158,6 +158,7 @@ constexpr long kKrBodyPartialsMax = 256;      // bodies up to which the finishin
 int krylov_body_partials(rmb_ctx* c, long n, double** part_out);
 // the basis and where the partial dots of the vector the operator has just produced go: part[r * n_bodies + body]
 struct DotsFuse { const double* V; long ldv, rows; double* part; };
+int plain_tt_with_dots(rmb_ctx* c, const double* v_dev, double eta, double* out_dev, const double* V_dev, long ldv, long rows, long* tiles_done);
 int rigid_operator_impl(rmb_ctx* c, long n_bodies, long n_b, const double* K_dev, const double* x_dev, double eta, double* out_dev,
                         const DotsFuse* dots, bool* dots_done);
 // z_ready: z_dev already holds P^-1 v_j (the previous step's fused launch); fuse_pc: leave P^-1 v_{j+1} in z_dev

@@ -552,7 +552,80 @@ __global__ __launch_bounds__(1024) void lanczos_finish_kernel(const LanFinArgs a
   }
 }
 
+// The plain product's finishing launch with the first Gram-Schmidt pass's dots (rmb_lanczos_device, M_tt): workgroup = tile of
+// 64 blobs.  Thread l < 64 finishes blob i = 64 tile + l as sym_finalize_kernel does, the 192 results go to LDS and from there
+// to `out` with consecutive addresses, then four waves take the tile's share of V[r] . out for every basis row.
+struct PlainFinArgs {
+  const double4* pos;
+  const double* x;        // the sweep's input (3N)
+  double* acc;            // [3][n_pad] raw sums of the symmetric tt sweep; re-zeroed here
+  double* out;            // 3N
+  long n, n_pad, n_tiles;
+  double prefactor;
+  rmb::PairConsts k;
+  const double* V;
+  long ldv, rows;
+  double* part;           // part[r * n_tiles + tile]
+};
+
+template <bool WALL>
+__global__ __launch_bounds__(256) void plain_finish_kernel(const PlainFinArgs a) {
+  __shared__ double res[192];
+  const long tile = blockIdx.x, first = 64 * tile;
+  const long cnt = (a.n - first) < 64 ? (a.n - first) : 64;
+  const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+  if (l < cnt) {
+    const long i = first + l;
+    rmb::Vec3 acc = {a.acc[i], a.acc[a.n_pad + i], a.acc[2 * a.n_pad + i]};
+    a.acc[i] = 0.0; a.acc[a.n_pad + i] = 0.0; a.acc[2 * a.n_pad + i] = 0.0;     // ready for the next product
+    const double4 p = a.pos[i];
+    const double b = p.w;
+    rmb::self_term<rmb::KIND_TT, WALL>(a.k, p.z, a.x[3 * i] * b, a.x[3 * i + 1] * b, a.x[3 * i + 2] * b, 0, 0, 0, acc);
+    const double sc = a.prefactor * b;
+    res[3 * l] = acc.x * sc; res[3 * l + 1] = acc.y * sc; res[3 * l + 2] = acc.z * sc;
+  }
+  __syncthreads();
+  const long len = 3 * cnt, base = 3 * first;
+  for (long e = l; e < len; e += blockDim.x) a.out[base + e] = res[e];
+  for (long r0 = 4L * wave; r0 < a.rows; r0 += 16) {
+    const double* row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row[q] = a.V + (r0 + q < a.rows ? r0 + q : r0) * a.ldv + base;
+    double s[4];
+    four_row_sums<true>(row[0], row[1], row[2], row[3], res, len, s, [](long e) { return e; });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double t = wave_sum(s[q]);
+      if (lane == 0 && r0 + q < a.rows) a.part[(r0 + q) * a.n_tiles + tile] = t;
+    }
+  }
+}
+
 }  // namespace
+
+// out = M_tt v on the resident configuration, with the partial dots of `out` against V[0 .. rows) left for the Gram-Schmidt
+// step (krylov_body_partials' buffer, one partial per tile of 64 blobs): *tiles_done = that count, or 0 when the plain path ran
+int plain_tt_with_dots(rmb_ctx* c, const double* v_dev, double eta, double* out_dev, const double* V_dev, long ldv, long rows, long* tiles_done) {
+  *tiles_done = 0;
+  const long n = c->n, n_tiles = (n + 63) / 64;
+  const bool periodic = c->L[0] > 0 || c->L[1] > 0 || c->L[2] > 0;
+  if (!(c->opt_gmres_fuse_dots && sym_applies(c) && !periodic && c->opt_deterministic == 0 && c->opt_precision == 64 && c->tgt_begin == 0 &&
+        c->tgt_end == n && n_tiles <= kKrBodyPartialsMax))
+    return matvec_device_impl(c, rmb::KIND_TT, 0, v_dev, nullptr, eta, out_dev);
+  PlainFinArgs a;
+  if (int rc = krylov_body_partials(c, 3 * n, &a.part)) return rc;
+  if (int rc = sym_device(c, rmb::KIND_TT, v_dev, eta, out_dev, 0, 1, false, true)) return rc;
+  a.pos = (const double4*)c->pos.p; a.x = v_dev; a.acc = (double*)c->symbuf.p; a.out = out_dev;
+  a.n = n; a.n_pad = 64 * n_tiles; a.n_tiles = n_tiles;
+  a.prefactor = 1.0 / (8.0 * M_PI * eta);
+  a.k = make_pair_consts(c->a);
+  a.V = V_dev; a.ldv = ldv; a.rows = rows;
+  if (c->wall) hipLaunchKernelGGL(plain_finish_kernel<true>, dim3((unsigned)n_tiles), dim3(256), 0, c->stream, a);
+  else         hipLaunchKernelGGL(plain_finish_kernel<false>, dim3((unsigned)n_tiles), dim3(256), 0, c->stream, a);
+  RMB_HIP(hipGetLastError());
+  *tiles_done = n_tiles;
+  return 0;
+}
 
 int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_dev, double* V_dev, long ldv, long i, double eta, double* pv_dev,
                       double* mw_dev, double* d_dev, double* col_dev, double* col_mapped_dev, bool pv_ready, bool fuse_next) {
