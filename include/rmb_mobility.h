@@ -152,6 +152,9 @@ int rmb_ctx_release_stream(rmb_ctx* ctx);
  *                          takes the first Gram-Schmidt pass's dots of its slices with every basis row (one partial per body, summed
  *                          by the first update launch): five launches per iteration; 0 = a separate dots launch.  The Lanczos
  *                          step's finishing launch ("lanczos_fuse_finish") does the same
+ *   "krylov_low_sync" [1]  steps of the native GMRES / Lanczos entries: the launch that subtracts the second Gram-Schmidt projection
+ *                          also normalises, with |w2|^2 = |w1|^2 - |h2|^2 from partials of the first update launch (orthonormal
+ *                          basis; h2 is rounding-sized): one launch less per iteration; 0 = separate norm / normalisation launch
  *   "lanczos_fuse_finish" [1]  rmb_rigid_lanczos_step_device / rmb_rigid_lanczos_device: the sweep leaves its raw sums and ONE
  *                          launch (workgroup = body) finishes them and multiplies by L_b^-1; 0 = finalize and block product as
  *                          two launches (same arithmetic)

@@ -208,6 +208,7 @@ int rmb_ctx_set_option(rmb_ctx* c, const char* key, long value) {
   if (!strcmp(key, "host_zero_copy_in")) { c->opt_host_zero_copy_in = value ? 1 : 0; return 0; }
   if (!strcmp(key, "gmres_fuse_pc")) { c->opt_gmres_fuse_pc = value ? 1 : 0; return 0; }
   if (!strcmp(key, "gmres_fuse_dots")) { c->opt_gmres_fuse_dots = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "krylov_low_sync")) { c->opt_krylov_low_sync = value ? 1 : 0; return 0; }
   if (!strcmp(key, "lanczos_fuse_finish")) { c->opt_lanczos_fuse_finish = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_zero_copy")) { c->opt_host_zero_copy = value < 0 ? 0 : value; return 0; }
   if (!strcmp(key, "sym_order")) { c->opt_sym_order = value ? 1 : 0; return 0; }
@@ -224,7 +225,7 @@ int rmb_ctx_get_option(rmb_ctx* c, const char* key, long* value) {
       {"fused_symmetric", &c->opt_fused_symmetric}, {"symx_single", &c->opt_symx_single},
       {"deterministic", &c->opt_deterministic}, {"det_workspace_mb", &c->opt_det_workspace_mb}, {"sym_wps", &c->opt_sym_wps},
       {"wave_clock", &c->opt_wave_clock}, {"skip_pairs", &c->opt_skip_pairs}, {"sym_pin", &c->opt_sym_pin},
-      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"force_cull", &c->opt_force_cull}, {"force_sort", &c->opt_force_sort}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps}, {"sym_coop", &c->opt_sym_coop}, {"sym_order", &c->opt_sym_order}, {"host_zero_copy", &c->opt_host_zero_copy}, {"host_zero_copy_in", &c->opt_host_zero_copy_in}, {"gmres_fuse_pc", &c->opt_gmres_fuse_pc}, {"gmres_fuse_dots", &c->opt_gmres_fuse_dots}, {"lanczos_fuse_finish", &c->opt_lanczos_fuse_finish}, {"sym_two_targets", &c->opt_sym_two_targets}, {"sym_chunk_steps", &c->opt_sym_chunk_steps}, {"sym_xcd", &c->opt_sym_xcd},
+      {"precision", &c->opt_precision}, {"force_precision", &c->opt_force_precision}, {"force_cull", &c->opt_force_cull}, {"force_sort", &c->opt_force_sort}, {"sym_oversub", &c->opt_sym_oversub}, {"sym_fine_steps", &c->opt_sym_fine_steps}, {"sym_coop", &c->opt_sym_coop}, {"sym_order", &c->opt_sym_order}, {"host_zero_copy", &c->opt_host_zero_copy}, {"host_zero_copy_in", &c->opt_host_zero_copy_in}, {"gmres_fuse_pc", &c->opt_gmres_fuse_pc}, {"gmres_fuse_dots", &c->opt_gmres_fuse_dots}, {"krylov_low_sync", &c->opt_krylov_low_sync}, {"lanczos_fuse_finish", &c->opt_lanczos_fuse_finish}, {"sym_two_targets", &c->opt_sym_two_targets}, {"sym_chunk_steps", &c->opt_sym_chunk_steps}, {"sym_xcd", &c->opt_sym_xcd},
       {"sym_min_steps", &c->opt_sym_min_steps}};
   // read-only: which kernel family the last product ran on (0 one-sided sweep, 1 symmetric per-wave, 2 deterministic
   // symmetric, 3 symmetric workgroup-cooperative)

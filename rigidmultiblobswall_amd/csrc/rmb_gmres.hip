@@ -586,7 +586,7 @@ int rmb_lanczos_device(rmb_ctx* c, int product, int in_plane, const double* z_de
       if (int rc = rmb_matvec_op_device(c, RMB_OP_GRAND, 0, 2, in, 2, out, eta)) return rc;
     }
     return krylov_orthogonalize_impl(c, dim, i + 1, b.V, b.ldv, b.x1, b.cols + (size_t)i * b.col_row, b.V + (i + 1) * b.ldv,
-                                     b.hcols_dev + (size_t)i * b.col_row, nullptr, tiles);
+                                     b.hcols_dev + (size_t)i * b.col_row, nullptr, tiles, true);
   };
   auto result = [&](double* combo, const LanczosBuffers&) -> int {
     RMB_HIP(hipMemcpyAsync(noise_dev, combo, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

@@ -95,6 +95,7 @@ struct rmb_ctx {
   double* host_in_dev = nullptr;
   size_t host_in_cap = 0;
   long opt_lanczos_fuse_finish = 1; // rmb_rigid_lanczos_step_device: finalize of the sweep + L_b^-1 product in one launch
+  long opt_krylov_low_sync = 1;     // native GMRES / Lanczos steps: second update + norm (by Pythagoras) + normalisation in one launch
   long opt_gmres_fuse_dots = 1;     // rmb_rigid_gmres_device: the operator's finishing launch also takes the first Gram-Schmidt dots (<= 256 bodies)
   long opt_gmres_fuse_pc = 1;       // rmb_rigid_gmres_device: the normalisation launch also applies the preconditioner for the next step
   long opt_host_zero_copy_in = 1;   // inputs of rmb_matvec through mapped memory + a pull kernel (sizes as host_zero_copy)
@@ -153,7 +154,7 @@ struct PcBlocks { long n_bodies, r1, r2; BlockRef a11, a12, a21, a22; double* z;
 // part1_bodies > 0: the first pass's partial dots are already there, one per body and basis row (krylov_body_partials'
 // buffer, written by the operator's finishing launch): the step starts with the first update launch
 int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
-                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc, long part1_bodies = 0);
+                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc, long part1_bodies = 0, bool low_sync = false);
 constexpr long kKrBodyPartialsMax = 256;      // bodies up to which the finishing launch takes the first dots (every update workgroup re-sums them)
 int krylov_body_partials(rmb_ctx* c, long n, double** part_out);
 // the basis and where the partial dots of the vector the operator has just produced go: part[r * n_bodies + body]

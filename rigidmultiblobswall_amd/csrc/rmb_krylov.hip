@@ -32,6 +32,8 @@ constexpr long kKrMaxChunk = 4096;   // doubles of w a workgroup keeps in LDS (3
 
 struct OrthoArgs {
   long n, rows, ldv, chunk, n_chunks;
+  int low_sync;     // 1: the first update launch also leaves |w1|^2 per chunk in part3; the LAST launch does the second update, the
+                    // norm (|w2|^2 = |w1|^2 - |h2|^2: the basis is orthonormal) and the normalisation -- one launch less
   long n_part1;     // partials per row of pass 1: n_chunks, or the body count when the operator's finishing launch took them
   const double* V;
   double* w;
@@ -70,8 +72,8 @@ __device__ __forceinline__ void chunk_dots(const OrthoArgs& a, const double* wl,
 // stride over the chunks (lane l adds partials l, l + 64, ... in that order), then the butterfly -- the same order in every
 // workgroup and launch, so every workgroup holds the same bits
 __device__ __forceinline__ void reduce_partials(const OrthoArgs& a, const double* part, long count, double* hl) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * kKrWaves) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
+  for (long r0 = 4L * wave; r0 < a.rows; r0 += 4L * n_waves) {
     const double* row[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) row[q] = part + (r0 + q < a.rows ? r0 + q : r0) * count;
@@ -139,9 +141,8 @@ __global__ __launch_bounds__(kKrT) void ortho_update_kernel(const OrthoArgs a) {
   chunk_update(a, wl, hl, base, len);
   __syncthreads();
   for (long e = threadIdx.x; e < len; e += kKrT) a.w[base + e] = wl[e];
-  if (PASS == 1) {
-    chunk_dots(a, wl, base, len, a.part2);
-  } else {
+  if (PASS == 1) chunk_dots(a, wl, base, len, a.part2);
+  if (PASS == 2 || a.low_sync) {
     __shared__ double wsum[kKrWaves];
     double s = 0.0;
     for (long e = threadIdx.x; e < len; e += kKrT) s += wl[e] * wl[e];
@@ -216,6 +217,95 @@ __global__ __launch_bounds__(1024) void ortho_normalise_pc_kernel(const NormPcAr
   }
   __syncthreads();
   two_by_two_rows(a.a11, a.a12, a.a21, a.a22, b, a.r1, a.r1, a.r2, a.r2, xl, xl + rows,
+                  [&](long row, double sum) { a.z[row < r1 ? b * r1 + row : a.n_top + a.r2 * b + (row - r1)] = sum; });
+}
+
+// ---- the low-synchronisation ending of a step (the native loops): second update + norm + normalisation in ONE launch ----------
+// After the first update launch  h2 = V^T w1  and  |w1|^2  are known as per-chunk partials.  With an orthonormal basis
+// |w1 - V h2|^2 = |w1|^2 - |h2|^2 (h2 is rounding-sized after the first pass, so the subtraction is benign; a negative result --
+// an exact breakdown -- counts as zero and the loops stop or hand back as they do on |w| = 0), so the launch that subtracts the
+// second projection can normalise at once: no separate norm / normalisation launch.  Every workgroup re-derives h2 and the norm
+// from the partials in the same fixed order.
+__device__ __forceinline__ double low_sync_norm(const OrthoArgs& a, const double* hl, double* scratch) {
+  // wave 0: |w1|^2 - |h2|^2; everybody gets the root through `scratch` (one shared double) after a barrier
+  if (threadIdx.x < 64) {
+    const double s = wave_strided_sum(a.part3, a.n_chunks);
+    double h = 0.0;
+    for (long r = threadIdx.x; r < a.rows; r += 64) h += hl[r] * hl[r];
+    h = wave_sum(h);
+    if (threadIdx.x == 0) { const double d = s - h; *scratch = d > 0.0 ? sqrt(d) : (d == d ? 0.0 : d); }
+  }
+  __syncthreads();
+  return *scratch;
+}
+
+// thread's entry e of the vector: w2 = w1 - sum_r hl[r] V[r][e], rows ascending, eight loads in flight
+__device__ __forceinline__ double second_update(const OrthoArgs& a, const double* hl, long e) {
+  double s = a.w[e];
+  const double* col = a.V + e;
+  long r = 0;
+  for (; r + 8 <= a.rows; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = col[(r + q) * a.ldv];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s -= hl[r + q] * v[q];
+  }
+  for (; r < a.rows; ++r) s -= hl[r] * col[r * a.ldv];
+  return s;
+}
+
+__device__ __forceinline__ void low_sync_column(const OrthoArgs& a, const double* hl, double nrm) {
+  for (long r = threadIdx.x; r < a.rows; r += blockDim.x) {
+    const double v = a.h1[r] + hl[r];
+    a.col[r] = v;
+    if (a.col_host) a.col_host[r] = v;
+  }
+  if (threadIdx.x == 0) {
+    a.col[a.rows] = nrm;
+    if (a.col_host) a.col_host[a.rows] = nrm;
+  }
+}
+
+__global__ __launch_bounds__(kKrT) void ortho_last_kernel(const OrthoArgs a) {
+  extern __shared__ double lds[];
+  double* hl = lds;                       // rows
+  __shared__ double nrm_s;
+  reduce_partials(a, a.part2, a.n_chunks, hl);
+  __syncthreads();
+  const double nrm = low_sync_norm(a, hl, &nrm_s);
+  if (blockIdx.x == 0) low_sync_column(a, hl, nrm);
+  const double inv = 1.0 / nrm;
+  const long base = blockIdx.x * a.chunk;
+  const long len = (a.n - base) < a.chunk ? (a.n - base) : a.chunk;
+  for (long e = threadIdx.x; e < len; e += kKrT) {
+    const double w2 = second_update(a, hl, base + e);
+    a.w[base + e] = w2;
+    a.v_next[base + e] = w2 * inv;
+  }
+}
+
+__global__ __launch_bounds__(1024) void ortho_last_pc_kernel(const NormPcArgs a) {
+  extern __shared__ double xl[];          // r1 + r2 slices of v_next, r1 + r2 row sums (two_by_two_rows), then `rows` coefficients
+  __shared__ double nrm_s;
+  const long b = blockIdx.x;
+  const long r1 = a.r1, rws = a.r1 + a.r2;
+  double* hl = xl + 2 * rws;
+  reduce_partials(a.o, a.o.part2, a.o.n_chunks, hl);
+  __syncthreads();
+  const double nrm = low_sync_norm(a.o, hl, &nrm_s);
+  if (b == 0) low_sync_column(a.o, hl, nrm);
+  const double inv = 1.0 / nrm;
+  for (long k = threadIdx.x; k < rws; k += blockDim.x) {
+    const long e = k < r1 ? b * r1 + k : a.n_top + a.r2 * b + (k - r1);
+    const double w2 = second_update(a.o, hl, e);
+    a.o.w[e] = w2;
+    const double v = w2 * inv;
+    a.o.v_next[e] = v;
+    xl[k] = v;
+  }
+  __syncthreads();
+  two_by_two_rows(a.a11, a.a12, a.a21, a.a22, b, a.r1, a.r1, a.r2, a.r2, xl, xl + rws,
                   [&](long row, double sum) { a.z[row < r1 ? b * r1 + row : a.n_top + a.r2 * b + (row - r1)] = sum; });
 }
 
@@ -295,7 +385,7 @@ int krylov_body_partials(rmb_ctx* c, long n, double** part_out) {
 }
 
 int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev, long ldv, double* w_dev, double* col_dev,
-                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc, long part1_bodies) {
+                              double* v_next_dev, double* col_mapped_dev, const PcBlocks* pc, long part1_bodies, bool low_sync) {
   if (!c) return fail(RMB_ERR_ARG, "null context");
   if (n < 1 || rows < 1 || rows > kKrMaxRows || ldv < n)
     return fail(RMB_ERR_ARG, "rmb_krylov_orthogonalize_device: need n >= 1, 1 <= rows <= 256, ldv >= n");
@@ -315,11 +405,29 @@ int krylov_orthogonalize_impl(rmb_ctx* c, long n, long rows, const double* V_dev
   a.part3 = a.part2 + rows * a.n_chunks;
   a.h1 = base + (size_t)2 * kKrMaxRows * a.n_chunks + a.n_chunks;
   a.n_part1 = a.n_chunks;
+  a.low_sync = low_sync && c->opt_krylov_low_sync ? 1 : 0;
   if (part1_bodies > 0) { a.part1 = a.h1 + kKrMaxRows; a.n_part1 = part1_bodies; }       // krylov_body_partials' buffer
   const dim3 grid((unsigned)a.n_chunks), block(kKrT);
   const size_t lds_w = (size_t)chunk * sizeof(double), lds_wh = lds_w + (size_t)rows * sizeof(double);
   if (part1_bodies == 0) hipLaunchKernelGGL(ortho_dots_kernel, grid, block, lds_w, c->stream, a);
   hipLaunchKernelGGL(ortho_update_kernel<1>, grid, block, lds_wh, c->stream, a);
+  if (a.low_sync) {
+    if (pc) {
+      if (pc->n_bodies * (pc->r1 + pc->r2) != n) return fail(RMB_ERR_ARG, "krylov_orthogonalize_impl: the blocks do not cover the vector (internal)");
+      NormPcArgs q;
+      q.o = a; q.n_bodies = pc->n_bodies; q.r1 = pc->r1; q.r2 = pc->r2; q.n_top = pc->n_bodies * pc->r1;
+      q.a11 = pc->a11; q.a12 = pc->a12; q.a21 = pc->a21; q.a22 = pc->a22; q.z = pc->z;
+      const long rws = pc->r1 + pc->r2;
+      const bool any_wave = wave_rows(q.a11, q.r1, q.r1) || wave_rows(q.a12, q.r1, q.r2) || wave_rows(q.a21, q.r2, q.r1) || wave_rows(q.a22, q.r2, q.r2);
+      unsigned threads = two_by_two_threads(rws, any_wave);
+      if (threads < 256) threads = 256;                       // four waves for the partial sums
+      hipLaunchKernelGGL(ortho_last_pc_kernel, dim3((unsigned)pc->n_bodies), dim3(threads), (size_t)(2 * rws + rows) * sizeof(double), c->stream, q);
+    } else {
+      hipLaunchKernelGGL(ortho_last_kernel, grid, block, (size_t)rows * sizeof(double), c->stream, a);
+    }
+    RMB_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(ortho_update_kernel<2>, grid, block, lds_wh, c->stream, a);
   if (pc) {
     if (pc->n_bodies * (pc->r1 + pc->r2) != n) return fail(RMB_ERR_ARG, "krylov_orthogonalize_impl: the blocks do not cover the vector (internal)");

@@ -677,7 +677,7 @@ int lanczos_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* Linv_de
   const BlockRef none{nullptr, 0, 0, 0};
   const PcBlocks pc{n_bodies, nn, 0, {Linv_dev, nn * nn, 1, nn}, none, none, none, pv_dev};
   return krylov_orthogonalize_impl(c, n3, i + 1, V_dev, ldv, d_dev, col_dev, V_dev + (i + 1) * ldv, col_mapped_dev, fuse_next ? &pc : nullptr,
-                                   dots_bodies);
+                                   dots_bodies, true);
 }
 
 int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev, const double* A12_dev, const double* A21_dev,
@@ -703,7 +703,7 @@ int arnoldi_step_impl(rmb_ctx* c, long n_bodies, long n_b, const double* A11_dev
   // two Gram-Schmidt passes against v_0 .. v_j, Hessenberg column, |w|, v_{j+1} (and, fused, z = P^-1 v_{j+1})
   const PcBlocks pc{n_bodies, nn, 6, {A11_dev, nn * nn, nn, 1}, {A12_dev, nn * 6, 6, 1}, {A21_dev, 6 * nn, nn, 1}, {A22_dev, 36, 6, 1}, z_dev};
   return krylov_orthogonalize_impl(c, n, j + 1, V_dev, ldv, w_dev, col_dev, V_dev + (j + 1) * ldv, col_mapped_dev, fuse_pc ? &pc : nullptr,
-                                   dots_done ? n_bodies : 0);
+                                   dots_done ? n_bodies : 0, true);
 }
 
 }  // namespace rmbi

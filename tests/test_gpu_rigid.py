@@ -477,7 +477,7 @@ def test_native_gmres_loop_equals_the_python_loop():
     assert i0["iterations"] == 0 and float(x0.abs().max()) == 0.0
     # the fused launch (normalisation + next step's preconditioner) off: same arithmetic in one launch more
     xf, inf = nat.solve(rhs, tol=1e-9, restart=7)
-    for opts in ({"gmres_fuse_pc": 0}, {"gmres_fuse_dots": 0}):
+    for opts in ({"gmres_fuse_pc": 0}, {"gmres_fuse_dots": 0}, {"krylov_low_sync": 0}, {"krylov_low_sync": 0, "gmres_fuse_pc": 0}):
       # (fuse_pc off: separate normalisation and preconditioner launches, and with them the separate dots; fuse_dots off: the
       #  operator's finishing launch without the first pass's dots)
       for key, val in opts.items():
@@ -569,7 +569,7 @@ def test_native_lanczos_loop_equals_the_generic_one():
     assert abs(float(torch.dot(w, w)) / zMz - 1.0) < 1e-8, float(torch.dot(w, w)) / zMz - 1.0
     # the fused launches of the library's step off (finalize + L^-1, normalisation + next L^-T): same arithmetic
     a0, i0 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
-    for keys in (("lanczos_fuse_finish", "gmres_fuse_pc"), ("gmres_fuse_dots",), ("gmres_fuse_pc",)):
+    for keys in (("lanczos_fuse_finish", "gmres_fuse_pc"), ("gmres_fuse_dots",), ("gmres_fuse_pc",), ("krylov_low_sync",), ("krylov_low_sync", "gmres_fuse_pc")):
       for key in keys:
         nat.ctx.set_option(key, 0)
       a1, i1 = nat.stochastic_forcing(z, 1.0, tol=1e-10)
