@@ -988,9 +988,32 @@ def rank_main(args):
                    "lanczos_iterations_per_step": round((integ.stoch_iterations_count - it0[1]) / n_steps, 1),
                    "rejected_steps": integ.invalid_configuration_count})
       integ.close()
-    return {"decks": rows, "note": "12-blob shells in a monolayer; defaults: the GMRES and Lanczos loops inside the library "
-                                    "(rmb_rigid_gmres_device / rmb_rigid_lanczos_device, five launches per iteration); round 4, captured "
-                                    "graphs: 1.69 / 6.33 / 2.25 ms per step"}
+    # single-blob rollers (quaternion_integrator_rollers.py schemes): the Brownian Adams-Bashforth step of a small deck, whose cost is
+    # the unpreconditioned Lanczos forcing (rmb_lanczos_device; tensor operations under a Python loop in round 4: 7.2 ms per step)
+    from rigidmultiblobswall_amd.rollers import RollersIntegrator
+    n_r, a_r, n_steps = 1000, 0.656, 20
+    loc_r, _, _ = st.roller_monolayer(n_r, radius=a_r, seed=7)
+    integ = RollersIntegrator(loc_r, "stochastic_adams_bashforth_rollers", a_r, 1.0e-3, tolerance=1e-6, device=device, seed=11)
+    integ.kT, integ.g = 0.0041419464, 0.0024892
+    integ.repulsion_strength = integ.repulsion_strength_wall = 0.0165677856
+    integ.debye_length = integ.debye_length_wall = 0.0656
+    integ.omega_one_roller = np.array([0.0, 62.8, 0.0])
+    integ.report_rejections = False
+    for _ in range(3):
+      integ.advance_time_step(0.016)
+    torch.cuda.synchronize(device)
+    l0, t0 = integ.stoch_iterations_count, time.perf_counter()
+    for _ in range(n_steps):
+      integ.advance_time_step(0.016)
+    torch.cuda.synchronize(device)
+    rows.append({"bodies": n_r, "blobs": n_r, "scheme": "stochastic_adams_bashforth_rollers", "solver_tolerance": 1e-6, "steps": n_steps,
+                 "ms_per_step": round(1e3 * (time.perf_counter() - t0) / n_steps, 3), "gmres_iterations_per_step": 0.0,
+                 "lanczos_iterations_per_step": round((integ.stoch_iterations_count - l0) / n_steps, 1),
+                 "rejected_steps": integ.invalid_configuration_count})
+    integ.close()
+    return {"decks": rows, "note": "12-blob shells in a monolayer (rows 1-3) and single-blob rollers (row 4); defaults: the GMRES and Lanczos "
+                                    "loops inside the library (rmb_rigid_gmres_device / rmb_rigid_lanczos_device / rmb_lanczos_device, four O(N) "
+                                    "launches per iteration); round 4, captured graphs / tensor operations: 1.69 / 6.33 / 2.25 / 7.2 ms per step"}
   if not args.no_sweep:
     stage("small_deck_steps", 8, small_deck_steps, single_rank_only=True)
 
