@@ -869,7 +869,7 @@ class RigidSuspension(object):
   native_lanczos = None       # None = automatic, False = never: the library's Lanczos step / loop (_lanczos_native)
   native_lanczos_loop = None  # None = automatic, False = one C call per iteration under a Python loop instead of rmb_rigid_lanczos_device
   lanczos_native_loop_calls = 0
-  lanczos_native_rows = 48    # basis rows of the native loop; a forcing that needs more falls back to the generic loop
+  lanczos_native_rows = 96    # basis rows of the native loop; a forcing that needs more falls back to the generic loop
   lanczos_native_max_blobs = 20000  # above, the iteration it discards at the end (a whole pair sweep) costs more than the host waits it
                                     # saves: 12 288 blobs 5.33 -> 4.55 ms per forcing, 16 392: 8.23 -> 7.63, 24 576: level (exp_lanczos_threshold.py)
 
